@@ -1,0 +1,97 @@
+"""ResNet stem + first two stages, the image encoder trunk of the 2-D branch.
+
+The reference takes this trunk from a third-party dependency that is not vendored:
+``mmdet==2.14.0`` ``mmdet.models.backbones.ResNet(depth=50, num_stages=2, strides=(1, 2),
+dilations=(1, 1), out_indices=(1,), norm_eval=True)`` (call site models/raft_core.py:10-25,
+pin README.md:78-79).  This file restates the published architecture (He et al. 2016, "pytorch"
+style: the stride sits on the 3x3 conv) with mmdet's parameter names -- ``conv1, bn1,
+layer{1,2}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.0,downsample.1}`` -- so reference
+checkpoints load.  Parity for this sub-module is UNPINNED (the dependency's source is absent from
+the reference tree); it is plain conv/BN/ReLU/max-pool executed by MIOpen and is not a HIP-kernel
+target.
+"""
+import torch.nn as nn
+
+_STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, with_downsample=False):
+        super().__init__()
+        out_planes = planes * self.expansion
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, out_planes, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if with_downsample:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(inplanes, out_planes, 1, stride=stride, bias=False),
+                nn.BatchNorm2d(out_planes),
+            )
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + shortcut)
+
+
+class ResNetTrunk(nn.Module):
+    """conv1/bn1/maxpool + ``num_stages`` bottleneck stages; returns a 1-tuple like mmdet does."""
+
+    def __init__(self, depth=50, num_stages=2, strides=(1, 2), norm_eval=True, **_unused):
+        super().__init__()
+        if depth not in _STAGE_BLOCKS:
+            raise KeyError('invalid depth %s for the bottleneck trunk' % depth)
+        self.norm_eval = norm_eval
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+
+        inplanes = 64
+        self.res_layers = []
+        for i in range(num_stages):
+            planes = 64 * 2 ** i
+            blocks = []
+            for j in range(_STAGE_BLOCKS[depth][i]):
+                stride = strides[i] if j == 0 else 1
+                need_ds = j == 0 and (stride != 1 or inplanes != planes * Bottleneck.expansion)
+                blocks.append(Bottleneck(inplanes, planes, stride, need_ds))
+                inplanes = planes * Bottleneck.expansion
+            name = 'layer%d' % (i + 1)
+            self.add_module(name, nn.Sequential(*blocks))
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                nn.init.constant_(m.bn3.weight, 0)  # mmdet default zero_init_residual=True
+
+    def train(self, mode=True):
+        super().train(mode)
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        for name in self.res_layers:
+            x = getattr(self, name)(x)
+        return (x,)

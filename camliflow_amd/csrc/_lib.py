@@ -1,0 +1,51 @@
+"""ctypes binding of libcamli_hip.so (prototypes: include/camli_hip.h)."""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+_c_float_p = ctypes.c_void_p   # device pointers travel as integers
+_c_i64_p = ctypes.c_void_p
+_int = ctypes.c_int
+_stream = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/camli_hip.h declares
+PROTOTYPES = {
+    "camli_version": (_int, []),
+    "camli_last_error_string": (ctypes.c_char_p, []),
+    "camli_knn": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _int, _int, _int, _int, _stream]),
+    "camli_fps": (_int, [_c_float_p, _c_i64_p, _int, _int, _int, _stream]),
+    "camli_corr2d_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
+    "camli_corr2d_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                _int, _int, _int, _int, _int, _stream]),
+}
+
+_lib = None
+
+
+class CamliHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CamliHipError(
+            "camliflow_amd: %s is missing -- build it with `python -m camliflow_amd.csrc.build` "
+            "(or __graft_entry__.build()).  The HIP library is mandatory; there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here == header / library mismatch
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().camli_last_error_string()
+        raise CamliHipError("%s failed (%d): %s" % (what, code, msg.decode() if msg else "?"))

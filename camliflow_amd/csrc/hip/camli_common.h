@@ -1,0 +1,30 @@
+// Shared helpers for the gfx950 kernels.  This translation unit set is compiled with
+// -ffp-contract=off: every a*b+c below is two roundings unless it is spelled __builtin_fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CAMLI_WAVE 64
+
+// error codes returned by every C-ABI entry point (include/camli_hip.h)
+#define CAMLI_OK 0
+#define CAMLI_EINVAL (-22)
+#define CAMLI_ELAUNCH (-5)
+#define CAMLI_ENOTSUP (-95)
+
+void camli_set_error(const char* fmt, ...);
+int camli_check_launch(const char* what);
+
+static inline int camli_divup(int a, int b) { return (a + b - 1) / b; }
+
+// lexicographic arg-max on (value, lowest index) across the 64 lanes of a wave
+__device__ __forceinline__ void wave_argmax_lowidx(float& v, int& i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ov = __shfl_xor(v, off, CAMLI_WAVE);
+        int oi = __shfl_xor(i, off, CAMLI_WAVE);
+        bool take = (ov > v) || (ov == v && oi < i);
+        v = take ? ov : v;
+        i = take ? oi : i;
+    }
+}

@@ -1,0 +1,328 @@
+// Brute-force k-nearest-neighbour for 2-D / 3-D points, gfx950.
+//
+// Replaces models/csrc/k_nearest_neighbor/k_nearest_neighbor_kernel.cu:9-113 of the reference
+// (one thread per query, 64-slot local arrays that spill).  Results are bit-identical to the
+// reference kernel's sequential insertion semantics (oracle/camli_oracle.c: oracle_knn), ties
+// included.
+//
+// Design (CDNA4):
+//   * one lane per query, 64 queries per wave; the candidate coordinates are wave-uniform, so
+//     they arrive through the scalar cache (s_load) and cost no VALU/LDS traffic
+//   * the k-entry sorted list of every lane lives in VGPRs (K is a template parameter, the
+//     insertion network is fully unrolled; no scratch)
+//   * a candidate that passes the (stale) k-th-distance test is appended to a small per-lane
+//     LDS queue; the 5*K-op insertion network only runs when some lane's queue is full, and
+//     then drains every lane's queue in candidate order -> exact sequential semantics while the
+//     wave-level "some lane accepts" branch stops dominating (64 independent queries per wave
+//     make that branch nearly always taken otherwise)
+//   * for small batches the candidate range is split over the NW waves of a workgroup; the NW
+//     partial lists are merged through LDS.  A merge is only order-exact when no candidate that
+//     ties the final k-th distance was dropped anywhere; that is detected from the minimum
+//     evicted distance and those (rare: exact duplicates only) queries are recomputed by a
+//     single-wave in-order scan.
+#include "camli_common.h"
+
+namespace {
+
+constexpr int QBUF = 12;          // per-lane queue depth of accepted-but-not-inserted candidates
+constexpr float KNN_INIT = 1e9f;  // k_nearest_neighbor_kernel.cu:27-30,70-73
+
+template <int D>
+__device__ __forceinline__ float sqdist(float ux, float uy, float uz, const float* __restrict__ p) {
+    float x = p[0], y = p[1];
+    float d = (ux - x) * (ux - x) + (uy - y) * (uy - y);
+    if (D == 3) {
+        float z = p[2];
+        d = d + (uz - z) * (uz - z);
+    }
+    return d;
+}
+
+// Insert (d, i) into the ascending list; precondition !(d > dist[K-1]).  Lands after every
+// entry with dist <= d, drops the old last entry (k_nearest_neighbor_kernel.cu:82-90).
+template <int K>
+__device__ __forceinline__ void list_insert(float (&dist)[K], int (&idx)[K], float d, int i, float& ev_min) {
+    ev_min = fminf(ev_min, dist[K - 1]);
+    bool prev = true;  // "the slot to the right shifted" (true for the virtual slot K)
+#pragma unroll
+    for (int j = K - 1; j >= 1; --j) {
+        const bool sh = dist[j - 1] > d;
+        // distances: clamp(d, dist[j-1], dist[j]) == the shifted / placed / kept value (one v_med3)
+        const float nd = (j == K - 1) ? fmaxf(dist[j - 1], d) : __builtin_amdgcn_fmed3f(dist[j - 1], dist[j], d);
+        // indices: two plain selects (kept un-nested so they lower to v_cndmask, not branches)
+        const int keep = prev ? i : idx[j];
+        const int ni = sh ? idx[j - 1] : keep;
+        dist[j] = nd;
+        idx[j] = ni;
+        prev = sh;
+    }
+    dist[0] = fminf(dist[0], d);
+    idx[0] = prev ? i : idx[0];
+}
+
+// In-order scan of candidates [lo, hi) for the lane's query.  lo/hi are wave-uniform, so the
+// candidate coordinates come in through scalar loads; four candidates are fetched per trip to
+// keep a batch of s_loads in flight.
+template <int D, int K>
+__device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int lo, int hi, float ux, float uy,
+                                           float uz, float (&dist)[K], int (&idx)[K], float& ev_min,
+                                           float* __restrict__ qd, int* __restrict__ qi, int qstride) {
+    constexpr int U = 4;
+    if (K == 1) {
+        float best = dist[0];
+        int bi = idx[0];
+        auto visit = [&](float d, int c) {
+            const bool take = !(d > best);  // a later candidate at equal distance replaces (kernel.cu:37)
+            best = take ? d : best;
+            bi = take ? c : bi;
+        };
+        int c = lo;
+        for (; c + U <= hi; c += U) {
+            float dd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dd[u] = sqdist<D>(ux, uy, uz, in_b + (size_t)(c + u) * D);
+#pragma unroll
+            for (int u = 0; u < U; ++u) visit(dd[u], c + u);
+        }
+        for (; c < hi; ++c) visit(sqdist<D>(ux, uy, uz, in_b + (size_t)c * D), c);
+        dist[0] = best;
+        idx[0] = bi;
+    } else if (K <= 4) {
+        int c = lo;
+        for (; c + U <= hi; c += U) {
+            float dd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dd[u] = sqdist<D>(ux, uy, uz, in_b + (size_t)(c + u) * D);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (!(dd[u] > dist[K - 1])) list_insert<K>(dist, idx, dd[u], c + u, ev_min);
+        }
+        for (; c < hi; ++c) {
+            float d = sqdist<D>(ux, uy, uz, in_b + (size_t)c * D);
+            if (!(d > dist[K - 1])) list_insert<K>(dist, idx, d, c, ev_min);
+        }
+    } else {
+        int cnt = 0;
+        float thr = dist[K - 1];
+        auto drain = [&]() {
+#pragma nounroll
+            for (int t = 0; t < QBUF; ++t) {
+                bool live = t < cnt;
+                if (!__ballot(live)) break;
+                if (live) {
+                    float d = qd[t * qstride];
+                    int c = qi[t * qstride];
+                    if (!(d > dist[K - 1])) list_insert<K>(dist, idx, d, c, ev_min);
+                }
+            }
+            cnt = 0;
+            thr = dist[K - 1];
+        };
+        auto enqueue = [&](float d, int c) {
+            if (!(d > thr)) {
+                qd[cnt * qstride] = d;
+                qi[cnt * qstride] = c;
+                ++cnt;
+            }
+        };
+        int c = lo;
+        for (; c + U <= hi; c += U) {
+            float dd[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) dd[u] = sqdist<D>(ux, uy, uz, in_b + (size_t)(c + u) * D);
+#pragma unroll
+            for (int u = 0; u < U; ++u) enqueue(dd[u], c + u);
+            if (__ballot(cnt > QBUF - U)) drain();  // room for the next U candidates in every lane
+        }
+        for (; c < hi; ++c) {
+            enqueue(sqdist<D>(ux, uy, uz, in_b + (size_t)c * D), c);
+            if (__ballot(cnt > QBUF - U)) drain();
+        }
+        drain();
+    }
+}
+
+// grid (ceil(Nq/64), B); block 64*NW threads.  LDS (dynamic):
+//   queue region : 2 * QBUF * 64*NW dwords            (K >= 8 only)
+//   merge region : NW * K * 64 * 2 dwords + NW*64     (NW > 1 only)   -- the two regions alias
+template <int D, int K>
+__global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_kernel(const float* __restrict__ input, const float* __restrict__ query,
+                                                    int64_t* __restrict__ out, int M, int Nq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nthreads = blockDim.x;
+    const int NW = nthreads >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int q_raw = blockIdx.x * 64 + lane;
+    const int q = q_raw < Nq ? q_raw : Nq - 1;
+
+    const float* __restrict__ in_b = input + (size_t)b * M * D;
+    const float* qp = query + ((size_t)b * Nq + q) * D;
+    const float ux = qp[0], uy = qp[1], uz = (D == 3) ? qp[2] : 0.0f;
+
+    float dist[K];
+    int idx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        dist[j] = KNN_INIT;
+        idx[j] = 0;
+    }
+    float ev_min = INFINITY;
+
+    float* qd = smem + threadIdx.x;
+    int* qi = reinterpret_cast<int*>(smem) + QBUF * nthreads + threadIdx.x;
+
+    const int lo = (int)(((long long)w * M) / NW);
+    const int hi = (int)(((long long)(w + 1) * M) / NW);
+    scan_range<D, K>(in_b, lo, hi, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads);
+
+    if (NW > 1) {
+        __syncthreads();  // queues are dead; the merge region aliases them
+        float* md = smem;                                          // [NW][K][64]
+        int* mi = reinterpret_cast<int*>(smem) + NW * K * 64;      // [NW][K][64]
+        float* mev = smem + 2 * NW * K * 64;                       // [NW][64]
+        if (w > 0) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                md[(w * K + j) * 64 + lane] = dist[j];
+                mi[(w * K + j) * 64 + lane] = idx[j];
+            }
+            mev[w * 64 + lane] = ev_min;
+        }
+        __syncthreads();
+        if (w > 0) return;
+        for (int s = 1; s < NW; ++s) {
+            ev_min = fminf(ev_min, mev[s * 64 + lane]);
+            for (int j = 0; j < K; ++j) {
+                float d = md[(s * K + j) * 64 + lane];
+                int c = mi[(s * K + j) * 64 + lane];
+                bool acc = !(d > dist[K - 1]);
+                if (!__ballot(acc)) break;
+                if (acc) {
+                    if (K == 1) {
+                        dist[0] = d;
+                        idx[0] = c;
+                    } else {
+                        list_insert<K>(dist, idx, d, c, ev_min);
+                    }
+                }
+            }
+        }
+        if (K > 1) {
+            // a candidate tying the final k-th distance was dropped somewhere: the merged list
+            // may differ from the in-order result in WHICH tied index it keeps -> redo in order
+            bool redo = (ev_min == dist[K - 1]);
+            if (__ballot(redo)) {
+                if (redo) {
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        dist[j] = KNN_INIT;
+                        idx[j] = 0;
+                    }
+                    float ev2 = INFINITY;
+                    // wave 0's own queue slice: region [0, 2*QBUF*64) laid out with stride 64
+                    float* rqd = smem + 2 * NW * K * 64 + NW * 64 + lane;
+                    int* rqi = reinterpret_cast<int*>(rqd) + QBUF * 64;
+                    scan_range<D, K>(in_b, 0, M, ux, uy, uz, dist, idx, ev2, rqd, rqi, 64);
+                }
+            }
+        }
+    }
+
+    if (q_raw < Nq) {
+        int64_t* o = out + ((size_t)b * Nq + q_raw) * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) o[j] = (int64_t)idx[j];
+    }
+}
+
+// Literal one-thread-per-query form for any k in 1..64 that has no specialisation above.
+template <int D>
+__global__ __launch_bounds__(64) void knn_generic_kernel(const float* __restrict__ input,
+                                                         const float* __restrict__ query,
+                                                         int64_t* __restrict__ out, int M, int Nq, int k) {
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= Nq) return;
+    const float* __restrict__ in_b = input + (size_t)b * M * D;
+    const float* qp = query + ((size_t)b * Nq + q) * D;
+    const float ux = qp[0], uy = qp[1], uz = (D == 3) ? qp[2] : 0.0f;
+    float nd[64];
+    int ni[64];
+    for (int i = 0; i < 64; ++i) {
+        nd[i] = KNN_INIT;
+        ni[i] = 0;
+    }
+    for (int c = 0; c < M; ++c) {
+        float d = sqdist<D>(ux, uy, uz, in_b + (size_t)c * D);
+        if (d > nd[k - 1]) continue;
+        int j = c < k - 1 ? c : k - 1;
+        while (j > 0 && nd[j - 1] > d) {
+            nd[j] = nd[j - 1];
+            ni[j] = ni[j - 1];
+            --j;
+        }
+        nd[j] = d;
+        ni[j] = c;
+    }
+    int64_t* o = out + ((size_t)b * Nq + q) * k;
+    for (int i = 0; i < k; ++i) o[i] = (int64_t)ni[i];
+}
+
+template <int D, int K>
+int launch_knn(const float* input, const float* query, int64_t* out, int B, int M, int Nq, hipStream_t stream) {
+    const int qblocks = camli_divup(Nq, 64);
+    // split the candidate range until the launch carries >= ~2 waves per SIMD (1024 SIMDs)
+    int nw = 1;
+    const long long base_waves = (long long)qblocks * B;
+    const int lds_cap_nw = K >= 32 ? 4 : (K >= 16 ? 8 : 16);   // merge region <= 64 KiB
+    while (nw < lds_cap_nw && base_waves * nw < 2048 && M / (nw * 2) >= 128) nw *= 2;
+    size_t q_bytes = (K >= 8) ? (size_t)2 * QBUF * 64 * nw * 4 : 0;
+    size_t m_bytes = (nw > 1) ? ((size_t)2 * nw * K * 64 + (size_t)nw * 64 + (size_t)2 * QBUF * 64) * 4 : 0;
+    size_t lds = q_bytes > m_bytes ? q_bytes : m_bytes;
+    dim3 grid(qblocks, B);
+    hipLaunchKernelGGL((knn_kernel<D, K>), grid, dim3(64 * nw), lds, stream, input, query, out, M, Nq);
+    return camli_check_launch("camli_knn");
+}
+
+template <int D>
+int dispatch_knn(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k,
+                 hipStream_t stream) {
+    switch (k) {
+        case 1: return launch_knn<D, 1>(input, query, out, B, M, Nq, stream);
+        case 3: return launch_knn<D, 3>(input, query, out, B, M, Nq, stream);
+        case 4: return launch_knn<D, 4>(input, query, out, B, M, Nq, stream);
+        case 8: return launch_knn<D, 8>(input, query, out, B, M, Nq, stream);
+        case 16: return launch_knn<D, 16>(input, query, out, B, M, Nq, stream);
+        case 32: return launch_knn<D, 32>(input, query, out, B, M, Nq, stream);
+        default: {
+            dim3 grid(camli_divup(Nq, 64), B);
+            hipLaunchKernelGGL((knn_generic_kernel<D>), grid, dim3(64), 0, stream, input, query, out, M, Nq, k);
+            return camli_check_launch("camli_knn(generic)");
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int camli_knn(const float* input, const float* query, int64_t* out_idx, int B, int M, int Nq, int D,
+                         int k, void* stream) {
+    if (!input || !query || !out_idx) {
+        camli_set_error("camli_knn: null pointer");
+        return CAMLI_EINVAL;
+    }
+    if (B < 0 || M < 1 || Nq < 0 || (D != 2 && D != 3) || k < 1 || k > 64) {
+        camli_set_error("camli_knn: bad shape B=%d M=%d Nq=%d D=%d k=%d (need D in {2,3}, 1<=k<=64, M>=1)", B, M, Nq,
+                        D, k);
+        return CAMLI_EINVAL;
+    }
+    if (B == 0 || Nq == 0) return CAMLI_OK;
+    if (B > 65535) {
+        camli_set_error("camli_knn: batch %d exceeds grid.y limit", B);
+        return CAMLI_EINVAL;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return D == 2 ? dispatch_knn<2>(input, query, out_idx, B, M, Nq, k, s)
+                  : dispatch_knn<3>(input, query, out_idx, B, M, Nq, k, s);
+}

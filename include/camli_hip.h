@@ -1,0 +1,72 @@
+/*
+ * camli_hip.h -- C ABI of libcamli_hip.so, the MI355X (gfx950) implementation of the
+ * CamLiFlow / CamLiRAFT fused 2D+3D flow hot path.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers + sizes, no torch types
+ *   - every pointer is a DEVICE pointer on the current HIP device; tensors are contiguous fp32
+ *     unless stated, index tensors are int64
+ *   - the caller allocates every output (and owns it); nothing is allocated inside
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); the reference launches
+ *     on the legacy default stream -- callers here pass torch's current stream
+ *   - return value: 0 = ok, negative = error (-22 invalid argument, -5 launch failure,
+ *     -95 unsupported size); the message is available from camli_last_error_string()
+ *     (thread-local).  Nothing throws.
+ *
+ * Citations are relative to the reference tree (MCG-NJU/CamLiFlow).
+ */
+#ifndef CAMLI_HIP_H
+#define CAMLI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library version: major*10000 + minor*100 + patch */
+int camli_version(void);
+/* message of the last failing call on this thread ("" if none) */
+const char *camli_last_error_string(void);
+
+/*
+ * k-nearest-neighbour (brute force, ascending distance), D in {2,3}, 1 <= k <= 64.
+ * Replaces _k_nearest_neighbor_cuda: models/csrc/k_nearest_neighbor/k_nearest_neighbor.cpp:6-24,
+ * kernels k_nearest_neighbor_kernel.cu:9-95; bound by models/csrc/wrapper.py:106-127.
+ *   input [B,M,D], query [B,Nq,D] (channel-last), out_idx int64 [B,Nq,k].
+ * Bit-exact to the reference kernel's in-order insertion semantics (ties included); requires
+ * finite coordinates with squared distances < 1e9.
+ */
+int camli_knn(const float *input, const float *query, int64_t *out_idx,
+              int B, int M, int Nq, int D, int k, void *stream);
+
+/*
+ * furthest-point sampling from seed index 0.
+ * Replaces _furthest_point_sampling_cuda: models/csrc/furthest_point_sampling/
+ * furthest_point_sampling.cpp:5-16, kernel furthest_point_sampling_kernel.cu:34-85; bound by
+ * models/csrc/wrapper.py:75-103.
+ *   xyz [B,N,3], out_idx int64 [B,n_samples], 1 <= n_samples <= N <= 24576.
+ * No scratch buffer: running distances live in registers (the reference allocates a [B,N] temp,
+ * furthest_point_sampling.cpp:12).  Ties -> lowest index.
+ */
+int camli_fps(const float *xyz, int64_t *out_idx, int B, int N, int n_samples, void *stream);
+
+/*
+ * local correlation (PWC cost volume), max displacement md, Dd = 2*md+1.
+ * Replaces _correlation_forward_cuda / _correlation_backward_cuda:
+ * models/csrc/correlation/correlation.cpp:11-35, kernels correlation_forward_kernel.cu:11-55,
+ * correlation_backward_kernel.cu:4-89; bound by models/csrc/wrapper.py:18-57.
+ *   in1, in2 NHWC [B,H,W,C]; out NCHW [B,Dd*Dd,H,W] (fully written, no pre-zeroing needed).
+ *   backward: gout NCHW; g1, g2 NHWC [B,H,W,C] (fully written) -- the layout wrapper.py:34-35
+ *   produces after its permute+contiguous, written directly.
+ */
+int camli_corr2d_fwd(const float *in1_nhwc, const float *in2_nhwc, float *out_nchw,
+                     int B, int C, int H, int W, int md, void *stream);
+int camli_corr2d_bwd(const float *gout_nchw, const float *in1_nhwc, const float *in2_nhwc,
+                     float *g1_nhwc, float *g2_nhwc,
+                     int B, int C, int H, int W, int md, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAMLI_HIP_H */

@@ -1,0 +1,9 @@
+"""CPU oracle (TEST INFRASTRUCTURE -- see camli_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+``camliflow_amd`` never does.  Parity pin: tests/golden/*.npz (generated from the reference's own
+Python path by tests/golden/make_golden.py) are checked against these functions in
+tests/test_oracle_golden.py.
+"""
+from .binding import (build, knn, fps, corr2d_fwd, corr2d_bwd, allpairs_lookup_fwd, allpairs_lookup_bwd,
+                      gather_cf, scatter_add_cf, knn_interp_fwd, LIB_PATH)

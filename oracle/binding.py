@@ -1,0 +1,138 @@
+"""numpy <-> liboracle.so (ctypes).  All arrays are C-contiguous float32 / int64."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(HERE, "camli_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(LIB_PATH):
+        subprocess.run(["make", "-C", HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RuntimeError("oracle %s failed: %d" % (name, rc))
+
+
+def knn(inp, query, k):
+    """inp [B,M,D], query [B,Nq,D] -> int64 [B,Nq,k]"""
+    inp, query = _f32(inp), _f32(query)
+    B, M, D = inp.shape
+    Nq = query.shape[1]
+    out = np.zeros((B, Nq, k), dtype=np.int64)
+    _chk(_load().oracle_knn(_p(inp), _p(query), _p(out), B, M, Nq, D, k), "knn")
+    return out
+
+
+def fps(xyz, n_samples):
+    """xyz [B,N,3] -> int64 [B,n_samples]"""
+    xyz = _f32(xyz)
+    B, N, _ = xyz.shape
+    out = np.zeros((B, n_samples), dtype=np.int64)
+    _chk(_load().oracle_fps(_p(xyz), _p(out), B, N, n_samples), "fps")
+    return out
+
+
+def corr2d_fwd(in1_nhwc, in2_nhwc, md):
+    in1, in2 = _f32(in1_nhwc), _f32(in2_nhwc)
+    B, H, W, C = in1.shape
+    d = 2 * md + 1
+    out = np.zeros((B, d * d, H, W), dtype=np.float32)
+    _chk(_load().oracle_corr2d_fwd(_p(in1), _p(in2), _p(out), B, C, H, W, md), "corr2d_fwd")
+    return out
+
+
+def corr2d_bwd(gout_nchw, in1_nhwc, in2_nhwc, md):
+    g, in1, in2 = _f32(gout_nchw), _f32(in1_nhwc), _f32(in2_nhwc)
+    B, H, W, C = in1.shape
+    g1, g2 = np.zeros_like(in1), np.zeros_like(in2)
+    _chk(_load().oracle_corr2d_bwd(_p(g), _p(in1), _p(in2), _p(g1), _p(g2), B, C, H, W, md), "corr2d_bwd")
+    return g1, g2
+
+
+def _level_args(vols):
+    L = len(vols)
+    ptrs = (ctypes.c_void_p * L)(*[v.ctypes.data for v in vols])
+    hs = (ctypes.c_int * L)(*[v.shape[-2] for v in vols])
+    ws = (ctypes.c_int * L)(*[v.shape[-1] for v in vols])
+    return L, ptrs, hs, ws
+
+
+def allpairs_lookup_fwd(vols, coords, radius):
+    """vols: list of [B*P, h_l, w_l]; coords [B,2,h,w] -> [B, L*(2r+1)^2, h, w]"""
+    vols = [_f32(v) for v in vols]
+    coords = _f32(coords)
+    B, _, h, w = coords.shape
+    L, ptrs, hs, ws = _level_args(vols)
+    d = 2 * radius + 1
+    out = np.zeros((B, L * d * d, h, w), dtype=np.float32)
+    _chk(_load().oracle_allpairs_lookup_fwd(ptrs, hs, ws, L, _p(coords), _p(out), B, h, w, radius), "lookup_fwd")
+    return out
+
+
+def allpairs_lookup_bwd(vol_shapes, coords, gout, radius):
+    """returns list of grads shaped like vol_shapes"""
+    coords, gout = _f32(coords), _f32(gout)
+    B, _, h, w = coords.shape
+    gvols = [np.zeros(s, dtype=np.float32) for s in vol_shapes]
+    L, ptrs, hs, ws = _level_args(gvols)
+    _chk(_load().oracle_allpairs_lookup_bwd(ptrs, hs, ws, L, _p(coords), _p(gout), B, h, w, radius), "lookup_bwd")
+    return gvols
+
+
+def gather_cf(data, idx):
+    """data [B,C,N], idx int64 [B,I] -> [B,C,I]"""
+    data, idx = _f32(data), _i64(idx)
+    B, C, N = data.shape
+    I = idx.shape[1]
+    out = np.zeros((B, C, I), dtype=np.float32)
+    _chk(_load().oracle_gather_cf(_p(data), _p(idx), _p(out), B, C, N, I), "gather_cf")
+    return out
+
+
+def scatter_add_cf(gout, idx, N):
+    gout, idx = _f32(gout), _i64(idx)
+    B, C, I = gout.shape
+    out = np.zeros((B, C, N), dtype=np.float32)
+    _chk(_load().oracle_scatter_add_cf(_p(gout), _p(idx), _p(out), B, C, N, I), "scatter_add_cf")
+    return out
+
+
+def knn_interp_fwd(in_xyz, feat, q_xyz, knn_idx):
+    """channel-first: in_xyz [B,3,M], feat [B,C,M], q_xyz [B,3,Nq], knn_idx [B,Nq,k] -> [B,C,Nq]"""
+    in_xyz, feat, q_xyz, knn_idx = _f32(in_xyz), _f32(feat), _f32(q_xyz), _i64(knn_idx)
+    B, C, M = feat.shape
+    Nq, k = knn_idx.shape[1], knn_idx.shape[2]
+    out = np.zeros((B, C, Nq), dtype=np.float32)
+    _chk(_load().oracle_knn_interp_fwd(_p(in_xyz), _p(feat), _p(q_xyz), _p(knn_idx), _p(out), B, C, M, Nq, k),
+         "knn_interp_fwd")
+    return out

@@ -1,0 +1,339 @@
+/*
+ * camli_oracle.c -- CPU restatement of the CamLiFlow/CamLiRAFT hot-path operators.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the executable specification the HIP kernels in
+ * camliflow_amd/csrc/hip are diffed against.  Nothing under camliflow_amd/ may import, link or
+ * call it; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Parity pin: every function here is checked against outputs of the reference's own Python
+ * path (models/csrc/wrapper.py fallbacks, models/raft_core.py, models/utils.py) imported in the
+ * build container; the resulting vectors are committed under tests/golden/ together with the
+ * generating script (tests/golden/make_golden.py).  The reference ships no golden vectors of
+ * its own and its CUDA path cannot be built here (no nvcc).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared  (see oracle/Makefile).  -ffp-contract=off
+ * matters: the index-producing ops (KNN, FPS) are specified with UNFUSED fp32 arithmetic.
+ *
+ * All citations are relative to /root/reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_MAX_K 64
+
+/* ------------------------------------------------------------------------------------------
+ * k_nearest_neighbor
+ * follows models/csrc/k_nearest_neighbor/k_nearest_neighbor_kernel.cu:9-50 (2-D) and :52-95
+ * (3-D); host shape handling k_nearest_neighbor.cpp:6-24.
+ *   input  [B, M, D] channel-last, query [B, Nq, D], out int64 [B, Nq, k], D in {2, 3}.
+ * Semantics that the HIP kernel must reproduce bit-for-bit:
+ *   - d = ((ux-x)*(ux-x) + (uy-y)*(uy-y)) [+ (uz-z)*(uz-z)], unfused fp32, left to right
+ *   - candidates scanned in index order; skipped iff d > dist[k-1]
+ *   - insertion starts at slot min(idx, k-1) and moves left past entries with dist > d
+ *     (stable: lands after every entry with dist <= d); the old slot k-1 is dropped, so a
+ *     candidate that ties the current k-th distance REPLACES slot k-1
+ *   - unfilled slots keep (1e9, index 0)
+ * ------------------------------------------------------------------------------------------ */
+int oracle_knn(const float *input, const float *query, int64_t *out,
+               int B, int M, int Nq, int D, int k)
+{
+    if (k < 1 || k > ORACLE_MAX_K || (D != 2 && D != 3)) return -1;
+    for (int b = 0; b < B; ++b) {
+        const float *in_b = input + (size_t)b * M * D;
+        for (int q = 0; q < Nq; ++q) {
+            const float *qp = query + ((size_t)b * Nq + q) * D;
+            float ux = qp[0], uy = qp[1], uz = (D == 3) ? qp[2] : 0.0f;
+            float nn_d[ORACLE_MAX_K];
+            int nn_i[ORACLE_MAX_K];
+            for (int i = 0; i < ORACLE_MAX_K; ++i) { nn_d[i] = 1e9f; nn_i[i] = 0; }
+            for (int idx = 0; idx < M; ++idx) {
+                float x = in_b[idx * D + 0], y = in_b[idx * D + 1];
+                float d = (ux - x) * (ux - x) + (uy - y) * (uy - y);
+                if (D == 3) { float z = in_b[idx * D + 2]; d = d + (uz - z) * (uz - z); }
+                if (d > nn_d[k - 1]) continue;
+                int j = idx < k - 1 ? idx : k - 1;
+                while (j > 0 && nn_d[j - 1] > d) {
+                    nn_d[j] = nn_d[j - 1];
+                    nn_i[j] = nn_i[j - 1];
+                    --j;
+                }
+                nn_d[j] = d;
+                nn_i[j] = idx;
+            }
+            int64_t *o = out + ((size_t)b * Nq + q) * k;
+            for (int i = 0; i < k; ++i) o[i] = nn_i[i];
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * furthest_point_sampling
+ * follows models/csrc/wrapper.py:83-96 (the path that runs on every machine) which is
+ * index-identical to furthest_point_sampling_kernel.cu:49-78 on tie-free data.
+ *   xyz [B, N, 3], out int64 [B, n_samples]; start index 0; dist init 1e10;
+ *   d = ((x2-x1)^2 + (y2-y1)^2) + (z2-z1)^2 unfused fp32; dist = min(dist, d);
+ *   next = argmax(dist), LOWEST index among equal maxima (torch.max on CPU; the CUDA tree
+ *   reduction's own tie order, kernel.cu:5-10,23-32, depends on the thread id bit pattern and
+ *   is documented, not imitated).
+ * ------------------------------------------------------------------------------------------ */
+int oracle_fps(const float *xyz, int64_t *out, int B, int N, int n_samples)
+{
+    if (n_samples < 1 || N < 1) return -1;
+    float *dist = (float *)malloc(sizeof(float) * (size_t)N);
+    if (!dist) return -2;
+    for (int b = 0; b < B; ++b) {
+        const float *p = xyz + (size_t)b * N * 3;
+        for (int i = 0; i < N; ++i) dist[i] = 1e10f;
+        int cur = 0;
+        for (int s = 0; s < n_samples; ++s) {
+            out[(size_t)b * n_samples + s] = cur;
+            float x1 = p[cur * 3 + 0], y1 = p[cur * 3 + 1], z1 = p[cur * 3 + 2];
+            float best = -1.0f;
+            int best_i = 0;
+            for (int i = 0; i < N; ++i) {
+                float dx = p[i * 3 + 0] - x1, dy = p[i * 3 + 1] - y1, dz = p[i * 3 + 2] - z1;
+                float d = dx * dx + dy * dy + dz * dz;
+                float nd = dist[i] < d ? dist[i] : d;
+                dist[i] = nd;
+                if (nd > best) { best = nd; best_i = i; }
+            }
+            cur = best_i;
+        }
+    }
+    free(dist);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * correlation2d forward / backward
+ * follows models/csrc/wrapper.py:41-50 == correlation_forward_kernel.cu:11-49 and
+ * correlation_backward_kernel.cu:4-74.
+ *   in1, in2: NHWC [B,H,W,C]   out: NCHW [B, Dd*Dd, H, W], Dd = 2*md+1
+ *   out[n, (dy+md)*Dd+(dx+md), y, x] = (1/C) * sum_c in1[n,y,x,c] * in2[n,y+dy,x+dx,c]
+ *   zero outside the image.  Tolerance-checked (fp32 summation order is not part of the spec;
+ *   the reference's own criterion is mean-abs < 1e-6, correlation_test.cpp:82-89).
+ *   backward returns NHWC grads (the layout wrapper.py:34-35 hands back to autograd).
+ * ------------------------------------------------------------------------------------------ */
+int oracle_corr2d_fwd(const float *in1, const float *in2, float *out,
+                      int B, int C, int H, int W, int md)
+{
+    int Dd = 2 * md + 1;
+    for (int n = 0; n < B; ++n)
+        for (int dy = -md; dy <= md; ++dy)
+            for (int dx = -md; dx <= md; ++dx) {
+                int tc = (dy + md) * Dd + (dx + md);
+                for (int y = 0; y < H; ++y)
+                    for (int x = 0; x < W; ++x) {
+                        int y2 = y + dy, x2 = x + dx;
+                        float s = 0.0f;
+                        if (x2 >= 0 && y2 >= 0 && x2 < W && y2 < H) {
+                            const float *a = in1 + (((size_t)n * H + y) * W + x) * C;
+                            const float *b = in2 + (((size_t)n * H + y2) * W + x2) * C;
+                            for (int c = 0; c < C; ++c) s += a[c] * b[c];
+                            s = s / (float)C;
+                        }
+                        out[(((size_t)n * Dd * Dd + tc) * H + y) * W + x] = s;
+                    }
+            }
+    return 0;
+}
+
+int oracle_corr2d_bwd(const float *gout, const float *in1, const float *in2,
+                      float *g1, float *g2, int B, int C, int H, int W, int md)
+{
+    int Dd = 2 * md + 1;
+    size_t total = (size_t)B * H * W * C;
+    memset(g1, 0, total * sizeof(float));
+    memset(g2, 0, total * sizeof(float));
+    for (int n = 0; n < B; ++n)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                for (int dy = -md; dy <= md; ++dy)
+                    for (int dx = -md; dx <= md; ++dx) {
+                        int y2 = y + dy, x2 = x + dx;
+                        if (x2 < 0 || y2 < 0 || x2 >= W || y2 >= H) continue;
+                        int tc = (dy + md) * Dd + (dx + md);
+                        float g = gout[(((size_t)n * Dd * Dd + tc) * H + y) * W + x] / (float)C;
+                        size_t o1 = (((size_t)n * H + y) * W + x) * C;
+                        size_t o2 = (((size_t)n * H + y2) * W + x2) * C;
+                        for (int c = 0; c < C; ++c) {
+                            g1[o1 + c] += g * in2[o2 + c];
+                            g2[o2 + c] += g * in1[o1 + c];
+                        }
+                    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * All-pairs cost-volume pyramid lookup (RAFT "Correlation2D.forward")
+ * follows models/raft_core.py:70-107 (grid_sample bilinear, align_corners=True, zeros padding).
+ *   vol_l : level l of the pyramid, [B*P, h_l, w_l] row-major (P = h*w source pixels)
+ *   coords: [B, 2, h, w] (x, y) in level-0 pixel units
+ *   out   : [B, L*(2r+1)^2, h, w]; channel l*(2r+1)^2 + i*(2r+1) + j samples level l at
+ *           (x/2^l + d[i], y/2^l + d[j]), d = -r..r  (the transposed RAFT window, SURVEY 8a
+ *           note +)
+ * The normalise/un-normalise round trip of raft_core.py:97-107 + grid_sample is restated
+ * literally (ix = ((2*x/(w-1) - 1) + 1)/2*(w-1)) so the fp32 sample positions agree.
+ * ------------------------------------------------------------------------------------------ */
+static inline float unnorm(float p, int size)
+{
+    float g = 2.0f * p / (float)(size - 1) - 1.0f;
+    return ((g + 1.0f) / 2.0f) * (float)(size - 1);
+}
+
+int oracle_allpairs_lookup_fwd(const float *const *vols, const int *hs, const int *ws, int L,
+                               const float *coords, float *out, int B, int h, int w, int r)
+{
+    int Dd = 2 * r + 1, P = h * w;
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < P; ++p) {
+            float cx = coords[((size_t)b * 2 + 0) * P + p];
+            float cy = coords[((size_t)b * 2 + 1) * P + p];
+            for (int l = 0; l < L; ++l) {
+                int hl = hs[l], wl = ws[l];
+                const float *v = vols[l] + ((size_t)b * P + p) * hl * wl;
+                float scale = (float)(1 << l);
+                float bx = cx / scale, by = cy / scale;
+                for (int i = 0; i < Dd; ++i)
+                    for (int j = 0; j < Dd; ++j) {
+                        float sx = unnorm(bx + (float)(i - r), wl);
+                        float sy = unnorm(by + (float)(j - r), hl);
+                        float fx = floorf(sx), fy = floorf(sy);
+                        int x0 = (int)fx, y0 = (int)fy;
+                        /* weights and accumulation order as ATen grid_sampler_2d (nw, ne, sw, se):
+                         * nw = (x1 - ix)*(y1 - iy) etc. with x1 = x0 + 1 */
+                        float wx1 = (fx + 1.0f) - sx, wx0 = sx - fx;
+                        float wy1 = (fy + 1.0f) - sy, wy0 = sy - fy;
+                        float acc = 0.0f;
+                        if (x0 >= 0 && x0 < wl && y0 >= 0 && y0 < hl)
+                            acc += v[y0 * wl + x0] * (wx1 * wy1);
+                        if (x0 + 1 >= 0 && x0 + 1 < wl && y0 >= 0 && y0 < hl)
+                            acc += v[y0 * wl + x0 + 1] * (wx0 * wy1);
+                        if (x0 >= 0 && x0 < wl && y0 + 1 >= 0 && y0 + 1 < hl)
+                            acc += v[(y0 + 1) * wl + x0] * (wx1 * wy0);
+                        if (x0 + 1 >= 0 && x0 + 1 < wl && y0 + 1 >= 0 && y0 + 1 < hl)
+                            acc += v[(y0 + 1) * wl + x0 + 1] * (wx0 * wy0);
+                        int ch = l * Dd * Dd + i * Dd + j;
+                        out[((size_t)b * L * Dd * Dd + ch) * P + p] = acc;
+                    }
+            }
+        }
+    return 0;
+}
+
+/* gradient of the lookup w.r.t. the pyramid levels (coords carry no gradient: they are built
+ * from detached flow, models/raft_core.py:248, camliraft_core.py:105-106).  gvols[l] must be
+ * zero-initialised by the caller; contributions are accumulated. */
+int oracle_allpairs_lookup_bwd(float *const *gvols, const int *hs, const int *ws, int L,
+                               const float *coords, const float *gout, int B, int h, int w, int r)
+{
+    int Dd = 2 * r + 1, P = h * w;
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < P; ++p) {
+            float cx = coords[((size_t)b * 2 + 0) * P + p];
+            float cy = coords[((size_t)b * 2 + 1) * P + p];
+            for (int l = 0; l < L; ++l) {
+                int hl = hs[l], wl = ws[l];
+                float *v = gvols[l] + ((size_t)b * P + p) * hl * wl;
+                float scale = (float)(1 << l);
+                float bx = cx / scale, by = cy / scale;
+                for (int i = 0; i < Dd; ++i)
+                    for (int j = 0; j < Dd; ++j) {
+                        float sx = unnorm(bx + (float)(i - r), wl);
+                        float sy = unnorm(by + (float)(j - r), hl);
+                        float fx = floorf(sx), fy = floorf(sy);
+                        int x0 = (int)fx, y0 = (int)fy;
+                        float wx1 = (fx + 1.0f) - sx, wx0 = sx - fx;
+                        float wy1 = (fy + 1.0f) - sy, wy0 = sy - fy;
+                        int ch = l * Dd * Dd + i * Dd + j;
+                        float g = gout[((size_t)b * L * Dd * Dd + ch) * P + p];
+                        if (x0 >= 0 && x0 < wl && y0 >= 0 && y0 < hl)
+                            v[y0 * wl + x0] += g * (wx1 * wy1);
+                        if (x0 + 1 >= 0 && x0 + 1 < wl && y0 >= 0 && y0 < hl)
+                            v[y0 * wl + x0 + 1] += g * (wx0 * wy1);
+                        if (x0 >= 0 && x0 < wl && y0 + 1 >= 0 && y0 + 1 < hl)
+                            v[(y0 + 1) * wl + x0] += g * (wx1 * wy0);
+                        if (x0 + 1 >= 0 && x0 + 1 < wl && y0 + 1 >= 0 && y0 + 1 < hl)
+                            v[(y0 + 1) * wl + x0 + 1] += g * (wx0 * wy0);
+                    }
+            }
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * batch_indexing (gather along the point axis) and its adjoint (scatter-add)
+ * follows models/utils.py:61-104.
+ *   channel-first: data [B,C,N], idx int64 [B,I] -> out [B,C,I]
+ * ------------------------------------------------------------------------------------------ */
+int oracle_gather_cf(const float *data, const int64_t *idx, float *out, int B, int C, int N, int I)
+{
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float *row = data + ((size_t)b * C + c) * N;
+            float *o = out + ((size_t)b * C + c) * I;
+            const int64_t *ix = idx + (size_t)b * I;
+            for (int i = 0; i < I; ++i) {
+                if (ix[i] < 0 || ix[i] >= N) return -1;
+                o[i] = row[ix[i]];
+            }
+        }
+    return 0;
+}
+
+int oracle_scatter_add_cf(const float *gout, const int64_t *idx, float *gdata, int B, int C, int N, int I)
+{
+    memset(gdata, 0, sizeof(float) * (size_t)B * C * N);
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float *row = gdata + ((size_t)b * C + c) * N;
+            const float *g = gout + ((size_t)b * C + c) * I;
+            const int64_t *ix = idx + (size_t)b * I;
+            for (int i = 0; i < I; ++i) {
+                if (ix[i] < 0 || ix[i] >= N) return -1;
+                row[ix[i]] += g[i];
+            }
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * knn_interpolation  (k nearest + inverse-distance weights)
+ * follows models/utils.py:130-146.
+ *   in_xyz [B,3,M], feat [B,C,M], q_xyz [B,3,Nq] (all channel-first), knn int64 [B,Nq,k]
+ *   dist_j = max(||in_xyz[:,knn_j] - q||_2, 1e-8); w_j = (1/dist_j) / sum_j (1/dist_j)
+ *   out[b,c,q] = sum_j feat[b,c,knn_j] * w_j
+ * ------------------------------------------------------------------------------------------ */
+int oracle_knn_interp_fwd(const float *in_xyz, const float *feat, const float *q_xyz,
+                          const int64_t *knn, float *out, int B, int C, int M, int Nq, int k)
+{
+    if (k > ORACLE_MAX_K) return -1;
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < Nq; ++q) {
+            float wgt[ORACLE_MAX_K], wsum = 0.0f;
+            const int64_t *ix = knn + ((size_t)b * Nq + q) * k;
+            for (int j = 0; j < k; ++j) {
+                float s = 0.0f;
+                for (int a = 0; a < 3; ++a) {
+                    float d = in_xyz[((size_t)b * 3 + a) * M + ix[j]] - q_xyz[((size_t)b * 3 + a) * Nq + q];
+                    s += d * d;
+                }
+                float dist = sqrtf(s);
+                if (dist < 1e-8f) dist = 1e-8f;
+                wgt[j] = 1.0f / dist;
+                wsum += wgt[j];
+            }
+            for (int c = 0; c < C; ++c) {
+                float acc = 0.0f;
+                for (int j = 0; j < k; ++j)
+                    acc += feat[((size_t)b * C + c) * M + ix[j]] * (wgt[j] / wsum);
+                out[((size_t)b * C + c) * Nq + q] = acc;
+            }
+        }
+    return 0;
+}
+
+int oracle_version(void) { return 1; }
