@@ -1,0 +1,109 @@
+"""1x1-convolution building blocks shared by every core (counterpart of models/mlp.py:1-162).
+
+Parameter names (``conv_fn``, ``norm_fn``, ``convs.N``) are those of the reference so that its
+checkpoints load; the classes are generated from one dimension-generic implementation.
+"""
+import torch
+import torch.nn as nn
+
+
+class _LayerNormCF(nn.Module):
+    """LayerNorm over the channel axis of a channel-first tensor (mlp.py:5-40), eps inside sqrt."""
+    extra_dims = 1
+
+    def __init__(self, normalized_shape, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.eps = eps
+        self.normalized_shape = (normalized_shape,)
+
+    def forward(self, x):
+        mean = x.mean(1, keepdim=True)
+        var = (x - mean).pow(2).mean(1, keepdim=True)
+        x = (x - mean) / torch.sqrt(var + self.eps)
+        shape = (-1,) + (1,) * self.extra_dims
+        return self.weight.view(shape) * x + self.bias.view(shape)
+
+
+class LayerNormCF1d(_LayerNormCF):
+    extra_dims = 1
+
+
+class LayerNormCF2d(_LayerNormCF):
+    extra_dims = 2
+
+
+def make_activation(act):
+    if act == 'relu':
+        return nn.ReLU(inplace=True)
+    if act == 'leaky_relu':
+        return nn.LeakyReLU(negative_slope=0.1, inplace=True)
+    if act == 'sigmoid':
+        return nn.Sigmoid()
+    if act is None:
+        return nn.Identity()
+    raise NotImplementedError('Unknown activation function: %s' % act)
+
+
+def _make_norm(norm, channels, dims):
+    bn, inorm, ln = ((nn.BatchNorm1d, nn.InstanceNorm1d, LayerNormCF1d) if dims == 1
+                     else (nn.BatchNorm2d, nn.InstanceNorm2d, LayerNormCF2d))
+    if norm == 'batch_norm':
+        return bn(channels)
+    if norm == 'instance_norm':
+        return inorm(channels)
+    if norm == 'instance_norm_affine':
+        return inorm(channels, affine=True)
+    if norm == 'layer_norm':
+        return ln(channels)
+    if norm is None:
+        return nn.Identity()
+    raise NotImplementedError('Unknown normalization function: %s' % norm)
+
+
+class _ConvNormAct(nn.Module):
+    dims = 1
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, dilation=1, groups=1,
+                 norm=None, act='leaky_relu'):
+        super().__init__()
+        conv = nn.Conv1d if self.dims == 1 else nn.Conv2d
+        self.conv_fn = conv(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                            dilation=dilation, groups=groups, bias=norm is None)
+        self.norm_fn = _make_norm(norm, out_channels, self.dims)
+        self.act_fn = make_activation(act)
+
+    def forward(self, x):
+        return self.act_fn(self.norm_fn(self.conv_fn(x)))
+
+
+class Conv1dNormRelu(_ConvNormAct):
+    dims = 1
+
+
+class Conv2dNormRelu(_ConvNormAct):
+    dims = 2
+
+
+class _MLP(nn.Module):
+    layer = Conv1dNormRelu
+
+    def __init__(self, in_channels, mlp_channels, norm=None, act='leaky_relu'):
+        super().__init__()
+        assert isinstance(in_channels, int) and isinstance(mlp_channels, list)
+        widths = [in_channels] + mlp_channels
+        self.convs = nn.ModuleList(self.layer(a, b, norm=norm, act=act) for a, b in zip(widths[:-1], widths[1:]))
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        return x
+
+
+class MLP1d(_MLP):
+    layer = Conv1dNormRelu
+
+
+class MLP2d(_MLP):
+    layer = Conv2dNormRelu

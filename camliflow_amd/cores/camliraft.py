@@ -1,0 +1,245 @@
+"""CamLiRAFT: the fused 2-D + 3-D RAFT model (counterpart of models/camliraft_core.py,
+models/camliraft.py and models/camliraft_l.py).
+
+Sub-module names (``core.branch_2d``, ``core.branch_3d``, ``clfm_*``) are a compatibility surface:
+reference checkpoints key on them and its optimizer splits parameter groups on the prefix
+``core.branch_3d`` (factory.py:50-58).
+"""
+import torch
+import torch.nn as nn
+
+from ..csrc import wrapper as _ops
+from .fusion import CLFM
+from .geometry import (InputPadder, backwarp_3d, build_pc_pyramid, knn_interpolation, mesh_grid, paral2persp,
+                       persp2paral, project_pc2image)
+from .objectives import FlowModel, calc_sequence_loss_2d, calc_sequence_loss_3d
+from .raft2d import RAFTCore
+from .raft3d import PYRAMID_SIZES, CamLiRAFT_L_Core
+
+_IMAGENET_MEAN = (123.675, 116.280, 103.530)
+_IMAGENET_STD = (58.395, 57.120, 57.375)
+
+
+class CamLiRAFT_Core(nn.Module):
+    def __init__(self, cfgs):
+        super().__init__()
+        self.cfgs = cfgs
+        self.corr_levels = 4
+        self.corr_radius = 4
+        self.branch_2d = RAFTCore(cfgs)
+        self.branch_3d = CamLiRAFT_L_Core(cfgs)
+        if cfgs.fuse_fnet:
+            self.clfm_fnet = CLFM(128, 128, norm='batch_norm')
+        if cfgs.fuse_cnet:
+            self.clfm_cnet = CLFM(128, 128, norm='batch_norm')
+        if cfgs.fuse_corr:
+            self.clfm_corr = CLFM(81 * 4, 128)
+        if cfgs.fuse_motion:
+            self.clfm_motion = CLFM(128, 128)
+        if cfgs.fuse_hidden:
+            self.clfm_hidden = CLFM(128, 128)
+
+    def _project_to_feature_grid(self, xyz, camera_info, feat_2d):
+        uv = project_pc2image(xyz, camera_info)
+        uv[:, 0] *= (feat_2d.shape[-1] - 1) / (camera_info['sensor_w'] - 1)
+        uv[:, 1] *= (feat_2d.shape[-2] - 1) / (camera_info['sensor_h'] - 1)
+        return uv
+
+    def forward(self, image1, image2, pc1, pc2, camera_info):
+        b2d, b3d, cfgs = self.branch_2d, self.branch_3d, self.cfgs
+
+        xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, PYRAMID_SIZES)
+
+        feat1_2d, feat2_2d, featc_2d = b2d.fnet(image1), b2d.fnet(image2), b2d.cnet(image1)
+        feat1_3d = b3d.fnet(xyzs1[:3])[2]
+        feat2_3d = b3d.fnet(xyzs2[:3])[2]
+        featc_3d = b3d.cnet(xyzs1[:3])[2]
+
+        xyzs1, xyzs2 = xyzs1[2:], xyzs2[2:]          # working pyramid [2048, 1024, 512, 256]
+        xyz1, xyz2 = xyzs1[0], xyzs2[0]
+        uv1 = self._project_to_feature_grid(xyz1, camera_info, feat1_2d)
+        uv2 = self._project_to_feature_grid(xyz2, camera_info, feat2_2d)
+
+        if cfgs.fuse_fnet:
+            feat1_2d, feat1_3d = self.clfm_fnet(uv1, feat1_2d, feat1_3d)
+            feat2_2d, feat2_3d = self.clfm_fnet(uv2, feat2_2d, feat2_3d)
+        if cfgs.fuse_cnet:
+            featc_2d, featc_3d = self.clfm_cnet(uv1, featc_2d, featc_3d)
+
+        h_2d, x_2d = torch.split(b2d.cnet_aligner(featc_2d), [128, 128], dim=1)
+        h_2d, x_2d = torch.tanh(h_2d), torch.relu(x_2d)
+        h_3d, x_3d = torch.split(b3d.cnet_aligner(featc_3d), [128, 128], dim=1)
+        h_3d, x_3d = torch.tanh(h_3d), torch.relu(x_3d)
+
+        b2d.correlation.build_cost_volume_pyramid(feat1_2d, feat2_2d)
+        b3d.correlation.build_cost_volume_pyramid(feat1_3d, feat2_3d, xyzs2)
+        knn_indices = _ops.k_nearest_neighbor(xyz1, xyz1, k=32)
+
+        n_iters = cfgs.n_iters_train if self.training else cfgs.n_iters_eval
+        bs, _, image_h, image_w = image1.shape
+        grid_coords = mesh_grid(bs, image_h // 8, image_w // 8, device=image1.device)
+        flow_2d_pred = torch.zeros_like(grid_coords)
+        flow_3d_pred = torch.zeros_like(xyz1)
+        xyzs2_warp = xyzs2
+
+        flow_2d_preds, flow_3d_preds = [], []
+        for it in range(n_iters):
+            if it > 0:
+                flow_2d_pred = flow_2d_pred.detach()
+                flow_3d_pred = flow_3d_pred.detach()
+                xyzs2_warp = [backwarp_3d(xyz1, level, flow_3d_pred) for level in xyzs2]
+
+            corr2d = b2d.correlation(grid_coords + flow_2d_pred)
+            corr3d = b3d.correlation(xyz1, xyzs2_warp)
+            if cfgs.fuse_corr:
+                corr2d, corr3d = self.clfm_corr(uv1, corr2d, corr3d)
+
+            motion_feat2d = b2d.motion_encoder(flow_2d_pred, corr2d)
+            motion_feat3d = b3d.motion_encoder(xyz1, flow_3d_pred, corr3d, knn_indices=knn_indices)
+            if cfgs.fuse_motion:
+                motion_feat2d, motion_feat3d = self.clfm_motion(uv1, motion_feat2d, motion_feat3d)
+
+            h_2d = b2d.gru(h=h_2d, x=torch.cat([x_2d, motion_feat2d], dim=1))
+            h_3d = b3d.gru(xyz1, h=h_3d, x=torch.cat([x_3d, motion_feat3d], dim=1), knn_indices=knn_indices)
+            if cfgs.fuse_hidden:
+                h_2d, h_3d = self.clfm_hidden(uv1, h_2d, h_3d)
+
+            flow_2d_pred = flow_2d_pred + b2d.flow_head(h_2d)
+            flow_2d_preds.append(b2d.convex_upsampler(h_2d, flow_2d_pred))
+
+            flow_3d_pred = flow_3d_pred + b3d.flow_head(xyz1, h_3d, knn_indices)
+            flow_3d_preds.append(knn_interpolation(xyz1, flow_3d_pred, pc1, k=3))
+
+        return flow_2d_preds, flow_3d_preds
+
+
+def _camera_pair(sensor_h, sensor_w, intrinsics):
+    """Perspective camera of the (padded) image and the 1/32-scale parallel camera the point
+    branch works in (camliraft.py:48-62)."""
+    persp = {'projection_mode': 'perspective', 'sensor_h': sensor_h, 'sensor_w': sensor_w,
+             'f': intrinsics[:, 0], 'cx': intrinsics[:, 1], 'cy': intrinsics[:, 2]}
+    paral_h, paral_w = round(sensor_h / 32), round(sensor_w / 32)
+    paral = {'projection_mode': 'parallel', 'sensor_h': paral_h, 'sensor_w': paral_w,
+             'cx': (paral_w - 1) / 2, 'cy': (paral_h - 1) / 2}
+    return persp, paral
+
+
+class _FreezableBN:
+    """``train()`` that optionally keeps every BatchNorm in eval mode (camliraft.py:17-30)."""
+
+    def train(self, mode=True):
+        self.training = mode
+        for module in self.children():
+            module.train(mode)
+        if self.cfgs.freeze_bn:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+
+class CamLiRAFT(_FreezableBN, FlowModel):
+    def __init__(self, cfgs):
+        super().__init__()
+        self.cfgs = cfgs
+        self.core = CamLiRAFT_Core(cfgs)
+
+    def forward(self, inputs):
+        images = inputs['images'].float()
+        pc1, pc2 = inputs['pcs'][:, :3], inputs['pcs'][:, 3:]
+
+        padder = InputPadder(images.shape, x=8)
+        image1, image2 = padder.pad(images[:, :3], images[:, 3:])
+        mean = torch.tensor(_IMAGENET_MEAN, device=images.device).reshape(1, 3, 1, 1)
+        std = torch.tensor(_IMAGENET_STD, device=images.device).reshape(1, 3, 1, 1)
+        image1 = (image1 - mean) / std
+        image2 = (image2 - mean) / std
+
+        persp, paral = _camera_pair(image1.shape[-2], image1.shape[-1], inputs['intrinsics'])
+        pc1 = persp2paral(pc1, persp, paral)
+        pc2 = persp2paral(pc2, persp, paral)
+
+        flow_2d_preds, flow_3d_preds = self.core(image1, image2, pc1, pc2, paral)
+        flow_2d_preds = [padder.unpad(f) for f in flow_2d_preds]
+        origin = paral2persp(pc1, persp, paral)
+        flow_3d_preds = [paral2persp(pc1 + f, persp, paral) - origin for f in flow_3d_preds]
+
+        final_flow_2d, final_flow_3d = flow_2d_preds[-1], flow_3d_preds[-1]
+        outputs = {'flow_2d': final_flow_2d, 'flow_3d': final_flow_3d}
+        if 'flow_2d' not in inputs or 'flow_3d' not in inputs:
+            return outputs
+
+        target_2d, target_3d = inputs['flow_2d'].float(), inputs['flow_3d'].float()
+        loss_2d = calc_sequence_loss_2d(flow_2d_preds, target_2d, cfgs=self.cfgs.loss2d)
+        loss_3d = calc_sequence_loss_3d(flow_3d_preds, target_3d, cfgs=self.cfgs.loss3d)
+        self.loss = loss_2d + loss_3d
+
+        self.update_metrics('loss', self.loss)
+        self.update_metrics('loss2d', loss_2d)
+        self.update_metrics('loss3d', loss_3d)
+        self.update_2d_metrics(final_flow_2d, target_2d)
+        self.update_3d_metrics(final_flow_3d, target_3d)
+        if 'occ_mask_3d' in inputs:
+            self.update_3d_metrics(final_flow_3d, target_3d, inputs['occ_mask_3d'])
+        return outputs
+
+    @staticmethod
+    def is_better(curr_metrics, best_metrics):
+        return best_metrics is None or curr_metrics['epe2d'] < best_metrics['epe2d']
+
+
+class CamLiRAFT_L(FlowModel):
+    """Point-cloud-only variant (models/camliraft_l.py:7-81).  The cameras are those of a fixed
+    540x960 sensor; ``cfgs.ids.enabled`` switches the inverse-depth-scaling transform; optional
+    ``src_mean/src_std/dst_mean/dst_std`` inputs re-standardise the clouds around the core."""
+
+    def __init__(self, cfgs):
+        super().__init__()
+        self.cfgs = cfgs
+        self.core = CamLiRAFT_L_Core(cfgs)
+
+    def forward(self, inputs):
+        pc1, pc2 = inputs['pcs'][:, :3], inputs['pcs'][:, 3:]
+        use_ids = self.cfgs.ids.enabled
+        persp, paral = _camera_pair(540, 960, inputs['intrinsics'])
+        if use_ids:
+            pc1 = persp2paral(pc1, persp, paral)
+            pc2 = persp2paral(pc2, persp, paral)
+
+        restandardise = 'src_mean' in inputs and 'dst_mean' in inputs
+        if restandardise:
+            src_mean, dst_mean = inputs['src_mean'][..., None], inputs['dst_mean'][..., None]
+            src_std, dst_std = inputs['src_std'][..., None], inputs['dst_std'][..., None]
+
+            def to_dst(pc):
+                return ((pc - src_mean) / src_std) * dst_std + dst_mean
+
+            def to_src(pc):
+                return ((pc - dst_mean) / dst_std) * src_std + src_mean
+            pc1, pc2 = to_dst(pc1), to_dst(pc2)
+
+        flow_preds = self.core.forward(pc1, pc2)
+
+        if restandardise:
+            flow_preds = [to_src(pc1 + f) - to_src(pc1) for f in flow_preds]
+            pc1 = to_src(pc1)
+        if use_ids:
+            origin = paral2persp(pc1, persp, paral)
+            flow_preds = [paral2persp(pc1 + f, persp, paral) - origin for f in flow_preds]
+
+        final_flow_3d = flow_preds[-1]
+        if 'flow_3d' not in inputs:
+            return {'flow_3d': final_flow_3d}
+
+        target_3d = inputs['flow_3d'][:, :3]
+        self.loss = calc_sequence_loss_3d(flow_preds, target_3d, self.cfgs.loss)
+        self.update_metrics('loss3d', self.loss)
+        self.update_3d_metrics(final_flow_3d, target_3d)
+        return {'flow_3d': final_flow_3d}
+
+    @staticmethod
+    def is_better(curr_metrics, best_metrics):
+        return best_metrics is None or curr_metrics['epe3d'] < best_metrics['epe3d']

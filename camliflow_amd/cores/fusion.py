@@ -1,0 +1,130 @@
+"""Bidirectional camera-LiDAR fusion module, CLFM (counterpart of models/clfm.py).
+
+2D<-3D: ``FusionAwareInterp`` -- every pixel takes its nearest projected point (2-D KNN, k=1), a
+score MLP on the pixel offset gates the point feature, then a 1x1 conv.
+3D<-2D: bilinear sample of the image feature at the projected points.
+Both directions are merged by selective-kernel fusion (``SKFusion``, the default) or the add /
+concat / gated variants.  Inputs to the cross paths are detached exactly where the reference
+detaches them (clfm.py:34,37-38).
+"""
+import torch
+import torch.nn as nn
+from torch.nn.functional import softmax
+
+from ..csrc import wrapper as _ops
+from .blocks import Conv1dNormRelu, Conv2dNormRelu
+from .geometry import batch_indexing, grid_sample_wrapper, mesh_grid
+
+
+def _aligner(feat_format):
+    if feat_format == 'nchw':
+        return Conv2dNormRelu
+    if feat_format == 'ncm':
+        return Conv1dNormRelu
+    raise ValueError(feat_format)
+
+
+class FusionAwareInterp(nn.Module):
+    def __init__(self, n_channels_3d, k=1, norm=None):
+        super().__init__()
+        self.k = k
+        self.out_conv = Conv2dNormRelu(n_channels_3d, n_channels_3d, norm=norm)
+        self.score_net = nn.Sequential(
+            Conv2dNormRelu(3, 16),
+            Conv2dNormRelu(16, n_channels_3d, act='sigmoid'),
+        )
+
+    def forward(self, uv, feat_2d, feat_3d):
+        bs, _, image_h, image_w = feat_2d.shape
+        n_channels_3d = feat_3d.shape[1]
+        grid = mesh_grid(bs, image_h, image_w, uv.device).reshape(bs, 2, -1)       # [B,2,HW]
+        knn_indices = _ops.k_nearest_neighbor(uv, grid, self.k)                     # [B,HW,k]
+        gathered = batch_indexing(torch.cat([uv, feat_3d], dim=1), knn_indices)    # [B,2+C,HW,k]
+        knn_uv, knn_feat3d = torch.split(gathered, [2, n_channels_3d], dim=1)
+        knn_offset = knn_uv - grid[..., None]
+        knn_offset_norm = torch.linalg.norm(knn_offset, dim=1, keepdim=True)
+        score = self.score_net(torch.cat([knn_offset, knn_offset_norm], dim=1))    # [B,C,HW,k]
+        final = (score * knn_feat3d).sum(dim=-1).reshape(bs, -1, image_h, image_w)
+        return self.out_conv(final)
+
+
+class AddFusion(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, out_channels, feat_format, norm=None):
+        super().__init__()
+        conv = _aligner(feat_format)
+        self.align1 = conv(in_channels_2d, out_channels, norm=norm)
+        self.align2 = conv(in_channels_3d, out_channels, norm=norm)
+        self.relu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+
+    def forward(self, feat_2d, feat_3d):
+        return self.relu(self.align1(feat_2d) + self.align2(feat_3d))
+
+
+class ConcatFusion(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, out_channels, feat_format, norm=None):
+        super().__init__()
+        self.mlp = _aligner(feat_format)(in_channels_2d + in_channels_3d, out_channels, norm=norm)
+
+    def forward(self, feat_2d, feat_3d):
+        return self.mlp(torch.cat([feat_2d, feat_3d], dim=1))
+
+
+class GatedFusion(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, out_channels, feat_format, norm=None):
+        super().__init__()
+        conv = _aligner(feat_format)
+        self.align1 = conv(in_channels_2d, out_channels, norm=norm)
+        self.align2 = conv(in_channels_3d, out_channels, norm=norm)
+        self.mlp1 = conv(out_channels, 2, norm=None, act='sigmoid')
+        self.mlp2 = conv(out_channels, 2, norm=None, act='sigmoid')
+
+    def forward(self, feat_2d, feat_3d):
+        feat_2d, feat_3d = self.align1(feat_2d), self.align2(feat_3d)
+        weight = softmax(self.mlp1(feat_2d) + self.mlp2(feat_3d), dim=1)
+        return feat_2d * weight[:, 0:1] + feat_3d * weight[:, 1:2]
+
+
+class SKFusion(nn.Module):
+    """Selective-kernel fusion (clfm.py:170-213): channel attention from the pooled sum decides,
+    per channel, the mix between the two aligned branches."""
+
+    def __init__(self, in_channels_2d, in_channels_3d, out_channels, feat_format, norm=None, reduction=1):
+        super().__init__()
+        conv = _aligner(feat_format)
+        self.align1 = conv(in_channels_2d, out_channels, norm=norm)
+        self.align2 = conv(in_channels_3d, out_channels, norm=norm)
+        self.avg_pool = nn.AdaptiveAvgPool2d(1) if feat_format == 'nchw' else nn.AdaptiveAvgPool1d(1)
+        self.fc_mid = nn.Sequential(nn.Linear(out_channels, out_channels // reduction, bias=False), nn.ReLU(inplace=True))
+        self.fc_out = nn.Sequential(nn.Linear(out_channels // reduction, out_channels * 2, bias=False), nn.Sigmoid())
+
+    def forward(self, feat_2d, feat_3d):
+        bs = feat_2d.shape[0]
+        feat_2d, feat_3d = self.align1(feat_2d), self.align2(feat_3d)
+        squeezed = self.avg_pool(feat_2d + feat_3d).reshape(bs, -1)
+        weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
+        bshape = [bs, -1] + [1] * (feat_2d.dim() - 2)
+        return feat_2d * weight[..., 0].reshape(bshape) + feat_3d * weight[..., 1].reshape(bshape)
+
+
+_FUSIONS = {'add': (AddFusion, {}), 'concat': (ConcatFusion, {}), 'gated': (GatedFusion, {}),
+            'sk': (SKFusion, {'reduction': 2})}
+
+
+class CLFM(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, fusion_fn='sk', norm=None):
+        super().__init__()
+        self.interp = FusionAwareInterp(in_channels_3d, k=1, norm=norm)
+        self.mlps3d = Conv1dNormRelu(in_channels_2d, in_channels_2d, norm=norm)
+        if fusion_fn not in _FUSIONS:
+            raise ValueError(fusion_fn)
+        cls, extra = _FUSIONS[fusion_fn]
+        self.fuse2d = cls(in_channels_2d, in_channels_3d, in_channels_2d, 'nchw', norm, **extra)
+        self.fuse3d = cls(in_channels_2d, in_channels_3d, in_channels_3d, 'ncm', norm, **extra)
+
+    def forward(self, uv, feat_2d, feat_3d):
+        feat_2d, feat_3d = feat_2d.float(), feat_3d.float()
+        feat_3d_interp = self.interp(uv, feat_2d.detach(), feat_3d.detach())
+        out2d = self.fuse2d(feat_2d, feat_3d_interp)
+        feat_2d_sampled = grid_sample_wrapper(feat_2d.detach(), uv)
+        out3d = self.fuse3d(self.mlps3d(feat_2d_sampled.detach()), feat_3d)
+        return out2d, out3d

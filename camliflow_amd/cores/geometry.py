@@ -1,0 +1,221 @@
+"""Index / interpolation / projection helpers of the hot path (counterpart of models/utils.py and
+models/ids.py).  Every function keeps the reference's name, argument order and tensor layout.
+"""
+import torch
+from torch.nn.functional import grid_sample, interpolate, pad, softmax, unfold
+
+from ..csrc import wrapper as _ops
+from . import runtime
+
+
+class InputPadder:
+    """Replicate-pad H and W up to a multiple of ``x`` (utils.py:7-20): width split left/right,
+    height padded at the bottom only."""
+
+    def __init__(self, dims, x=8):
+        self.ht, self.wd = dims[-2:]
+        pad_ht = (((self.ht // x) + 1) * x - self.ht) % x
+        pad_wd = (((self.wd // x) + 1) * x - self.wd) % x
+        self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+
+    def pad(self, *inputs):
+        return [pad(x, self._pad, mode='replicate').contiguous() for x in inputs]
+
+    def unpad(self, x):
+        ht, wd = x.shape[-2:]
+        left, right, top, bottom = self._pad
+        return x[..., top:ht - bottom, left:wd - right]
+
+
+def batch_indexing(batched_data, batched_indices, layout='channel_first'):
+    """Gather along the point axis (utils.py:61-104).
+
+    channel_first: data [B,C,N], indices [B,I1..Im] -> [B,C,I1..Im]
+    channel_last : data [B,N,C] (or [B,N]), indices [B,I1..Im] -> [B,I1..Im,C]
+    """
+    assert batched_data.shape[0] == batched_indices.shape[0]
+    bs = batched_data.shape[0]
+    idx_shape = list(batched_indices.shape[1:])
+    if layout == 'channel_first':
+        n_channels = batched_data.shape[1]
+        flat = batched_indices.reshape(bs, 1, -1).expand(bs, n_channels, -1).to(torch.int64)
+        return torch.gather(batched_data, 2, flat).view([bs, n_channels] + idx_shape)
+    if layout == 'channel_last':
+        rows = torch.arange(bs, dtype=torch.long, device=batched_data.device)
+        rows = rows.view([bs] + [1] * len(idx_shape)).expand([bs] + idx_shape)
+        if batched_data.dim() == 2:
+            return batched_data[rows, batched_indices.to(torch.long)]
+        return batched_data[rows, batched_indices.to(torch.long), :]
+    raise ValueError(layout)
+
+
+def build_pc_pyramid(pc1, pc2, n_samples_list):
+    """One FPS over both clouds; level l keeps the first n_l picks (utils.py:107-127)."""
+    batch_size, _, n_points = pc1.shape
+    both = torch.cat([pc1, pc2], dim=0).transpose(1, 2)
+    picks = _ops.furthest_point_sampling(both, max(n_samples_list))
+    picks1, picks2 = picks[:batch_size], picks[batch_size:]
+
+    identity = torch.arange(n_points, device=pc1.device)[None, :].expand(batch_size, n_points)
+    xyzs1, xyzs2, sample_indices1, sample_indices2 = [pc1], [pc2], [identity], [identity]
+    for n_samples in n_samples_list:
+        sample_indices1.append(picks1[:, :n_samples])
+        sample_indices2.append(picks2[:, :n_samples])
+        xyzs1.append(batch_indexing(pc1, picks1[:, :n_samples]))
+        xyzs2.append(batch_indexing(pc2, picks2[:, :n_samples]))
+    return xyzs1, xyzs2, sample_indices1, sample_indices2
+
+
+def knn_interpolation(input_xyz, input_features, query_xyz, k=3):
+    """Inverse-distance interpolation from the k nearest inputs (utils.py:130-146).
+    [B,3,M] x [B,C,M] x [B,3,Nq] -> [B,C,Nq]; gradients flow to features AND coordinates."""
+    knn_indices = _ops.k_nearest_neighbor(input_xyz, query_xyz, k)
+    knn_xyz = batch_indexing(input_xyz, knn_indices)
+    knn_dists = torch.linalg.norm(knn_xyz - query_xyz[..., None], dim=1).clamp(1e-8)
+    knn_weights = 1.0 / knn_dists
+    knn_weights = knn_weights / torch.sum(knn_weights, dim=-1, keepdim=True)
+    knn_features = batch_indexing(input_features, knn_indices)
+    return torch.sum(knn_features * knn_weights[:, None, :, :], dim=-1)
+
+
+def backwarp_3d(xyz1, xyz2, flow12, k=3):
+    """Warp cloud 2 towards cloud 1 with the interpolated inverse flow (utils.py:149-159)."""
+    flow21 = knn_interpolation(xyz1 + flow12, -flow12, query_xyz=xyz2, k=k)
+    return xyz2 + flow21
+
+
+_grid_cache = {}
+
+
+def mesh_grid(n, h, w, device, channel_first=True):
+    """Pixel-coordinate grid [n,2,h,w] (x then y), cached per shape/device (utils.py:161-173)."""
+    key = (n, h, w, str(device), channel_first)
+    grid = _grid_cache.get(key)
+    if grid is None:
+        xs = torch.arange(0, w, dtype=torch.float32, device=device).view(1, 1, w).expand(n, h, w)
+        ys = torch.arange(0, h, dtype=torch.float32, device=device).view(1, h, 1).expand(n, h, w)
+        grid = torch.stack([xs, ys], 1)
+        if not channel_first:
+            grid = grid.permute(0, 2, 3, 1)
+        _grid_cache[key] = grid
+    return grid
+
+
+def backwarp_2d(x, flow12, padding_mode):
+    """Bilinear backward warp, align_corners=True (utils.py:176-188)."""
+    assert x.size()[-2:] == flow12.size()[-2:]
+    batch_size, _, image_h, image_w = x.size()
+    target = mesh_grid(batch_size, image_h, image_w, device=x.device) + flow12
+    norm = torch.zeros_like(target)
+    norm[:, 0] = 2.0 * target[:, 0] / (image_w - 1) - 1.0
+    norm[:, 1] = 2.0 * target[:, 1] / (image_h - 1) - 1.0
+    return grid_sample(x, norm.permute(0, 2, 3, 1), padding_mode=padding_mode, align_corners=True)
+
+
+def convex_upsample(flow, mask, scale_factor=8):
+    """RAFT convex upsampling: softmax over the 3x3 neighbourhood (utils.py:191-204)."""
+    batch_size, _, image_h, image_w = flow.shape
+    mask = softmax(mask.float().view(batch_size, 1, 9, scale_factor, scale_factor, image_h, image_w), dim=2)
+    patches = unfold(flow.float() * scale_factor, [3, 3], padding=1).view(batch_size, 2, 9, 1, 1, image_h, image_w)
+    up = torch.sum(mask * patches, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(batch_size, 2, image_h * scale_factor, image_w * scale_factor)
+
+
+def resize_flow2d(flow, target_h, target_w):
+    origin_h, origin_w = flow.shape[2:]
+    if target_h == origin_h and target_w == origin_w:
+        return flow
+    flow = interpolate(flow, size=(target_h, target_w), mode='bilinear', align_corners=True)
+    flow[:, 0] *= target_w / origin_w
+    flow[:, 1] *= target_h / origin_h
+    return flow
+
+
+def resize_to_64x(inputs, target, x=64):
+    """Bilinear resize up to the next multiple of 64 (utils.py:217-231); flow targets are rescaled."""
+    n, c, h, w = inputs.shape
+    if h % x == 0 and w % x == 0:
+        return inputs, target
+    resized_h, resized_w = ((h + x - 1) // x) * x, ((w + x - 1) // x) * x
+    inputs = interpolate(inputs, size=(resized_h, resized_w), mode='bilinear', align_corners=True)
+    if target is not None:
+        target = interpolate(target, size=(resized_h, resized_w), mode='bilinear', align_corners=True)
+        target[:, 0] *= resized_w / w
+        target[:, 1] *= resized_h / h
+    return inputs, target
+
+
+def project_pc2image(pc, camera_info):
+    """[B,3,N] -> pixel coordinates [B,2,N] under a perspective or parallel camera (utils.py:234-259)."""
+    assert pc.shape[1] == 3
+    batch_size, n_points = pc.shape[0], pc.shape[-1]
+    cx, cy = camera_info['cx'], camera_info['cy']
+    if isinstance(cx, torch.Tensor):
+        cx = cx[:, None].expand(batch_size, n_points)
+        cy = cy[:, None].expand(batch_size, n_points)
+    mode = camera_info['projection_mode']
+    if mode == 'perspective':
+        f = camera_info['f'][:, None].expand(batch_size, n_points)
+        image_x = cx + (f / pc[:, 2, :]) * pc[:, 0, :]
+        image_y = cy + (f / pc[:, 2, :]) * pc[:, 1, :]
+    elif mode == 'parallel':
+        image_x = pc[:, 0, :] + cx
+        image_y = pc[:, 1, :] + cy
+    else:
+        raise NotImplementedError(mode)
+    return torch.cat([image_x[:, None, :], image_y[:, None, :]], dim=1)
+
+
+def grid_sample_wrapper(feat_2d, uv):
+    """Bilinear sample of [B,C,H,W] at pixel coordinates uv [B,2,N] -> [B,C,N], fp32 (utils.py:262-269)."""
+    with torch.autocast(device_type=feat_2d.device.type, enabled=False):
+        image_h, image_w = feat_2d.shape[2:]
+        new_x = 2.0 * uv[:, 0] / (image_w - 1) - 1.0
+        new_y = 2.0 * uv[:, 1] / (image_h - 1) - 1.0
+        new_xy = torch.cat([new_x[:, :, None, None], new_y[:, :, None, None]], dim=-1)
+        return grid_sample(feat_2d.float(), new_xy, 'bilinear', align_corners=True)[..., 0]
+
+
+# ----------------------------------------------------------------------------------------------
+# inverse depth scaling (models/ids.py): perspective camera <-> low-resolution parallel camera
+# ----------------------------------------------------------------------------------------------
+def _ids_scales(persp, paral):
+    ratio_w = (paral['sensor_w'] - 1) / (persp['sensor_w'] - 1)
+    ratio_h = (paral['sensor_h'] - 1) / (persp['sensor_h'] - 1)
+    return ratio_w, ratio_h
+
+
+def persp2paral(xyz, perspect_camera_info, parallel_camera_info):
+    """ids.py:4-33: project, take f*log(z)+1 as depth, rescale to the parallel sensor."""
+    x, y, z = xyz[:, 0, :], xyz[:, 1, :], xyz[:, 2, :]
+    shape = x.shape
+    f = perspect_camera_info['f'][:, None].expand(shape)
+    cx = perspect_camera_info['cx'][:, None].expand(shape)
+    cy = perspect_camera_info['cy'][:, None].expand(shape)
+    u = cx + (f / z) * x
+    v = cy + (f / z) * y
+    depth = f * torch.log(z) + 1
+    ratio_w, ratio_h = _ids_scales(perspect_camera_info, parallel_camera_info)
+    paral_w, paral_h = parallel_camera_info['sensor_w'], parallel_camera_info['sensor_h']
+    return torch.cat([
+        u[:, None, :] * ratio_w - (paral_w - 1) / 2,
+        v[:, None, :] * ratio_h - (paral_h - 1) / 2,
+        depth[:, None, :] * min(ratio_w, ratio_h),
+    ], dim=1)
+
+
+def paral2persp(xyz, perspect_camera_info, parallel_camera_info):
+    """ids.py:36-67: inverse of persp2paral."""
+    ratio_w, ratio_h = _ids_scales(perspect_camera_info, parallel_camera_info)
+    paral_w, paral_h = parallel_camera_info['sensor_w'], parallel_camera_info['sensor_h']
+    u = (xyz[:, 0, :] + (paral_w - 1) / 2) / ratio_w
+    v = (xyz[:, 1, :] + (paral_h - 1) / 2) / ratio_h
+    depth = xyz[:, 2, :] / min(ratio_w, ratio_h)
+    shape = u.shape
+    f = perspect_camera_info['f'][:, None].expand(shape)
+    cx = perspect_camera_info['cx'][:, None].expand(shape)
+    cy = perspect_camera_info['cy'][:, None].expand(shape)
+    z = torch.exp((depth - 1) / f)
+    x = (u - cx) * z / f
+    y = (v - cy) * z / f
+    return torch.cat([x[:, None, :], y[:, None, :], z[:, None, :]], dim=1)

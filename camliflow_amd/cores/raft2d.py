@@ -1,0 +1,194 @@
+"""2-D RAFT branch (counterpart of models/raft_core.py): image encoder, all-pairs cost-volume
+pyramid with radius-4 lookup, conv-GRU update block, flow head and convex upsampler.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.functional import avg_pool2d, grid_sample
+
+from . import runtime
+from .blocks import Conv2dNormRelu
+from .geometry import convex_upsample, mesh_grid
+from .resnet import ResNetTrunk
+
+
+class Encoder2D(ResNetTrunk):
+    """ResNet-50 stem + stages 1-2 (stride 8, 512 ch) followed by a 1x1 ``align`` conv to 128 ch
+    (raft_core.py:10-38).  BatchNorm layers of the trunk always run in eval mode (norm_eval=True)."""
+
+    def __init__(self, depth=50, pretrained=None):
+        super().__init__(depth=depth, num_stages=2, strides=(1, 2), norm_eval=True)
+        self.align = Conv2dNormRelu(self.feat_dim, 128)
+        self.init_weights()
+        if pretrained is not None:
+            import os
+            if os.path.exists(pretrained):
+                state = torch.load(pretrained, map_location='cpu')
+                self.load_state_dict(state.get('state_dict', state), strict=False)
+
+    def forward(self, x):
+        return self.align(super().forward(x)[0])
+
+
+def _window_offsets(radius, device):
+    return torch.linspace(-radius, radius, 2 * radius + 1, device=device)
+
+
+class Correlation2D(nn.Module):
+    """All-pairs correlation volume + pooled pyramid, looked up in a (2r+1)^2 window per level
+    (raft_core.py:41-107).  The pyramid is module state between ``build`` and the lookups, exactly
+    like the reference (not re-entrant)."""
+
+    def __init__(self, num_levels=4, radius=4):
+        super().__init__()
+        self.num_levels = num_levels
+        self.radius = radius
+        self.fnet_aligner = nn.Conv2d(128, 256, kernel_size=1)
+        self.cost_volume_pyramid = None
+
+    def build_cost_volume_pyramid(self, fmap1, fmap2):
+        fmap1 = self.fnet_aligner(fmap1.float())
+        fmap2 = self.fnet_aligner(fmap2.float())
+        bs, dim, h, w = fmap1.shape
+        if runtime.fused():
+            from ..csrc import fused
+            self.cost_volume_pyramid = fused.allpairs_pyramid(fmap1, fmap2, self.num_levels)
+            return
+        volume = torch.matmul(fmap1.view(bs, dim, h * w).transpose(1, 2), fmap2.view(bs, dim, h * w))
+        volume = (volume / torch.sqrt(torch.tensor(dim))).reshape(bs * h * w, 1, h, w)
+        self.cost_volume_pyramid = [volume]
+        for _ in range(self.num_levels - 1):
+            volume = avg_pool2d(volume, 2, stride=2)
+            self.cost_volume_pyramid.append(volume)
+
+    def forward(self, coords):
+        """coords [B,2,h,w] (x,y) at 1/8 resolution -> [B, levels*(2r+1)^2, h, w].
+        Channel l*81 + i*9 + j samples level l at (x/2^l + d[i], y/2^l + d[j]) -- the transposed
+        window of the reference (raft_core.py:79-85)."""
+        if runtime.fused():
+            from ..csrc import fused
+            return fused.allpairs_lookup(self.cost_volume_pyramid, coords.float(), self.radius)
+        coords = coords.permute(0, 2, 3, 1).float()
+        bs, h, w, _ = coords.shape
+        r = self.radius
+        d = _window_offsets(r, coords.device)
+        delta = torch.stack(torch.meshgrid(d, d, indexing='ij'), dim=-1).view(1, 2 * r + 1, 2 * r + 1, 2)
+        out = []
+        for lvl, volume in enumerate(self.cost_volume_pyramid):
+            centre = coords.reshape(bs * h * w, 1, 1, 2) / 2 ** lvl
+            sampled = self.bilinear_sampler(volume, centre + delta)
+            out.append(sampled.view(bs, h, w, -1))
+        return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def bilinear_sampler(feat, coords):
+        """grid_sample in pixel units, align_corners=True, zeros padding (raft_core.py:96-107)."""
+        h, w = feat.shape[-2:]
+        xgrid, ygrid = coords.split([1, 1], dim=-1)
+        grid = torch.cat([2 * xgrid / (w - 1) - 1, 2 * ygrid / (h - 1) - 1], dim=-1)
+        return grid_sample(feat, grid, align_corners=True)
+
+
+class GRU2D(nn.Module):
+    """Separable (1x5 then 5x1) convolutional GRU (raft_core.py:110-139)."""
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        for suffix, ksize, padding in (('1', (1, 5), (0, 2)), ('2', (5, 1), (2, 0))):
+            for gate in 'zrq':
+                setattr(self, 'conv%s%s' % (gate, suffix),
+                        nn.Conv2d(hidden_dim + input_dim, hidden_dim, ksize, padding=padding))
+
+    def _half_step(self, h, x, convz, convr, convq):
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(convz(hx))
+        r = torch.sigmoid(convr(hx))
+        q = torch.tanh(convq(torch.cat([r * h, x], dim=1)))
+        return (1 - z) * h + z * q
+
+    def forward(self, h, x):
+        h = self._half_step(h, x, self.convz1, self.convr1, self.convq1)
+        h = self._half_step(h, x, self.convz2, self.convr2, self.convq2)
+        return torch.nan_to_num(h)
+
+
+class MotionEncoder2D(nn.Module):
+    def __init__(self, corr_levels, corr_radius):
+        super().__init__()
+        corr_planes = corr_levels * (2 * corr_radius + 1) ** 2
+        self.conv_c1 = nn.Conv2d(corr_planes, 256, kernel_size=1, padding=0)
+        self.conv_c2 = nn.Conv2d(256, 192, kernel_size=3, padding=1)
+        self.conv_f1 = nn.Conv2d(2, 128, kernel_size=7, padding=3)
+        self.conv_f2 = nn.Conv2d(128, 64, kernel_size=3, padding=1)
+        self.conv = nn.Conv2d(64 + 192, 128 - 2, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, flow, corr):
+        corr_feat = self.relu(self.conv_c2(self.relu(self.conv_c1(corr))))
+        flow_feat = self.relu(self.conv_f2(self.relu(self.conv_f1(flow))))
+        out = self.relu(self.conv(torch.cat([corr_feat, flow_feat], dim=1)))
+        return torch.cat([torch.nan_to_num(out), flow], dim=1)
+
+
+class FlowHead2D(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 2, kernel_size=3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return torch.nan_to_num(self.conv2(self.relu(self.conv1(x))).float())
+
+
+class ConvexUpsampler2D(nn.Module):
+    def __init__(self, input_dim):
+        super().__init__()
+        self.mask = nn.Sequential(
+            nn.Conv2d(input_dim, 256, 3, padding=1),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(256, 64 * 9, 1, padding=0),
+        )
+
+    def forward(self, h, flow):
+        return convex_upsample(flow, 0.25 * self.mask(h.float()))  # 0.25 balances gradients (raft_core.py:195)
+
+
+class RAFTCore(nn.Module):
+    def __init__(self, cfgs):
+        super().__init__()
+        self.cfgs = cfgs
+        self.hidden_dim = 128
+        self.context_dim = 128
+        self.corr_levels = 4
+        self.corr_radius = 4
+        self.fnet = Encoder2D(cfgs.backbone.depth, cfgs.backbone.pretrained)
+        self.cnet = Encoder2D(cfgs.backbone.depth, cfgs.backbone.pretrained)
+        self.cnet_aligner = nn.Conv2d(128, 256, kernel_size=1)
+        self.correlation = Correlation2D(self.corr_levels, self.corr_radius)
+        self.motion_encoder = MotionEncoder2D(self.corr_levels, self.corr_radius)
+        self.gru = GRU2D(hidden_dim=self.hidden_dim, input_dim=self.hidden_dim + 128)
+        self.flow_head = FlowHead2D(self.hidden_dim)
+        self.convex_upsampler = ConvexUpsampler2D(self.hidden_dim)
+
+    def forward(self, image1, image2):
+        fmap1, fmap2 = self.fnet(image1), self.fnet(image2)
+        self.correlation.build_cost_volume_pyramid(fmap1, fmap2)
+        h, x = torch.split(self.cnet_aligner(self.cnet(image1)), [self.hidden_dim, self.context_dim], dim=1)
+        h, x = torch.tanh(h), torch.relu(x)
+
+        bs, _, image_h, image_w = image1.shape
+        grid_coords = mesh_grid(bs, image_h // 8, image_w // 8, device=image1.device)
+        flow_pred = torch.zeros_like(grid_coords)
+        n_iters = self.cfgs.n_iters_train if self.training else self.cfgs.n_iters_eval
+
+        flow_preds = []
+        for _ in range(n_iters):
+            flow_pred = flow_pred.detach()
+            corr = self.correlation(grid_coords + flow_pred)
+            motion_features = self.motion_encoder(flow_pred, corr)
+            h = self.gru(h, torch.cat([x, motion_features], dim=1))
+            flow_pred = flow_pred + self.flow_head(h)
+            flow_preds.append(self.convex_upsampler(h, flow_pred))
+        return flow_preds

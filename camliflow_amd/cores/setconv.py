@@ -1,0 +1,75 @@
+"""Point set-convolutions (counterpart of models/point_conv.py:7-70 and :102-130).
+
+``PointConv``    weighted set-conv:  W = MLP2d(3->8->16)(dxyz);  Linear(16*(C+3) -> Cout)(W @ F_knn)
+``PointConvDW``  depth-wise set-conv: max_k( gather(MLP1d(F)) * MLP2d(3->8->32->Cout, relu)(dxyz) )
+(the reference's ``PointNet2`` is never instantiated and is not restated.)
+"""
+import torch
+import torch.nn as nn
+
+from ..csrc import wrapper as _ops
+from .blocks import LayerNormCF1d, MLP1d, MLP2d, make_activation
+from .geometry import batch_indexing
+
+
+def _neighbourhood(xyz, sampled_xyz, knn_indices, k):
+    """Shared prologue: resolve centres, slice / compute the k nearest, centre the neighbours.
+    A precomputed index tensor may be wider than k: KNN output is ascending, so its first k columns
+    are the k nearest (point_conv.py:50-55,116-120)."""
+    if sampled_xyz is None:
+        sampled_xyz = xyz
+    if knn_indices is None:
+        knn_indices = _ops.k_nearest_neighbor(xyz, sampled_xyz, k)
+    else:
+        bs, n_samples = sampled_xyz.shape[0], sampled_xyz.shape[-1]
+        assert knn_indices.shape[:2] == torch.Size([bs, n_samples])
+        assert knn_indices.shape[2] >= k
+        knn_indices = knn_indices[:, :, :k]
+    knn_offset = batch_indexing(xyz, knn_indices) - sampled_xyz[:, :, :, None]  # [B,3,n,k]
+    return sampled_xyz, knn_indices, knn_offset
+
+
+class PointConv(nn.Module):
+    def __init__(self, in_channels, out_channels, norm=None, act='leaky_relu', k=16):
+        super().__init__()
+        self.k = k
+        self.weight_net = MLP2d(3, [8, 16], act=act)
+        self.linear = nn.Linear(16 * (in_channels + 3), out_channels)
+        if norm == 'batch_norm':
+            self.norm_fn = nn.BatchNorm1d(out_channels, affine=True)
+        elif norm == 'instance_norm':
+            self.norm_fn = nn.InstanceNorm1d(out_channels, affine=True)
+        elif norm == 'layer_norm':
+            self.norm_fn = LayerNormCF1d(out_channels)
+        elif norm is None:
+            self.norm_fn = nn.Identity()
+        else:
+            raise NotImplementedError('Unknown normalization function: %s' % norm)
+        if act not in ('relu', 'leaky_relu', None):
+            raise NotImplementedError('Unknown activation function: %s' % act)
+        self.act_fn = make_activation(act)
+
+    def forward(self, xyz, features, sampled_xyz=None, knn_indices=None):
+        """xyz [B,3,N], features [B,C,N], sampled_xyz [B,3,n] -> [B,Cout,n]"""
+        sampled_xyz, knn_indices, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
+        bs, n_samples = sampled_xyz.shape[0], sampled_xyz.shape[-1]
+        weights = self.weight_net(knn_offset).transpose(1, 2)                 # [B,n,16,k]
+        points_cl = torch.cat([xyz, features], dim=1).transpose(1, 2)         # [B,N,3+C]
+        knn_points = batch_indexing(points_cl, knn_indices, layout='channel_last')  # [B,n,k,3+C]
+        mixed = torch.matmul(weights, knn_points).view(bs, n_samples, -1)     # [B,n,16*(3+C)]
+        out = self.linear(mixed).transpose(1, 2)
+        return self.act_fn(self.norm_fn(out))
+
+
+class PointConvDW(nn.Module):
+    def __init__(self, in_channels, out_channels, norm=None, act='leaky_relu', k=16):
+        super().__init__()
+        self.k = k
+        self.mlp = MLP1d(in_channels, [out_channels], norm, act)
+        self.weight_net = MLP2d(3, [8, 32, out_channels], act='relu')
+
+    def forward(self, xyz, features, sampled_xyz=None, knn_indices=None):
+        sampled_xyz, knn_indices, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
+        features = batch_indexing(self.mlp(features), knn_indices)            # [B,Cout,n,k]
+        features = features * self.weight_net(knn_offset)
+        return torch.max(features, dim=-1)[0]

@@ -1,0 +1,54 @@
+"""Per-kernel timings of the boundary operators on one GPU (HIP events on torch's stream)."""
+import sys
+import os
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from camliflow_amd import csrc  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def main():
+    g = torch.Generator(device='cpu').manual_seed(0)
+    print('%-44s %10s %14s' % ('case', 'us', 'rate'))
+    for (b, n, ns) in [(2, 8192, 4096), (16, 8192, 4096), (2, 16384, 4096)]:
+        xyz = (torch.rand(b, n, 3, generator=g) * 10).cuda()
+        us = timeit(lambda: csrc.furthest_point_sampling(xyz, ns), iters=5, warmup=1)
+        print('%-44s %10.1f %10.2f Gupd/s' % ('fps B%d N%d n%d' % (b, n, ns), us, b * n * ns / us / 1e3))
+    for (b, m, nq, d, k) in [(8, 2048, 2048, 3, 16), (8, 2048, 2048, 3, 32), (8, 8192, 4096, 3, 16), (8, 4096, 2048, 3, 16),
+                             (8, 2048, 8192, 3, 3), (8, 2048, 2048, 3, 3), (8, 2048, 8160, 2, 1), (1, 2048, 2048, 3, 16),
+                             (1, 4096, 34560, 2, 1), (1, 16384, 4096, 3, 16), (8, 256, 2048, 3, 16)]:
+        inp = (torch.rand(b, m, d, generator=g) * 10).cuda()
+        qry = (torch.rand(b, nq, d, generator=g) * 10).cuda()
+        us = timeit(lambda: csrc.k_nearest_neighbor(inp, qry, k))
+        print('%-44s %10.1f %10.2f Gpair/s' % ('knn B%d M%d Nq%d D%d k%d' % (b, m, nq, d, k), us, b * m * nq / us / 1e3))
+    for (b, c, h, w) in [(1, 32, 144, 240), (1, 64, 72, 120), (1, 96, 36, 60), (8, 32, 144, 240), (32, 128, 144, 240)]:
+        x1 = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+        x2 = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+        in1 = x1.detach().permute(0, 2, 3, 1).contiguous()
+        in2 = x2.detach().permute(0, 2, 3, 1).contiguous()
+        us = timeit(lambda: csrc.wrapper.CorrelationFunction.apply(in1, in2, 4))
+        byt = 4 * b * h * w * (2 * c + 81)
+        print('%-44s %10.1f %10.1f GB/s' % ('corr2d fwd B%d C%d %dx%d' % (b, c, h, w), us, byt / us / 1e3))
+        go = torch.randn(b, 81, h, w, device='cuda')
+        in1r, in2r = in1.clone().requires_grad_(True), in2.clone().requires_grad_(True)
+        out = csrc.wrapper.CorrelationFunction.apply(in1r, in2r, 4)
+        us = timeit(lambda: torch.autograd.grad(out, [in1r, in2r], go, retain_graph=True))
+        byt = 4 * b * h * w * (81 + 4 * c)
+        print('%-44s %10.1f %10.1f GB/s' % ('corr2d bwd B%d C%d %dx%d' % (b, c, h, w), us, byt / us / 1e3))
+
+
+if __name__ == '__main__':
+    main()
