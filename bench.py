@@ -1,0 +1,204 @@
+"""Headline benchmark: CamLiRAFT training step (forward + sequence losses + backward + clip + AdamW)
+on synthetic FlyingThings3D-shaped inputs, 960x540 images + 8192 points (BASELINE.json configs[2]).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One process per GPU, batch-dimension data parallel (DDP over RCCL); per-GPU batch is fixed, so the
+scaling is weak.  Rank 0 prints ONE JSON line.  `value` = global frame-pairs per second with the
+inputs resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from types import SimpleNamespace as NS  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# the kernel the roofline object reports: the adjoint of the all-pairs lookup (HBM-bound
+# read-modify-write of the gradient pyramid); algorithmic bytes per launch, DESIGN.md section 5
+ROOFLINE_KERNEL = 'camli_allpairs_lookup_bwd'
+
+
+def model_cfg(n_iters):
+    return NS(name='camliraft', batch_size=1, freeze_bn=False, backbone=NS(depth=50, pretrained=None),
+              n_iters_train=n_iters, n_iters_eval=n_iters, fuse_fnet=True, fuse_cnet=True, fuse_corr=True,
+              fuse_motion=True, fuse_hidden=False, loss2d=NS(gamma=0.8, order='l2-norm'),
+              loss3d=NS(gamma=0.8, order='l2-norm'))
+
+
+def synthetic_batch(b, h, w, n_points, seed):
+    """uint8-valued images, points whose projections land inside the image, small flows."""
+    g = torch.Generator().manual_seed(seed)
+    f, cx, cy = 1050.0, 479.5, 269.5
+    images = torch.randint(0, 256, (b, 6, h, w), generator=g).float()
+    z = torch.rand(b, n_points, generator=g) * 30.0 + 5.0
+    u = torch.rand(b, n_points, generator=g) * (w - 1)
+    v = torch.rand(b, n_points, generator=g) * (h - 1)
+    pc1 = torch.stack([(u - cx) * z / f, (v - cy) * z / f, z], dim=1)
+    pc2 = pc1 + torch.randn(b, 3, n_points, generator=g) * 0.05
+    return {'images': images, 'pcs': torch.cat([pc1, pc2], dim=1),
+            'intrinsics': torch.tensor([[f, cx, cy]]).repeat(b, 1),
+            'flow_2d': torch.cat([torch.randn(b, 2, h, w, generator=g), torch.ones(b, 1, h, w)], dim=1),
+            'flow_3d': torch.randn(b, 3, n_points, generator=g) * 0.05}
+
+
+def make_optimizer(model):
+    """AdamW with the reference's split learning rates (conf/training/flyingthings3d_subset/camliraft.yaml,
+    factory.py:50-58: parameters under core.branch_3d get lr_3d)."""
+    p3d = [p for n, p in model.named_parameters() if 'core.branch_3d' in n]
+    p2d = [p for n, p in model.named_parameters() if 'core.branch_3d' not in n]
+    return torch.optim.AdamW([{'params': p2d, 'lr': 2e-4}, {'params': p3d, 'lr': 2e-3}], weight_decay=1e-6)
+
+
+def train_step(model, raw_model, optimizer, batch):
+    model(batch)
+    loss = raw_model.get_loss()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(raw_model.parameters(), 1.0)
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    raw_model.clear_metrics()
+    return loss
+
+
+def cpu_baseline(args):
+    """The CPU restatement path (this repo's cores driven by the C oracle operators) timed on the
+    host cores: ONE training step at batch 1 of the same workload.  Reported, not the target."""
+    from modelutils import oracle_boundary
+    from camliflow_amd.cores import CamLiRAFT
+    threads = torch.get_num_threads()
+    torch.manual_seed(0)
+    model = CamLiRAFT(model_cfg(args.iters)).train()
+    opt = make_optimizer(model)
+    batch = synthetic_batch(1, args.height, args.width, args.points, seed=1)
+    with oracle_boundary():
+        t0 = time.perf_counter()
+        train_step(model, model, opt, batch)
+        dt = time.perf_counter() - t0
+    return {'value': 1.0 / dt, 'unit': 'frame-pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': '1 training step (fwd+bwd+AdamW), batch 1, %dx%d + %d pts, %d iters, %.1f s, cold'
+                      % (args.width, args.height, args.points, args.iters, dt)}
+
+
+def lookup_bwd_bytes(b, h, w, levels=4, radius=4):
+    """Algorithmic HBM bytes of one camli_allpairs_lookup_bwd launch: read grad_out once, read +
+    write a (2r+2)^2 window per (pixel, level), read coords."""
+    p = h * w
+    win = (2 * radius + 2) ** 2
+    return 4 * b * p * (levels * (2 * radius + 1) ** 2 + 2 * levels * win + 2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (configs[2]: 8)')
+    ap.add_argument('--iters', type=int, default=12)
+    ap.add_argument('--height', type=int, default=540)
+    ap.add_argument('--width', type=int, default=960)
+    ap.add_argument('--points', type=int, default=8192)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path is the product, there is no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+
+    from camliflow_amd.cores import CamLiRAFT, runtime
+    from camliflow_amd.csrc import _lib
+    _lib.load()
+    runtime.set_backend('hip')
+    torch.backends.cudnn.benchmark = False
+
+    torch.manual_seed(0)
+    raw_model = CamLiRAFT(model_cfg(args.iters))
+    if world > 1:
+        raw_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(raw_model)
+    raw_model = raw_model.to(device).train()
+    model = raw_model
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(raw_model, device_ids=[local_rank],
+                                                          gradient_as_bucket_view=True)
+    optimizer = make_optimizer(raw_model)
+    batch = {k: v.to(device) for k, v in synthetic_batch(args.batch, args.height, args.width, args.points,
+                                                         seed=100 + rank).items()}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(model, raw_model, optimizer, batch)
+    barrier()
+    _lib.TIMER.reset()
+    _lib.TIMER.only = {ROOFLINE_KERNEL}
+    _lib.TIMER.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(model, raw_model, optimizer, batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.TIMER.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        global_batch = args.batch * world
+        hpad, wpad = (args.height + 7) // 8 * 8, (args.width + 7) // 8 * 8
+        launches, total_ms = _lib.TIMER.summary().get(ROOFLINE_KERNEL, (0, 0.0))
+        roofline = None
+        if launches:
+            per_launch_ms = total_ms / launches
+            achieved = lookup_bwd_bytes(args.batch, hpad // 8, wpad // 8) / (per_launch_ms * 1e-3) / 1e9
+            roofline = {'kernel': ROOFLINE_KERNEL, 'bound': 'hbm', 'achieved': round(achieved, 1),
+                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                        'traffic': None, 'launches': launches, 'avg_launch_us': round(per_launch_ms * 1e3, 2)}
+        line = {
+            'metric': 'frame-pairs/sec (fwd+bwd) 960x540 + 8192 pts, CamLiRAFT',
+            'value': round(global_batch * args.steps / elapsed, 4),
+            'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'CamLiRAFT training step (fwd + sequence losses + bwd + clip + AdamW), '
+                                   '%dx%d + %d pts, %d GRU iters, batch %d per GPU (BASELINE configs[2])'
+                                   % (args.width, args.height, args.points, args.iters, args.batch),
+                       'global_batch': global_batch, 'parallelism': 'dp%d' % world,
+                       'loss': round(float(loss), 4)},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -18,6 +18,10 @@ PROTOTYPES = {
     "camli_corr2d_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
     "camli_corr2d_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                 _int, _int, _int, _int, _int, _stream]),
+    "camli_allpairs_lookup_fwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
+                                         _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_allpairs_lookup_bwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
+                                         _c_float_p, _int, _int, _int, _int, _stream]),
 }
 
 _lib = None
@@ -49,3 +53,43 @@ def check(code, what):
     if code != 0:
         msg = load().camli_last_error_string()
         raise CamliHipError("%s failed (%d): %s" % (what, code, msg.decode() if msg else "?"))
+
+
+# ------------------------------------------------------------------------------------------------
+# optional per-kernel timing (HIP events on the launching stream); used by bench.py's roofline leg
+# ------------------------------------------------------------------------------------------------
+class KernelTimer:
+    """Records a (start, end) event pair around every launch routed through ``launch()`` while
+    enabled.  Events go on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.enabled = False
+        self.only = None        # optional set of entry-point names to restrict timing to
+        self.records = {}
+
+    def reset(self):
+        self.records = {}
+
+    def summary(self):
+        """name -> (launches, total_ms).  Call after torch.cuda.synchronize()."""
+        out = {}
+        for name, pairs in self.records.items():
+            out[name] = (len(pairs), sum(s.elapsed_time(e) for s, e in pairs))
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def launch(name, fn, *args):
+    """Call a C-ABI entry point, check its status, optionally time it."""
+    if TIMER.enabled and (TIMER.only is None or name in TIMER.only):
+        import torch
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        code = fn(*args)
+        end.record()
+        TIMER.records.setdefault(name, []).append((start, end))
+    else:
+        code = fn(*args)
+    check(code, name)

@@ -1,0 +1,124 @@
+"""Composite operators of the cores that have a fused gfx950 kernel (internal API, used when
+``cores.runtime.backend() == 'hip'``).  Each function documents the reference composition it
+replaces; the torch-composed twin lives next to its call site in ``camliflow_amd/cores``.
+"""
+import ctypes
+import math
+
+import torch
+from torch.nn.functional import avg_pool2d
+
+from . import _lib
+from .wrapper import _require_cuda, _stream_ptr
+
+
+# ------------------------------------------------------------------------------------------------
+# all-pairs cost-volume pyramid (models/raft_core.py:52-107)
+# ------------------------------------------------------------------------------------------------
+class AllPairsPyramid:
+    """The 4-level all-pairs volume of one forward pass plus the state its backward needs.
+
+    Autograd design: the levels are plain (non-differentiable) tensors.  Every lookup depends on a
+    1-element ``token`` produced by the build node; each lookup's backward ADDS its window
+    gradients into ONE persistent gradient pyramid (allocated + zeroed once) and hands a dummy
+    gradient to the token, so the build node's backward runs after the last lookup and turns the
+    accumulated volume gradient into feature-map gradients with two GEMMs.  The reference instead
+    materialises a volume-sized gradient per level per GRU iteration and sums them.
+    """
+
+    def __init__(self):
+        self.levels = None      # list of [B*P, h_l, w_l] fp32
+        self.grads = None       # same shapes, lazily allocated by the first lookup backward
+        self.token = None
+        self.shape = None       # (B, h, w)
+
+    def _level_args(self, tensors):
+        n = len(tensors)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        hs = (ctypes.c_int * n)(*[t.shape[-2] for t in tensors])
+        ws = (ctypes.c_int * n)(*[t.shape[-1] for t in tensors])
+        return n, ptrs, hs, ws
+
+
+class _BuildPyramid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, num_levels, pyr):
+        bs, dim, h, w = fmap1.shape
+        f1 = fmap1.reshape(bs, dim, h * w)
+        f2 = fmap2.reshape(bs, dim, h * w)
+        volume = torch.matmul(f1.transpose(1, 2), f2)
+        volume = (volume / math.sqrt(dim)).reshape(bs * h * w, 1, h, w)
+        levels = [volume]
+        for _ in range(num_levels - 1):
+            levels.append(avg_pool2d(levels[-1], 2, stride=2))
+        pyr.levels = [lvl.reshape(bs * h * w, lvl.shape[-2], lvl.shape[-1]) for lvl in levels]
+        pyr.shape = (bs, h, w)
+        ctx.save_for_backward(f1, f2)
+        ctx.pyr = pyr
+        ctx.dims = (bs, dim, h, w)
+        return fmap1.new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _gtoken):
+        pyr = ctx.pyr
+        f1, f2 = ctx.saved_tensors
+        bs, dim, h, w = ctx.dims
+        grads, pyr.grads = pyr.grads, None
+        if grads is None:
+            return torch.zeros(bs, dim, h, w, device=f1.device), torch.zeros(bs, dim, h, w, device=f1.device), None, None
+        # adjoint of the avg_pool2d chain: fold coarse levels into level 0
+        total = grads[-1]
+        for lvl in range(len(grads) - 2, -1, -1):
+            h2, w2 = total.shape[-2:]
+            up = total.repeat_interleave(2, dim=-2).repeat_interleave(2, dim=-1)
+            grads[lvl][:, :2 * h2, :2 * w2] += up * 0.25
+            total = grads[lvl]
+        gvol = total.reshape(bs, h * w, h * w) / math.sqrt(dim)
+        g1 = torch.matmul(f2, gvol.transpose(1, 2)).reshape(bs, dim, h, w)   # [B,C,P2] x [B,P2,P1]
+        g2 = torch.matmul(f1, gvol).reshape(bs, dim, h, w)                   # [B,C,P1] x [B,P1,P2]
+        return g1, g2, None, None
+
+
+class _Lookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, coords, radius, pyr):
+        lib = _lib.load()
+        bs, h, w = pyr.shape
+        n, ptrs, hs, ws = pyr._level_args(pyr.levels)
+        d = 2 * radius + 1
+        out = torch.empty((bs, n * d * d, h, w), dtype=torch.float32, device=coords.device)
+        with torch.cuda.device(coords.device):
+            _lib.launch('camli_allpairs_lookup_fwd', lib.camli_allpairs_lookup_fwd, ptrs, hs, ws, n, coords.data_ptr(), out.data_ptr(),
+                                                     bs, h, w, radius, _stream_ptr(coords))
+        ctx.save_for_backward(coords)
+        ctx.pyr, ctx.radius = pyr, radius
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        (coords,) = ctx.saved_tensors
+        pyr = ctx.pyr
+        bs, h, w = pyr.shape
+        if pyr.grads is None:
+            pyr.grads = [torch.zeros_like(lvl) for lvl in pyr.levels]
+        gout = gout.contiguous().float()
+        n, ptrs, hs, ws = pyr._level_args(pyr.grads)
+        with torch.cuda.device(coords.device):
+            _lib.launch('camli_allpairs_lookup_bwd', lib.camli_allpairs_lookup_bwd, ptrs, hs, ws, n, coords.data_ptr(), gout.data_ptr(),
+                                                     bs, h, w, ctx.radius, _stream_ptr(coords))
+        return gout.new_zeros(1), None, None, None
+
+
+def allpairs_pyramid(fmap1, fmap2, num_levels=4):
+    """fmap1/fmap2 [B,C,h,w] (already through ``fnet_aligner``) -> AllPairsPyramid."""
+    _require_cuda('allpairs_pyramid', fmap1, fmap2)
+    pyr = AllPairsPyramid()
+    pyr.token = _BuildPyramid.apply(fmap1.float().contiguous(), fmap2.float().contiguous(), num_levels, pyr)
+    return pyr
+
+
+def allpairs_lookup(pyr, coords, radius=4):
+    """coords [B,2,h,w] -> [B, L*(2r+1)^2, h, w] (raft_core.py:70-94 in one launch)."""
+    _require_cuda('allpairs_lookup', coords)
+    return _Lookup.apply(pyr.token, coords.detach().float().contiguous(), radius, pyr)

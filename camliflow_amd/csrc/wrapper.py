@@ -46,9 +46,8 @@ class CorrelationFunction(torch.autograd.Function):
         d = 2 * max_displacement + 1
         output = torch.empty((b, d * d, h, w), dtype=torch.float32, device=input1.device)
         with torch.cuda.device(input1.device):
-            _lib.check(lib.camli_corr2d_fwd(input1.data_ptr(), input2.data_ptr(), output.data_ptr(),
-                                            b, c, h, w, max_displacement, _stream_ptr(input1)),
-                       'camli_corr2d_fwd')
+            _lib.launch('camli_corr2d_fwd', lib.camli_corr2d_fwd, input1.data_ptr(), input2.data_ptr(), output.data_ptr(),
+                                            b, c, h, w, max_displacement, _stream_ptr(input1))
         return output
 
     @staticmethod
@@ -60,10 +59,9 @@ class CorrelationFunction(torch.autograd.Function):
         grad_input1 = torch.empty_like(input1)
         grad_input2 = torch.empty_like(input2)
         with torch.cuda.device(input1.device):
-            _lib.check(lib.camli_corr2d_bwd(grad_output.data_ptr(), input1.data_ptr(), input2.data_ptr(),
+            _lib.launch('camli_corr2d_bwd', lib.camli_corr2d_bwd, grad_output.data_ptr(), input1.data_ptr(), input2.data_ptr(),
                                             grad_input1.data_ptr(), grad_input2.data_ptr(),
-                                            b, c, h, w, ctx.max_displacement, _stream_ptr(input1)),
-                       'camli_corr2d_bwd')
+                                            b, c, h, w, ctx.max_displacement, _stream_ptr(input1))
         return grad_input1, grad_input2, None
 
 
@@ -118,7 +116,7 @@ def furthest_point_sampling(xyz: torch.Tensor, n_samples: int, cpp_impl=True):
     b, n, _ = xyz.shape
     out = torch.empty((b, n_samples), dtype=torch.int64, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _lib.check(lib.camli_fps(xyz.data_ptr(), out.data_ptr(), b, n, n_samples, _stream_ptr(xyz)), 'camli_fps')
+        _lib.launch('camli_fps', lib.camli_fps, xyz.data_ptr(), out.data_ptr(), b, n, n_samples, _stream_ptr(xyz))
     return out
 
 
@@ -146,6 +144,6 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     assert query_xyz.shape[0] == b and query_xyz.shape[2] == d
     out = torch.empty((b, nq, k), dtype=torch.int64, device=query_xyz.device)
     with torch.cuda.device(input_xyz.device):
-        _lib.check(lib.camli_knn(input_xyz.data_ptr(), query_xyz.data_ptr(), out.data_ptr(),
-                                 b, m, nq, d, k, _stream_ptr(input_xyz)), 'camli_knn')
+        _lib.launch('camli_knn', lib.camli_knn, input_xyz.data_ptr(), query_xyz.data_ptr(), out.data_ptr(),
+                                 b, m, nq, d, k, _stream_ptr(input_xyz))
     return out

@@ -66,6 +66,22 @@ int camli_corr2d_bwd(const float *gout_nchw, const float *in1_nhwc, const float 
                      float *g1_nhwc, float *g2_nhwc,
                      int B, int C, int H, int W, int md, void *stream);
 
+/*
+ * All-pairs cost-volume pyramid lookup and its adjoint (internal composite op of the cores; the
+ * reference composes it from grid_sample/cat/permute: models/raft_core.py:70-107, and its
+ * backward from grid_sampler_2d_backward).
+ *   vols[l]  device pointer to level l, [B*P, hs[l], ws[l]], P = h*w   (vols/hs/ws are HOST arrays)
+ *   coords   [B,2,h,w] (x,y) in level-0 pixels;  out / gout [B, L*(2r+1)^2, h, w];  r must be 4
+ *   channel l*81 + i*9 + j samples level l at (x/2^l + (i-r), y/2^l + (j-r)), bilinear,
+ *   align_corners=True, zeros padding.
+ *   bwd ACCUMULATES into gvols (caller zero-fills once, then may call once per GRU iteration);
+ *   coords carry no gradient (they are built from detached flow, raft_core.py:248).
+ */
+int camli_allpairs_lookup_fwd(const float *const *vols, const int *hs, const int *ws, int L,
+                              const float *coords, float *out, int B, int h, int w, int r, void *stream);
+int camli_allpairs_lookup_bwd(float *const *gvols, const int *hs, const int *ws, int L,
+                              const float *coords, const float *gout, int B, int h, int w, int r, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
