@@ -131,13 +131,15 @@ def main():
     from camliflow_amd.csrc import _lib
     _lib.load()
     runtime.set_backend('hip')
-    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.benchmark = os.environ.get('CAMLI_MIOPEN_FIND', '0') == '1'
 
     torch.manual_seed(0)
     raw_model = CamLiRAFT(model_cfg(args.iters))
     if world > 1:
         raw_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(raw_model)
     raw_model = raw_model.to(device).train()
+    if os.environ.get('CAMLI_CHANNELS_LAST', '0') == '1':
+        raw_model = raw_model.to(memory_format=torch.channels_last)
     model = raw_model
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(raw_model, device_ids=[local_rank],
