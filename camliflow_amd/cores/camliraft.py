@@ -15,6 +15,7 @@ from .geometry import (InputPadder, backwarp_3d, build_pc_pyramid, knn_interpola
 from .objectives import FlowModel, calc_sequence_loss_2d, calc_sequence_loss_3d
 from .raft2d import RAFTCore
 from .raft3d import PYRAMID_SIZES, CamLiRAFT_L_Core
+from .setconv import pass_cache
 
 _IMAGENET_MEAN = (123.675, 116.280, 103.530)
 _IMAGENET_STD = (58.395, 57.120, 57.375)
@@ -46,6 +47,10 @@ class CamLiRAFT_Core(nn.Module):
         return uv
 
     def forward(self, image1, image2, pc1, pc2, camera_info):
+        with pass_cache():   # iteration-invariant set-conv weights live for exactly one pass
+            return self._forward(image1, image2, pc1, pc2, camera_info)
+
+    def _forward(self, image1, image2, pc1, pc2, camera_info):
         b2d, b3d, cfgs = self.branch_2d, self.branch_3d, self.cfgs
 
         xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, PYRAMID_SIZES)

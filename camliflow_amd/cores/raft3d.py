@@ -7,7 +7,7 @@ import torch.nn as nn
 from ..csrc import wrapper as _ops
 from .blocks import Conv1dNormRelu, MLP1d, MLP2d
 from .geometry import backwarp_3d, batch_indexing, build_pc_pyramid, knn_interpolation
-from .setconv import PointConv, PointConvDW
+from .setconv import PointConv, PointConvDW, pass_cache
 
 PYRAMID_SIZES = [4096, 2048, 1024, 512, 256]   # hard-coded in every CamLi* model (camliraft_l_core.py:174-176)
 
@@ -125,6 +125,10 @@ class CamLiRAFT_L_Core(nn.Module):
         self.flow_head = FlowHead3D(input_dim=128)
 
     def forward(self, pc1, pc2):
+        with pass_cache():
+            return self._forward(pc1, pc2)
+
+    def _forward(self, pc1, pc2):
         xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, PYRAMID_SIZES)
         feat1 = self.fnet(xyzs1[:3])[2]
         feat2 = self.fnet(xyzs2[:3])[2]

@@ -4,12 +4,30 @@
 ``PointConvDW``  depth-wise set-conv: max_k( gather(MLP1d(F)) * MLP2d(3->8->32->Cout, relu)(dxyz) )
 (the reference's ``PointNet2`` is never instantiated and is not restated.)
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
 from ..csrc import wrapper as _ops
+from . import runtime
 from .blocks import LayerNormCF1d, MLP1d, MLP2d, make_activation
 from .geometry import batch_indexing
+
+# Iteration-invariant state of one forward pass.  Inside ``pass_cache()`` the fused PointConvDW
+# path computes ``weight_net(knn_offset)`` once per (module, xyz, centres, knn_indices, k) and
+# reuses it for every GRU iteration; outside it nothing is cached.
+_pass_cache = None
+
+
+@contextlib.contextmanager
+def pass_cache():
+    global _pass_cache
+    prev, _pass_cache = _pass_cache, {}
+    try:
+        yield
+    finally:
+        _pass_cache = prev
 
 
 def _neighbourhood(xyz, sampled_xyz, knn_indices, k):
@@ -69,7 +87,26 @@ class PointConvDW(nn.Module):
         self.weight_net = MLP2d(3, [8, 32, out_channels], act='relu')
 
     def forward(self, xyz, features, sampled_xyz=None, knn_indices=None):
+        if runtime.fused():
+            return self._forward_fused(xyz, features, sampled_xyz, knn_indices)
         sampled_xyz, knn_indices, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
         features = batch_indexing(self.mlp(features), knn_indices)            # [B,Cout,n,k]
         features = features * self.weight_net(knn_offset)
         return torch.max(features, dim=-1)[0]
+
+    def _forward_fused(self, xyz, features, sampled_xyz, knn_indices):
+        """Same math through camli_pointconv_dw_{fwd,bwd}: no [B,C,n,k] gather / product tensors,
+        one atomic per output element in the backward, neighbour weights shared across the pass."""
+        from ..csrc import fused
+        centres = xyz if sampled_xyz is None else sampled_xyz
+        if knn_indices is None:
+            knn_indices = _ops.k_nearest_neighbor(xyz, centres, self.k)
+        key = (id(self), xyz.data_ptr(), centres.data_ptr(), knn_indices.data_ptr(), self.k,
+               tuple(knn_indices.shape), torch.is_grad_enabled())
+        shared = _pass_cache.get(key) if _pass_cache is not None else None
+        if shared is None:
+            _, _, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
+            shared = fused.SharedSetConvWeights(self.weight_net(knn_offset))
+            if _pass_cache is not None:
+                _pass_cache[key] = shared
+        return fused.pointconv_dw(self.mlp(features), shared, knn_indices, self.k)

@@ -22,6 +22,10 @@ PROTOTYPES = {
                                          _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_allpairs_lookup_bwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                          _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_pointconv_dw_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p, ctypes.c_void_p,
+                                      _int, _int, _int, _int, _int, _stream]),
+    "camli_pointconv_dw_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, ctypes.c_void_p, _c_float_p,
+                                      _c_float_p, _int, _int, _int, _int, _int, _stream]),
 }
 
 _lib = None

@@ -122,3 +122,85 @@ def allpairs_lookup(pyr, coords, radius=4):
     """coords [B,2,h,w] -> [B, L*(2r+1)^2, h, w] (raft_core.py:70-94 in one launch)."""
     _require_cuda('allpairs_lookup', coords)
     return _Lookup.apply(pyr.token, coords.detach().float().contiguous(), radius, pyr)
+
+
+# ------------------------------------------------------------------------------------------------
+# depth-wise set-conv core (models/point_conv.py:122-128)
+# ------------------------------------------------------------------------------------------------
+class SharedSetConvWeights:
+    """The neighbour weights ``weight_net(knn_offset)`` [B,C,N,k] of one PointConvDW instance,
+    shared by every call of one forward pass (they depend only on xyz / knn_indices, which are
+    fixed across the GRU iterations: models/camliraft_core.py:88,119,127,140).
+
+    Autograd: ``weight`` enters a ``_ShareWeights`` node that hands out a 1-element token.  Every
+    fused call depends on the token and ADDS its (one-slot-per-row) weight gradient into one
+    persistent buffer; the node's backward returns that buffer as the gradient of ``weight``, so
+    ``weight_net`` is differentiated once per pass instead of once per iteration.
+    """
+
+    def __init__(self, weight):
+        self.weight = weight.detach().contiguous()
+        self.grad = None
+        self.token = _ShareWeights.apply(weight, self)
+
+
+class _ShareWeights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, shared):
+        ctx.shared = shared
+        return weight.new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _gtoken):
+        shared = ctx.shared
+        grad, shared.grad = shared.grad, None
+        if grad is None:
+            grad = torch.zeros_like(shared.weight)
+        return grad, None
+
+
+class _PointConvDW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, token, knn_indices, k, shared):
+        lib = _lib.load()
+        weight = shared.weight
+        b, c, m = feat.shape
+        n = weight.shape[2]
+        out = torch.empty((b, c, n), dtype=torch.float32, device=feat.device)
+        arg = torch.empty((b, c, n), dtype=torch.uint8, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _lib.launch('camli_pointconv_dw_fwd', lib.camli_pointconv_dw_fwd, feat.data_ptr(), weight.data_ptr(),
+                        knn_indices.data_ptr(), knn_indices.stride(1), out.data_ptr(), arg.data_ptr(),
+                        b, c, m, n, k, _stream_ptr(feat))
+        ctx.save_for_backward(feat, knn_indices, arg)
+        ctx.shared, ctx.k = shared, k
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        feat, knn_indices, arg = ctx.saved_tensors
+        shared = ctx.shared
+        b, c, m = feat.shape
+        n = shared.weight.shape[2]
+        gout = gout.contiguous().float()
+        gfeat = torch.zeros_like(feat) if ctx.needs_input_grad[0] else None
+        if shared.grad is None:
+            shared.grad = torch.zeros_like(shared.weight)
+        with torch.cuda.device(feat.device):
+            _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd, gout.data_ptr(), feat.data_ptr(),
+                        shared.weight.data_ptr(), knn_indices.data_ptr(), knn_indices.stride(1), arg.data_ptr(),
+                        gfeat.data_ptr() if gfeat is not None else None, shared.grad.data_ptr(),
+                        b, c, m, n, ctx.k, _stream_ptr(feat))
+        return gfeat, gout.new_zeros(1), None, None, None
+
+
+def pointconv_dw(feat, shared, knn_indices, k):
+    """feat [B,C,M] (already through the 1x1 ``mlp``), shared weights [B,C,N,k], knn_indices int64
+    [B,N,>=k] (row-contiguous) -> [B,C,N] = max_j feat[:, :, idx_j] * weight[..., j]."""
+    _require_cuda('pointconv_dw', feat, knn_indices)
+    assert knn_indices.dtype == torch.int64 and knn_indices.stride(2) == 1 and knn_indices.shape[2] >= k
+    assert knn_indices.stride(0) == knn_indices.shape[1] * knn_indices.stride(1)
+    assert shared.weight.shape[0] == feat.shape[0] and shared.weight.shape[1] == feat.shape[1]
+    assert shared.weight.shape[3] == k
+    return _PointConvDW.apply(feat.float().contiguous(), shared.token, knn_indices, k, shared)

@@ -82,6 +82,21 @@ int camli_allpairs_lookup_fwd(const float *const *vols, const int *hs, const int
 int camli_allpairs_lookup_bwd(float *const *gvols, const int *hs, const int *ws, int L,
                               const float *coords, const float *gout, int B, int h, int w, int r, void *stream);
 
+/*
+ * Depth-wise set-conv core and adjoint (internal composite op; the reference composes it from
+ * gather * weight_net(...) -> max, models/point_conv.py:122-128).
+ *   feat [B,C,M]; weight [B,C,N,k]; idx int64, row n of batch b at idx + (b*N+n)*idx_stride, first k
+ *   entries used (lets a wider precomputed KNN tensor be sliced without a copy, point_conv.py:116-120)
+ *   out [B,C,N] = max_j feat[b,c,idx[b,n,j]] * weight[b,c,n,j]; arg uint8 [B,C,N] = first arg-max j.
+ *   bwd: gfeat [B,C,M] += (float atomics), gweight [B,C,N,k] += at the arg-max slot only; both
+ *   buffers are caller-zeroed and may be NULL (skipped).  k <= 255.
+ */
+int camli_pointconv_dw_fwd(const float *feat, const float *weight, const int64_t *idx, int idx_stride,
+                           float *out, unsigned char *arg, int B, int C, int M, int N, int k, void *stream);
+int camli_pointconv_dw_bwd(const float *gout, const float *feat, const float *weight, const int64_t *idx,
+                           int idx_stride, const unsigned char *arg, float *gfeat, float *gweight,
+                           int B, int C, int M, int N, int k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

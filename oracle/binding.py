@@ -136,3 +136,26 @@ def knn_interp_fwd(in_xyz, feat, q_xyz, knn_idx):
     _chk(_load().oracle_knn_interp_fwd(_p(in_xyz), _p(feat), _p(q_xyz), _p(knn_idx), _p(out), B, C, M, Nq, k),
          "knn_interp_fwd")
     return out
+
+
+def pointconv_dw_fwd(feat, weight, idx, k):
+    """feat [B,C,M], weight [B,C,N,k], idx int64 [B,N,kk>=k] -> out [B,C,N], arg uint8 [B,C,N]"""
+    feat, weight, idx = _f32(feat), _f32(weight), _i64(idx)
+    B, C, M = feat.shape
+    N = weight.shape[2]
+    out = np.zeros((B, C, N), dtype=np.float32)
+    arg = np.zeros((B, C, N), dtype=np.uint8)
+    _chk(_load().oracle_pointconv_dw_fwd(_p(feat), _p(weight), _p(idx), idx.shape[2], _p(out), _p(arg),
+                                         B, C, M, N, k), "pointconv_dw_fwd")
+    return out, arg
+
+
+def pointconv_dw_bwd(gout, feat, weight, idx, arg, k):
+    gout, feat, weight, idx = _f32(gout), _f32(feat), _f32(weight), _i64(idx)
+    arg = np.ascontiguousarray(arg, dtype=np.uint8)
+    B, C, M = feat.shape
+    N = weight.shape[2]
+    gfeat, gweight = np.zeros_like(feat), np.zeros_like(weight)
+    _chk(_load().oracle_pointconv_dw_bwd(_p(gout), _p(feat), _p(weight), _p(idx), idx.shape[2], _p(arg),
+                                         _p(gfeat), _p(gweight), B, C, M, N, k), "pointconv_dw_bwd")
+    return gfeat, gweight

@@ -336,4 +336,50 @@ int oracle_knn_interp_fwd(const float *in_xyz, const float *feat, const float *q
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * PointConvDW core: gather * weight -> max over the k neighbours, and its adjoint
+ * follows models/point_conv.py:122-128 (batch_indexing, multiply, torch.max(dim=-1)).
+ *   feat [B,C,M], weight [B,C,N,k], idx int64 rows of length idx_stride (first k used)
+ *   out [B,C,N]; arg = FIRST index attaining the maximum (ties only matter where weight == 0,
+ *   whose gradient the ReLU of weight_net masks anyway)
+ * ------------------------------------------------------------------------------------------ */
+int oracle_pointconv_dw_fwd(const float *feat, const float *weight, const int64_t *idx, int idx_stride,
+                            float *out, unsigned char *arg, int B, int C, int M, int N, int k)
+{
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int n = 0; n < N; ++n) {
+                const int64_t *ir = idx + ((size_t)b * N + n) * idx_stride;
+                const float *w = weight + (((size_t)b * C + c) * N + n) * k;
+                const float *f = feat + ((size_t)b * C + c) * M;
+                float best = -INFINITY;
+                int bj = 0;
+                for (int j = 0; j < k; ++j) {
+                    if (ir[j] < 0 || ir[j] >= M) return -1;
+                    float p = f[ir[j]] * w[j];
+                    if (p > best) { best = p; bj = j; }
+                }
+                out[((size_t)b * C + c) * N + n] = best;
+                arg[((size_t)b * C + c) * N + n] = (unsigned char)bj;
+            }
+    return 0;
+}
+
+int oracle_pointconv_dw_bwd(const float *gout, const float *feat, const float *weight, const int64_t *idx,
+                            int idx_stride, const unsigned char *arg, float *gfeat, float *gweight,
+                            int B, int C, int M, int N, int k)
+{
+    /* accumulates into gfeat / gweight (caller zero-fills) */
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int n = 0; n < N; ++n) {
+                size_t e = ((size_t)b * C + c) * N + n;
+                int j = arg[e];
+                int64_t m = idx[((size_t)b * N + n) * idx_stride + j];
+                gfeat[((size_t)b * C + c) * M + m] += gout[e] * weight[e * k + j];
+                gweight[e * k + j] += gout[e] * feat[((size_t)b * C + c) * M + m];
+            }
+    return 0;
+}
+
 int oracle_version(void) { return 1; }
