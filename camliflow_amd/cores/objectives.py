@@ -19,7 +19,10 @@ def _masked_mean_error(diff, mask, order):
         err = torch.pow(diff.abs().sum(dim=1) + 0.01, 0.4)
     else:
         raise ValueError(order)
-    return err[mask].mean()
+    # mean over the masked elements without boolean indexing (err[mask] costs a device->host sync
+    # per loss term); identical value whenever the mask is not empty
+    zero = torch.zeros((), dtype=err.dtype, device=err.device)
+    return torch.where(mask, err, zero).sum() / mask.sum()
 
 
 def _sequence_loss(flow_preds, target, cfgs, n_flow_channels):
