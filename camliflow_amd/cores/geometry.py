@@ -37,6 +37,9 @@ def batch_indexing(batched_data, batched_indices, layout='channel_first'):
     bs = batched_data.shape[0]
     idx_shape = list(batched_indices.shape[1:])
     if layout == 'channel_first':
+        if runtime.fused() and batched_data.dim() == 3 and batched_data.dtype == torch.float32:
+            from ..csrc import fused
+            return fused.gather_points(batched_data, batched_indices)
         n_channels = batched_data.shape[1]
         flat = batched_indices.reshape(bs, 1, -1).expand(bs, n_channels, -1).to(torch.int64)
         return torch.gather(batched_data, 2, flat).view([bs, n_channels] + idx_shape)
@@ -70,6 +73,9 @@ def knn_interpolation(input_xyz, input_features, query_xyz, k=3):
     """Inverse-distance interpolation from the k nearest inputs (utils.py:130-146).
     [B,3,M] x [B,C,M] x [B,3,Nq] -> [B,C,Nq]; gradients flow to features AND coordinates."""
     knn_indices = _ops.k_nearest_neighbor(input_xyz, query_xyz, k)
+    if runtime.fused() and k <= 8 and not input_xyz.requires_grad and not query_xyz.requires_grad:
+        from ..csrc import fused
+        return fused.knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
     knn_xyz = batch_indexing(input_xyz, knn_indices)
     knn_dists = torch.linalg.norm(knn_xyz - query_xyz[..., None], dim=1).clamp(1e-8)
     knn_weights = 1.0 / knn_dists

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from ..csrc import wrapper as _ops
+from . import runtime
 from .blocks import Conv1dNormRelu, MLP1d, MLP2d
 from .geometry import backwarp_3d, batch_indexing, build_pc_pyramid, knn_interpolation
 from .setconv import PointConv, PointConvDW, pass_cache
@@ -53,6 +54,10 @@ class Correlation3D(nn.Module):
     def calc_matching_cost(self, xyz1, xyz2, cost_volume):
         bs, n_points1, n_points2 = cost_volume.shape
         knn_cross = _ops.k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)       # [B,N,k]
+        if runtime.fused() and not xyz1.requires_grad and not xyz2.requires_grad:
+            from ..csrc import fused
+            lookup = fused.corr3d_lookup_input(cost_volume, xyz1, xyz2, knn_cross)            # [B,4,N,k]
+            return torch.sum(self.cost_mlp(lookup), dim=-1)
         knn_offset = batch_indexing(xyz2, knn_cross) - xyz1.view(bs, 3, n_points1, 1)
         knn_corr = batch_indexing(cost_volume.reshape(bs * n_points1, n_points2),
                                   knn_cross.reshape(bs * n_points1, self.k),

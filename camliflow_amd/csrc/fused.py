@@ -204,3 +204,116 @@ def pointconv_dw(feat, shared, knn_indices, k):
     assert shared.weight.shape[0] == feat.shape[0] and shared.weight.shape[1] == feat.shape[1]
     assert shared.weight.shape[3] == k
     return _PointConvDW.apply(feat.float().contiguous(), shared.token, knn_indices, k, shared)
+
+
+# ------------------------------------------------------------------------------------------------
+# gather / interpolation / point cost-volume lookup (models/utils.py, models/camliraft_l_core.py)
+# ------------------------------------------------------------------------------------------------
+class _GatherCF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, idx_flat):
+        lib = _lib.load()
+        b, c, m = data.shape
+        i = idx_flat.shape[1]
+        out = torch.empty((b, c, i), dtype=torch.float32, device=data.device)
+        with torch.cuda.device(data.device):
+            _lib.launch('camli_gather_cf_fwd', lib.camli_gather_cf_fwd, data.data_ptr(), idx_flat.data_ptr(),
+                        out.data_ptr(), b, c, m, i, _stream_ptr(data))
+        ctx.save_for_backward(idx_flat)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        (idx_flat,) = ctx.saved_tensors
+        gout = gout.contiguous().float()
+        b, c, i = gout.shape
+        gdata = torch.zeros((b, c, ctx.m), dtype=torch.float32, device=gout.device)
+        with torch.cuda.device(gout.device):
+            _lib.launch('camli_gather_cf_bwd', lib.camli_gather_cf_bwd, gout.data_ptr(), idx_flat.data_ptr(),
+                        gdata.data_ptr(), b, c, ctx.m, i, _stream_ptr(gout))
+        return gdata, None
+
+
+def gather_points(data, indices):
+    """batch_indexing, channel-first: data [B,C,M], indices [B,I1..Im] -> [B,C,I1..Im] (utils.py:61-83)."""
+    _require_cuda('gather_points', data, indices)
+    b, c = data.shape[:2]
+    flat = indices.reshape(b, -1).to(torch.int64).contiguous()
+    out = _GatherCF.apply(data.float().contiguous(), flat)
+    return out.view([b, c] + list(indices.shape[1:]))
+
+
+class _KnnInterp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, in_xyz, feat, q_xyz, knn, k):
+        lib = _lib.load()
+        b, c, m = feat.shape
+        nq = q_xyz.shape[2]
+        out = torch.empty((b, c, nq), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            _lib.launch('camli_knn_interp_fwd', lib.camli_knn_interp_fwd, in_xyz.data_ptr(), feat.data_ptr(),
+                        q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), out.data_ptr(), b, c, m, nq, k,
+                        _stream_ptr(feat))
+        ctx.save_for_backward(in_xyz, q_xyz, knn)
+        ctx.dims = (b, c, m, nq, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        in_xyz, q_xyz, knn = ctx.saved_tensors
+        b, c, m, nq, k = ctx.dims
+        gout = gout.contiguous().float()
+        gfeat = torch.zeros((b, c, m), dtype=torch.float32, device=gout.device)
+        with torch.cuda.device(gout.device):
+            _lib.launch('camli_knn_interp_bwd', lib.camli_knn_interp_bwd, in_xyz.data_ptr(), gout.data_ptr(),
+                        q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), gfeat.data_ptr(), b, c, m, nq, k,
+                        _stream_ptr(gout))
+        return None, gfeat, None, None, None
+
+
+def knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k):
+    """IDW interpolation given the k nearest inputs per query (utils.py:138-146).  Gradient flows to
+    the features only; callers route coordinate-differentiable cases to the composed formulation."""
+    _require_cuda('knn_interpolate', input_xyz, input_features, query_xyz, knn_indices)
+    assert not input_xyz.requires_grad and not query_xyz.requires_grad
+    return _KnnInterp.apply(input_xyz.float().contiguous(), input_features.float().contiguous(),
+                            query_xyz.float().contiguous(), knn_indices, k)
+
+
+class _Corr3DGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cost, xyz1, xyz2, knn):
+        lib = _lib.load()
+        b, n, m = cost.shape
+        k = knn.shape[2]
+        out = torch.empty((b, 4, n, k), dtype=torch.float32, device=cost.device)
+        with torch.cuda.device(cost.device):
+            _lib.launch('camli_corr3d_gather_fwd', lib.camli_corr3d_gather_fwd, xyz1.data_ptr(), xyz2.data_ptr(),
+                        cost.data_ptr(), knn.data_ptr(), out.data_ptr(), b, n, m, k, _stream_ptr(cost))
+        ctx.save_for_backward(knn)
+        ctx.dims = (b, n, m, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        (knn,) = ctx.saved_tensors
+        b, n, m, k = ctx.dims
+        gout = gout.contiguous().float()
+        gcost = torch.zeros((b, n, m), dtype=torch.float32, device=gout.device)
+        with torch.cuda.device(gout.device):
+            _lib.launch('camli_corr3d_gather_bwd', lib.camli_corr3d_gather_bwd, gout.data_ptr(), knn.data_ptr(),
+                        gcost.data_ptr(), b, n, m, k, _stream_ptr(gout))
+        return gcost, None, None, None
+
+
+def corr3d_lookup_input(cost_volume, xyz1, xyz2, knn_indices):
+    """[B,N,M] cost volume + coordinates + cross KNN -> the [B,4,N,k] tensor (dxyz, cost entry) the
+    cost MLP consumes (camliraft_l_core.py:62-76) in one launch; gradient to the cost volume only."""
+    _require_cuda('corr3d_lookup_input', cost_volume, xyz1, xyz2, knn_indices)
+    assert not xyz1.requires_grad and not xyz2.requires_grad
+    return _Corr3DGather.apply(cost_volume.float().contiguous(), xyz1.float().contiguous(),
+                               xyz2.float().contiguous(), knn_indices.contiguous())

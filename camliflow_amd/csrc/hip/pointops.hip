@@ -1,0 +1,212 @@
+// Point gather / scatter, k-NN inverse-distance interpolation and the point cost-volume lookup
+// gather, gfx950.  All are HBM/L2-bound index ops; the reference composes each from torch.gather /
+// advanced indexing plus a chain of elementwise kernels, and their backward is torch's generic
+// scatter_add / index_put(accumulate) with one atomic per gathered element.
+//
+//   gather_cf      models/utils.py:61-83   data [B,C,M], idx [B,I]          -> out [B,C,I]
+//   knn_interp     models/utils.py:130-146 IDW of the k nearest             -> out [B,C,Nq]
+//   corr3d_gather  models/camliraft_l_core.py:62-76 (dxyz, cost entry)      -> out [B,4,N,k]
+//
+// Layout rule everywhere: the query / output-point index is the fastest thread axis, so outputs
+// are written in full 256-byte wave rows and the index row of a point is read once per thread.
+#include "camli_common.h"
+
+namespace {
+
+// ---- gather along the point axis, channel-first --------------------------------------------------
+__global__ __launch_bounds__(256) void gather_cf_fwd_kernel(const float* __restrict__ data,
+                                                             const int64_t* __restrict__ idx,
+                                                             float* __restrict__ out, int C, int M, int I) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    if (i >= I) return;
+    const int m = (int)idx[(size_t)b * I + i];
+    for (int c = blockIdx.y; c < C; c += gridDim.y)
+        out[((size_t)b * C + c) * I + i] = data[((size_t)b * C + c) * M + m];
+}
+
+__global__ __launch_bounds__(256) void gather_cf_bwd_kernel(const float* __restrict__ gout,
+                                                             const int64_t* __restrict__ idx,
+                                                             float* __restrict__ gdata, int C, int M, int I) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    if (i >= I) return;
+    const int m = (int)idx[(size_t)b * I + i];
+    for (int c = blockIdx.y; c < C; c += gridDim.y)
+        unsafeAtomicAdd(gdata + ((size_t)b * C + c) * M + m, gout[((size_t)b * C + c) * I + i]);
+}
+
+// ---- inverse-distance interpolation from precomputed k nearest neighbours -------------------------
+// dist_j = max(||in_xyz[:,idx_j] - q||, 1e-8); w_j = (1/dist_j) / sum_j(1/dist_j)
+constexpr int KI_MAXK = 8;
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void knn_interp_kernel(const float* __restrict__ in_xyz,
+                                                          const float* __restrict__ q_xyz,
+                                                          const int64_t* __restrict__ knn, int knn_stride,
+                                                          const float* __restrict__ src /* feat | gout */,
+                                                          float* __restrict__ dst /* out | gfeat */, int C, int M,
+                                                          int Nq, int k) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    if (q >= Nq) return;
+    const float qx = q_xyz[((size_t)b * 3 + 0) * Nq + q];
+    const float qy = q_xyz[((size_t)b * 3 + 1) * Nq + q];
+    const float qz = q_xyz[((size_t)b * 3 + 2) * Nq + q];
+    int m[KI_MAXK];
+    float w[KI_MAXK];
+    float wsum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KI_MAXK; ++j) {
+        if (j < k) {
+            m[j] = (int)knn[((size_t)b * Nq + q) * knn_stride + j];
+            const float dx = in_xyz[((size_t)b * 3 + 0) * M + m[j]] - qx;
+            const float dy = in_xyz[((size_t)b * 3 + 1) * M + m[j]] - qy;
+            const float dz = in_xyz[((size_t)b * 3 + 2) * M + m[j]] - qz;
+            const float dist = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
+            w[j] = 1.0f / dist;
+            wsum += w[j];
+        } else {
+            m[j] = 0;
+            w[j] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KI_MAXK; ++j) w[j] = w[j] / wsum;
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        const size_t row = ((size_t)b * C + c) * M;
+        if (!BACKWARD) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KI_MAXK; ++j)
+                if (j < k) acc += src[row + m[j]] * w[j];
+            dst[((size_t)b * C + c) * Nq + q] = acc;
+        } else {
+            const float g = src[((size_t)b * C + c) * Nq + q];
+#pragma unroll
+            for (int j = 0; j < KI_MAXK; ++j)
+                if (j < k) unsafeAtomicAdd(dst + row + m[j], g * w[j]);
+        }
+    }
+}
+
+// ---- point cost-volume lookup gather ---------------------------------------------------------------
+// out[b,0:3,n,j] = xyz2[b,:,idx[b,n,j]] - xyz1[b,:,n];  out[b,3,n,j] = cost[b,n,idx[b,n,j]]
+// thread = (b, n, j), j fastest (k contiguous outputs per point)
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void corr3d_gather_kernel(const float* __restrict__ xyz1,
+                                                             const float* __restrict__ xyz2,
+                                                             float* __restrict__ cost /* cost | gcost */,
+                                                             const int64_t* __restrict__ knn,
+                                                             float* __restrict__ io /* out | gout */, int B, int N,
+                                                             int M, int k) {
+    const size_t total = (size_t)B * N * k;
+    const size_t plane = (size_t)N * k;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t bn = e / k;
+        const int b = (int)(bn / N);
+        const int n = (int)(bn - (size_t)b * N);
+        const int m = (int)knn[e];
+        const size_t o = (size_t)b * 4 * plane + (e - (size_t)b * plane);
+        if (!BACKWARD) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                io[o + a * plane] = xyz2[((size_t)b * 3 + a) * M + m] - xyz1[((size_t)b * 3 + a) * N + n];
+            io[o + 3 * plane] = cost[bn * M + m];
+        } else {
+            unsafeAtomicAdd(cost + bn * M + m, io[o + 3 * plane]);
+        }
+    }
+}
+
+int grid_y_for(int C) { return C < 64 ? C : 64; }
+
+}  // namespace
+
+extern "C" int camli_gather_cf_fwd(const float* data, const int64_t* idx, float* out, int B, int C, int M, int I,
+                                   void* stream) {
+    if (!data || !idx || !out) { camli_set_error("camli_gather_cf_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || C < 1 || M < 1 || I < 0 || B > 65535) {
+        camli_set_error("camli_gather_cf_fwd: bad shape B=%d C=%d M=%d I=%d", B, C, M, I);
+        return CAMLI_EINVAL;
+    }
+    if (B == 0 || I == 0) return CAMLI_OK;
+    hipLaunchKernelGGL(gather_cf_fwd_kernel, dim3(camli_divup(I, 256), grid_y_for(C), B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), data, idx, out, C, M, I);
+    return camli_check_launch("camli_gather_cf_fwd");
+}
+
+extern "C" int camli_gather_cf_bwd(const float* gout, const int64_t* idx, float* gdata, int B, int C, int M, int I,
+                                   void* stream) {
+    if (!gout || !idx || !gdata) { camli_set_error("camli_gather_cf_bwd: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || C < 1 || M < 1 || I < 0 || B > 65535) {
+        camli_set_error("camli_gather_cf_bwd: bad shape B=%d C=%d M=%d I=%d", B, C, M, I);
+        return CAMLI_EINVAL;
+    }
+    if (B == 0 || I == 0) return CAMLI_OK;
+    hipLaunchKernelGGL(gather_cf_bwd_kernel, dim3(camli_divup(I, 256), grid_y_for(C), B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gout, idx, gdata, C, M, I);
+    return camli_check_launch("camli_gather_cf_bwd");
+}
+
+static int knn_interp_args_ok(const char* what, const void* a, const void* b, const void* c, const void* d,
+                              const void* e, int B, int C, int M, int Nq, int k, int knn_stride) {
+    if (!a || !b || !c || !d || !e) { camli_set_error("%s: null pointer", what); return 0; }
+    if (B < 0 || C < 1 || M < 1 || Nq < 0 || k < 1 || k > KI_MAXK || knn_stride < k || B > 65535) {
+        camli_set_error("%s: bad shape B=%d C=%d M=%d Nq=%d k=%d (k <= %d)", what, B, C, M, Nq, k, KI_MAXK);
+        return 0;
+    }
+    return 1;
+}
+
+extern "C" int camli_knn_interp_fwd(const float* in_xyz, const float* feat, const float* q_xyz, const int64_t* knn,
+                                    int knn_stride, float* out, int B, int C, int M, int Nq, int k, void* stream) {
+    if (!knn_interp_args_ok("camli_knn_interp_fwd", in_xyz, feat, q_xyz, knn, out, B, C, M, Nq, k, knn_stride))
+        return CAMLI_EINVAL;
+    if (B == 0 || Nq == 0) return CAMLI_OK;
+    hipLaunchKernelGGL((knn_interp_kernel<false>), dim3(camli_divup(Nq, 256), C < 16 ? 1 : grid_y_for(C / 4), B),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in_xyz, q_xyz, knn, knn_stride, feat, out, C,
+                       M, Nq, k);
+    return camli_check_launch("camli_knn_interp_fwd");
+}
+
+extern "C" int camli_knn_interp_bwd(const float* in_xyz, const float* gout, const float* q_xyz, const int64_t* knn,
+                                    int knn_stride, float* gfeat, int B, int C, int M, int Nq, int k, void* stream) {
+    if (!knn_interp_args_ok("camli_knn_interp_bwd", in_xyz, gout, q_xyz, knn, gfeat, B, C, M, Nq, k, knn_stride))
+        return CAMLI_EINVAL;
+    if (B == 0 || Nq == 0) return CAMLI_OK;
+    hipLaunchKernelGGL((knn_interp_kernel<true>), dim3(camli_divup(Nq, 256), C < 16 ? 1 : grid_y_for(C / 4), B),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in_xyz, q_xyz, knn, knn_stride, gout, gfeat,
+                       C, M, Nq, k);
+    return camli_check_launch("camli_knn_interp_bwd");
+}
+
+extern "C" int camli_corr3d_gather_fwd(const float* xyz1, const float* xyz2, const float* cost, const int64_t* knn,
+                                       float* out, int B, int N, int M, int k, void* stream) {
+    if (!xyz1 || !xyz2 || !cost || !knn || !out) { camli_set_error("camli_corr3d_gather_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || N < 1 || M < 1 || k < 1) {
+        camli_set_error("camli_corr3d_gather_fwd: bad shape B=%d N=%d M=%d k=%d", B, N, M, k);
+        return CAMLI_EINVAL;
+    }
+    if (B == 0) return CAMLI_OK;
+    const size_t total = (size_t)B * N * k;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL((corr3d_gather_kernel<false>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       xyz1, xyz2, const_cast<float*>(cost), knn, out, B, N, M, k);
+    return camli_check_launch("camli_corr3d_gather_fwd");
+}
+
+extern "C" int camli_corr3d_gather_bwd(const float* gout, const int64_t* knn, float* gcost, int B, int N, int M, int k,
+                                       void* stream) {
+    if (!gout || !knn || !gcost) { camli_set_error("camli_corr3d_gather_bwd: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || N < 1 || M < 1 || k < 1) {
+        camli_set_error("camli_corr3d_gather_bwd: bad shape B=%d N=%d M=%d k=%d", B, N, M, k);
+        return CAMLI_EINVAL;
+    }
+    if (B == 0) return CAMLI_OK;
+    const size_t total = (size_t)B * N * k;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL((corr3d_gather_kernel<true>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       nullptr, nullptr, gcost, knn, const_cast<float*>(gout), B, N, M, k);
+    return camli_check_launch("camli_corr3d_gather_bwd");
+}

@@ -97,6 +97,37 @@ int camli_pointconv_dw_bwd(const float *gout, const float *feat, const float *we
                            int idx_stride, const unsigned char *arg, float *gfeat, float *gweight,
                            int B, int C, int M, int N, int k, void *stream);
 
+/*
+ * batch_indexing, channel-first (models/utils.py:61-83): out[b,c,i] = data[b,c,idx[b,i]].
+ *   data [B,C,M], idx int64 [B,I] (contiguous), out [B,C,I].  bwd: gdata [B,C,M] += (float atomics,
+ *   caller zero-fills).
+ */
+int camli_gather_cf_fwd(const float *data, const int64_t *idx, float *out, int B, int C, int M, int I, void *stream);
+int camli_gather_cf_bwd(const float *gout, const int64_t *idx, float *gdata, int B, int C, int M, int I, void *stream);
+
+/*
+ * knn_interpolation tail (models/utils.py:138-146) given the k <= 8 nearest inputs of every query:
+ *   w_j = (1/max(|in_xyz[:,knn_j] - q|, 1e-8)) / sum_j(...);  out[b,c,q] = sum_j feat[b,c,knn_j] * w_j
+ *   in_xyz [B,3,M], feat [B,C,M], q_xyz [B,3,Nq] channel-first; knn int64 rows of stride knn_stride.
+ *   bwd: gradient w.r.t. feat only (gfeat += with atomics, caller zero-fills); the coordinate
+ *   gradient is never needed on the path (coordinates come from inputs / detached flow).
+ */
+int camli_knn_interp_fwd(const float *in_xyz, const float *feat, const float *q_xyz, const int64_t *knn,
+                         int knn_stride, float *out, int B, int C, int M, int Nq, int k, void *stream);
+int camli_knn_interp_bwd(const float *in_xyz, const float *gout, const float *q_xyz, const int64_t *knn,
+                         int knn_stride, float *gfeat, int B, int C, int M, int Nq, int k, void *stream);
+
+/*
+ * input tensor of the point cost-volume lookup (models/camliraft_l_core.py:62-76):
+ *   out[b,0:3,n,j] = xyz2[b,:,knn[b,n,j]] - xyz1[b,:,n];  out[b,3,n,j] = cost[b,n,knn[b,n,j]]
+ *   xyz1 [B,3,N], xyz2 [B,3,M], cost [B,N,M], knn int64 [B,N,k] contiguous, out [B,4,N,k].
+ *   bwd: gcost [B,N,M] += gout[b,3,n,j] (atomics; caller zero-fills).
+ */
+int camli_corr3d_gather_fwd(const float *xyz1, const float *xyz2, const float *cost, const int64_t *knn,
+                            float *out, int B, int N, int M, int k, void *stream);
+int camli_corr3d_gather_bwd(const float *gout, const int64_t *knn, float *gcost, int B, int N, int M, int k,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

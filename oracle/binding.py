@@ -159,3 +159,23 @@ def pointconv_dw_bwd(gout, feat, weight, idx, arg, k):
     _chk(_load().oracle_pointconv_dw_bwd(_p(gout), _p(feat), _p(weight), _p(idx), idx.shape[2], _p(arg),
                                          _p(gfeat), _p(gweight), B, C, M, N, k), "pointconv_dw_bwd")
     return gfeat, gweight
+
+
+def knn_interp_bwd(in_xyz, gout, q_xyz, knn_idx, M):
+    in_xyz, gout, q_xyz, knn_idx = _f32(in_xyz), _f32(gout), _f32(q_xyz), _i64(knn_idx)
+    B, C, Nq = gout.shape
+    k = knn_idx.shape[2]
+    gfeat = np.zeros((B, C, M), dtype=np.float32)
+    _chk(_load().oracle_knn_interp_bwd(_p(in_xyz), _p(gout), _p(q_xyz), _p(knn_idx), _p(gfeat), B, C, M, Nq, k),
+         "knn_interp_bwd")
+    return gfeat
+
+
+def corr3d_gather_fwd(xyz1, xyz2, cost, knn_idx):
+    xyz1, xyz2, cost, knn_idx = _f32(xyz1), _f32(xyz2), _f32(cost), _i64(knn_idx)
+    B, N, M = cost.shape
+    k = knn_idx.shape[2]
+    out = np.zeros((B, 4, N, k), dtype=np.float32)
+    _chk(_load().oracle_corr3d_gather_fwd(_p(xyz1), _p(xyz2), _p(cost), _p(knn_idx), _p(out), B, N, M, k),
+         "corr3d_gather_fwd")
+    return out

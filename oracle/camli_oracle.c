@@ -382,4 +382,51 @@ int oracle_pointconv_dw_bwd(const float *gout, const float *feat, const float *w
     return 0;
 }
 
+/* adjoint of oracle_knn_interp_fwd w.r.t. the features (accumulates into gfeat, caller zero-fills) */
+int oracle_knn_interp_bwd(const float *in_xyz, const float *gout, const float *q_xyz,
+                          const int64_t *knn, float *gfeat, int B, int C, int M, int Nq, int k)
+{
+    if (k > ORACLE_MAX_K) return -1;
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < Nq; ++q) {
+            float wgt[ORACLE_MAX_K], wsum = 0.0f;
+            const int64_t *ix = knn + ((size_t)b * Nq + q) * k;
+            for (int j = 0; j < k; ++j) {
+                float s = 0.0f;
+                for (int a = 0; a < 3; ++a) {
+                    float d = in_xyz[((size_t)b * 3 + a) * M + ix[j]] - q_xyz[((size_t)b * 3 + a) * Nq + q];
+                    s += d * d;
+                }
+                float dist = sqrtf(s);
+                if (dist < 1e-8f) dist = 1e-8f;
+                wgt[j] = 1.0f / dist;
+                wsum += wgt[j];
+            }
+            for (int c = 0; c < C; ++c)
+                for (int j = 0; j < k; ++j)
+                    gfeat[((size_t)b * C + c) * M + ix[j]] += gout[((size_t)b * C + c) * Nq + q] * (wgt[j] / wsum);
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * input of the point cost-volume lookup: follows models/camliraft_l_core.py:62-76
+ *   out[b,0:3,n,j] = xyz2[b,:,knn[b,n,j]] - xyz1[b,:,n];  out[b,3,n,j] = cost[b,n,knn[b,n,j]]
+ * ------------------------------------------------------------------------------------------ */
+int oracle_corr3d_gather_fwd(const float *xyz1, const float *xyz2, const float *cost, const int64_t *knn,
+                             float *out, int B, int N, int M, int k)
+{
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n)
+            for (int j = 0; j < k; ++j) {
+                int64_t m = knn[((size_t)b * N + n) * k + j];
+                if (m < 0 || m >= M) return -1;
+                for (int a = 0; a < 3; ++a)
+                    out[(((size_t)b * 4 + a) * N + n) * k + j] =
+                        xyz2[((size_t)b * 3 + a) * M + m] - xyz1[((size_t)b * 3 + a) * N + n];
+                out[(((size_t)b * 4 + 3) * N + n) * k + j] = cost[((size_t)b * N + n) * M + m];
+            }
+    return 0;
+}
+
 int oracle_version(void) { return 1; }

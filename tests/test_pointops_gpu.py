@@ -1,0 +1,86 @@
+"""gather / knn-interpolation / point-cost-volume gather kernels against the oracle (fp32).
+Forward results are pure copies or short fixed-order sums -> compared exactly or to 1e-6;
+backward uses float atomics -> 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize('case', [(2, 5, 40, (17, 3)), (8, 130, 2048, (8160, 1)), (2, 2048, 2048, (1024, 3)), (1, 3, 8192, (4096,))],
+                         ids=str)
+def test_gather_points(case, oracle_lib):
+    from camliflow_amd.csrc import fused
+    b, c, m, ishape = case
+    rng = np.random.default_rng(c)
+    data = rng.standard_normal((b, c, m)).astype(np.float32)
+    idx = rng.integers(0, m, size=(b,) + ishape).astype(np.int64)
+    t = dev(data).requires_grad_(True)
+    out = fused.gather_points(t, dev(idx))
+    assert out.shape == (b, c) + ishape
+    flat = idx.reshape(b, -1)
+    want = oracle_lib.gather_cf(data, flat).reshape(out.shape)
+    assert np.array_equal(out.detach().cpu().numpy(), want)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(g))
+    assert np.allclose(t.grad.cpu().numpy(), oracle_lib.scatter_add_cf(g.reshape(b, c, -1), flat, m), rtol=1e-5, atol=1e-5)
+
+
+def test_gather_golden(golden):
+    from camliflow_amd.csrc import fused
+    g = golden('batch_indexing')
+    out = fused.gather_points(dev(g['data']), dev(g['indices']))
+    assert np.array_equal(out.cpu().numpy(), g['out_cf'])
+
+
+@pytest.mark.parametrize('case', [(2, 3, 2048, 8192, 3), (8, 3, 2048, 256, 3), (1, 67, 512, 1024, 3), (2, 7, 200, 90, 5)], ids=str)
+def test_knn_interpolate(case, oracle_lib):
+    from camliflow_amd.csrc import fused, k_nearest_neighbor
+    b, c, m, nq, k = case
+    rng = np.random.default_rng(nq)
+    in_xyz = rng.standard_normal((b, 3, m)).astype(np.float32)
+    q_xyz = rng.standard_normal((b, 3, nq)).astype(np.float32)
+    q_xyz[:, :, :4] = in_xyz[:, :, :4]       # coincident points -> clamp(1e-8)
+    feat = rng.standard_normal((b, c, m)).astype(np.float32)
+    knn = k_nearest_neighbor(dev(in_xyz), dev(q_xyz), k)
+    tf = dev(feat).requires_grad_(True)
+    out = fused.knn_interpolate(dev(in_xyz), tf, dev(q_xyz), knn, k)
+    want = oracle_lib.knn_interp_fwd(in_xyz, feat, q_xyz, knn.cpu().numpy())
+    assert np.allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(g))
+    assert np.allclose(tf.grad.cpu().numpy(), oracle_lib.knn_interp_bwd(in_xyz, g, q_xyz, knn.cpu().numpy(), m),
+                       rtol=1e-4, atol=1e-5)
+
+
+def test_knn_interpolation_golden_through_the_core_function(golden):
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.geometry import knn_interpolation
+    g = golden('knn_interpolation')
+    with runtime.use_backend('hip'):
+        out = knn_interpolation(dev(g['in_xyz']), dev(g['feat']), dev(g['q_xyz']), k=3)
+    assert np.allclose(out.cpu().numpy(), g['out'], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', [(2, 2048, 2048, 16), (8, 2048, 256, 16), (1, 300, 77, 5)], ids=str)
+def test_corr3d_lookup_input(case, oracle_lib):
+    from camliflow_amd.csrc import fused
+    b, n, m, k = case
+    rng = np.random.default_rng(m)
+    xyz1 = rng.standard_normal((b, 3, n)).astype(np.float32)
+    xyz2 = rng.standard_normal((b, 3, m)).astype(np.float32)
+    cost = rng.standard_normal((b, n, m)).astype(np.float32)
+    knn = np.stack([np.stack([rng.permutation(m)[:k] for _ in range(n)]) for _ in range(b)]).astype(np.int64)
+    tc = dev(cost).requires_grad_(True)
+    out = fused.corr3d_lookup_input(tc, dev(xyz1), dev(xyz2), dev(knn))
+    assert np.array_equal(out.detach().cpu().numpy(), oracle_lib.corr3d_gather_fwd(xyz1, xyz2, cost, knn))
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(g))
+    want = np.zeros_like(cost)
+    np.add.at(want, (np.arange(b)[:, None, None], np.arange(n)[None, :, None], knn), g[:, 3])
+    assert np.allclose(tc.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
