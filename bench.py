@@ -131,6 +131,7 @@ def main():
     from camliflow_amd.csrc import _lib
     _lib.load()
     runtime.set_backend('hip')
+    runtime.set_overlap(os.environ.get('CAMLI_OVERLAP', '0') == '1')
     torch.backends.cudnn.benchmark = os.environ.get('CAMLI_MIOPEN_FIND', '0') == '1'
 
     torch.manual_seed(0)

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ..csrc import wrapper as _ops
+from . import runtime
 from .fusion import CLFM
 from .geometry import (InputPadder, backwarp_3d, build_pc_pyramid, knn_interpolation, mesh_grid, paral2persp,
                        persp2paral, project_pc2image)
@@ -40,10 +41,10 @@ class CamLiRAFT_Core(nn.Module):
         if cfgs.fuse_hidden:
             self.clfm_hidden = CLFM(128, 128)
 
-    def _project_to_feature_grid(self, xyz, camera_info, feat_2d):
+    def _project_to_feature_grid(self, xyz, camera_info, feat_hw):
         uv = project_pc2image(xyz, camera_info)
-        uv[:, 0] *= (feat_2d.shape[-1] - 1) / (camera_info['sensor_w'] - 1)
-        uv[:, 1] *= (feat_2d.shape[-2] - 1) / (camera_info['sensor_h'] - 1)
+        uv[:, 0] *= (feat_hw[1] - 1) / (camera_info['sensor_w'] - 1)
+        uv[:, 1] *= (feat_hw[0] - 1) / (camera_info['sensor_h'] - 1)
         return uv
 
     def forward(self, image1, image2, pc1, pc2, camera_info):
@@ -51,70 +52,93 @@ class CamLiRAFT_Core(nn.Module):
             return self._forward(image1, image2, pc1, pc2, camera_info)
 
     def _forward(self, image1, image2, pc1, pc2, camera_info):
+        """Op order, detach points and module call sequence are those of camliraft_core.py:33-145.
+        The image branch is issued on the current stream, the point branch inside ``lanes.side()``
+        (a second HIP stream when ``runtime.overlap()`` is on, otherwise a no-op context); the two
+        only meet at the CLFM fusion points, where ``to_main`` / ``to_side`` order the streams."""
         b2d, b3d, cfgs = self.branch_2d, self.branch_3d, self.cfgs
+        lanes = runtime.Lanes(image1.device)
+        feat_hw = (image1.shape[-2] // 8, image1.shape[-1] // 8)
 
-        xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, PYRAMID_SIZES)
-
+        lanes.to_side(pc1, pc2)
+        with lanes.side():
+            xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, PYRAMID_SIZES)
+            feat1_3d = b3d.fnet(xyzs1[:3])[2]
+            feat2_3d = b3d.fnet(xyzs2[:3])[2]
+            featc_3d = b3d.cnet(xyzs1[:3])[2]
+            xyzs1, xyzs2 = xyzs1[2:], xyzs2[2:]          # working pyramid [2048, 1024, 512, 256]
+            xyz1, xyz2 = xyzs1[0], xyzs2[0]
+            uv1 = self._project_to_feature_grid(xyz1, camera_info, feat_hw)
+            uv2 = self._project_to_feature_grid(xyz2, camera_info, feat_hw)
         feat1_2d, feat2_2d, featc_2d = b2d.fnet(image1), b2d.fnet(image2), b2d.cnet(image1)
-        feat1_3d = b3d.fnet(xyzs1[:3])[2]
-        feat2_3d = b3d.fnet(xyzs2[:3])[2]
-        featc_3d = b3d.cnet(xyzs1[:3])[2]
+        assert tuple(feat1_2d.shape[-2:]) == feat_hw
 
-        xyzs1, xyzs2 = xyzs1[2:], xyzs2[2:]          # working pyramid [2048, 1024, 512, 256]
-        xyz1, xyz2 = xyzs1[0], xyzs2[0]
-        uv1 = self._project_to_feature_grid(xyz1, camera_info, feat1_2d)
-        uv2 = self._project_to_feature_grid(xyz2, camera_info, feat2_2d)
-
+        lanes.to_main(feat1_3d, feat2_3d, featc_3d, uv1, uv2)
         if cfgs.fuse_fnet:
             feat1_2d, feat1_3d = self.clfm_fnet(uv1, feat1_2d, feat1_3d)
             feat2_2d, feat2_3d = self.clfm_fnet(uv2, feat2_2d, feat2_3d)
         if cfgs.fuse_cnet:
             featc_2d, featc_3d = self.clfm_cnet(uv1, featc_2d, featc_3d)
 
+        lanes.to_side(feat1_3d, feat2_3d, featc_3d)
+        with lanes.side():
+            h_3d, x_3d = torch.split(b3d.cnet_aligner(featc_3d), [128, 128], dim=1)
+            h_3d, x_3d = torch.tanh(h_3d), torch.relu(x_3d)
+            b3d.correlation.build_cost_volume_pyramid(feat1_3d, feat2_3d, xyzs2)
+            knn_indices = _ops.k_nearest_neighbor(xyz1, xyz1, k=32)
+            flow_3d_pred = torch.zeros_like(xyz1)
         h_2d, x_2d = torch.split(b2d.cnet_aligner(featc_2d), [128, 128], dim=1)
         h_2d, x_2d = torch.tanh(h_2d), torch.relu(x_2d)
-        h_3d, x_3d = torch.split(b3d.cnet_aligner(featc_3d), [128, 128], dim=1)
-        h_3d, x_3d = torch.tanh(h_3d), torch.relu(x_3d)
-
         b2d.correlation.build_cost_volume_pyramid(feat1_2d, feat2_2d)
-        b3d.correlation.build_cost_volume_pyramid(feat1_3d, feat2_3d, xyzs2)
-        knn_indices = _ops.k_nearest_neighbor(xyz1, xyz1, k=32)
 
         n_iters = cfgs.n_iters_train if self.training else cfgs.n_iters_eval
-        bs, _, image_h, image_w = image1.shape
-        grid_coords = mesh_grid(bs, image_h // 8, image_w // 8, device=image1.device)
+        bs = image1.shape[0]
+        grid_coords = mesh_grid(bs, feat_hw[0], feat_hw[1], device=image1.device)
         flow_2d_pred = torch.zeros_like(grid_coords)
-        flow_3d_pred = torch.zeros_like(xyz1)
         xyzs2_warp = xyzs2
 
         flow_2d_preds, flow_3d_preds = [], []
         for it in range(n_iters):
+            # ---- correlation lookups -----------------------------------------------------------
+            with lanes.side():
+                if it > 0:
+                    flow_3d_pred = flow_3d_pred.detach()
+                    xyzs2_warp = [backwarp_3d(xyz1, level, flow_3d_pred) for level in xyzs2]
+                corr3d = b3d.correlation(xyz1, xyzs2_warp)
             if it > 0:
                 flow_2d_pred = flow_2d_pred.detach()
-                flow_3d_pred = flow_3d_pred.detach()
-                xyzs2_warp = [backwarp_3d(xyz1, level, flow_3d_pred) for level in xyzs2]
-
             corr2d = b2d.correlation(grid_coords + flow_2d_pred)
-            corr3d = b3d.correlation(xyz1, xyzs2_warp)
             if cfgs.fuse_corr:
+                lanes.to_main(corr3d)
                 corr2d, corr3d = self.clfm_corr(uv1, corr2d, corr3d)
+                lanes.to_side(corr3d)
 
+            # ---- motion features ---------------------------------------------------------------
+            with lanes.side():
+                motion_feat3d = b3d.motion_encoder(xyz1, flow_3d_pred, corr3d, knn_indices=knn_indices)
             motion_feat2d = b2d.motion_encoder(flow_2d_pred, corr2d)
-            motion_feat3d = b3d.motion_encoder(xyz1, flow_3d_pred, corr3d, knn_indices=knn_indices)
             if cfgs.fuse_motion:
+                lanes.to_main(motion_feat3d)
                 motion_feat2d, motion_feat3d = self.clfm_motion(uv1, motion_feat2d, motion_feat3d)
+                lanes.to_side(motion_feat3d)
 
+            # ---- recurrent update --------------------------------------------------------------
+            with lanes.side():
+                h_3d = b3d.gru(xyz1, h=h_3d, x=torch.cat([x_3d, motion_feat3d], dim=1), knn_indices=knn_indices)
             h_2d = b2d.gru(h=h_2d, x=torch.cat([x_2d, motion_feat2d], dim=1))
-            h_3d = b3d.gru(xyz1, h=h_3d, x=torch.cat([x_3d, motion_feat3d], dim=1), knn_indices=knn_indices)
             if cfgs.fuse_hidden:
+                lanes.to_main(h_3d)
                 h_2d, h_3d = self.clfm_hidden(uv1, h_2d, h_3d)
+                lanes.to_side(h_3d)
 
+            # ---- flow heads --------------------------------------------------------------------
+            with lanes.side():
+                flow_3d_pred = flow_3d_pred + b3d.flow_head(xyz1, h_3d, knn_indices)
+                flow_3d_preds.append(knn_interpolation(xyz1, flow_3d_pred, pc1, k=3))
             flow_2d_pred = flow_2d_pred + b2d.flow_head(h_2d)
             flow_2d_preds.append(b2d.convex_upsampler(h_2d, flow_2d_pred))
 
-            flow_3d_pred = flow_3d_pred + b3d.flow_head(xyz1, h_3d, knn_indices)
-            flow_3d_preds.append(knn_interpolation(xyz1, flow_3d_pred, pc1, k=3))
-
+        lanes.to_main(flow_3d_preds)
         return flow_2d_preds, flow_3d_preds
 
 

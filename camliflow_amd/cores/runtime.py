@@ -38,3 +38,64 @@ def use_backend(name):
 
 def fused():
     return _BACKEND == 'hip'
+
+
+# ------------------------------------------------------------------------------------------------
+# two-lane execution: point branch on a side HIP stream next to the image branch
+# ------------------------------------------------------------------------------------------------
+_OVERLAP = False
+_side_streams = {}
+
+
+def set_overlap(enabled):
+    """Run the 3-D (point) branch of the fused model on a second HIP stream.  The point kernels are
+    small (B*2048 points) and leave most CUs idle; the image branch's convolutions do not depend
+    on them between fusion points, so the two lanes overlap.  Results are unchanged."""
+    global _OVERLAP
+    _OVERLAP = bool(enabled)
+
+
+def overlap():
+    return _OVERLAP
+
+
+def _flatten(items):
+    for it in items:
+        if isinstance(it, (list, tuple)):
+            yield from _flatten(it)
+        elif it is not None:
+            yield it
+
+
+class Lanes:
+    """Fork/join helper.  ``side()`` is a context that issues work on the side stream;
+    ``to_side(...)`` / ``to_main(...)`` order the two streams at a hand-over and tell the caching
+    allocator that the handed-over tensors are in use on the other stream."""
+
+    def __init__(self, device):
+        import torch
+        self.enabled = _OVERLAP and _BACKEND == 'hip' and device.type == 'cuda'
+        if self.enabled:
+            self._torch = torch
+            self.main = torch.cuda.current_stream(device)
+            key = (device.index, self.main.cuda_stream)
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device)
+            self.side_stream = _side_streams[key]
+
+    def side(self):
+        if not self.enabled:
+            return contextlib.nullcontext()
+        return self._torch.cuda.stream(self.side_stream)
+
+    def to_side(self, *tensors):
+        if self.enabled:
+            self.side_stream.wait_stream(self.main)
+            for t in _flatten(tensors):
+                t.record_stream(self.side_stream)
+
+    def to_main(self, *tensors):
+        if self.enabled:
+            self.main.wait_stream(self.side_stream)
+            for t in _flatten(tensors):
+                t.record_stream(self.main)

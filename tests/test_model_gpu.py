@@ -101,3 +101,34 @@ def test_gpu_core_vs_cpu_oracle_core_epe_parity():
         assert abs(epe3d_cpu - epe3d_gpu) <= 1e-4, (it, epe3d_cpu, epe3d_gpu)
     print('final-iteration flow difference: 2d %.2e px, 3d %.2e' %
           (_epe(f2d_cpu[-1], f2d_gpu[-1].cpu()), _epe(f3d_cpu[-1], f3d_gpu[-1].cpu())))
+
+
+def test_two_lane_stream_overlap_matches_single_stream():
+    """runtime.set_overlap(True): point branch on a side HIP stream.  Same kernels, same inputs ->
+    flows agree to float-atomic noise and the gradients in norm; repeated to shake out races."""
+    from camliflow_amd.cores import runtime
+    _, model = _models(3, 'train')
+    inputs = _to(synthetic_inputs(2, 128, 160, 4608), 'cuda')
+
+    def run():
+        model.zero_grad()
+        out = model(inputs)
+        loss = model.get_loss()
+        loss.backward()
+        torch.cuda.synchronize()
+        return out, loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    with runtime.use_backend('hip'):
+        base_out, base_loss, base_grads = run()
+        runtime.set_overlap(True)
+        try:
+            for _ in range(3):
+                out, loss, grads = run()
+                for key in ('flow_2d', 'flow_3d'):
+                    assert _epe(out[key], base_out[key]) <= 1e-5, key
+                assert abs(loss - base_loss) <= 1e-5 * max(1.0, abs(base_loss))
+                num = sum(((grads[n] - base_grads[n]).double() ** 2).sum().item() for n in grads) ** 0.5
+                den = sum((base_grads[n].double() ** 2).sum().item() for n in grads) ** 0.5
+                assert num / den < 1e-4, num / den
+        finally:
+            runtime.set_overlap(False)
