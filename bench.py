@@ -131,7 +131,7 @@ def main():
     from camliflow_amd.csrc import _lib
     _lib.load()
     runtime.set_backend('hip')
-    runtime.set_overlap(os.environ.get('CAMLI_OVERLAP', '0') == '1')
+    runtime.set_overlap(os.environ.get('CAMLI_OVERLAP', '1') == '1')
     torch.backends.cudnn.benchmark = os.environ.get('CAMLI_MIOPEN_FIND', '0') == '1'
 
     torch.manual_seed(0)
@@ -161,8 +161,11 @@ def main():
     _lib.TIMER.only = {ROOFLINE_KERNEL}
     _lib.TIMER.enabled = True
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = train_step(model, raw_model, optimizer, batch)
+        host_s += time.perf_counter() - h0
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.TIMER.enabled = False
@@ -192,7 +195,8 @@ def main():
                                    '%dx%d + %d pts, %d GRU iters, batch %d per GPU (BASELINE configs[2])'
                                    % (args.width, args.height, args.points, args.iters, args.batch),
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world,
-                       'loss': round(float(loss), 4)},
+                       'loss': round(float(loss.detach()), 4),
+                       'host_enqueue_ms_per_step': round(host_s / args.steps * 1e3, 1)},
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

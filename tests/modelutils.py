@@ -20,7 +20,7 @@ def camliraft_l_cfg(n_iters=2):
               ids=NS(enabled=True), loss=NS(gamma=0.8, order='l2-norm'))
 
 
-def hashed_fill_(module):
+def hashed_fill_(module, scale=1.0):
     """Deterministic, name-keyed parameter fill: seed = crc32(name); weights ~ N(0, 1/fan_in);
     BatchNorm running stats are filled too.  No weights are ever shipped."""
     with torch.no_grad():
@@ -40,7 +40,7 @@ def hashed_fill_(module):
                     t.copy_(torch.randn(t.shape, generator=g) * 0.1)
             else:
                 fan_in = t[0].numel()
-                t.copy_(torch.randn(t.shape, generator=g) * fan_in ** -0.5)
+                t.copy_(torch.randn(t.shape, generator=g) * fan_in ** -0.5 * scale)
     return module
 
 
@@ -78,3 +78,49 @@ def oracle_boundary():
     finally:
         for n, fn in saved.items():
             setattr(wrapper, n, fn)
+
+
+def camlipwc_cfg():
+    norm2d = NS(feature_pyramid='batch_norm', flow_estimator=None, context_network=None)
+    norm3d = NS(feature_pyramid='batch_norm', correlation=None, flow_estimator=None)
+    weights = NS(level_weights=[8, 4, 2, 1, 0.5], order='l2-norm')
+    return NS(name='camlipwc', batch_size=1, freeze_bn=False,
+              pwc2d=NS(norm=norm2d, max_displacement=4, lite_estimator=False, fixed=False),
+              pwc3d=NS(norm=norm3d, fixed=False, k=16),
+              fusion=NS(fuse_pyramid=True, fuse_correlation=True, fuse_estimator=True),
+              loss2d=weights, loss3d=weights)
+
+
+def camlipwc_l_cfg():
+    return NS(name='camlipwc_l', batch_size=1, ids=NS(enabled=True),
+              norm=NS(feature_pyramid='batch_norm', correlation=None, flow_estimator=None),
+              loss=NS(level_weights=[8, 4, 2, 1, 0.5], order='l2-norm'))
+
+
+def pwc_cfg():
+    return NS(name='pwc', batch_size=1, max_displacement=4, lite_estimator=False,
+              norm=NS(feature_pyramid='batch_norm', flow_estimator=None, context_network=None),
+              loss=NS(level_weights=[8, 4, 2, 1, 0.5], order='l2-norm'))
+
+
+def raft_cfg():
+    return NS(name='raft', batch_size=1, backbone=NS(depth=50, pretrained=None), n_iters_train=2, n_iters_eval=2,
+              loss=NS(gamma=0.8, order='l2-norm'))
+
+
+# fixture name -> (reference module, class name, cfg factory, synthetic_inputs args (b, h, w, n_points))
+MODEL_CASES = {
+    'camliraft': ('camliraft', 'CamLiRAFT', lambda: camliraft_cfg(2), (1, 128, 160, 4608)),
+    'camliraft_l': ('camliraft_l', 'CamLiRAFT_L', lambda: camliraft_l_cfg(2), (1, 128, 160, 4608)),
+    'camlipwc': ('camlipwc', 'CamLiPWC', camlipwc_cfg, (1, 128, 192, 4608)),
+    'camlipwc_l': ('camlipwc_l', 'CamLiPWC_L', camlipwc_l_cfg, (1, 128, 192, 4608)),
+    'pwc': ('pwc', 'PWC', pwc_cfg, (1, 128, 192, 4608)),
+    'raft': ('raft', 'RAFT', raft_cfg, (1, 128, 160, 4608)),
+}
+
+
+def grad_fingerprint(model, every=7):
+    """(names, L2 norms) of every `every`-th parameter gradient -- a compact backward-pass check."""
+    import numpy as np
+    named = [(n, p) for n, p in model.named_parameters() if p.grad is not None][::every]
+    return [n for n, _ in named], np.array([p.grad.double().norm().item() for _, p in named])
