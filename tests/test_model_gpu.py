@@ -132,3 +132,46 @@ def test_two_lane_stream_overlap_matches_single_stream():
                 assert num / den < 1e-4, num / den
         finally:
             runtime.set_overlap(False)
+
+
+@pytest.mark.parametrize('name', ['camlipwc', 'camlipwc_l', 'pwc', 'raft', 'camliraft_l'])
+def test_other_model_families_hip_vs_composed(name):
+    """Every model family of the reference (factory.py:21-35) through the product path vs the
+    torch-composed formulation on the same device: final flows within 1e-4 EPE, same loss."""
+    import camliflow_amd.cores as cores
+    from camliflow_amd.cores import runtime
+    from modelutils import MODEL_CASES
+    _, cls, cfg_fn, shape = MODEL_CASES[name]
+    torch.manual_seed(0)
+    model = hashed_fill_(getattr(cores, cls)(cfg_fn()), scale=0.5).cuda().train()
+    inputs = _to(synthetic_inputs(*shape), 'cuda')
+    res = {}
+    for backend in ('hip', 'composed'):
+        with runtime.use_backend(backend):
+            model.zero_grad()
+            out = model(inputs)
+            loss = model.get_loss()
+            loss.backward()
+            res[backend] = (out, loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    (oh, lh, gh), (oc, lc, gc) = res['hip'], res['composed']
+    for key in oh:
+        assert _epe(oh[key], oc[key]) <= 1e-4, key
+    assert abs(lh - lc) <= 1e-4 * max(1.0, abs(lc))
+    num = sum(((gh[n] - gc[n]).double() ** 2).sum().item() for n in gh) ** 0.5
+    den = sum((gc[n].double() ** 2).sum().item() for n in gh) ** 0.5
+    assert num / den < 1e-3, num / den
+
+
+def test_camlipwc_config2_shape_runs():
+    """BASELINE configs[1]: CamLiPWC 960x540 + 8192 points, fp32, batch 1 (forward + backward)."""
+    import camliflow_amd.cores as cores
+    from camliflow_amd.cores import runtime
+    from modelutils import camlipwc_cfg
+    torch.manual_seed(0)
+    model = cores.CamLiPWC(camlipwc_cfg()).cuda().train()
+    inputs = _to(synthetic_inputs(1, 540, 960, 8192), 'cuda')
+    with runtime.use_backend('hip'):
+        out = model(inputs)
+        model.get_loss().backward()
+    assert out['flow_2d'].shape == (1, 2, 540, 960) and out['flow_3d'].shape == (1, 3, 8192)
+    assert torch.isfinite(out['flow_2d']).all() and torch.isfinite(out['flow_3d']).all()
