@@ -23,9 +23,11 @@ PROTOTYPES = {
     "camli_allpairs_lookup_bwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                          _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_pointconv_dw_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p, ctypes.c_void_p,
-                                      _int, _int, _int, _int, _int, _stream]),
-    "camli_pointconv_dw_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, ctypes.c_void_p, _c_float_p,
-                                      _c_float_p, _int, _int, _int, _int, _int, _stream]),
+                                      _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _int, _stream]),
+    "camli_pointconv_dw_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p,
+                                      _int, _int, _int, _int, _stream]),
+    "camli_pointconv_dw_expand": (_int, [ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
+                                         _int, _int, _int, _int, _stream]),
     "camli_gather_cf_fwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_gather_cf_bwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_knn_interp_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p,

@@ -133,14 +133,15 @@ class SharedSetConvWeights:
     fixed across the GRU iterations: models/camliraft_core.py:88,119,127,140).
 
     Autograd: ``weight`` enters a ``_ShareWeights`` node that hands out a 1-element token.  Every
-    fused call depends on the token and ADDS its (one-slot-per-row) weight gradient into one
-    persistent buffer; the node's backward returns that buffer as the gradient of ``weight``, so
+    fused call depends on the token; its backward leaves a COMPACT record (one value + one slot per
+    output element, because max() passes gradient to a single neighbour).  The node's backward
+    expands the records of all calls into the dense weight gradient in one pass and returns it, so
     ``weight_net`` is differentiated once per pass instead of once per iteration.
     """
 
     def __init__(self, weight):
         self.weight = weight.detach().contiguous()
-        self.grad = None
+        self.records = []          # [(gwsel [B,C,N] fp32, arg [B,C,N] uint8)] appended by the backward calls
         self.token = _ShareWeights.apply(weight, self)
 
 
@@ -152,10 +153,24 @@ class _ShareWeights(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _gtoken):
+        lib = _lib.load()
         shared = ctx.shared
-        grad, shared.grad = shared.grad, None
-        if grad is None:
-            grad = torch.zeros_like(shared.weight)
+        records, shared.records = shared.records, []
+        weight = shared.weight
+        if not records:
+            return torch.zeros_like(weight), None
+        b, c, n, k = weight.shape
+        grad = torch.empty_like(weight)
+        with torch.cuda.device(weight.device):
+            for start in range(0, len(records), 64):       # the kernel takes <= 64 calls at a time
+                chunk = records[start:start + 64]
+                part = grad if start == 0 else torch.empty_like(weight)
+                gptrs = (ctypes.c_void_p * len(chunk))(*[g.data_ptr() for g, _ in chunk])
+                aptrs = (ctypes.c_void_p * len(chunk))(*[a.data_ptr() for _, a in chunk])
+                _lib.launch('camli_pointconv_dw_expand', lib.camli_pointconv_dw_expand, gptrs, aptrs, len(chunk),
+                            part.data_ptr(), b, c, n, k, _stream_ptr(weight))
+                if start:
+                    grad += part
         return grad, None
 
 
@@ -168,30 +183,34 @@ class _PointConvDW(torch.autograd.Function):
         n = weight.shape[2]
         out = torch.empty((b, c, n), dtype=torch.float32, device=feat.device)
         arg = torch.empty((b, c, n), dtype=torch.uint8, device=feat.device)
+        need_grad = torch.is_grad_enabled() and (feat.requires_grad or token.requires_grad)
+        wsel = torch.empty((b, c, n), dtype=torch.float32, device=feat.device) if need_grad else None
+        msel = torch.empty((b, c, n), dtype=torch.int32, device=feat.device) if need_grad else None
         with torch.cuda.device(feat.device):
             _lib.launch('camli_pointconv_dw_fwd', lib.camli_pointconv_dw_fwd, feat.data_ptr(), weight.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), out.data_ptr(), arg.data_ptr(),
+                        wsel.data_ptr() if need_grad else None, msel.data_ptr() if need_grad else None,
                         b, c, m, n, k, _stream_ptr(feat))
-        ctx.save_for_backward(feat, knn_indices, arg)
-        ctx.shared, ctx.k = shared, k
+        if need_grad:
+            ctx.save_for_backward(feat, wsel, msel, arg)
+        ctx.shared = shared
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.load()
-        feat, knn_indices, arg = ctx.saved_tensors
+        feat, wsel, msel, arg = ctx.saved_tensors
         shared = ctx.shared
         b, c, m = feat.shape
-        n = shared.weight.shape[2]
+        n = wsel.shape[2]
         gout = gout.contiguous().float()
         gfeat = torch.zeros_like(feat) if ctx.needs_input_grad[0] else None
-        if shared.grad is None:
-            shared.grad = torch.zeros_like(shared.weight)
+        gwsel = torch.empty_like(wsel)
         with torch.cuda.device(feat.device):
             _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd, gout.data_ptr(), feat.data_ptr(),
-                        shared.weight.data_ptr(), knn_indices.data_ptr(), knn_indices.stride(1), arg.data_ptr(),
-                        gfeat.data_ptr() if gfeat is not None else None, shared.grad.data_ptr(),
-                        b, c, m, n, ctx.k, _stream_ptr(feat))
+                        wsel.data_ptr(), msel.data_ptr(), gfeat.data_ptr() if gfeat is not None else None,
+                        gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat))
+        shared.records.append((gwsel, arg))
         return gfeat, gout.new_zeros(1), None, None, None
 
 

@@ -60,10 +60,13 @@ struct __attribute__((aligned(16))) FpsSlot {
 // point i = j*1024 + tid  (j = register slot).  Slots past N carry dist = -1 bits?  No: keys are
 // compared as unsigned, so padding points use key 0 with index 0xffffffff and can only win when
 // every real distance is 0 too, in which case the index min still prefers a real point.
-template <int P>
+template <int P, bool PICKS_IN_LDS>
 __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz_all,
                                                            int64_t* __restrict__ out_all, int N, int n_samples) {
     __shared__ FpsSlot slots[2][FPS_WAVES];
+    // picks are collected in LDS and written once at the end: a global store inside the step loop
+    // drags an `s_waitcnt vmcnt(0)` (store round trip to L2) into every one of the n_samples steps
+    extern __shared__ int picks[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
@@ -86,7 +89,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
 
     for (int s = 0; s < n_samples; ++s) {
-        if (tid == 0) out[s] = (int64_t)cur;
+        if (tid == 0) {
+            if (PICKS_IN_LDS) picks[s] = cur; else out[s] = (int64_t)cur;
+        }
         if (s == n_samples - 1) break;
 
         // ---- register update + thread-local arg-max (lowest slot wins ties: strict >) ----
@@ -148,11 +153,19 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
         cy = win->y;
         cz = win->z;
     }
+    if (PICKS_IN_LDS) {
+        __syncthreads();
+        for (int s = tid; s < n_samples; s += FPS_THREADS) out[s] = (int64_t)picks[s];
+    }
 }
 
 template <int P>
 int launch_fps(const float* xyz, int64_t* out, int B, int N, int n_samples, hipStream_t stream) {
-    hipLaunchKernelGGL((fps_kernel<P>), dim3(B), dim3(FPS_THREADS), 0, stream, xyz, out, N, n_samples);
+    const size_t pick_bytes = (size_t)n_samples * sizeof(int);
+    if (pick_bytes <= 96 * 1024)
+        hipLaunchKernelGGL((fps_kernel<P, true>), dim3(B), dim3(FPS_THREADS), pick_bytes, stream, xyz, out, N, n_samples);
+    else
+        hipLaunchKernelGGL((fps_kernel<P, false>), dim3(B), dim3(FPS_THREADS), 0, stream, xyz, out, N, n_samples);
     return camli_check_launch("camli_fps");
 }
 

@@ -64,18 +64,31 @@ __global__ __launch_bounds__(64) void allpairs_lookup_kernel(LookupLevels lv, co
     float* __restrict__ chan = io + ((size_t)b * L + l) * DD * DD * plane + p;   // + t*plane per tap
 
     if (!BACKWARD) {
-        // ---- stage the 64 windows: lanes run along the window elements ----
-        for (int pp = 0; pp < npix; ++pp) {
-            const int sx = __shfl(x0, pp, 64), sy = __shfl(y0, pp, 64);
-            const float* __restrict__ src = vol + (size_t)pp * hl * wl;
+        // ---- stage the 64 windows: lanes run along the window elements; U windows (2U loads) are
+        // put in flight before any is written to LDS -- the kernel is latency-bound otherwise ----
+        constexpr int U = 16;
+        for (int pp0 = 0; pp0 < npix; pp0 += U) {
+            float v[U][2];
 #pragma unroll
-            for (int e0 = 0; e0 < WE; e0 += 64) {
-                const int e = e0 + lane;
-                if (e < WE) {
+            for (int u = 0; u < U; ++u) {
+                const int pp = min(pp0 + u, npix - 1);
+                const int sx = __shfl(x0, pp, 64), sy = __shfl(y0, pp, 64);
+                const float* __restrict__ src = vol + (size_t)pp * hl * wl;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = h * 64 + lane;
                     const int r = e / WN, c = e - r * WN;
                     const int gy = sy + r, gx = sx + c;
-                    const bool in = (gx >= 0) & (gx < wl) & (gy >= 0) & (gy < hl);
-                    win[pp * LD + e] = in ? src[gy * wl + gx] : 0.0f;
+                    const bool in = (e < WE) & (gx >= 0) & (gx < wl) & (gy >= 0) & (gy < hl);
+                    v[u][h] = in ? src[gy * wl + gx] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pp = pp0 + u;
+                if (pp < npix) {
+                    win[pp * LD + lane] = v[u][0];
+                    if (lane + 64 < WE) win[pp * LD + 64 + lane] = v[u][1];
                 }
             }
         }
@@ -122,18 +135,33 @@ __global__ __launch_bounds__(64) void allpairs_lookup_kernel(LookupLevels lv, co
 #pragma unroll
             for (int c = 0; c < WN; ++c) win[lane * LD + r * WN + c] = g[r][c];
         __syncthreads();
-        // ---- add each window into the gradient volume (disjoint per source pixel: plain RMW) ----
-        for (int pp = 0; pp < npix; ++pp) {
-            const int sx = __shfl(x0, pp, 64), sy = __shfl(y0, pp, 64);
-            float* __restrict__ dst = vol + (size_t)pp * hl * wl;
+        // ---- add each window into the gradient volume (disjoint per source pixel: plain RMW);
+        // U windows' loads are issued before the first add/store ----
+        constexpr int U = 8;
+        for (int pp0 = 0; pp0 < npix; pp0 += U) {
+            float v[U][2];
+            int off[U][2];
 #pragma unroll
-            for (int e0 = 0; e0 < WE; e0 += 64) {
-                const int e = e0 + lane;
-                if (e < WE) {
+            for (int u = 0; u < U; ++u) {
+                const int pp = pp0 + u;
+                const int ppc = min(pp, npix - 1);
+                const int sx = __shfl(x0, ppc, 64), sy = __shfl(y0, ppc, 64);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = h * 64 + lane;
                     const int r = e / WN, c = e - r * WN;
                     const int gy = sy + r, gx = sx + c;
-                    if ((gx >= 0) & (gx < wl) & (gy >= 0) & (gy < hl)) dst[gy * wl + gx] += win[pp * LD + e];
+                    const bool in = (pp < npix) & (e < WE) & (gx >= 0) & (gx < wl) & (gy >= 0) & (gy < hl);
+                    off[u][h] = in ? (ppc * hl + gy) * wl + gx : -1;
+                    v[u][h] = in ? vol[off[u][h]] : 0.0f;
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ppc = min(pp0 + u, npix - 1);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    if (off[u][h] >= 0) vol[off[u][h]] = v[u][h] + win[ppc * LD + h * 64 + lane];
             }
         }
     }

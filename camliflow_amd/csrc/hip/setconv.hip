@@ -28,8 +28,9 @@ __global__ __launch_bounds__(256) void pointconv_dw_fwd_kernel(const float* __re
                                                                 const float* __restrict__ weight,
                                                                 const int64_t* __restrict__ idx, int idx_stride,
                                                                 float* __restrict__ out,
-                                                                unsigned char* __restrict__ arg, int C, int M,
-                                                                int N, int k_rt) {
+                                                                unsigned char* __restrict__ arg,
+                                                                float* __restrict__ wsel, int* __restrict__ msel,
+                                                                int C, int M, int N, int k_rt) {
     const int k = K > 0 ? K : k_rt;
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int c0 = (blockIdx.y * SC_CGRP + (threadIdx.x >> 6)) * SC_CPT;
@@ -86,40 +87,70 @@ __global__ __launch_bounds__(256) void pointconv_dw_fwd_kernel(const float* __re
             const size_t o = ((size_t)b * C + c0 + u) * N + n;
             out[o] = best[u];
             arg[o] = (unsigned char)barg[u];
+            if (wsel) {   // compact record for the adjoint: the winning weight and neighbour
+                wsel[o] = wrow[u][barg[u]];
+                msel[o] = (int)irow[barg[u]];
+            }
         }
     }
 }
 
-// thread = (b, c, n), n fastest
+// Adjoint, compact form.  thread = (b, c, n), n fastest: everything it touches except the feature
+// row is a coalesced [B,C,N] stream.
+//   gfeat[b,c,msel] += gout * wsel          (float atomic; rows of M floats stay in L2)
+//   gwsel[b,c,n]     = gout * feat[b,c,msel] (the ONE non-zero of d/dweight[b,c,n,:], at slot arg)
 __global__ __launch_bounds__(256) void pointconv_dw_bwd_kernel(const float* __restrict__ gout,
                                                                 const float* __restrict__ feat,
-                                                                const float* __restrict__ weight,
-                                                                const int64_t* __restrict__ idx, int idx_stride,
-                                                                const unsigned char* __restrict__ arg,
-                                                                float* __restrict__ gfeat, float* __restrict__ gweight,
-                                                                int B, int C, int M, int N, int k) {
-    const size_t total = (size_t)B * C * N;
+                                                                const float* __restrict__ wsel,
+                                                                const int* __restrict__ msel,
+                                                                float* __restrict__ gfeat, float* __restrict__ gwsel,
+                                                                size_t total, int M, int N) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int n = (int)(e % N);
         const size_t bc = e / N;
-        const int b = (int)(bc / C);
         const float g = gout[e];
-        const int j = arg[e];
-        const int m = (int)idx[((size_t)b * N + n) * idx_stride + j];
-        const size_t wpos = e * (size_t)k + j;
-        const float w = weight[wpos];
-        const float f = feat[bc * M + m];
-        if (gfeat) unsafeAtomicAdd(gfeat + bc * M + m, g * w);
-        if (gweight) gweight[wpos] += g * f;
+        const int m = msel[e];
+        if (gwsel) gwsel[e] = g * feat[bc * M + m];
+        if (gfeat) unsafeAtomicAdd(gfeat + bc * M + m, g * wsel[e]);
+    }
+}
+
+// Dense weight gradient of one pass from the compact records of all its calls:
+//   gweight[b,c,n,j] = sum_i [arg_i[b,c,n] == j] * gwsel_i[b,c,n]
+// block = 256 consecutive (b,c,n) rows = one contiguous 256*k tile of gweight; rows are accumulated
+// in LDS (stride k+1: conflict-free) and the tile is written once, fully coalesced.
+constexpr int EX_MAX_CALLS = 64;
+struct ExpandCalls {
+    const float* gwsel[EX_MAX_CALLS];
+    const unsigned char* arg[EX_MAX_CALLS];
+};
+
+__global__ __launch_bounds__(256) void pointconv_dw_expand_kernel(ExpandCalls calls, int n_calls,
+                                                                   float* __restrict__ gweight, size_t rows, int k) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [256][k+1]
+    const int ld = k + 1;
+    const size_t row0 = (size_t)blockIdx.x * 256;
+    const size_t row = row0 + threadIdx.x;
+    float* mine = tile + threadIdx.x * ld;
+    for (int j = 0; j < k; ++j) mine[j] = 0.0f;
+    if (row < rows) {
+        for (int i = 0; i < n_calls; ++i) mine[calls.arg[i][row]] += calls.gwsel[i][row];
+    }
+    __syncthreads();
+    const size_t nrows = rows - row0 < 256 ? rows - row0 : 256;
+    const size_t count = nrows * (size_t)k;
+    float* __restrict__ dst = gweight + row0 * (size_t)k;
+    for (size_t e = threadIdx.x; e < count; e += 256) {
+        const int r = (int)(e / k), j = (int)(e - (size_t)r * k);
+        dst[e] = tile[r * ld + j];
     }
 }
 
 }  // namespace
 
 extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, const int64_t* idx, int idx_stride,
-                                      float* out, unsigned char* arg, int B, int C, int M, int N, int k,
-                                      void* stream) {
-    if (!feat || !weight || !idx || !out || !arg) {
+                                      float* out, unsigned char* arg, float* wsel, int* msel, int B, int C, int M,
+                                      int N, int k, void* stream) {
+    if (!feat || !weight || !idx || !out || !arg || ((wsel == nullptr) != (msel == nullptr))) {
         camli_set_error("camli_pointconv_dw_fwd: null pointer");
         return CAMLI_EINVAL;
     }
@@ -133,7 +164,7 @@ extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, co
     dim3 grid(camli_divup(N, 64), camli_divup(C, SC_CPT * SC_CGRP), B);
 #define CAMLI_DW_LAUNCH(KK)                                                                                    \
     hipLaunchKernelGGL((pointconv_dw_fwd_kernel<KK>), grid, dim3(256), 0, s, feat, weight, idx, idx_stride, out, \
-                       arg, C, M, N, k)
+                       arg, wsel, msel, C, M, N, k)
     switch (k) {
         case 4: CAMLI_DW_LAUNCH(4); break;
         case 8: CAMLI_DW_LAUNCH(8); break;
@@ -145,21 +176,48 @@ extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, co
     return camli_check_launch("camli_pointconv_dw_fwd");
 }
 
-extern "C" int camli_pointconv_dw_bwd(const float* gout, const float* feat, const float* weight, const int64_t* idx,
-                                      int idx_stride, const unsigned char* arg, float* gfeat, float* gweight, int B,
-                                      int C, int M, int N, int k, void* stream) {
-    if (!gout || !feat || !weight || !idx || !arg || (!gfeat && !gweight)) {
+extern "C" int camli_pointconv_dw_bwd(const float* gout, const float* feat, const float* wsel, const int* msel,
+                                      float* gfeat, float* gwsel, int B, int C, int M, int N, void* stream) {
+    if (!gout || !feat || !wsel || !msel || (!gfeat && !gwsel)) {
         camli_set_error("camli_pointconv_dw_bwd: null pointer");
         return CAMLI_EINVAL;
     }
-    if (B < 0 || C < 1 || M < 1 || N < 1 || k < 1 || k > 255 || idx_stride < k) {
-        camli_set_error("camli_pointconv_dw_bwd: bad shape B=%d C=%d M=%d N=%d k=%d", B, C, M, N, k);
+    if (B < 0 || C < 1 || M < 1 || N < 1) {
+        camli_set_error("camli_pointconv_dw_bwd: bad shape B=%d C=%d M=%d N=%d", B, C, M, N);
         return CAMLI_EINVAL;
     }
     if (B == 0) return CAMLI_OK;
     const size_t total = (size_t)B * C * N;
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(pointconv_dw_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gout,
-                       feat, weight, idx, idx_stride, arg, gfeat, gweight, B, C, M, N, k);
+                       feat, wsel, msel, gfeat, gwsel, total, M, N);
     return camli_check_launch("camli_pointconv_dw_bwd");
+}
+
+extern "C" int camli_pointconv_dw_expand(const float* const* gwsel_list, const unsigned char* const* arg_list,
+                                         int n_calls, float* gweight, int B, int C, int N, int k, void* stream) {
+    if (!gwsel_list || !arg_list || !gweight) {
+        camli_set_error("camli_pointconv_dw_expand: null pointer");
+        return CAMLI_EINVAL;
+    }
+    if (n_calls < 0 || n_calls > EX_MAX_CALLS || B < 0 || C < 1 || N < 1 || k < 1 || k > 255) {
+        camli_set_error("camli_pointconv_dw_expand: bad arguments n_calls=%d (max %d) B=%d C=%d N=%d k=%d", n_calls,
+                        EX_MAX_CALLS, B, C, N, k);
+        return CAMLI_EINVAL;
+    }
+    if (B == 0) return CAMLI_OK;
+    ExpandCalls calls;
+    for (int i = 0; i < n_calls; ++i) {
+        if (!gwsel_list[i] || !arg_list[i]) {
+            camli_set_error("camli_pointconv_dw_expand: call %d has a null record", i);
+            return CAMLI_EINVAL;
+        }
+        calls.gwsel[i] = gwsel_list[i];
+        calls.arg[i] = arg_list[i];
+    }
+    const size_t rows = (size_t)B * C * N;
+    const size_t lds = (size_t)256 * (k + 1) * sizeof(float);
+    hipLaunchKernelGGL(pointconv_dw_expand_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), lds,
+                       reinterpret_cast<hipStream_t>(stream), calls, n_calls, gweight, rows, k);
+    return camli_check_launch("camli_pointconv_dw_expand");
 }

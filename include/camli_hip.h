@@ -87,15 +87,21 @@ int camli_allpairs_lookup_bwd(float *const *gvols, const int *hs, const int *ws,
  * gather * weight_net(...) -> max, models/point_conv.py:122-128).
  *   feat [B,C,M]; weight [B,C,N,k]; idx int64, row n of batch b at idx + (b*N+n)*idx_stride, first k
  *   entries used (lets a wider precomputed KNN tensor be sliced without a copy, point_conv.py:116-120)
- *   out [B,C,N] = max_j feat[b,c,idx[b,n,j]] * weight[b,c,n,j]; arg uint8 [B,C,N] = first arg-max j.
- *   bwd: gfeat [B,C,M] += (float atomics), gweight [B,C,N,k] += at the arg-max slot only; both
- *   buffers are caller-zeroed and may be NULL (skipped).  k <= 255.
+ *   out [B,C,N] = max_j feat[b,c,idx[b,n,j]] * weight[b,c,n,j]; arg uint8 [B,C,N] = first arg-max j;
+ *   optional compact record for the adjoint: wsel [B,C,N] = weight at arg, msel int32 [B,C,N] = idx at
+ *   arg (both or neither).  k <= 255.
+ *   bwd (from the compact record): gfeat [B,C,M] += gout*wsel (float atomics, caller zero-fills; may be
+ *   NULL), gwsel [B,C,N] = gout*feat[msel] (fully written; may be NULL).
+ *   expand: dense gweight [B,C,N,k] (fully written) = sum over the n_calls <= 64 calls of one pass of
+ *   one-hot(arg_i) * gwsel_i; gwsel_list / arg_list are HOST arrays of device pointers.
  */
 int camli_pointconv_dw_fwd(const float *feat, const float *weight, const int64_t *idx, int idx_stride,
-                           float *out, unsigned char *arg, int B, int C, int M, int N, int k, void *stream);
-int camli_pointconv_dw_bwd(const float *gout, const float *feat, const float *weight, const int64_t *idx,
-                           int idx_stride, const unsigned char *arg, float *gfeat, float *gweight,
+                           float *out, unsigned char *arg, float *wsel, int *msel,
                            int B, int C, int M, int N, int k, void *stream);
+int camli_pointconv_dw_bwd(const float *gout, const float *feat, const float *wsel, const int *msel,
+                           float *gfeat, float *gwsel, int B, int C, int M, int N, void *stream);
+int camli_pointconv_dw_expand(const float *const *gwsel_list, const unsigned char *const *arg_list, int n_calls,
+                              float *gweight, int B, int C, int N, int k, void *stream);
 
 /*
  * batch_indexing, channel-first (models/utils.py:61-83): out[b,c,i] = data[b,c,idx[b,i]].

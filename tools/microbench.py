@@ -50,5 +50,49 @@ def main():
         print('%-44s %10.1f %10.1f GB/s' % ('corr2d bwd B%d C%d %dx%d' % (b, c, h, w), us, byt / us / 1e3))
 
 
+def composite():
+    from camliflow_amd.csrc import fused
+    g = torch.Generator(device='cpu').manual_seed(0)
+    print('--- composite ops (config-3 shapes, batch 8)')
+    b, h, w = 8, 68, 120
+    p = h * w
+    pyr = fused.AllPairsPyramid()
+    pyr.levels = [torch.randn(b * p, h >> l, w >> l, device='cuda') for l in range(4)]
+    pyr.shape = (b, h, w)
+    pyr.token = torch.zeros(1, device='cuda', requires_grad=True)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    coords = (torch.stack([xs, ys])[None].repeat(b, 1, 1, 1) + torch.randn(b, 2, h, w, generator=g) * 3).cuda()
+    us = timeit(lambda: fused.allpairs_lookup(pyr, coords, 4))
+    byt = 4 * b * p * (4 * 81 + 4 * 100 + 2)
+    print('%-44s %10.1f %10.1f GB/s' % ('allpairs lookup fwd', us, byt / us / 1e3))
+    out = fused.allpairs_lookup(pyr, coords, 4)
+    go = torch.randn_like(out)
+    pyr.grads = [torch.zeros_like(l) for l in pyr.levels]
+    us = timeit(lambda: torch.autograd.grad(out, pyr.token, go, retain_graph=True))
+    byt = 4 * b * p * (4 * 81 + 2 * 4 * 100 + 2)
+    print('%-44s %10.1f %10.1f GB/s' % ('allpairs lookup bwd', us, byt / us / 1e3))
+    for (c, k) in [(128, 32), (128, 16), (128, 4), (32, 32)]:
+        n = 2048
+        feat = torch.randn(b, c, n, device='cuda', requires_grad=True)
+        wgt = torch.rand(b, c, n, k, device='cuda', requires_grad=True)
+        idx = torch.randint(0, n, (b, n, 32), device='cuda')
+        shared = fused.SharedSetConvWeights(wgt)
+        us = timeit(lambda: fused.pointconv_dw(feat, shared, idx, k))
+        byt = 4 * b * c * n * k + 4 * b * c * n * 3
+        print('%-44s %10.1f %10.1f GB/s' % ('pointconv_dw fwd C%d k%d' % (c, k), us, byt / us / 1e3))
+        o = fused.pointconv_dw(feat, shared, idx, k)
+        go = torch.randn_like(o)
+        def bwd():
+            shared.records = []
+            torch.autograd.grad(o, feat, go, retain_graph=True)
+        us = timeit(bwd)
+        byt = b * c * n * 28
+        print('%-44s %10.1f %10.1f GB/s' % ('pointconv_dw bwd C%d k%d' % (c, k), us, byt / us / 1e3))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'composite':
+        composite()
+    else:
+        main()
+        composite()
