@@ -183,7 +183,7 @@ class _PointConvDW(torch.autograd.Function):
         n = weight.shape[2]
         out = torch.empty((b, c, n), dtype=torch.float32, device=feat.device)
         arg = torch.empty((b, c, n), dtype=torch.uint8, device=feat.device)
-        need_grad = torch.is_grad_enabled() and (feat.requires_grad or token.requires_grad)
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]   # grad mode is off inside forward()
         wsel = torch.empty((b, c, n), dtype=torch.float32, device=feat.device) if need_grad else None
         msel = torch.empty((b, c, n), dtype=torch.int32, device=feat.device) if need_grad else None
         with torch.cuda.device(feat.device):

@@ -7,20 +7,27 @@
 // the LOWEST index among equal maxima.
 //
 // Design (CDNA4): the algorithm is a chain of n_samples dependent steps, so the only lever is
-// the latency of one step.  One 1024-thread workgroup (16 waves, one CU) owns a cloud; every
-// thread keeps P = ceil(N/1024) points AND their running distances in VGPRs for the whole kernel
-// (no memory traffic inside the loop: the algorithmic traffic is one read of the cloud and one
-// write of the indices).  Per step: register update + thread-local arg-max, wave arg-max with
-// DPP / permlane-swap (no LDS), one LDS slot per wave carrying (dist, index, xyz of the wave's
-// winner), ONE barrier (slots are double-buffered by step parity), then every wave re-reduces
-// the 16 slots itself.  Distances are non-negative, so their fp32 bit patterns order like
-// unsigned integers and the reductions run as u32 max / u32 min.
+// the latency of one step, and on one CU that latency is instruction issue: (update + reductions)
+// x resident waves.  One workgroup (one CU) owns a cloud; every thread keeps P = ceil(N/T) points
+// AND their running distances in VGPRs for the whole kernel (no memory traffic inside the loop:
+// the algorithmic traffic is one read of the cloud and one write of the indices).  T = 256 or 512
+// threads (1-2 waves per SIMD): the per-wave reduction overhead is paid 4-8 times per step instead
+// of 16, which measured 2x faster than a 1024-thread block.  Per step:
+//   * register update + thread-local arg-max (packed fp32 math)
+//   * wave all-max of the distance bits with DPP + permlane-swap (no LDS); the winning lane is
+//     found with ONE ballot -- a unique maximum is the common case, ties take a min-index reduce
+//   * one 8-byte LDS slot per wave, ONE barrier (slots double-buffered by step parity), then
+//     every wave re-reduces the <= 8 slots itself
+//   * the new centre's coordinates come from an LDS copy of the cloud (one broadcast ds_read)
+//     when it fits, otherwise from the owner lane through the slot
+// Distances are non-negative, so their fp32 bit patterns order like unsigned integers.
+// Picks are collected in LDS and written once at the end.
 #include "camli_common.h"
+
+#include <stdlib.h>
 
 namespace {
 
-constexpr int FPS_THREADS = 1024;
-constexpr int FPS_WAVES = FPS_THREADS / 64;
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
@@ -53,20 +60,34 @@ __device__ __forceinline__ unsigned wave_allmin_u32(unsigned v) {
 struct __attribute__((aligned(16))) FpsSlot {
     unsigned key;  // fp32 bits of the wave's max distance
     unsigned idx;  // lowest point index attaining it
-    float x, y, z;
+    float x, y, z; // its coordinates (only used when the cloud does not fit in LDS)
     unsigned pad[3];
 };
 
-// point i = j*1024 + tid  (j = register slot).  Slots past N carry dist = -1 bits?  No: keys are
-// compared as unsigned, so padding points use key 0 with index 0xffffffff and can only win when
-// every real distance is 0 too, in which case the index min still prefers a real point.
-template <int P, bool PICKS_IN_LDS>
-__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restrict__ xyz_all,
-                                                           int64_t* __restrict__ out_all, int N, int n_samples) {
-    __shared__ FpsSlot slots[2][FPS_WAVES];
-    // picks are collected in LDS and written once at the end: a global store inside the step loop
-    // drags an `s_waitcnt vmcnt(0)` (store round trip to L2) into every one of the n_samples steps
-    extern __shared__ int picks[];
+constexpr unsigned FPS_NOIDX = 0xffffffffu;
+
+// (max key, lowest index among the lanes holding it) over the wave, result in every lane.
+__device__ __forceinline__ void wave_argmax(unsigned key, unsigned idx, unsigned& out_key, unsigned& out_idx) {
+    out_key = wave_allmax_u32(key);
+    const unsigned long long hit = __ballot(key == out_key);
+    if (__builtin_popcountll(hit) == 1) {      // wave-uniform branch; unique maximum: no second reduction
+        out_idx = (unsigned)__shfl((int)idx, (int)__builtin_ctzll(hit), 64);
+    } else {
+        out_idx = wave_allmin_u32(key == out_key ? idx : FPS_NOIDX);
+    }
+}
+
+// point i = j*T + tid (j = register slot).  Padding slots (i >= N) hold distance -1 forever and
+// report key 0 / index FPS_NOIDX, so they lose against any real point.
+// dynamic LDS: picks[n_samples] ints, then (LDS_COORDS) the cloud as 3 float planes of N.
+template <int P, int T, bool LDS_COORDS>
+__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz_all, int64_t* __restrict__ out_all,
+                                                 int N, int n_samples) {
+    constexpr int NW = T / 64;
+    __shared__ FpsSlot slots[2][NW];
+    extern __shared__ __attribute__((aligned(16))) int dyn[];
+    int* picks = dyn;
+    float* tab = reinterpret_cast<float*>(dyn + ((n_samples + 3) & ~3));   // x[N], y[N], z[N]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
@@ -76,22 +97,25 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
     float px[P], py[P], pz[P], dist[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-        int i = j * FPS_THREADS + tid;
-        bool ok = i < N;
-        int ic = ok ? i : 0;
+        const int i = j * T + tid;
+        const bool ok = i < N;
+        const int ic = ok ? i : 0;
         px[j] = xyz[ic * 3 + 0];
         py[j] = xyz[ic * 3 + 1];
         pz[j] = xyz[ic * 3 + 2];
-        dist[j] = ok ? 1e10f : -1.0f;  // negative: never updated upward, never selected (see below)
+        dist[j] = ok ? 1e10f : -1.0f;
+        if (LDS_COORDS && ok) {
+            tab[i] = px[j];
+            tab[N + i] = py[j];
+            tab[2 * N + i] = pz[j];
+        }
     }
-
     int cur = 0;
     float cx = xyz[0], cy = xyz[1], cz = xyz[2];
+    if (LDS_COORDS) __syncthreads();
 
     for (int s = 0; s < n_samples; ++s) {
-        if (tid == 0) {
-            if (PICKS_IN_LDS) picks[s] = cur; else out[s] = (int64_t)cur;
-        }
+        if (tid == 0) picks[s] = cur;
         if (s == n_samples - 1) break;
 
         // ---- register update + thread-local arg-max (lowest slot wins ties: strict >) ----
@@ -99,73 +123,84 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
         int bj = 0;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
-            float d = dx * dx + dy * dy + dz * dz;
-            float nd = fminf(dist[j], d);
+            const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+            const float d = dx * dx + dy * dy + dz * dz;
+            const float nd = fminf(dist[j], d);
             dist[j] = nd;
-            bool gt = nd > best;
+            const bool gt = nd > best;
             best = gt ? nd : best;
             bj = gt ? j : bj;
         }
-        // padding points hold -1 forever (min(-1, d) = -1); a thread with only padding reports
-        // best = -1 -> clamp to key 0 / index max so it cannot beat a real point
         const bool real = best >= 0.0f;
         const unsigned key = real ? __float_as_uint(best) : 0u;
-        const unsigned bi = real ? (unsigned)(bj * FPS_THREADS + tid) : 0xffffffffu;
+        const unsigned bi = real ? (unsigned)(bj * T + tid) : FPS_NOIDX;
 
-        // ---- wave arg-max ----
-        const unsigned wkey = wave_allmax_u32(key);
-        const unsigned widx = wave_allmin_u32(key == wkey ? bi : 0xffffffffu);
-        if (bi == widx && widx != 0xffffffffu) {
-            // exactly one lane: the owner of the wave's winner publishes its coordinates
-            float ox = px[0], oy = py[0], oz = pz[0];
+        // ---- wave arg-max, one slot per wave ----
+        unsigned wkey, widx;
+        wave_argmax(key, bi, wkey, widx);
+        FpsSlot& mine = slots[s & 1][w];
+        if (LDS_COORDS) {
+            if (lane == 0) {
+                mine.key = wkey;
+                mine.idx = widx;
+            }
+        } else if (bi == widx && widx != FPS_NOIDX) {
+            float ox = px[0], oy = py[0], oz = pz[0];   // the owner lane publishes the coordinates
 #pragma unroll
             for (int j = 1; j < P; ++j) {
-                bool m = bj == j;
+                const bool m = bj == j;
                 ox = m ? px[j] : ox;
                 oy = m ? py[j] : oy;
                 oz = m ? pz[j] : oz;
             }
-            FpsSlot& sl = slots[s & 1][w];
-            sl.key = wkey;
-            sl.idx = widx;
-            sl.x = ox;
-            sl.y = oy;
-            sl.z = oz;
-        } else if (lane == 0 && widx == 0xffffffffu) {
-            FpsSlot& sl = slots[s & 1][w];
-            sl.key = 0u;
-            sl.idx = 0xffffffffu;
+            mine.key = wkey;
+            mine.idx = widx;
+            mine.x = ox;
+            mine.y = oy;
+            mine.z = oz;
+        } else if (lane == 0 && widx == FPS_NOIDX) {
+            mine.key = 0u;
+            mine.idx = FPS_NOIDX;
         }
         __syncthreads();
 
-        // ---- every wave reduces the 16 slots on its own (no second barrier) ----
-        const FpsSlot* sp = &slots[s & 1][lane & (FPS_WAVES - 1)];
-        const unsigned k2 = sp->key;
-        const unsigned i2 = sp->idx;
-        const unsigned gkey = wave_allmax_u32(k2);
-        const unsigned gidx = wave_allmin_u32(k2 == gkey ? i2 : 0xffffffffu);
-        const unsigned long long hit = __ballot(k2 == gkey && i2 == gidx);
-        const int wsel = __builtin_ctzll(hit) & (FPS_WAVES - 1);
-        const FpsSlot* win = &slots[s & 1][wsel];
+        // ---- every wave reduces the NW slots on its own (no second barrier) ----
+        const FpsSlot* sp = &slots[s & 1][lane & (NW - 1)];
+        const unsigned k2 = sp->key, i2 = sp->idx;
+        unsigned gkey, gidx;
+        wave_argmax(k2, i2, gkey, gidx);
         cur = (int)gidx;
-        cx = win->x;
-        cy = win->y;
-        cz = win->z;
+        if (LDS_COORDS) {
+            cx = tab[cur];
+            cy = tab[N + cur];
+            cz = tab[2 * N + cur];
+        } else {
+            const unsigned long long hit = __ballot(k2 == gkey && i2 == gidx);
+            const FpsSlot* win = &slots[s & 1][__builtin_ctzll(hit) & (NW - 1)];
+            cx = win->x;
+            cy = win->y;
+            cz = win->z;
+        }
     }
-    if (PICKS_IN_LDS) {
-        __syncthreads();
-        for (int s = tid; s < n_samples; s += FPS_THREADS) out[s] = (int64_t)picks[s];
-    }
+    __syncthreads();
+    for (int s = tid; s < n_samples; s += T) out[s] = (int64_t)picks[s];
 }
 
-template <int P>
+constexpr size_t FPS_LDS_BUDGET = 150 * 1024;
+
+template <int P, int T>
 int launch_fps(const float* xyz, int64_t* out, int B, int N, int n_samples, hipStream_t stream) {
-    const size_t pick_bytes = (size_t)n_samples * sizeof(int);
-    if (pick_bytes <= 96 * 1024)
-        hipLaunchKernelGGL((fps_kernel<P, true>), dim3(B), dim3(FPS_THREADS), pick_bytes, stream, xyz, out, N, n_samples);
-    else
-        hipLaunchKernelGGL((fps_kernel<P, false>), dim3(B), dim3(FPS_THREADS), 0, stream, xyz, out, N, n_samples);
+    const size_t pick_bytes = (size_t)((n_samples + 3) & ~3) * sizeof(int);
+    const size_t tab_bytes = (size_t)3 * N * sizeof(float);
+    if (pick_bytes + tab_bytes <= FPS_LDS_BUDGET) {
+        hipLaunchKernelGGL((fps_kernel<P, T, true>), dim3(B), dim3(T), pick_bytes + tab_bytes, stream, xyz, out, N,
+                           n_samples);
+    } else if (pick_bytes <= FPS_LDS_BUDGET) {
+        hipLaunchKernelGGL((fps_kernel<P, T, false>), dim3(B), dim3(T), pick_bytes, stream, xyz, out, N, n_samples);
+    } else {
+        camli_set_error("camli_fps: n_samples=%d does not fit the LDS pick buffer", n_samples);
+        return CAMLI_ENOTSUP;
+    }
     return camli_check_launch("camli_fps");
 }
 
@@ -182,14 +217,24 @@ extern "C" int camli_fps(const float* xyz, int64_t* out_idx, int B, int N, int n
     }
     if (B == 0) return CAMLI_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int P = camli_divup(N, FPS_THREADS);
-    if (P <= 1) return launch_fps<1>(xyz, out_idx, B, N, n_samples, s);
-    if (P <= 2) return launch_fps<2>(xyz, out_idx, B, N, n_samples, s);
-    if (P <= 4) return launch_fps<4>(xyz, out_idx, B, N, n_samples, s);
-    if (P <= 8) return launch_fps<8>(xyz, out_idx, B, N, n_samples, s);
-    if (P <= 16) return launch_fps<16>(xyz, out_idx, B, N, n_samples, s);
-    if (P <= 24) return launch_fps<24>(xyz, out_idx, B, N, n_samples, s);
-    camli_set_error("camli_fps: N=%d exceeds the register-resident limit of %d points per cloud", N,
-                    24 * FPS_THREADS);
+    // threads per cloud: 512 (2 waves/SIMD) while <= 32 points per thread, i.e. N <= 16384; the
+    // env var CAMLI_FPS_THREADS=256|512 overrides for experiments
+    static const int forced = [] { const char* e = getenv("CAMLI_FPS_THREADS"); return e ? atoi(e) : 0; }();
+    const int T = forced == 256 ? 256 : 512;
+    const int P = camli_divup(N, T);
+#define CAMLI_FPS_CASE(PP)                                                        \
+    if (P <= PP) return T == 256 ? launch_fps<PP, 256>(xyz, out_idx, B, N, n_samples, s) \
+                                 : launch_fps<PP, 512>(xyz, out_idx, B, N, n_samples, s)
+    CAMLI_FPS_CASE(1);
+    CAMLI_FPS_CASE(2);
+    CAMLI_FPS_CASE(4);
+    CAMLI_FPS_CASE(8);
+    CAMLI_FPS_CASE(16);
+    CAMLI_FPS_CASE(24);
+    CAMLI_FPS_CASE(32);
+    CAMLI_FPS_CASE(48);
+    CAMLI_FPS_CASE(64);
+#undef CAMLI_FPS_CASE
+    camli_set_error("camli_fps: N=%d exceeds the register-resident limit of %d points per cloud", N, 64 * T);
     return CAMLI_ENOTSUP;
 }

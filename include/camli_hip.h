@@ -45,7 +45,7 @@ int camli_knn(const float *input, const float *query, int64_t *out_idx,
  * Replaces _furthest_point_sampling_cuda: models/csrc/furthest_point_sampling/
  * furthest_point_sampling.cpp:5-16, kernel furthest_point_sampling_kernel.cu:34-85; bound by
  * models/csrc/wrapper.py:75-103.
- *   xyz [B,N,3], out_idx int64 [B,n_samples], 1 <= n_samples <= N <= 24576.
+ *   xyz [B,N,3], out_idx int64 [B,n_samples], 1 <= n_samples <= N <= 32768.
  * No scratch buffer: running distances live in registers (the reference allocates a [B,N] temp,
  * furthest_point_sampling.cpp:12).  Ties -> lowest index.
  */
