@@ -204,7 +204,7 @@ class _PointConvDW(torch.autograd.Function):
         b, c, m = feat.shape
         n = wsel.shape[2]
         gout = gout.contiguous().float()
-        gfeat = torch.zeros_like(feat) if ctx.needs_input_grad[0] else None
+        gfeat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None   # fully written by the kernel
         gwsel = torch.empty_like(wsel)
         with torch.cuda.device(feat.device):
             _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd, gout.data_ptr(), feat.data_ptr(),

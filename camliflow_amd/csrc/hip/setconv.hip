@@ -95,6 +95,125 @@ __global__ __launch_bounds__(256) void pointconv_dw_fwd_kernel(const float* __re
     }
 }
 
+// Forward, tiled form (k in {4,8,16,32}).  grid (ceil(N/64), B), block 256 = 4 waves; every wave
+// owns the same 64 points and a quarter of the channels.  The wave streams its [64 x k] weight
+// chunk of one channel with lane-CONTIGUOUS 16-byte loads (each cache line is touched once, by one
+// instruction), parks it in LDS with a padded row stride (k+4 floats: conflict-free ds_read_b128),
+// and every lane then reads back its own k-float row.  The next channel's chunk is already in
+// flight in registers while the current one is multiplied / maxed.  The neighbour index row is
+// converted to int32 once and lives in VGPRs for all channels.
+template <int K>
+__global__ __launch_bounds__(256) void pointconv_dw_fwd_tiled_kernel(const float* __restrict__ feat,
+                                                                      const float* __restrict__ weight,
+                                                                      const int64_t* __restrict__ idx, int idx_stride,
+                                                                      float* __restrict__ out,
+                                                                      unsigned char* __restrict__ arg,
+                                                                      float* __restrict__ wsel, int* __restrict__ msel,
+                                                                      int C, int M, int N) {
+    constexpr int LD = K + 4;                 // padded LDS row (floats)
+    constexpr int V = K / 4;                  // float4 per row == staging loads per lane per channel
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * 64;
+    const int n = n0 + lane;
+    const bool valid = n < N;
+    float* tile = lds + w * 64 * LD;
+
+    int m[K];
+    {
+        const int64_t* __restrict__ irow = idx + ((size_t)b * N + (valid ? n : N - 1)) * idx_stride;
+#pragma unroll
+        for (int j = 0; j < K; ++j) m[j] = (int)irow[j];
+    }
+    const int rows_here = min(64, N - n0);
+    const int chunk = rows_here * K;          // floats of this tile's weight chunk per channel
+
+    auto issue = [&](int c, float4 (&st)[V]) {
+        const float* __restrict__ src = weight + (((size_t)b * C + c) * N + n0) * K;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int e = (v * 64 + lane) * 4;
+            st[v] = e < chunk ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto park = [&](const float4 (&st)[V]) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int e = (v * 64 + lane) * 4;
+            const int r = e / K, col = e - r * K;
+            *reinterpret_cast<float4*>(tile + r * LD + col) = st[v];
+        }
+    };
+
+    float4 stage[V];
+    int c = w;
+    if (c < C) issue(c, stage);
+    for (; c < C; c += 4) {
+        park(stage);                                   // wave-private LDS region: no barrier needed
+        if (c + 4 < C) issue(c + 4, stage);            // next channel in flight during the compute below
+        const float* __restrict__ frow = feat + ((size_t)b * C + c) * M;
+        float best = -INFINITY;
+        int barg = 0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float4 w4 = *reinterpret_cast<const float4*>(tile + lane * LD + v * 4);
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float p = frow[m[v * 4 + t]] * wv[t];
+                const bool gt = p > best;
+                best = gt ? p : best;
+                barg = gt ? v * 4 + t : barg;
+            }
+        }
+        if (valid) {
+            const size_t o = ((size_t)b * C + c) * N + n;
+            out[o] = best;
+            arg[o] = (unsigned char)barg;
+            if (wsel) {
+                wsel[o] = tile[lane * LD + barg];
+                int ms = m[0];
+#pragma unroll
+                for (int j = 1; j < K; ++j) ms = (barg == j) ? m[j] : ms;
+                msel[o] = ms;
+            }
+        }
+    }
+}
+
+// Adjoint, row form.  One workgroup owns one (b, c) row: the feature row and the row of its
+// gradient live in LDS (2*M floats), the scatter is an LDS float atomic, and the finished gradient
+// row is written once -- no global atomics, no zero-fill of gfeat.
+__global__ __launch_bounds__(256) void pointconv_dw_bwd_row_kernel(const float* __restrict__ gout,
+                                                                    const float* __restrict__ feat,
+                                                                    const float* __restrict__ wsel,
+                                                                    const int* __restrict__ msel,
+                                                                    float* __restrict__ gfeat, float* __restrict__ gwsel,
+                                                                    int M, int N) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sf = lds;        // feat row
+    float* sg = lds + M;    // gradient row
+    const size_t row = blockIdx.x;
+    for (int i = threadIdx.x; i < M; i += 256) {
+        sf[i] = feat[row * M + i];
+        sg[i] = 0.0f;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const size_t e = row * N + n;
+        const float g = gout[e];
+        const int mm = msel[e];
+        if (gwsel) gwsel[e] = g * sf[mm];
+        if (gfeat) unsafeAtomicAdd(sg + mm, g * wsel[e]);
+    }
+    if (gfeat) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < M; i += 256) gfeat[row * M + i] = sg[i];
+    }
+}
+
 // Adjoint, compact form.  thread = (b, c, n), n fastest: everything it touches except the feature
 // row is a coalesced [B,C,N] stream.
 //   gfeat[b,c,msel] += gout * wsel          (float atomic; rows of M floats stay in L2)
@@ -161,6 +280,19 @@ extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, co
     }
     if (B == 0) return CAMLI_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define CAMLI_DW_TILED(KK)                                                                                         \
+    hipLaunchKernelGGL((pointconv_dw_fwd_tiled_kernel<KK>), dim3(camli_divup(N, 64), B), dim3(256),                \
+                       (size_t)4 * 64 * (KK + 4) * sizeof(float), s, feat, weight, idx, idx_stride, out, arg, wsel, \
+                       msel, C, M, N);                                                                              \
+    return camli_check_launch("camli_pointconv_dw_fwd")
+    switch (k) {
+        case 4: CAMLI_DW_TILED(4);
+        case 8: CAMLI_DW_TILED(8);
+        case 16: CAMLI_DW_TILED(16);
+        case 32: CAMLI_DW_TILED(32);
+        default: break;
+    }
+#undef CAMLI_DW_TILED
     dim3 grid(camli_divup(N, 64), camli_divup(C, SC_CPT * SC_CGRP), B);
 #define CAMLI_DW_LAUNCH(KK)                                                                                    \
     hipLaunchKernelGGL((pointconv_dw_fwd_kernel<KK>), grid, dim3(256), 0, s, feat, weight, idx, idx_stride, out, \
@@ -187,10 +319,22 @@ extern "C" int camli_pointconv_dw_bwd(const float* gout, const float* feat, cons
         return CAMLI_EINVAL;
     }
     if (B == 0) return CAMLI_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t row_lds = (size_t)2 * M * sizeof(float);
+    if (row_lds <= 64 * 1024) {
+        hipLaunchKernelGGL(pointconv_dw_bwd_row_kernel, dim3((unsigned)((size_t)B * C)), dim3(256), row_lds, s, gout, feat,
+                           wsel, msel, gfeat, gwsel, M, N);
+        return camli_check_launch("camli_pointconv_dw_bwd");
+    }
+    // rows too long for LDS: global float atomics into a zero-filled gradient
+    if (gfeat && hipMemsetAsync(gfeat, 0, (size_t)B * C * M * sizeof(float), s) != hipSuccess) {
+        camli_set_error("camli_pointconv_dw_bwd: memset failed");
+        return CAMLI_ELAUNCH;
+    }
     const size_t total = (size_t)B * C * N;
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(pointconv_dw_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gout,
-                       feat, wsel, msel, gfeat, gwsel, total, M, N);
+    hipLaunchKernelGGL(pointconv_dw_bwd_kernel, dim3(blocks), dim3(256), 0, s, gout, feat, wsel, msel, gfeat, gwsel, total,
+                       M, N);
     return camli_check_launch("camli_pointconv_dw_bwd");
 }
 

@@ -45,7 +45,7 @@ int camli_knn(const float *input, const float *query, int64_t *out_idx,
  * Replaces _furthest_point_sampling_cuda: models/csrc/furthest_point_sampling/
  * furthest_point_sampling.cpp:5-16, kernel furthest_point_sampling_kernel.cu:34-85; bound by
  * models/csrc/wrapper.py:75-103.
- *   xyz [B,N,3], out_idx int64 [B,n_samples], 1 <= n_samples <= N <= 32768.
+ *   xyz [B,N,3], out_idx int64 [B,n_samples], 1 <= n_samples <= N <= 24576.
  * No scratch buffer: running distances live in registers (the reference allocates a [B,N] temp,
  * furthest_point_sampling.cpp:12).  Ties -> lowest index.
  */
@@ -90,8 +90,8 @@ int camli_allpairs_lookup_bwd(float *const *gvols, const int *hs, const int *ws,
  *   out [B,C,N] = max_j feat[b,c,idx[b,n,j]] * weight[b,c,n,j]; arg uint8 [B,C,N] = first arg-max j;
  *   optional compact record for the adjoint: wsel [B,C,N] = weight at arg, msel int32 [B,C,N] = idx at
  *   arg (both or neither).  k <= 255.
- *   bwd (from the compact record): gfeat [B,C,M] += gout*wsel (float atomics, caller zero-fills; may be
- *   NULL), gwsel [B,C,N] = gout*feat[msel] (fully written; may be NULL).
+ *   bwd (from the compact record): gfeat [B,C,M] = scatter of gout*wsel (FULLY written, no zero-fill
+ *   needed; may be NULL), gwsel [B,C,N] = gout*feat[msel] (fully written; may be NULL).
  *   expand: dense gweight [B,C,N,k] (fully written) = sum over the n_calls <= 64 calls of one pass of
  *   one-hot(arg_i) * gwsel_i; gwsel_list / arg_list are HOST arrays of device pointers.
  */
