@@ -26,9 +26,9 @@ from types import SimpleNamespace as NS  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
-# the kernel the roofline object reports: the adjoint of the all-pairs lookup (HBM-bound
-# read-modify-write of the gradient pyramid); algorithmic bytes per launch, DESIGN.md section 5
-ROOFLINE_KERNEL = 'camli_allpairs_lookup_bwd'
+# Every C-ABI launch of the timed region is bracketed by HIP events on its launch stream and carries
+# its algorithmic work.  The roofline object reports the HBM-bound entry point
+# with the largest total time; KNN (VALU-bound) and FPS (latency-bound) are listed beside it.
 
 
 def model_cfg(n_iters):
@@ -92,12 +92,25 @@ def cpu_baseline(args):
                       % (args.width, args.height, args.points, args.iters, dt)}
 
 
-def lookup_bwd_bytes(b, h, w, levels=4, radius=4):
-    """Algorithmic HBM bytes of one camli_allpairs_lookup_bwd launch: read grad_out once, read +
-    write a (2r+2)^2 window per (pixel, level), read coords."""
-    p = h * w
-    win = (2 * radius + 2) ** 2
-    return 4 * b * p * (levels * (2 * radius + 1) ** 2 + 2 * levels * win + 2)
+def roofline_report(summary, steps):
+    """summary: _lib.TIMER.summary().  Returns (roofline object, per-kernel table)."""
+    table = {}
+    for name, rec in sorted(summary.items(), key=lambda kv: -kv[1]['total_ms']):
+        rate = rec['work'] / (rec['total_ms'] * 1e-3) if rec['total_ms'] > 0 else 0.0
+        table[name] = {'launches_per_step': round(rec['launches'] / steps, 1),
+                       'ms_per_step': round(rec['total_ms'] / steps, 3),
+                       'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
+                       'rate': round(rate / 1e9, 2), 'rate_unit': 'G' + rec['unit'] + '/s'}
+    hbm = [(n, r) for n, r in summary.items() if r['unit'] == 'B' and r['total_ms'] > 0]
+    if not hbm:
+        return None, table
+    name, rec = max(hbm, key=lambda kv: kv[1]['total_ms'])
+    achieved = rec['work'] / (rec['total_ms'] * 1e-3) / 1e9
+    roofline = {'kernel': name, 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'launches': rec['launches'], 'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
+                'algorithmic_bytes_per_launch': round(rec['work'] / rec['launches'])}
+    return roofline, table
 
 
 def main():
@@ -158,7 +171,7 @@ def main():
         train_step(model, raw_model, optimizer, batch)
     barrier()
     _lib.TIMER.reset()
-    _lib.TIMER.only = {ROOFLINE_KERNEL}
+    _lib.TIMER.only = None
     _lib.TIMER.enabled = True
     t0 = time.perf_counter()
     host_s = 0.0
@@ -176,15 +189,7 @@ def main():
 
     if rank == 0:
         global_batch = args.batch * world
-        hpad, wpad = (args.height + 7) // 8 * 8, (args.width + 7) // 8 * 8
-        launches, total_ms = _lib.TIMER.summary().get(ROOFLINE_KERNEL, (0, 0.0))
-        roofline = None
-        if launches:
-            per_launch_ms = total_ms / launches
-            achieved = lookup_bwd_bytes(args.batch, hpad // 8, wpad // 8) / (per_launch_ms * 1e-3) / 1e9
-            roofline = {'kernel': ROOFLINE_KERNEL, 'bound': 'hbm', 'achieved': round(achieved, 1),
-                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                        'traffic': None, 'launches': launches, 'avg_launch_us': round(per_launch_ms * 1e3, 2)}
+        roofline, kernel_table = roofline_report(_lib.TIMER.summary(), args.steps)
         line = {
             'metric': 'frame-pairs/sec (fwd+bwd) 960x540 + 8192 pts, CamLiRAFT',
             'value': round(global_batch * args.steps / elapsed, 4),
@@ -198,6 +203,7 @@ def main():
                        'loss': round(float(loss.detach()), 4),
                        'host_enqueue_ms_per_step': round(host_s / args.steps * 1e3, 1)},
             'roofline': roofline,
+            'hip_kernels': kernel_table,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)

@@ -75,7 +75,9 @@ def check(code, what):
 # ------------------------------------------------------------------------------------------------
 class KernelTimer:
     """Records a (start, end) event pair around every launch routed through ``launch()`` while
-    enabled.  Events go on torch's current stream, which is the stream the kernels are launched on."""
+    enabled, together with the launch's algorithmic work (bytes for the HBM-bound kernels, pairs /
+    point-updates for KNN / FPS).  Events go on torch's current stream, which is the stream the
+    kernels are launched on."""
 
     def __init__(self):
         self.enabled = False
@@ -86,25 +88,28 @@ class KernelTimer:
         self.records = {}
 
     def summary(self):
-        """name -> (launches, total_ms).  Call after torch.cuda.synchronize()."""
+        """name -> dict(launches, total_ms, work, unit).  Call after torch.cuda.synchronize()."""
         out = {}
-        for name, pairs in self.records.items():
-            out[name] = (len(pairs), sum(s.elapsed_time(e) for s, e in pairs))
+        for name, recs in self.records.items():
+            out[name] = {'launches': len(recs), 'total_ms': sum(s.elapsed_time(e) for s, e, _, _ in recs),
+                         'work': float(sum(w for _, _, w, _ in recs)), 'unit': recs[0][3]}
         return out
 
 
 TIMER = KernelTimer()
 
 
-def launch(name, fn, *args):
-    """Call a C-ABI entry point, check its status, optionally time it."""
+def launch(name, fn, *args, work=None):
+    """Call a C-ABI entry point, check its status, optionally time it.  ``work`` = (amount, unit) of
+    algorithmic work of this launch, only evaluated bookkeeping-wise."""
     if TIMER.enabled and (TIMER.only is None or name in TIMER.only):
         import torch
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         code = fn(*args)
         end.record()
-        TIMER.records.setdefault(name, []).append((start, end))
+        amount, unit = work if work is not None else (0.0, 'B')
+        TIMER.records.setdefault(name, []).append((start, end, amount, unit))
     else:
         code = fn(*args)
     check(code, name)

@@ -89,7 +89,8 @@ class _Lookup(torch.autograd.Function):
         out = torch.empty((bs, n * d * d, h, w), dtype=torch.float32, device=coords.device)
         with torch.cuda.device(coords.device):
             _lib.launch('camli_allpairs_lookup_fwd', lib.camli_allpairs_lookup_fwd, ptrs, hs, ws, n, coords.data_ptr(), out.data_ptr(),
-                                                     bs, h, w, radius, _stream_ptr(coords))
+                                                     bs, h, w, radius, _stream_ptr(coords),
+                        work=(4.0 * bs * h * w * (n * d * d + n * (d + 1) ** 2 + 2), 'B'))
         ctx.save_for_backward(coords)
         ctx.pyr, ctx.radius = pyr, radius
         return out
@@ -106,7 +107,8 @@ class _Lookup(torch.autograd.Function):
         n, ptrs, hs, ws = pyr._level_args(pyr.grads)
         with torch.cuda.device(coords.device):
             _lib.launch('camli_allpairs_lookup_bwd', lib.camli_allpairs_lookup_bwd, ptrs, hs, ws, n, coords.data_ptr(), gout.data_ptr(),
-                                                     bs, h, w, ctx.radius, _stream_ptr(coords))
+                                                     bs, h, w, ctx.radius, _stream_ptr(coords),
+                        work=(4.0 * bs * h * w * (n * (2 * ctx.radius + 1) ** 2 + 2 * n * (2 * ctx.radius + 2) ** 2 + 2), 'B'))
         return gout.new_zeros(1), None, None, None
 
 
@@ -168,7 +170,8 @@ class _ShareWeights(torch.autograd.Function):
                 gptrs = (ctypes.c_void_p * len(chunk))(*[g.data_ptr() for g, _ in chunk])
                 aptrs = (ctypes.c_void_p * len(chunk))(*[a.data_ptr() for _, a in chunk])
                 _lib.launch('camli_pointconv_dw_expand', lib.camli_pointconv_dw_expand, gptrs, aptrs, len(chunk),
-                            part.data_ptr(), b, c, n, k, _stream_ptr(weight))
+                            part.data_ptr(), b, c, n, k, _stream_ptr(weight),
+                        work=(4.0 * b * c * n * k + 5.0 * len(chunk) * b * c * n, 'B'))
                 if start:
                     grad += part
         return grad, None
@@ -190,7 +193,8 @@ class _PointConvDW(torch.autograd.Function):
             _lib.launch('camli_pointconv_dw_fwd', lib.camli_pointconv_dw_fwd, feat.data_ptr(), weight.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), out.data_ptr(), arg.data_ptr(),
                         wsel.data_ptr() if need_grad else None, msel.data_ptr() if need_grad else None,
-                        b, c, m, n, k, _stream_ptr(feat))
+                        b, c, m, n, k, _stream_ptr(feat),
+                        work=(4.0 * b * c * n * k + 4.0 * b * c * m + 8.0 * b * n * k + 13.0 * b * c * n, 'B'))
         if need_grad:
             ctx.save_for_backward(feat, wsel, msel, arg)
         ctx.shared = shared
@@ -209,7 +213,8 @@ class _PointConvDW(torch.autograd.Function):
         with torch.cuda.device(feat.device):
             _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd, gout.data_ptr(), feat.data_ptr(),
                         wsel.data_ptr(), msel.data_ptr(), gfeat.data_ptr() if gfeat is not None else None,
-                        gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat))
+                        gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat),
+                        work=(16.0 * b * c * n + 8.0 * b * c * m, 'B'))
         shared.records.append((gwsel, arg))
         return gfeat, gout.new_zeros(1), None, None, None
 
@@ -237,7 +242,8 @@ class _GatherCF(torch.autograd.Function):
         out = torch.empty((b, c, i), dtype=torch.float32, device=data.device)
         with torch.cuda.device(data.device):
             _lib.launch('camli_gather_cf_fwd', lib.camli_gather_cf_fwd, data.data_ptr(), idx_flat.data_ptr(),
-                        out.data_ptr(), b, c, m, i, _stream_ptr(data))
+                        out.data_ptr(), b, c, m, i, _stream_ptr(data),
+                        work=(8.0 * b * c * i + 8.0 * b * i, 'B'))
         ctx.save_for_backward(idx_flat)
         ctx.m = m
         return out
@@ -251,7 +257,8 @@ class _GatherCF(torch.autograd.Function):
         gdata = torch.zeros((b, c, ctx.m), dtype=torch.float32, device=gout.device)
         with torch.cuda.device(gout.device):
             _lib.launch('camli_gather_cf_bwd', lib.camli_gather_cf_bwd, gout.data_ptr(), idx_flat.data_ptr(),
-                        gdata.data_ptr(), b, c, ctx.m, i, _stream_ptr(gout))
+                        gdata.data_ptr(), b, c, ctx.m, i, _stream_ptr(gout),
+                        work=(8.0 * b * c * i + 8.0 * b * i, 'B'))
         return gdata, None
 
 
@@ -274,7 +281,8 @@ class _KnnInterp(torch.autograd.Function):
         with torch.cuda.device(feat.device):
             _lib.launch('camli_knn_interp_fwd', lib.camli_knn_interp_fwd, in_xyz.data_ptr(), feat.data_ptr(),
                         q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), out.data_ptr(), b, c, m, nq, k,
-                        _stream_ptr(feat))
+                        _stream_ptr(feat),
+                        work=(4.0 * b * c * nq * (1 + k) + 8.0 * b * nq * k + 12.0 * b * nq * (1 + k), 'B'))
         ctx.save_for_backward(in_xyz, q_xyz, knn)
         ctx.dims = (b, c, m, nq, k)
         return out
@@ -289,7 +297,8 @@ class _KnnInterp(torch.autograd.Function):
         with torch.cuda.device(gout.device):
             _lib.launch('camli_knn_interp_bwd', lib.camli_knn_interp_bwd, in_xyz.data_ptr(), gout.data_ptr(),
                         q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), gfeat.data_ptr(), b, c, m, nq, k,
-                        _stream_ptr(gout))
+                        _stream_ptr(gout),
+                        work=(4.0 * b * c * nq * (1 + 2 * k) + 8.0 * b * nq * k + 12.0 * b * nq * (1 + k), 'B'))
         return None, gfeat, None, None, None
 
 
@@ -311,7 +320,8 @@ class _Corr3DGather(torch.autograd.Function):
         out = torch.empty((b, 4, n, k), dtype=torch.float32, device=cost.device)
         with torch.cuda.device(cost.device):
             _lib.launch('camli_corr3d_gather_fwd', lib.camli_corr3d_gather_fwd, xyz1.data_ptr(), xyz2.data_ptr(),
-                        cost.data_ptr(), knn.data_ptr(), out.data_ptr(), b, n, m, k, _stream_ptr(cost))
+                        cost.data_ptr(), knn.data_ptr(), out.data_ptr(), b, n, m, k, _stream_ptr(cost),
+                        work=(b * n * k * (8.0 + 16.0 + 4.0 + 12.0), 'B'))
         ctx.save_for_backward(knn)
         ctx.dims = (b, n, m, k)
         return out
@@ -325,7 +335,8 @@ class _Corr3DGather(torch.autograd.Function):
         gcost = torch.zeros((b, n, m), dtype=torch.float32, device=gout.device)
         with torch.cuda.device(gout.device):
             _lib.launch('camli_corr3d_gather_bwd', lib.camli_corr3d_gather_bwd, gout.data_ptr(), knn.data_ptr(),
-                        gcost.data_ptr(), b, n, m, k, _stream_ptr(gout))
+                        gcost.data_ptr(), b, n, m, k, _stream_ptr(gout),
+                        work=(b * n * k * (8.0 + 4.0 + 8.0), 'B'))
         return gcost, None, None, None
 
 

@@ -47,7 +47,8 @@ class CorrelationFunction(torch.autograd.Function):
         output = torch.empty((b, d * d, h, w), dtype=torch.float32, device=input1.device)
         with torch.cuda.device(input1.device):
             _lib.launch('camli_corr2d_fwd', lib.camli_corr2d_fwd, input1.data_ptr(), input2.data_ptr(), output.data_ptr(),
-                                            b, c, h, w, max_displacement, _stream_ptr(input1))
+                                            b, c, h, w, max_displacement, _stream_ptr(input1),
+                        work=(4.0 * b * h * w * (2 * c + d * d), 'B'))
         return output
 
     @staticmethod
@@ -61,7 +62,8 @@ class CorrelationFunction(torch.autograd.Function):
         with torch.cuda.device(input1.device):
             _lib.launch('camli_corr2d_bwd', lib.camli_corr2d_bwd, grad_output.data_ptr(), input1.data_ptr(), input2.data_ptr(),
                                             grad_input1.data_ptr(), grad_input2.data_ptr(),
-                                            b, c, h, w, ctx.max_displacement, _stream_ptr(input1))
+                                            b, c, h, w, ctx.max_displacement, _stream_ptr(input1),
+                        work=(4.0 * b * h * w * ((2 * ctx.max_displacement + 1) ** 2 + 4 * c), 'B'))
         return grad_input1, grad_input2, None
 
 
@@ -116,7 +118,8 @@ def furthest_point_sampling(xyz: torch.Tensor, n_samples: int, cpp_impl=True):
     b, n, _ = xyz.shape
     out = torch.empty((b, n_samples), dtype=torch.int64, device=xyz.device)
     with torch.cuda.device(xyz.device):
-        _lib.launch('camli_fps', lib.camli_fps, xyz.data_ptr(), out.data_ptr(), b, n, n_samples, _stream_ptr(xyz))
+        _lib.launch('camli_fps', lib.camli_fps, xyz.data_ptr(), out.data_ptr(), b, n, n_samples, _stream_ptr(xyz),
+                        work=(float(b) * n * n_samples, 'point-updates'))
     return out
 
 
@@ -145,5 +148,6 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     out = torch.empty((b, nq, k), dtype=torch.int64, device=query_xyz.device)
     with torch.cuda.device(input_xyz.device):
         _lib.launch('camli_knn', lib.camli_knn, input_xyz.data_ptr(), query_xyz.data_ptr(), out.data_ptr(),
-                                 b, m, nq, d, k, _stream_ptr(input_xyz))
+                                 b, m, nq, d, k, _stream_ptr(input_xyz),
+                        work=(float(b) * m * nq, 'pairs'))
     return out
