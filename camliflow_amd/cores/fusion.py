@@ -12,6 +12,7 @@ import torch.nn as nn
 from torch.nn.functional import softmax
 
 from ..csrc import wrapper as _ops
+from . import runtime
 from .blocks import Conv1dNormRelu, Conv2dNormRelu
 from .geometry import batch_indexing, grid_sample_wrapper, mesh_grid
 
@@ -34,11 +35,25 @@ class FusionAwareInterp(nn.Module):
             Conv2dNormRelu(16, n_channels_3d, act='sigmoid'),
         )
 
+    def _nearest_points(self, uv, grid, image_h, image_w):
+        """2-D KNN of every pixel against the projected points.  The reference recomputes it in every
+        CLFM call although (uv, grid) never change across GRU iterations; inside a
+        ``pass_cache()`` the index tensor is computed once per (uv tensor, grid size, k)."""
+        from . import setconv
+        cache = setconv._pass_cache if runtime.fused() else None
+        key = ('knn2d', uv.data_ptr(), tuple(uv.shape), image_h, image_w, self.k)
+        if cache is not None and key in cache:
+            return cache[key]
+        knn_indices = _ops.k_nearest_neighbor(uv, grid, self.k)
+        if cache is not None:
+            cache[key] = knn_indices
+        return knn_indices
+
     def forward(self, uv, feat_2d, feat_3d):
         bs, _, image_h, image_w = feat_2d.shape
         n_channels_3d = feat_3d.shape[1]
         grid = mesh_grid(bs, image_h, image_w, uv.device).reshape(bs, 2, -1)       # [B,2,HW]
-        knn_indices = _ops.k_nearest_neighbor(uv, grid, self.k)                     # [B,HW,k]
+        knn_indices = self._nearest_points(uv, grid, image_h, image_w)              # [B,HW,k]
         gathered = batch_indexing(torch.cat([uv, feat_3d], dim=1), knn_indices)    # [B,2+C,HW,k]
         knn_uv, knn_feat3d = torch.split(gathered, [2, n_channels_3d], dim=1)
         knn_offset = knn_uv - grid[..., None]

@@ -22,9 +22,14 @@
 //     single-wave in-order scan.
 #include "camli_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
-constexpr int QBUF = 12;          // per-lane queue depth of accepted-but-not-inserted candidates
+#ifndef KNN_UNROLL
+#define KNN_UNROLL 8
+#endif
+constexpr int QBUF = KNN_UNROLL + 8;          // per-lane queue depth of accepted-but-not-inserted candidates
 constexpr float KNN_INIT = 1e9f;  // k_nearest_neighbor_kernel.cu:27-30,70-73
 
 template <int D>
@@ -67,7 +72,7 @@ template <int D, int K>
 __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int lo, int hi, float ux, float uy,
                                            float uz, float (&dist)[K], int (&idx)[K], float& ev_min,
                                            float* __restrict__ qd, int* __restrict__ qi, int qstride) {
-    constexpr int U = 4;
+    constexpr int U = KNN_UNROLL;
     if (K == 1) {
         float best = dist[0];
         int bi = idx[0];
@@ -277,7 +282,8 @@ int launch_knn(const float* input, const float* query, int64_t* out, int B, int 
     int nw = 1;
     const long long base_waves = (long long)qblocks * B;
     const int lds_cap_nw = K >= 32 ? 4 : (K >= 16 ? 8 : 16);   // merge region <= 64 KiB
-    while (nw < lds_cap_nw && base_waves * nw < 2048 && M / (nw * 2) >= 128) nw *= 2;
+    static const long long target_waves = [] { const char* e = getenv("CAMLI_KNN_TARGET_WAVES"); return e ? atoll(e) : 4096LL; }();
+    while (nw < lds_cap_nw && base_waves * nw < target_waves && M / (nw * 2) >= 128) nw *= 2;
     size_t q_bytes = (K >= 8) ? (size_t)2 * QBUF * 64 * nw * 4 : 0;
     size_t m_bytes = (nw > 1) ? ((size_t)2 * nw * K * 64 + (size_t)nw * 64 + (size_t)2 * QBUF * 64) * 4 : 0;
     size_t lds = q_bytes > m_bytes ? q_bytes : m_bytes;
