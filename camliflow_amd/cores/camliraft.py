@@ -90,6 +90,7 @@ class CamLiRAFT_Core(nn.Module):
         h_2d, x_2d = torch.split(b2d.cnet_aligner(featc_2d), [128, 128], dim=1)
         h_2d, x_2d = torch.tanh(h_2d), torch.relu(x_2d)
         b2d.correlation.build_cost_volume_pyramid(feat1_2d, feat2_2d)
+        gru2d_state = b2d.gru.prepare(x_2d) if runtime.fused() else None
 
         n_iters = cfgs.n_iters_train if self.training else cfgs.n_iters_eval
         bs = image1.shape[0]
@@ -125,7 +126,10 @@ class CamLiRAFT_Core(nn.Module):
             # ---- recurrent update --------------------------------------------------------------
             with lanes.side():
                 h_3d = b3d.gru(xyz1, h=h_3d, x=torch.cat([x_3d, motion_feat3d], dim=1), knn_indices=knn_indices)
-            h_2d = b2d.gru(h=h_2d, x=torch.cat([x_2d, motion_feat2d], dim=1))
+            if gru2d_state is not None:
+                h_2d = b2d.gru.step(h_2d, motion_feat2d, gru2d_state)
+            else:
+                h_2d = b2d.gru(h=h_2d, x=torch.cat([x_2d, motion_feat2d], dim=1))
             if cfgs.fuse_hidden:
                 lanes.to_main(h_3d)
                 h_2d, h_3d = self.clfm_hidden(uv1, h_2d, h_3d)

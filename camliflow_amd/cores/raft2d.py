@@ -112,6 +112,37 @@ class GRU2D(nn.Module):
         h = self._half_step(h, x, self.convz2, self.convr2, self.convq2)
         return torch.nan_to_num(h)
 
+    # ---- iteration-invariant hoisting (used by the cores under the 'hip' backend) -------------
+    # x = cat([context, motion]); the context half never changes across GRU iterations
+    # (raft_core.py:236-259: `x` is computed once from cnet).  A convolution is linear in its input
+    # channels, so conv(cat[h, context, motion]) = conv_{h,motion}(cat[h, motion]) + conv_context(context):
+    # the context term (+ bias) is evaluated ONCE per pass for all six gates, and z / r share one
+    # convolution.  One third of the GRU's convolution work (forward, data-gradient and
+    # weight-gradient) disappears; values agree with the literal form up to fp32 summation order.
+    def prepare(self, context):
+        """context [B,128,h,w] -> per-pass state for ``step``."""
+        hd = self.convz1.weight.shape[0]
+        cd = context.shape[1]
+        state = {}
+        for suffix, padding in (('1', (0, 2)), ('2', (2, 0))):
+            gates = [getattr(self, 'conv%s%s' % (g, suffix)) for g in 'zrq']
+            w_ctx = torch.cat([g.weight[:, hd:hd + cd] for g in gates], dim=0)
+            bias = torch.cat([g.bias for g in gates], dim=0)
+            ctx = torch.nn.functional.conv2d(context, w_ctx, bias, padding=padding)
+            keep = [torch.cat([g.weight[:, :hd], g.weight[:, hd + cd:]], dim=1) for g in gates]
+            state[suffix] = (torch.cat(keep[:2], dim=0), keep[2], ctx[:, :2 * hd], ctx[:, 2 * hd:], padding)
+        return state
+
+    def step(self, h, motion, state):
+        hd = h.shape[1]
+        for suffix in ('1', '2'):
+            w_zr, w_q, ctx_zr, ctx_q, padding = state[suffix]
+            zr = torch.sigmoid(torch.nn.functional.conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding) + ctx_zr)
+            z, r = zr[:, :hd], zr[:, hd:]
+            q = torch.tanh(torch.nn.functional.conv2d(torch.cat([r * h, motion], dim=1), w_q, None, padding=padding) + ctx_q)
+            h = (1 - z) * h + z * q
+        return torch.nan_to_num(h)
+
 
 class MotionEncoder2D(nn.Module):
     def __init__(self, corr_levels, corr_radius):
@@ -184,11 +215,15 @@ class RAFTCore(nn.Module):
         n_iters = self.cfgs.n_iters_train if self.training else self.cfgs.n_iters_eval
 
         flow_preds = []
+        gru_state = self.gru.prepare(x) if runtime.fused() else None
         for _ in range(n_iters):
             flow_pred = flow_pred.detach()
             corr = self.correlation(grid_coords + flow_pred)
             motion_features = self.motion_encoder(flow_pred, corr)
-            h = self.gru(h, torch.cat([x, motion_features], dim=1))
+            if gru_state is not None:
+                h = self.gru.step(h, motion_features, gru_state)
+            else:
+                h = self.gru(h, torch.cat([x, motion_features], dim=1))
             flow_pred = flow_pred + self.flow_head(h)
             flow_preds.append(self.convex_upsampler(h, flow_pred))
         return flow_preds
