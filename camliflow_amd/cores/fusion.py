@@ -35,30 +35,44 @@ class FusionAwareInterp(nn.Module):
             Conv2dNormRelu(16, n_channels_3d, act='sigmoid'),
         )
 
-    def _nearest_points(self, uv, grid, image_h, image_w):
-        """2-D KNN of every pixel against the projected points.  The reference recomputes it in every
-        CLFM call although (uv, grid) never change across GRU iterations; inside a
-        ``pass_cache()`` the index tensor is computed once per (uv tensor, grid size, k)."""
+    def _geometry(self, uv, grid, image_h, image_w):
+        """(knn_indices, score) for this module.  The reference recomputes the 2-D KNN of every pixel
+        and ``score_net(offset, |offset|)`` in every CLFM call although (uv, grid) never change across
+        GRU iterations (11 calls per 4-iteration forward).  Inside a ``pass_cache()`` the
+        index tensor is shared by every CLFM that sees the same ``uv`` and the score is evaluated once
+        per module; its gradient is accumulated by autograd over the iterations.  Same values."""
         from . import setconv
-        cache = setconv._pass_cache if runtime.fused() else None
-        key = ('knn2d', uv.data_ptr(), tuple(uv.shape), image_h, image_w, self.k)
-        if cache is not None and key in cache:
-            return cache[key]
-        knn_indices = _ops.k_nearest_neighbor(uv, grid, self.k)
+        cache = setconv._pass_cache
+        base = (uv.data_ptr(), tuple(uv.shape), image_h, image_w, self.k, torch.is_grad_enabled())
+        knn_key, score_key = ('knn2d',) + base, ('score2d', id(self)) + base
+        if cache is not None and score_key in cache:
+            return cache[knn_key], cache[score_key]
+        knn_indices = cache.get(knn_key) if cache is not None else None
+        if knn_indices is None:
+            knn_indices = _ops.k_nearest_neighbor(uv, grid, self.k)
+        knn_offset = batch_indexing(uv, knn_indices) - grid[..., None]
+        knn_offset_norm = torch.linalg.norm(knn_offset, dim=1, keepdim=True)
+        score = self.score_net(torch.cat([knn_offset, knn_offset_norm], dim=1))
         if cache is not None:
-            cache[key] = knn_indices
-        return knn_indices
+            cache[knn_key], cache[score_key] = knn_indices, score
+        return knn_indices, score
 
     def forward(self, uv, feat_2d, feat_3d):
         bs, _, image_h, image_w = feat_2d.shape
         n_channels_3d = feat_3d.shape[1]
         grid = mesh_grid(bs, image_h, image_w, uv.device).reshape(bs, 2, -1)       # [B,2,HW]
-        knn_indices = self._nearest_points(uv, grid, image_h, image_w)              # [B,HW,k]
-        gathered = batch_indexing(torch.cat([uv, feat_3d], dim=1), knn_indices)    # [B,2+C,HW,k]
-        knn_uv, knn_feat3d = torch.split(gathered, [2, n_channels_3d], dim=1)
-        knn_offset = knn_uv - grid[..., None]
-        knn_offset_norm = torch.linalg.norm(knn_offset, dim=1, keepdim=True)
-        score = self.score_net(torch.cat([knn_offset, knn_offset_norm], dim=1))    # [B,C,HW,k]
+        if runtime.fused():
+            # the pixel -> nearest-point assignment and the score it induces depend only on
+            # (uv, grid size), not on the features: one evaluation per pass (see _geometry)
+            knn_indices, score = self._geometry(uv, grid, image_h, image_w)
+            knn_feat3d = batch_indexing(feat_3d, knn_indices)                       # [B,C,HW,k]
+        else:
+            knn_indices = _ops.k_nearest_neighbor(uv, grid, self.k)                 # [B,HW,k]
+            gathered = batch_indexing(torch.cat([uv, feat_3d], dim=1), knn_indices)    # [B,2+C,HW,k]
+            knn_uv, knn_feat3d = torch.split(gathered, [2, n_channels_3d], dim=1)
+            knn_offset = knn_uv - grid[..., None]
+            knn_offset_norm = torch.linalg.norm(knn_offset, dim=1, keepdim=True)
+            score = self.score_net(torch.cat([knn_offset, knn_offset_norm], dim=1))    # [B,C,HW,k]
         final = (score * knn_feat3d).sum(dim=-1).reshape(bs, -1, image_h, image_w)
         return self.out_conv(final)
 

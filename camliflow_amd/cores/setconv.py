@@ -71,10 +71,15 @@ class PointConv(nn.Module):
         """xyz [B,3,N], features [B,C,N], sampled_xyz [B,3,n] -> [B,Cout,n]"""
         sampled_xyz, knn_indices, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
         bs, n_samples = sampled_xyz.shape[0], sampled_xyz.shape[-1]
-        weights = self.weight_net(knn_offset).transpose(1, 2)                 # [B,n,16,k]
         points_cl = torch.cat([xyz, features], dim=1).transpose(1, 2)         # [B,N,3+C]
-        knn_points = batch_indexing(points_cl, knn_indices, layout='channel_last')  # [B,n,k,3+C]
-        mixed = torch.matmul(weights, knn_points).view(bs, n_samples, -1)     # [B,n,16*(3+C)]
+        if runtime.fused():
+            from ..csrc import fused     # gather + per-point matmul in one kernel, no [B,n,k,3+C] tensor
+            mixed = fused.pointconv_mix(points_cl, self.weight_net(knn_offset), knn_indices, self.k)
+            mixed = mixed.view(bs, n_samples, -1)
+        else:
+            weights = self.weight_net(knn_offset).transpose(1, 2)             # [B,n,16,k]
+            knn_points = batch_indexing(points_cl, knn_indices, layout='channel_last')  # [B,n,k,3+C]
+            mixed = torch.matmul(weights, knn_points).view(bs, n_samples, -1)     # [B,n,16*(3+C)]
         out = self.linear(mixed).transpose(1, 2)
         return self.act_fn(self.norm_fn(out))
 

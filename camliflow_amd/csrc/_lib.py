@@ -37,6 +37,10 @@ PROTOTYPES = {
     "camli_corr3d_gather_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _c_float_p,
                                        _int, _int, _int, _int, _stream]),
     "camli_corr3d_gather_bwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_pointconv_mix_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p,
+                                       _int, _int, _int, _int, _int, _int, _stream]),
+    "camli_pointconv_mix_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p, _c_float_p,
+                                       _int, _int, _int, _int, _int, _int, _stream]),
 }
 
 _lib = None

@@ -347,3 +347,50 @@ def corr3d_lookup_input(cost_volume, xyz1, xyz2, knn_indices):
     assert not xyz1.requires_grad and not xyz2.requires_grad
     return _Corr3DGather.apply(cost_volume.float().contiguous(), xyz1.float().contiguous(),
                                xyz2.float().contiguous(), knn_indices.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+# PointConv neighbourhood mixing (models/point_conv.py:60-66)
+# ------------------------------------------------------------------------------------------------
+class _PointConvMix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat_cl, wgt, knn_indices, k):
+        lib = _lib.load()
+        b, m, ch = feat_cl.shape
+        wn, n = wgt.shape[1], wgt.shape[2]
+        out = torch.empty((b, n, wn, ch), dtype=torch.float32, device=feat_cl.device)
+        with torch.cuda.device(feat_cl.device):
+            _lib.launch('camli_pointconv_mix_fwd', lib.camli_pointconv_mix_fwd, feat_cl.data_ptr(), wgt.data_ptr(),
+                        knn_indices.data_ptr(), knn_indices.stride(1), out.data_ptr(), b, m, n, ch, wn, k,
+                        _stream_ptr(feat_cl), work=(4.0 * b * n * (k * ch + wn * k + wn * ch) + 8.0 * b * n * k, 'B'))
+        ctx.save_for_backward(feat_cl, wgt, knn_indices)
+        ctx.k = k
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        feat_cl, wgt, knn_indices = ctx.saved_tensors
+        b, m, ch = feat_cl.shape
+        wn, n = wgt.shape[1], wgt.shape[2]
+        k = ctx.k
+        gout = gout.contiguous().float()
+        gfeat = torch.zeros_like(feat_cl) if ctx.needs_input_grad[0] else None
+        gwgt = torch.empty_like(wgt) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(feat_cl.device):
+            _lib.launch('camli_pointconv_mix_bwd', lib.camli_pointconv_mix_bwd, gout.data_ptr(), feat_cl.data_ptr(),
+                        wgt.data_ptr(), knn_indices.data_ptr(), knn_indices.stride(1),
+                        gfeat.data_ptr() if gfeat is not None else None, gwgt.data_ptr() if gwgt is not None else None,
+                        b, m, n, ch, wn, k, _stream_ptr(feat_cl),
+                        work=(4.0 * b * n * (wn * ch + 2 * k * ch + 2 * wn * k) + 8.0 * b * n * k, 'B'))
+        return gfeat, gwgt, None, None
+
+
+def pointconv_mix(feat_cl, wgt, knn_indices, k):
+    """feat_cl [B,M,CH] channel-last, wgt [B,Wn,N,k] (as weight_net emits it), knn_indices int64
+    [B,N,>=k] -> [B,N,Wn,CH] = per-point (Wn x k) @ (k x CH) over the gathered neighbour rows."""
+    _require_cuda('pointconv_mix', feat_cl, wgt, knn_indices)
+    assert knn_indices.dtype == torch.int64 and knn_indices.stride(2) == 1 and knn_indices.shape[2] >= k
+    assert knn_indices.stride(0) == knn_indices.shape[1] * knn_indices.stride(1)
+    assert wgt.shape[3] == k and wgt.shape[1] <= 16
+    return _PointConvMix.apply(feat_cl.float().contiguous(), wgt.float().contiguous(), knn_indices, k)

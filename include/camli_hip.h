@@ -134,6 +134,21 @@ int camli_corr3d_gather_fwd(const float *xyz1, const float *xyz2, const float *c
 int camli_corr3d_gather_bwd(const float *gout, const int64_t *knn, float *gcost, int B, int N, int M, int k,
                             void *stream);
 
+/*
+ * PointConv neighbourhood mixing and adjoint (internal composite op; the reference composes it from a
+ * channel-last gather + matmul, models/point_conv.py:60-66).
+ *   feat_cl [B,M,CH] channel-last (CH = in_channels + 3); wgt [B,Wn,N,k] (Wn <= 16, the layout
+ *   weight_net produces); idx int64 rows of stride idx_stride (first k used); out [B,N,Wn,CH]:
+ *   out[b,n,w,ch] = sum_j wgt[b,w,n,j] * feat_cl[b, idx[b,n,j], ch]
+ *   bwd: gfeat_cl [B,M,CH] += (float atomics, caller zero-fills; may be NULL),
+ *        gwgt [B,Wn,N,k] fully written (may be NULL).
+ */
+int camli_pointconv_mix_fwd(const float *feat_cl, const float *wgt, const int64_t *idx, int idx_stride,
+                            float *out, int B, int M, int N, int CH, int Wn, int k, void *stream);
+int camli_pointconv_mix_bwd(const float *gout, const float *feat_cl, const float *wgt, const int64_t *idx,
+                            int idx_stride, float *gfeat_cl, float *gwgt,
+                            int B, int M, int N, int CH, int Wn, int k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

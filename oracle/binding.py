@@ -179,3 +179,14 @@ def corr3d_gather_fwd(xyz1, xyz2, cost, knn_idx):
     _chk(_load().oracle_corr3d_gather_fwd(_p(xyz1), _p(xyz2), _p(cost), _p(knn_idx), _p(out), B, N, M, k),
          "corr3d_gather_fwd")
     return out
+
+
+def pointconv_mix_fwd(feat_cl, wgt, idx, k):
+    """feat_cl [B,M,CH], wgt [B,Wn,N,k], idx int64 [B,N,kk>=k] -> [B,N,Wn,CH]"""
+    feat_cl, wgt, idx = _f32(feat_cl), _f32(wgt), _i64(idx)
+    B, M, CH = feat_cl.shape
+    Wn, N = wgt.shape[1], wgt.shape[2]
+    out = np.zeros((B, N, Wn, CH), dtype=np.float32)
+    _chk(_load().oracle_pointconv_mix_fwd(_p(feat_cl), _p(wgt), _p(idx), idx.shape[2], _p(out), B, M, N, CH, Wn, k),
+         "pointconv_mix_fwd")
+    return out

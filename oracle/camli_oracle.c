@@ -429,4 +429,27 @@ int oracle_corr3d_gather_fwd(const float *xyz1, const float *xyz2, const float *
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * PointConv neighbourhood mixing: follows models/point_conv.py:60-66
+ *   out[b,n,w,ch] = sum_j wgt[b,w,n,j] * feat_cl[b, idx[b,n,j], ch]
+ *   feat_cl [B,M,CH], wgt [B,Wn,N,k], idx rows of stride idx_stride, out [B,N,Wn,CH]
+ * ------------------------------------------------------------------------------------------ */
+int oracle_pointconv_mix_fwd(const float *feat_cl, const float *wgt, const int64_t *idx, int idx_stride,
+                             float *out, int B, int M, int N, int CH, int Wn, int k)
+{
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n)
+            for (int w = 0; w < Wn; ++w)
+                for (int ch = 0; ch < CH; ++ch) {
+                    float acc = 0.0f;
+                    for (int j = 0; j < k; ++j) {
+                        int64_t m = idx[((size_t)b * N + n) * idx_stride + j];
+                        if (m < 0 || m >= M) return -1;
+                        acc += wgt[(((size_t)b * Wn + w) * N + n) * k + j] * feat_cl[((size_t)b * M + m) * CH + ch];
+                    }
+                    out[(((size_t)b * N + n) * Wn + w) * CH + ch] = acc;
+                }
+    return 0;
+}
+
 int oracle_version(void) { return 1; }

@@ -1,6 +1,7 @@
 """Batch-dimension data parallelism of the training step, world_size 2, gloo backend on CPU.
 
-What bench.py does on RCCL is exercised here with the same functions (train_step, make_optimizer):
+What bench.py does on RCCL is exercised here with the same functions (train_step,
+allreduce_gradients, make_optimizer):
 two ranks each take one sample; the averaged gradients / updated weights must equal a single
 process stepping on the 2-sample batch.  BatchNorm is frozen (freeze_bn) because SyncBatchNorm has
 no CPU implementation; the operators are the oracle-backed ones (no GPU in this container)."""
@@ -42,14 +43,14 @@ def _worker(rank, world, port, out_path):
         bench, model, full = _build()
         from modelutils import oracle_boundary
         shard = {k: v[rank:rank + 1] for k, v in full.items()}
-        ddp = torch.nn.parallel.DistributedDataParallel(model)
         opt = bench.make_optimizer(model)
         with oracle_boundary():
-            ddp(shard)
-            model.get_loss().backward()            # DDP all-reduces (averages) the gradients here
+            model(shard)
+            model.get_loss().backward()
+            bench.allreduce_gradients(model, world)    # one flat-bucket all-reduce (mean)
             grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
             model.zero_grad()
-            loss = bench.train_step(ddp, model, opt, shard)   # and the full harness step runs under DDP
+            loss = bench.train_step(model, opt, shard, world)   # and the full harness step, data parallel
         metrics = model.get_metrics()              # packed all-reduce across both ranks (empty after clear)
         assert isinstance(metrics, dict)
         assert all(torch.isfinite(p).all() for p in model.parameters())
