@@ -109,7 +109,21 @@ def cpu_baseline(args):
                       % (args.width, args.height, args.points, args.iters, dt)}
 
 
-def roofline_report(summary, steps):
+def pmc_traffic(entry_point, args):
+    """HBM bytes per launch of `entry_point` from the committed PMC measurement of this same workload
+    (profiles/roofline_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+    bench.py, corrected as MI355X_MICROARCH.md prescribes).  None when no matching record exists."""
+    path = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
+    if not os.path.exists(path):
+        return None
+    want = {'batch': args.batch, 'iters': args.iters, 'height': args.height, 'width': args.width, 'points': args.points}
+    for rec in json.load(open(path)):
+        if rec.get('entry_point') == entry_point and rec.get('workload') == want:
+            return rec['traffic_bytes_per_launch']
+    return None
+
+
+def roofline_report(summary, steps, args):
     """summary: _lib.TIMER.summary().  Returns (roofline object, per-kernel table)."""
     table = {}
     for name, rec in sorted(summary.items(), key=lambda kv: -kv[1]['total_ms']):
@@ -124,7 +138,7 @@ def roofline_report(summary, steps):
     name, rec = max(hbm, key=lambda kv: kv[1]['total_ms'])
     achieved = rec['work'] / (rec['total_ms'] * 1e-3) / 1e9
     roofline = {'kernel': name, 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(name, args),
                 'launches': rec['launches'], 'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
                 'algorithmic_bytes_per_launch': round(rec['work'] / rec['launches'])}
     return roofline, table
@@ -203,7 +217,7 @@ def main():
 
     if rank == 0:
         global_batch = args.batch * world
-        roofline, kernel_table = roofline_report(_lib.TIMER.summary(), args.steps)
+        roofline, kernel_table = roofline_report(_lib.TIMER.summary(), args.steps, args)
         line = {
             'metric': 'frame-pairs/sec (fwd+bwd) 960x540 + 8192 pts, CamLiRAFT',
             'value': round(global_batch * args.steps / elapsed, 4),
