@@ -123,6 +123,30 @@ def pmc_traffic(entry_point, args):
     return None
 
 
+def isolated_dw_fwd(batch, device):
+    """The roofline kernel alone on an idle GPU (its largest shape in the step: C=128, k=32,
+    2048 points): context for the in-situ figure, which is measured while the image branch's
+    convolutions share the chip with it on another stream."""
+    from camliflow_amd.csrc import fused
+    c, n, k = 128, 2048, 32
+    feat = torch.randn(batch, c, n, device=device)
+    shared = fused.SharedSetConvWeights(torch.rand(batch, c, n, k, device=device))
+    idx = torch.randint(0, n, (batch, n, 32), device=device)
+    for _ in range(3):
+        fused.pointconv_dw(feat, shared, idx, k)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    start.record()
+    for _ in range(reps):
+        fused.pointconv_dw(feat, shared, idx, k)
+    end.record()
+    torch.cuda.synchronize()
+    us = start.elapsed_time(end) / reps * 1e3
+    byt = 4.0 * batch * c * n * k + 4.0 * batch * c * n + 8.0 * batch * n * k + 5.0 * batch * c * n
+    return {'shape': 'B%d C%d N%d k%d, inference form' % (batch, c, n, k), 'avg_launch_us': round(us, 2),
+            'achieved': round(byt / us / 1e3, 1), 'frac': round(byt / us / 1e3 / HBM_PEAK_GBS, 4)}
+
+
 def roofline_report(summary, steps, args):
     """summary: _lib.TIMER.summary().  Returns (roofline object, per-kernel table)."""
     table = {}
@@ -218,6 +242,8 @@ def main():
     if rank == 0:
         global_batch = args.batch * world
         roofline, kernel_table = roofline_report(_lib.TIMER.summary(), args.steps, args)
+        if roofline and roofline['kernel'] == 'camli_pointconv_dw_fwd':
+            roofline['isolated'] = isolated_dw_fwd(args.batch, device)
         line = {
             'metric': 'frame-pairs/sec (fwd+bwd) 960x540 + 8192 pts, CamLiRAFT',
             'value': round(global_batch * args.steps / elapsed, 4),
