@@ -1,0 +1,105 @@
+"""Edge cases of the C-ABI entry points: empty batches / queries, minimum and maximum sizes, bad
+arguments (status code + message, never a crash), non-default streams."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_empty_batch_and_empty_queries_are_noops():
+    from camliflow_amd import csrc
+    x = torch.rand(0, 100, 3, device='cuda')
+    assert csrc.k_nearest_neighbor(x, x, 3).shape == (0, 100, 3)
+    assert csrc.furthest_point_sampling(x, 10).shape == (0, 10)
+    inp = torch.rand(2, 50, 3, device='cuda')
+    qry = torch.rand(2, 0, 3, device='cuda')
+    # the reference's layout sniffing (shape[1] <= 3) treats a 0-row tensor as channel-first; feed channel-first
+    assert csrc.k_nearest_neighbor(inp.transpose(1, 2), qry.transpose(1, 2), 4).shape == (2, 0, 4)
+    out = csrc.correlation2d(torch.rand(0, 8, 5, 6, device='cuda'), torch.rand(0, 8, 5, 6, device='cuda'), 2)
+    assert out.shape == (0, 25, 5, 6)
+
+
+def test_knn_fewer_inputs_than_k_pads_with_index_zero(oracle_lib):
+    """k_nearest_neighbor_kernel.cu:68-72,93-94: unfilled slots keep index 0"""
+    from camliflow_amd import csrc
+    rng = np.random.default_rng(0)
+    inp = rng.random((1, 5, 3), dtype=np.float32)
+    qry = rng.random((1, 9, 3), dtype=np.float32)
+    got = csrc.k_nearest_neighbor(dev(inp), dev(qry), 16).cpu().numpy()
+    assert np.array_equal(got, oracle_lib.knn(inp, qry, 16))
+    assert (got[:, :, 5:] == 0).all()
+
+
+def test_k_max_64_and_rejects_65(oracle_lib):
+    from camliflow_amd import csrc
+    from camliflow_amd.csrc._lib import CamliHipError
+    rng = np.random.default_rng(1)
+    inp = rng.random((1, 200, 3), dtype=np.float32)
+    got = csrc.k_nearest_neighbor(dev(inp), dev(inp), 64).cpu().numpy()
+    assert np.array_equal(got, oracle_lib.knn(inp, inp, 64))
+    with pytest.raises(CamliHipError, match='k'):
+        csrc.k_nearest_neighbor(dev(inp), dev(inp), 65)
+
+
+def test_fps_limits(oracle_lib):
+    from camliflow_amd import csrc
+    from camliflow_amd.csrc._lib import CamliHipError
+    rng = np.random.default_rng(2)
+    xyz = rng.random((1, 24576, 3), dtype=np.float32)          # the documented maximum
+    got = csrc.furthest_point_sampling(dev(xyz), 300).cpu().numpy()
+    assert np.array_equal(got, oracle_lib.fps(xyz, 300))
+    with pytest.raises(CamliHipError, match='register-resident'):
+        csrc.furthest_point_sampling(torch.rand(1, 30000, 3, device='cuda'), 16)
+    two = rng.random((1, 2, 3), dtype=np.float32)              # smallest legal cloud (N > n_samples)
+    assert np.array_equal(csrc.furthest_point_sampling(dev(two), 1).cpu().numpy(), [[0]])
+
+
+def test_kernels_honour_the_current_stream(oracle_lib):
+    from camliflow_amd import csrc
+    rng = np.random.default_rng(3)
+    inp = rng.random((2, 1000, 3), dtype=np.float32)
+    side = torch.cuda.Stream()
+    tin = dev(inp)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        busy = torch.randn(4096, 4096, device='cuda') @ torch.randn(4096, 4096, device='cuda')   # keep `side` busy
+        scaled = tin * 2.0                                       # produced on `side` ...
+        got = csrc.k_nearest_neighbor(scaled, scaled, 8)         # ... and consumed by a kernel on `side`
+    side.synchronize()
+    assert np.array_equal(got.cpu().numpy(), oracle_lib.knn(inp * 2.0, inp * 2.0, 8))
+    del busy
+
+
+def test_lookup_rejects_other_radius():
+    from camliflow_amd.csrc import fused
+    from camliflow_amd.csrc._lib import CamliHipError
+    pyr = fused.AllPairsPyramid()
+    pyr.levels = [torch.randn(64, 8, 8, device='cuda')]
+    pyr.shape = (1, 8, 8)
+    pyr.token = torch.zeros(1, device='cuda')
+    with pytest.raises(CamliHipError, match='radius'):
+        fused.allpairs_lookup(pyr, torch.zeros(1, 2, 8, 8, device='cuda'), 3)
+
+
+def test_kitti_shape_bf16_autocast_config5():
+    """BASELINE configs[4]: KITTI-shape 1242x375 + 16384 points under bf16 autocast (convs / GEMMs only;
+    KNN, FPS, correlation and CLFM stay fp32 as in the reference).  bf16 is not the fp32 parity bar:
+    the flows must stay finite and within 0.5 px / 0.05 of the fp32 run (4 iterations)."""
+    from camliflow_amd.cores import CamLiRAFT, runtime
+    from modelutils import camliraft_cfg, hashed_fill_, synthetic_inputs
+    torch.manual_seed(0)
+    model = hashed_fill_(CamLiRAFT(camliraft_cfg(n_iters=4)), scale=0.5).cuda().eval()
+    inputs = {k: v.cuda() for k, v in synthetic_inputs(1, 375, 1242, 16384, f=721.5, with_targets=False, zmax=90.0).items()}
+    with torch.no_grad(), runtime.use_backend('hip'):
+        ref = model(inputs)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            low = model(inputs)
+    assert ref['flow_2d'].shape == (1, 2, 375, 1242) and ref['flow_3d'].shape == (1, 3, 16384)
+    for key, tol in (('flow_2d', 0.5), ('flow_3d', 0.05)):
+        assert torch.isfinite(low[key]).all()
+        assert torch.linalg.norm(low[key].float() - ref[key], dim=1).mean().item() < tol, key
