@@ -171,6 +171,7 @@ int launch_fwd(const float* in1, const float* in2, float* out, int B, int C, int
 
 extern "C" int camli_corr2d_fwd(const float* in1_nhwc, const float* in2_nhwc, float* out_nchw, int B, int C, int H,
                                 int W, int md, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!in1_nhwc || !in2_nhwc || !out_nchw) {
         camli_set_error("camli_corr2d_fwd: null pointer");
         return CAMLI_EINVAL;
@@ -196,6 +197,7 @@ extern "C" int camli_corr2d_fwd(const float* in1_nhwc, const float* in2_nhwc, fl
 
 extern "C" int camli_corr2d_bwd(const float* gout_nchw, const float* in1_nhwc, const float* in2_nhwc, float* g1_nhwc,
                                 float* g2_nhwc, int B, int C, int H, int W, int md, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!gout_nchw || !in1_nhwc || !in2_nhwc || !g1_nhwc || !g2_nhwc) {
         camli_set_error("camli_corr2d_bwd: null pointer");
         return CAMLI_EINVAL;

@@ -205,6 +205,7 @@ int launch_fps(const float* xyz, int64_t* out, int B, int N, int n_samples, hipS
 }  // namespace
 
 extern "C" int camli_fps(const float* xyz, int64_t* out_idx, int B, int N, int n_samples, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!xyz || !out_idx) {
         camli_set_error("camli_fps: null pointer");
         return CAMLI_EINVAL;

@@ -314,6 +314,7 @@ int dispatch_knn(const float* input, const float* query, int64_t* out, int B, in
 
 extern "C" int camli_knn(const float* input, const float* query, int64_t* out_idx, int B, int M, int Nq, int D,
                          int k, void* stream) {
+    if (B == 0 || Nq == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!input || !query || !out_idx) {
         camli_set_error("camli_knn: null pointer");
         return CAMLI_EINVAL;

@@ -203,6 +203,7 @@ int launch_lookup(float* const* vols, const int* hs, const int* ws, int L, const
 
 extern "C" int camli_allpairs_lookup_fwd(const float* const* vols, const int* hs, const int* ws, int L,
                                          const float* coords, float* out, int B, int h, int w, int r, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     return launch_lookup<false>(const_cast<float* const*>(vols), hs, ws, L, coords, out, B, h, w, r,
                                 reinterpret_cast<hipStream_t>(stream), "camli_allpairs_lookup_fwd");
 }
@@ -210,6 +211,7 @@ extern "C" int camli_allpairs_lookup_fwd(const float* const* vols, const int* hs
 extern "C" int camli_allpairs_lookup_bwd(float* const* gvols, const int* hs, const int* ws, int L,
                                          const float* coords, const float* gout, int B, int h, int w, int r,
                                          void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     return launch_lookup<true>(gvols, hs, ws, L, coords, const_cast<float*>(gout), B, h, w, r,
                                reinterpret_cast<hipStream_t>(stream), "camli_allpairs_lookup_bwd");
 }

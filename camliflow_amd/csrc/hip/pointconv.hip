@@ -106,6 +106,7 @@ int mix_args_ok(const char* what, int B, int M, int N, int CH, int Wn, int k, in
 
 extern "C" int camli_pointconv_mix_fwd(const float* feat_cl, const float* wgt, const int64_t* idx, int idx_stride,
                                        float* out, int B, int M, int N, int CH, int Wn, int k, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!feat_cl || !wgt || !idx || !out) { camli_set_error("camli_pointconv_mix_fwd: null pointer"); return CAMLI_EINVAL; }
     if (!mix_args_ok("camli_pointconv_mix_fwd", B, M, N, CH, Wn, k, idx_stride)) return CAMLI_EINVAL;
     if (B == 0) return CAMLI_OK;
@@ -118,6 +119,7 @@ extern "C" int camli_pointconv_mix_fwd(const float* feat_cl, const float* wgt, c
 extern "C" int camli_pointconv_mix_bwd(const float* gout, const float* feat_cl, const float* wgt, const int64_t* idx,
                                        int idx_stride, float* gfeat_cl, float* gwgt, int B, int M, int N, int CH, int Wn,
                                        int k, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!gout || !feat_cl || !wgt || !idx || (!gfeat_cl && !gwgt)) {
         camli_set_error("camli_pointconv_mix_bwd: null pointer");
         return CAMLI_EINVAL;

@@ -125,6 +125,7 @@ int grid_y_for(int C) { return C < 64 ? C : 64; }
 
 extern "C" int camli_gather_cf_fwd(const float* data, const int64_t* idx, float* out, int B, int C, int M, int I,
                                    void* stream) {
+    if (B == 0 || I == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!data || !idx || !out) { camli_set_error("camli_gather_cf_fwd: null pointer"); return CAMLI_EINVAL; }
     if (B < 0 || C < 1 || M < 1 || I < 0 || B > 65535) {
         camli_set_error("camli_gather_cf_fwd: bad shape B=%d C=%d M=%d I=%d", B, C, M, I);
@@ -138,6 +139,7 @@ extern "C" int camli_gather_cf_fwd(const float* data, const int64_t* idx, float*
 
 extern "C" int camli_gather_cf_bwd(const float* gout, const int64_t* idx, float* gdata, int B, int C, int M, int I,
                                    void* stream) {
+    if (B == 0 || I == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!gout || !idx || !gdata) { camli_set_error("camli_gather_cf_bwd: null pointer"); return CAMLI_EINVAL; }
     if (B < 0 || C < 1 || M < 1 || I < 0 || B > 65535) {
         camli_set_error("camli_gather_cf_bwd: bad shape B=%d C=%d M=%d I=%d", B, C, M, I);
@@ -161,6 +163,7 @@ static int knn_interp_args_ok(const char* what, const void* a, const void* b, co
 
 extern "C" int camli_knn_interp_fwd(const float* in_xyz, const float* feat, const float* q_xyz, const int64_t* knn,
                                     int knn_stride, float* out, int B, int C, int M, int Nq, int k, void* stream) {
+    if (B == 0 || Nq == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!knn_interp_args_ok("camli_knn_interp_fwd", in_xyz, feat, q_xyz, knn, out, B, C, M, Nq, k, knn_stride))
         return CAMLI_EINVAL;
     if (B == 0 || Nq == 0) return CAMLI_OK;
@@ -172,6 +175,7 @@ extern "C" int camli_knn_interp_fwd(const float* in_xyz, const float* feat, cons
 
 extern "C" int camli_knn_interp_bwd(const float* in_xyz, const float* gout, const float* q_xyz, const int64_t* knn,
                                     int knn_stride, float* gfeat, int B, int C, int M, int Nq, int k, void* stream) {
+    if (B == 0 || Nq == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!knn_interp_args_ok("camli_knn_interp_bwd", in_xyz, gout, q_xyz, knn, gfeat, B, C, M, Nq, k, knn_stride))
         return CAMLI_EINVAL;
     if (B == 0 || Nq == 0) return CAMLI_OK;
@@ -183,6 +187,7 @@ extern "C" int camli_knn_interp_bwd(const float* in_xyz, const float* gout, cons
 
 extern "C" int camli_corr3d_gather_fwd(const float* xyz1, const float* xyz2, const float* cost, const int64_t* knn,
                                        float* out, int B, int N, int M, int k, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!xyz1 || !xyz2 || !cost || !knn || !out) { camli_set_error("camli_corr3d_gather_fwd: null pointer"); return CAMLI_EINVAL; }
     if (B < 0 || N < 1 || M < 1 || k < 1) {
         camli_set_error("camli_corr3d_gather_fwd: bad shape B=%d N=%d M=%d k=%d", B, N, M, k);
@@ -198,6 +203,7 @@ extern "C" int camli_corr3d_gather_fwd(const float* xyz1, const float* xyz2, con
 
 extern "C" int camli_corr3d_gather_bwd(const float* gout, const int64_t* knn, float* gcost, int B, int N, int M, int k,
                                        void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!gout || !knn || !gcost) { camli_set_error("camli_corr3d_gather_bwd: null pointer"); return CAMLI_EINVAL; }
     if (B < 0 || N < 1 || M < 1 || k < 1) {
         camli_set_error("camli_corr3d_gather_bwd: bad shape B=%d N=%d M=%d k=%d", B, N, M, k);

@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void pointconv_dw_expand_kernel(ExpandCalls ca
 extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, const int64_t* idx, int idx_stride,
                                       float* out, unsigned char* arg, float* wsel, int* msel, int B, int C, int M,
                                       int N, int k, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!feat || !weight || !idx || !out || !arg || ((wsel == nullptr) != (msel == nullptr))) {
         camli_set_error("camli_pointconv_dw_fwd: null pointer");
         return CAMLI_EINVAL;
@@ -310,6 +311,7 @@ extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, co
 
 extern "C" int camli_pointconv_dw_bwd(const float* gout, const float* feat, const float* wsel, const int* msel,
                                       float* gfeat, float* gwsel, int B, int C, int M, int N, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!gout || !feat || !wsel || !msel || (!gfeat && !gwsel)) {
         camli_set_error("camli_pointconv_dw_bwd: null pointer");
         return CAMLI_EINVAL;
@@ -340,6 +342,7 @@ extern "C" int camli_pointconv_dw_bwd(const float* gout, const float* feat, cons
 
 extern "C" int camli_pointconv_dw_expand(const float* const* gwsel_list, const unsigned char* const* arg_list,
                                          int n_calls, float* gweight, int B, int C, int N, int k, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!gwsel_list || !arg_list || !gweight) {
         camli_set_error("camli_pointconv_dw_expand: null pointer");
         return CAMLI_EINVAL;
