@@ -1,6 +1,10 @@
 """Composite operators of the cores that have a fused gfx950 kernel (internal API, used when
 ``cores.runtime.backend() == 'hip'``).  Each function documents the reference composition it
 replaces; the torch-composed twin lives next to its call site in ``camliflow_amd/cores``.
+
+Every autograd Function here runs with autocast DISABLED and fp32 inputs (``custom_fwd(cast_inputs=
+torch.float32)``): the kernels take raw fp32 device pointers, and the reference keeps these ops in
+fp32 under AMP as well (``.float()`` at raft_core.py:53-54, clfm.py:31-32, camliraft_l_core.py:52).
 """
 import ctypes
 import math
@@ -42,6 +46,7 @@ class AllPairsPyramid:
 
 class _BuildPyramid(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, fmap1, fmap2, num_levels, pyr):
         bs, dim, h, w = fmap1.shape
         f1 = fmap1.reshape(bs, dim, h * w)
@@ -59,6 +64,7 @@ class _BuildPyramid(torch.autograd.Function):
         return fmap1.new_zeros(1)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, _gtoken):
         pyr = ctx.pyr
         f1, f2 = ctx.saved_tensors
@@ -81,9 +87,12 @@ class _BuildPyramid(torch.autograd.Function):
 
 class _Lookup(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, token, coords, radius, pyr):
         lib = _lib.load()
         bs, h, w = pyr.shape
+        assert all(lvl.dtype == torch.float32 and lvl.is_contiguous() for lvl in pyr.levels), 'pyramid must be fp32'
+        assert coords.dtype == torch.float32 and coords.is_contiguous()
         n, ptrs, hs, ws = pyr._level_args(pyr.levels)
         d = 2 * radius + 1
         out = torch.empty((bs, n * d * d, h, w), dtype=torch.float32, device=coords.device)
@@ -96,6 +105,7 @@ class _Lookup(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gout):
         lib = _lib.load()
         (coords,) = ctx.saved_tensors
@@ -142,18 +152,20 @@ class SharedSetConvWeights:
     """
 
     def __init__(self, weight):
-        self.weight = weight.detach().contiguous()
+        self.weight = weight.detach().float().contiguous()     # fp32 even when weight_net ran under autocast
         self.records = []          # [(gwsel [B,C,N] fp32, arg [B,C,N] uint8)] appended by the backward calls
         self.token = _ShareWeights.apply(weight, self)
 
 
 class _ShareWeights(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, weight, shared):
         ctx.shared = shared
         return weight.new_zeros(1)
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, _gtoken):
         lib = _lib.load()
         shared = ctx.shared
@@ -179,6 +191,7 @@ class _ShareWeights(torch.autograd.Function):
 
 class _PointConvDW(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, feat, token, knn_indices, k, shared):
         lib = _lib.load()
         weight = shared.weight
@@ -201,6 +214,7 @@ class _PointConvDW(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gout):
         lib = _lib.load()
         feat, wsel, msel, arg = ctx.saved_tensors
@@ -235,6 +249,7 @@ def pointconv_dw(feat, shared, knn_indices, k):
 # ------------------------------------------------------------------------------------------------
 class _GatherCF(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, data, idx_flat):
         lib = _lib.load()
         b, c, m = data.shape
@@ -249,6 +264,7 @@ class _GatherCF(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gout):
         lib = _lib.load()
         (idx_flat,) = ctx.saved_tensors
@@ -273,6 +289,7 @@ def gather_points(data, indices):
 
 class _KnnInterp(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, in_xyz, feat, q_xyz, knn, k):
         lib = _lib.load()
         b, c, m = feat.shape
@@ -288,6 +305,7 @@ class _KnnInterp(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gout):
         lib = _lib.load()
         in_xyz, q_xyz, knn = ctx.saved_tensors
@@ -313,6 +331,7 @@ def knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k):
 
 class _Corr3DGather(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, cost, xyz1, xyz2, knn):
         lib = _lib.load()
         b, n, m = cost.shape
@@ -327,6 +346,7 @@ class _Corr3DGather(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gout):
         lib = _lib.load()
         (knn,) = ctx.saved_tensors
@@ -354,6 +374,7 @@ def corr3d_lookup_input(cost_volume, xyz1, xyz2, knn_indices):
 # ------------------------------------------------------------------------------------------------
 class _PointConvMix(torch.autograd.Function):
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, feat_cl, wgt, knn_indices, k):
         lib = _lib.load()
         b, m, ch = feat_cl.shape
@@ -368,6 +389,7 @@ class _PointConvMix(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gout):
         lib = _lib.load()
         feat_cl, wgt, knn_indices = ctx.saved_tensors

@@ -36,6 +36,7 @@ class CorrelationFunction(torch.autograd.Function):
     """Counterpart of wrapper.py:18-37.  Inputs are NHWC, the cost volume is NCHW."""
 
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, input1, input2, max_displacement):
         lib = _lib.load()
         assert input1.is_contiguous() and input2.is_contiguous(), 'inputs must be contiguous (correlation.cpp:12-13)'
@@ -52,6 +53,7 @@ class CorrelationFunction(torch.autograd.Function):
         return output
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, grad_output):
         lib = _lib.load()
         input1, input2 = ctx.saved_tensors
