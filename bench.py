@@ -54,12 +54,36 @@ def synthetic_batch(b, h, w, n_points, seed):
             'flow_3d': torch.randn(b, 3, n_points, generator=g) * 0.05}
 
 
-def make_optimizer(model):
+class GraphedStep:
+    """The whole training step (forward, losses, backward, clip, AdamW) captured once into a HIP graph
+    and replayed: removes the ~16k kernel launches per step from the host.  Both HIP streams of the
+    two-lane execution are captured (the side stream forks from and joins the capture stream).
+    Single GPU only (collectives stay outside graphs here)."""
+
+    def __init__(self, model, optimizer, batch, warmup=3):
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(model, optimizer, batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(model, optimizer, batch)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss
+
+
+def make_optimizer(model, capturable=False):
     """AdamW with the reference's split learning rates (conf/training/flyingthings3d_subset/camliraft.yaml,
     factory.py:50-58: parameters under core.branch_3d get lr_3d)."""
     p3d = [p for n, p in model.named_parameters() if 'core.branch_3d' in n]
     p2d = [p for n, p in model.named_parameters() if 'core.branch_3d' not in n]
-    return torch.optim.AdamW([{'params': p2d, 'lr': 2e-4}, {'params': p3d, 'lr': 2e-3}], weight_decay=1e-6)
+    return torch.optim.AdamW([{'params': p2d, 'lr': 2e-4}, {'params': p3d, 'lr': 2e-3}], weight_decay=1e-6,
+                             capturable=capturable)
 
 
 def allreduce_gradients(model, world):
@@ -179,6 +203,7 @@ def main():
     ap.add_argument('--width', type=int, default=960)
     ap.add_argument('--points', type=int, default=8192)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='capture the whole training step in one HIP graph (single GPU)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -210,7 +235,8 @@ def main():
     if world > 1:   # identical replicas: broadcast rank 0's parameters and buffers once
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
-    optimizer = make_optimizer(model)
+    use_graph = args.graph and world == 1
+    optimizer = make_optimizer(model, capturable=use_graph)
     batch = {k: v.to(device) for k, v in synthetic_batch(args.batch, args.height, args.width, args.points,
                                                          seed=100 + rank).items()}
 
@@ -219,17 +245,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphed = GraphedStep(model, optimizer, batch) if use_graph else None
     for _ in range(args.warmup):
-        train_step(model, optimizer, batch, world)
+        graphed() if graphed else train_step(model, optimizer, batch, world)
     barrier()
     _lib.TIMER.reset()
     _lib.TIMER.only = None
-    _lib.TIMER.enabled = True
+    _lib.TIMER.enabled = graphed is None   # events cannot be recorded through a graph replay
     t0 = time.perf_counter()
     host_s = 0.0
     for _ in range(args.steps):
         h0 = time.perf_counter()
-        loss = train_step(model, optimizer, batch, world)
+        loss = graphed() if graphed else train_step(model, optimizer, batch, world)
         host_s += time.perf_counter() - h0
     barrier()
     elapsed = time.perf_counter() - t0
@@ -253,7 +280,7 @@ def main():
             'config': {'workload': 'CamLiRAFT training step (fwd + sequence losses + bwd + clip + AdamW), '
                                    '%dx%d + %d pts, %d GRU iters, batch %d per GPU (BASELINE configs[2])'
                                    % (args.width, args.height, args.points, args.iters, args.batch),
-                       'global_batch': global_batch, 'parallelism': 'dp%d' % world,
+                       'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hip_graph': bool(graphed),
                        'loss': round(float(loss.detach()), 4),
                        'host_enqueue_ms_per_step': round(host_s / args.steps * 1e3, 1)},
             'roofline': roofline,

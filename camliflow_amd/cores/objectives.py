@@ -94,7 +94,7 @@ class FlowModel(nn.Module):
         var = var.reshape(-1).float()
         if var.numel() == 0:
             return
-        entry = torch.stack([var.sum(), torch.tensor(float(var.numel()), device=var.device)])
+        entry = torch.stack([var.sum(), var.new_full((), float(var.numel()))])   # no host->device copy: graph-capturable
         self.metrics[name] = self.metrics[name] + entry if name in self.metrics else entry
 
     def get_metrics(self):
