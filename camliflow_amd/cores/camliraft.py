@@ -185,6 +185,10 @@ class CamLiRAFT(_FreezableBN, FlowModel):
         super().__init__()
         self.cfgs = cfgs
         self.core = CamLiRAFT_Core(cfgs)
+        # normalisation constants live on the device (non-persistent: not part of the state dict);
+        # the reference re-uploads them from Python lists on every forward (camliraft.py:41-42)
+        self.register_buffer('_norm_mean', torch.tensor(_IMAGENET_MEAN).reshape(1, 3, 1, 1), persistent=False)
+        self.register_buffer('_norm_std', torch.tensor(_IMAGENET_STD).reshape(1, 3, 1, 1), persistent=False)
 
     def forward(self, inputs):
         images = inputs['images'].float()
@@ -192,8 +196,7 @@ class CamLiRAFT(_FreezableBN, FlowModel):
 
         padder = InputPadder(images.shape, x=8)
         image1, image2 = padder.pad(images[:, :3], images[:, 3:])
-        mean = torch.tensor(_IMAGENET_MEAN, device=images.device).reshape(1, 3, 1, 1)
-        std = torch.tensor(_IMAGENET_STD, device=images.device).reshape(1, 3, 1, 1)
+        mean, std = self._norm_mean, self._norm_std
         image1 = (image1 - mean) / std
         image2 = (image2 - mean) / std
 
