@@ -90,11 +90,18 @@ class FlowModel(nn.Module):
         self.metrics = {}
 
     @torch.no_grad()
-    def update_metrics(self, name, var):
-        var = var.reshape(-1).float()
-        if var.numel() == 0:
-            return
-        entry = torch.stack([var.sum(), var.new_full((), float(var.numel()))])   # no host->device copy: graph-capturable
+    def update_metrics(self, name, var, mask=None):
+        """Accumulate [sum, count] of ``var`` (over ``mask`` if given) on the device.  No boolean
+        indexing / ``.item()``: nothing here synchronises with the host, so a whole step stays
+        capturable in a HIP graph."""
+        var = var.float()
+        if mask is None:
+            if var.numel() == 0:
+                return
+            entry = torch.stack([var.sum(), var.new_full((), float(var.numel()))])
+        else:
+            keep = mask.to(var.dtype)
+            entry = torch.stack([(var * keep).sum(), keep.sum()])
         self.metrics[name] = self.metrics[name] + entry if name in self.metrics else entry
 
     def get_metrics(self):
@@ -105,7 +112,7 @@ class FlowModel(nn.Module):
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(packed)                        # one collective for everything
         packed = packed.cpu()
-        return {n: (packed[i, 0] / packed[i, 1]).item() for i, n in enumerate(names) if packed[i, 1] > 0}
+        return {n: (packed[i, 0] / packed[i, 1]).item() for i, n in enumerate(names) if packed[i, 1] > 0}   # empty masks are dropped (base.py:25-26)
 
     def get_loss(self):
         if self.loss is None:
@@ -123,10 +130,10 @@ class FlowModel(nn.Module):
         else:
             mask = torch.ones_like(target)[:, 0] > 0
         epe = torch.linalg.norm(pred - target, dim=1)
-        self.update_metrics('epe2d', epe[mask])
-        self.update_metrics('acc2d_1px', (epe < 1.0)[mask])
+        self.update_metrics('epe2d', epe, mask)
+        self.update_metrics('acc2d_1px', epe < 1.0, mask)
         mag = torch.linalg.norm(target, dim=1) + 1e-5
-        self.update_metrics('outlier2d', torch.logical_and(epe > 3.0, epe / mag > 0.05)[mask])
+        self.update_metrics('outlier2d', torch.logical_and(epe > 3.0, epe / mag > 0.05), mask)
 
     @torch.no_grad()
     def update_3d_metrics(self, pred, target, occ_mask=None):
@@ -138,8 +145,8 @@ class FlowModel(nn.Module):
         acc = epe < 0.05
         if occ_mask is not None:
             mask = torch.logical_and(occ_mask == 0, mask)
-            self.update_metrics('epe3d_noc', epe[mask])
-            self.update_metrics('acc3d_5cm_noc', acc[mask])
+            self.update_metrics('epe3d_noc', epe, mask)
+            self.update_metrics('acc3d_5cm_noc', acc, mask)
         else:
-            self.update_metrics('epe3d', epe[mask])
-            self.update_metrics('acc3d_5cm', acc[mask])
+            self.update_metrics('epe3d', epe, mask)
+            self.update_metrics('acc3d_5cm', acc, mask)
