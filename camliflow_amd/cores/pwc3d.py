@@ -32,11 +32,11 @@ class FeaturePyramid3D(nn.Module):
 
 
 class Correlation3D(nn.Module):
-    """PointPWC cost volume (camlipwc_l_core.py:39-106).
+    """PointPWC learnable cost volume (camlipwc_l_core.py:39-106), three stages per source point p:
 
-    point-to-point:    MLP2d([f1 | f2_knn | dxyz]) over the k nearest points of cloud 2
-    point-to-patch:    sum_k weight_net2(dxyz) * p2p
-    patch-to-patch:    sum_k weight_net1(dxyz_self) * gather(p2patch, self-KNN)
+    point-to-point   c(p, q)  = MLP2d([f1(p) | f2(q) | q - p])            q in KNN_k(p; cloud 2)
+    point-to-patch   C(p)     = sum_q  weight_net2(q - p) * c(p, q)
+    patch-to-patch   out(p)   = sum_p' weight_net1(p' - p) * C(p')         p' in KNN_k(p; cloud 1)
     """
 
     def __init__(self, in_channels, out_channels, align_channels=None, k=16):
@@ -45,28 +45,30 @@ class Correlation3D(nn.Module):
         self.cost_mlp = MLP2d(3 + 2 * in_channels, [out_channels, out_channels], act='leaky_relu')
         self.weight_net1 = MLP2d(3, [8, 8, out_channels], act='relu')
         self.weight_net2 = MLP2d(3, [8, 8, out_channels], act='relu')
-        self.feat_aligner = Conv1dNormRelu(out_channels, align_channels) if align_channels is not None else nn.Identity()
+        self.feat_aligner = nn.Identity() if align_channels is None else Conv1dNormRelu(out_channels, align_channels)
+
+    def _self_neighbours(self, xyz1, given):
+        if given is None:
+            return _ops.k_nearest_neighbor(input_xyz=xyz1, query_xyz=xyz1, k=self.k)
+        assert given.shape[:2] == torch.Size([xyz1.shape[0], xyz1.shape[2]]) and given.shape[2] >= self.k
+        return given[:, :, :self.k]
 
     def forward(self, xyz1, feat1, xyz2, feat2, knn_indices_1in1=None):
-        batch_size, in_channels, n_points = feat1.shape
-        centre = xyz1.view(batch_size, 3, n_points, 1)
+        bs, channels, n = feat1.shape
+        origin = xyz1.view(bs, 3, n, 1)
 
-        knn_1in2 = _ops.k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)
-        offset2 = batch_indexing(xyz2, knn_1in2) - centre                               # [B,3,N,k]
-        feat2_knn = batch_indexing(feat2, knn_1in2)                                     # [B,C,N,k]
-        feat1_rep = feat1[:, :, :, None].expand(batch_size, in_channels, n_points, self.k)
-        p2p_cost = self.cost_mlp(torch.cat([feat1_rep, feat2_knn, offset2], dim=1))
-        p2n_cost = torch.sum(self.weight_net2(offset2) * p2p_cost, dim=3)               # [B,Cout,N]
+        # cloud-2 neighbourhood of every source point
+        cross = _ops.k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)
+        d_cross = batch_indexing(xyz2, cross) - origin                                  # [B,3,N,k]
+        pair = torch.cat([feat1[:, :, :, None].expand(bs, channels, n, self.k), batch_indexing(feat2, cross), d_cross],
+                         dim=1)
+        to_patch = (self.weight_net2(d_cross) * self.cost_mlp(pair)).sum(dim=3)         # [B,Cout,N]
 
-        if knn_indices_1in1 is not None:
-            assert knn_indices_1in1.shape[:2] == torch.Size([batch_size, n_points])
-            assert knn_indices_1in1.shape[2] >= self.k
-            knn_indices_1in1 = knn_indices_1in1[:, :, :self.k]
-        else:
-            knn_indices_1in1 = _ops.k_nearest_neighbor(input_xyz=xyz1, query_xyz=xyz1, k=self.k)
-        offset1 = batch_indexing(xyz1, knn_indices_1in1) - centre
-        n2n_cost = torch.sum(self.weight_net1(offset1) * batch_indexing(p2n_cost, knn_indices_1in1), dim=3)
-        return self.feat_aligner(n2n_cost)
+        # cloud-1 neighbourhood: aggregate the point-to-patch costs of the neighbours
+        own = self._self_neighbours(xyz1, knn_indices_1in1)
+        d_own = batch_indexing(xyz1, own) - origin
+        patch = (self.weight_net1(d_own) * batch_indexing(to_patch, own)).sum(dim=3)
+        return self.feat_aligner(patch)
 
 
 class FlowEstimator3D(nn.Module):
@@ -100,22 +102,21 @@ class CamLiPWC_L_Core(nn.Module):
         return self.feature_pyramid(xyzs)
 
     def decode(self, xyzs1, xyzs2, feats1_3d, feats2_3d):
-        flows_3d = []
-        top = len(xyzs1) - 1
-        for level in range(top, 0, -1):
+        """coarse-to-fine: at each level warp cloud 2 with the up-sampled flow of the coarser level,
+        build the cost volume, estimate the residual (camlipwc_l_core.py:172-208)."""
+        coarsest = len(xyzs1) - 1
+        coarse_to_fine = []
+        for level in range(coarsest, 0, -1):
             xyz1, xyz2 = xyzs1[level], xyzs2[level]
-            knn1 = _ops.k_nearest_neighbor(xyz1, xyz1, k=16)
-            bs, _, n_points = xyz1.shape
-            if level == top:
-                last_flow = torch.zeros([bs, 3, n_points], device=xyz1.device)
-                xyz2_warp = xyz2
+            own = _ops.k_nearest_neighbor(xyz1, xyz1, k=16)
+            if level == coarsest:
+                prior = torch.zeros([xyz1.shape[0], 3, xyz1.shape[2]], device=xyz1.device)
+                warped = xyz2
             else:
-                last_flow = knn_interpolation(xyzs1[level + 1], flows_3d[-1], xyz1)
-                xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow)
-            x = torch.cat([self.pyramid_feat_aligners[level](feats1_3d[level]),
-                           self.correlations[level](xyz1, feats1_3d[level], xyz2_warp, feats2_3d[level], knn1),
-                           last_flow], dim=1)
-            _, flow_delta = self.flow_estimator(xyz1, x, knn1)
-            flows_3d.append(last_flow + flow_delta)
-        flows_3d = [f.float() for f in flows_3d][::-1]
-        return [knn_interpolation(xyzs1[i + 1], flow, xyzs1[i]) for i, flow in enumerate(flows_3d)]
+                prior = knn_interpolation(xyzs1[level + 1], coarse_to_fine[-1], xyz1)
+                warped = backwarp_3d(xyz1, xyz2, prior)
+            cost = self.correlations[level](xyz1, feats1_3d[level], warped, feats2_3d[level], own)
+            x = torch.cat([self.pyramid_feat_aligners[level](feats1_3d[level]), cost, prior], dim=1)
+            coarse_to_fine.append(prior + self.flow_estimator(xyz1, x, own)[1])
+        fine_to_coarse = [f.float() for f in reversed(coarse_to_fine)]
+        return [knn_interpolation(xyzs1[i + 1], flow, xyzs1[i]) for i, flow in enumerate(fine_to_coarse)]

@@ -144,46 +144,54 @@ class GRU2D(nn.Module):
         return torch.nan_to_num(h)
 
 
+def _conv(cin, cout, ksize):
+    return nn.Conv2d(cin, cout, kernel_size=ksize, padding=ksize // 2)
+
+
 class MotionEncoder2D(nn.Module):
+    """(flow, correlation window) -> 126 motion channels + the flow itself (raft_core.py:142-166)."""
+
     def __init__(self, corr_levels, corr_radius):
         super().__init__()
         corr_planes = corr_levels * (2 * corr_radius + 1) ** 2
-        self.conv_c1 = nn.Conv2d(corr_planes, 256, kernel_size=1, padding=0)
-        self.conv_c2 = nn.Conv2d(256, 192, kernel_size=3, padding=1)
-        self.conv_f1 = nn.Conv2d(2, 128, kernel_size=7, padding=3)
-        self.conv_f2 = nn.Conv2d(128, 64, kernel_size=3, padding=1)
-        self.conv = nn.Conv2d(64 + 192, 128 - 2, kernel_size=3, padding=1)
+        self.conv_c1 = _conv(corr_planes, 256, 1)
+        self.conv_c2 = _conv(256, 192, 3)
+        self.conv_f1 = _conv(2, 128, 7)
+        self.conv_f2 = _conv(128, 64, 3)
+        self.conv = _conv(64 + 192, 128 - 2, 3)
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, flow, corr):
-        corr_feat = self.relu(self.conv_c2(self.relu(self.conv_c1(corr))))
-        flow_feat = self.relu(self.conv_f2(self.relu(self.conv_f1(flow))))
-        out = self.relu(self.conv(torch.cat([corr_feat, flow_feat], dim=1)))
-        return torch.cat([torch.nan_to_num(out), flow], dim=1)
+        c = self.relu(self.conv_c1(corr))
+        c = self.relu(self.conv_c2(c))
+        f = self.relu(self.conv_f1(flow))
+        f = self.relu(self.conv_f2(f))
+        joint = torch.nan_to_num(self.relu(self.conv(torch.cat([c, f], dim=1))))
+        return torch.cat([joint, flow], dim=1)
 
 
 class FlowHead2D(nn.Module):
     def __init__(self, input_dim=128, hidden_dim=256):
         super().__init__()
-        self.conv1 = nn.Conv2d(input_dim, hidden_dim, kernel_size=3, padding=1)
-        self.conv2 = nn.Conv2d(hidden_dim, 2, kernel_size=3, padding=1)
+        self.conv1 = _conv(input_dim, hidden_dim, 3)
+        self.conv2 = _conv(hidden_dim, 2, 3)
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return torch.nan_to_num(self.conv2(self.relu(self.conv1(x))).float())
+        delta = self.conv2(self.relu(self.conv1(x)))
+        return torch.nan_to_num(delta.float())
 
 
 class ConvexUpsampler2D(nn.Module):
+    """8x convex up-sampling; the mask head's output is scaled by 0.25 "to balance gradients"
+    (raft_core.py:183-197)."""
+
     def __init__(self, input_dim):
         super().__init__()
-        self.mask = nn.Sequential(
-            nn.Conv2d(input_dim, 256, 3, padding=1),
-            nn.ReLU(inplace=True),
-            nn.Conv2d(256, 64 * 9, 1, padding=0),
-        )
+        self.mask = nn.Sequential(_conv(input_dim, 256, 3), nn.ReLU(inplace=True), _conv(256, 64 * 9, 1))
 
     def forward(self, h, flow):
-        return convex_upsample(flow, 0.25 * self.mask(h.float()))  # 0.25 balances gradients (raft_core.py:195)
+        return convex_upsample(flow, 0.25 * self.mask(h.float()))
 
 
 class RAFTCore(nn.Module):
@@ -204,26 +212,25 @@ class RAFTCore(nn.Module):
         self.convex_upsampler = ConvexUpsampler2D(self.hidden_dim)
 
     def forward(self, image1, image2):
-        fmap1, fmap2 = self.fnet(image1), self.fnet(image2)
-        self.correlation.build_cost_volume_pyramid(fmap1, fmap2)
-        h, x = torch.split(self.cnet_aligner(self.cnet(image1)), [self.hidden_dim, self.context_dim], dim=1)
-        h, x = torch.tanh(h), torch.relu(x)
+        """image-only RAFT (raft_core.py:226-270): encode, build the all-pairs pyramid, iterate."""
+        self.correlation.build_cost_volume_pyramid(self.fnet(image1), self.fnet(image2))
+        state = self.cnet_aligner(self.cnet(image1))
+        hidden, context = torch.tanh(state[:, :self.hidden_dim]), torch.relu(state[:, self.hidden_dim:])
 
         bs, _, image_h, image_w = image1.shape
-        grid_coords = mesh_grid(bs, image_h // 8, image_w // 8, device=image1.device)
-        flow_pred = torch.zeros_like(grid_coords)
+        grid = mesh_grid(bs, image_h // 8, image_w // 8, device=image1.device)
+        flow = torch.zeros_like(grid)
         n_iters = self.cfgs.n_iters_train if self.training else self.cfgs.n_iters_eval
+        hoisted = self.gru.prepare(context) if runtime.fused() else None
 
-        flow_preds = []
-        gru_state = self.gru.prepare(x) if runtime.fused() else None
+        predictions = []
         for _ in range(n_iters):
-            flow_pred = flow_pred.detach()
-            corr = self.correlation(grid_coords + flow_pred)
-            motion_features = self.motion_encoder(flow_pred, corr)
-            if gru_state is not None:
-                h = self.gru.step(h, motion_features, gru_state)
+            flow = flow.detach()
+            motion = self.motion_encoder(flow, self.correlation(grid + flow))
+            if hoisted is not None:
+                hidden = self.gru.step(hidden, motion, hoisted)
             else:
-                h = self.gru(h, torch.cat([x, motion_features], dim=1))
-            flow_pred = flow_pred + self.flow_head(h)
-            flow_preds.append(self.convex_upsampler(h, flow_pred))
-        return flow_preds
+                hidden = self.gru(hidden, torch.cat([context, motion], dim=1))
+            flow = flow + self.flow_head(hidden)
+            predictions.append(self.convex_upsampler(hidden, flow))
+        return predictions

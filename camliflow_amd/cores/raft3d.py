@@ -1,5 +1,13 @@
-"""3-D (point) RAFT branch (counterpart of models/camliraft_l_core.py): point encoder, point
-cost-volume pyramid with KNN lookup, set-conv GRU, motion encoder and flow head.
+"""Point branch of CamLiRAFT (host-side counterpart of the reference's models/camliraft_l_core.py).
+
+Pieces, in data-flow order:
+  Encoder3D        point-feature pyramid: shared MLPs + down-sampling PointConv
+  Correlation3D    dense point cost volume, pooled over the target pyramid, looked up through KNN
+  MotionEncoder3D  (correlation, flow) -> motion features           [4 depth-wise set-convs]
+  GRU3D            gated recurrent update of the hidden state       [3 depth-wise set-convs]
+  FlowHead3D       hidden state -> residual scene flow              [2 depth-wise set-convs + 1x1]
+  CamLiRAFT_L_Core the point-only model built from them
+Module / parameter names are a checkpoint-compatibility surface and match the reference.
 """
 import torch
 import torch.nn as nn
@@ -10,63 +18,77 @@ from .blocks import Conv1dNormRelu, MLP1d, MLP2d
 from .geometry import backwarp_3d, batch_indexing, build_pc_pyramid, knn_interpolation
 from .setconv import PointConv, PointConvDW, pass_cache
 
-PYRAMID_SIZES = [4096, 2048, 1024, 512, 256]   # hard-coded in every CamLi* model (camliraft_l_core.py:174-176)
+# number of points kept at each pyramid level; every CamLi* model hard-codes it
+# (camliraft_l_core.py:174-176) and the iterations run on level 2 (2048 points)
+PYRAMID_SIZES = [4096, 2048, 1024, 512, 256]
+HIDDEN = 128          # hidden-state / context width of the recurrent update
+SELF_KNN = 32         # width of the precomputed self-neighbour table; set-convs slice what they need
 
 
 class Encoder3D(nn.Module):
+    """level 0: MLP(3 -> c0 -> c0); level i+1: MLP(c_i -> c_i -> c_{i+1}) then PointConv onto the
+    next (sparser) pyramid level (camliraft_l_core.py:8-37)."""
+
     def __init__(self, n_channels, norm=None, k=16):
         super().__init__()
-        self.level0_mlp = MLP1d(3, [n_channels[0], n_channels[0]])
-        self.mlps = nn.ModuleList()
-        self.convs = nn.ModuleList()
-        for c_in, c_out in zip(n_channels[:-1], n_channels[1:]):
-            self.mlps.append(MLP1d(c_in, [c_in, c_out]))
-            self.convs.append(PointConv(c_out, c_out, norm=norm, k=k))
+        first = n_channels[0]
+        self.level0_mlp = MLP1d(3, [first, first])
+        stages = list(zip(n_channels[:-1], n_channels[1:]))
+        self.mlps = nn.ModuleList(MLP1d(a, [a, b]) for a, b in stages)
+        self.convs = nn.ModuleList(PointConv(b, b, norm=norm, k=k) for _, b in stages)
 
     def forward(self, xyzs):
         assert len(xyzs) == len(self.mlps) + 1
-        feats = [self.level0_mlp(xyzs[0])]
-        for i, (mlp, conv) in enumerate(zip(self.mlps, self.convs)):
-            feats.append(conv(xyzs[i], mlp(feats[-1]), xyzs[i + 1]))
-        return feats
+        pyramid = [self.level0_mlp(xyzs[0])]
+        for level in range(len(self.mlps)):
+            widened = self.mlps[level](pyramid[level])
+            pyramid.append(self.convs[level](xyzs[level], widened, xyzs[level + 1]))
+        return pyramid
 
 
 class Correlation3D(nn.Module):
-    """RAFT-style point cost volume (camliraft_l_core.py:40-101): dense [N,N] feature correlation,
-    pooled over the target pyramid by k=3 neighbour averaging; each lookup takes the k=16 nearest
-    warped targets per level, runs (dxyz, cost) through a small MLP and sums over neighbours."""
+    """RAFT-style point cost volume (camliraft_l_core.py:40-101).
+
+    build : V0 = f1^T f2 / C  [B,N,M0];  V_l = mean over the 3 nearest level-(l-1) targets
+    lookup: per level take the k nearest (warped) targets of every source point, feed
+            (dxyz, V_l entry) through ``cost_mlp`` and sum over the neighbours; the four levels are
+            concatenated and merged by a 1x1 conv.
+    The pyramid is module state between ``build_cost_volume_pyramid`` and the lookups, like the
+    reference's (not re-entrant)."""
 
     def __init__(self, out_channels, k=16):
         super().__init__()
         self.k = k
-        self.cost_mlp = MLP2d(4, [out_channels // 4, out_channels // 4], act='relu')
+        quarter = out_channels // 4
+        self.cost_mlp = MLP2d(4, [quarter, quarter], act='relu')
         self.merge = Conv1dNormRelu(out_channels, out_channels)
         self.cost_volume_pyramid = None
 
     def build_cost_volume_pyramid(self, feat1, feat2, xyzs2, k=3):
-        volume = torch.bmm(feat1.float().transpose(1, 2), feat2.float()) / feat1.shape[1]   # [B,N,M0]
-        self.cost_volume_pyramid = [volume]
-        for i in range(1, len(xyzs2)):
-            knn_indices = _ops.k_nearest_neighbor(xyzs2[i - 1], xyzs2[i], k=k)
-            pooled = torch.mean(batch_indexing(self.cost_volume_pyramid[i - 1], knn_indices), dim=-1)
-            self.cost_volume_pyramid.append(pooled)
+        dense = torch.bmm(feat1.float().transpose(1, 2), feat2.float()) / feat1.shape[1]
+        levels = [dense]
+        for coarse, fine in zip(xyzs2[1:], xyzs2[:-1]):
+            parents = _ops.k_nearest_neighbor(fine, coarse, k=k)               # [B,M_l,k] into level l-1
+            levels.append(batch_indexing(levels[-1], parents).mean(dim=-1))
+        self.cost_volume_pyramid = levels
 
     def calc_matching_cost(self, xyz1, xyz2, cost_volume):
-        bs, n_points1, n_points2 = cost_volume.shape
-        knn_cross = _ops.k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)       # [B,N,k]
-        if runtime.fused() and not xyz1.requires_grad and not xyz2.requires_grad:
+        bs, n_src, n_dst = cost_volume.shape
+        cross = _ops.k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)       # [B,N,k]
+        plain = not (xyz1.requires_grad or xyz2.requires_grad)
+        if runtime.fused() and plain:
             from ..csrc import fused
-            lookup = fused.corr3d_lookup_input(cost_volume, xyz1, xyz2, knn_cross)            # [B,4,N,k]
-            return torch.sum(self.cost_mlp(lookup), dim=-1)
-        knn_offset = batch_indexing(xyz2, knn_cross) - xyz1.view(bs, 3, n_points1, 1)
-        knn_corr = batch_indexing(cost_volume.reshape(bs * n_points1, n_points2),
-                                  knn_cross.reshape(bs * n_points1, self.k),
-                                  layout='channel_last').reshape(bs, 1, n_points1, self.k)
-        return torch.sum(self.cost_mlp(torch.cat([knn_offset, knn_corr], dim=1)), dim=-1)
+            lookup = fused.corr3d_lookup_input(cost_volume, xyz1, xyz2, cross)            # [B,4,N,k]
+        else:
+            offset = batch_indexing(xyz2, cross) - xyz1.view(bs, 3, n_src, 1)
+            entry = batch_indexing(cost_volume.reshape(bs * n_src, n_dst), cross.reshape(bs * n_src, self.k),
+                                   layout='channel_last').reshape(bs, 1, n_src, self.k)
+            lookup = torch.cat([offset, entry], dim=1)
+        return self.cost_mlp(lookup).sum(dim=-1)
 
     def forward(self, xyz1, xyzs2):
-        costs = [self.calc_matching_cost(xyz1, xyzs2[lvl], self.cost_volume_pyramid[lvl]) for lvl in range(4)]
-        return self.merge(torch.cat(costs, dim=1))
+        per_level = [self.calc_matching_cost(xyz1, xyzs2[lvl], self.cost_volume_pyramid[lvl]) for lvl in range(4)]
+        return self.merge(torch.cat(per_level, dim=1))
 
 
 class FlowHead3D(nn.Module):
@@ -77,25 +99,30 @@ class FlowHead3D(nn.Module):
         self.fc = nn.Conv1d(64, 3, kernel_size=1)
 
     def forward(self, xyz, features, knn_indices=None):
-        features = self.conv1(xyz, features.float(), knn_indices=knn_indices)
-        features = self.conv2(xyz, features, knn_indices=knn_indices)
-        return self.fc(features)
+        x = features.float()
+        for conv in (self.conv1, self.conv2):
+            x = conv(xyz, x, knn_indices=knn_indices)
+        return self.fc(x)
 
 
 class GRU3D(nn.Module):
+    """h' = (1-z) h + z q with z, r, q three k=4 depth-wise set-convs over [h | x]
+    (camliraft_l_core.py:119-134)."""
+
     def __init__(self, input_dim, hidden_dim):
         super().__init__()
-        self.conv_z = PointConvDW(hidden_dim + input_dim, hidden_dim, act=None, k=4)
-        self.conv_r = PointConvDW(hidden_dim + input_dim, hidden_dim, act=None, k=4)
-        self.conv_q = PointConvDW(hidden_dim + input_dim, hidden_dim, act=None, k=4)
+        width = hidden_dim + input_dim
+        self.conv_z = PointConvDW(width, hidden_dim, act=None, k=4)
+        self.conv_r = PointConvDW(width, hidden_dim, act=None, k=4)
+        self.conv_q = PointConvDW(width, hidden_dim, act=None, k=4)
 
     def forward(self, xyz, h, x, knn_indices=None):
         h, x = h.float(), x.float()
-        hx = torch.cat([h, x], dim=1)
-        z = torch.sigmoid(self.conv_z(xyz, hx, knn_indices=knn_indices))
-        r = torch.sigmoid(self.conv_r(xyz, hx, knn_indices=knn_indices))
-        q = torch.tanh(self.conv_q(xyz, torch.cat([r * h, x], dim=1), knn_indices=knn_indices))
-        return (1 - z) * h + z * q
+        joint = torch.cat([h, x], dim=1)
+        update = torch.sigmoid(self.conv_z(xyz, joint, knn_indices=knn_indices))
+        reset = torch.sigmoid(self.conv_r(xyz, joint, knn_indices=knn_indices))
+        candidate = torch.tanh(self.conv_q(xyz, torch.cat([reset * h, x], dim=1), knn_indices=knn_indices))
+        return (1 - update) * h + update * candidate
 
 
 class MotionEncoder3D(nn.Module):
@@ -108,56 +135,58 @@ class MotionEncoder3D(nn.Module):
 
     def forward(self, xyz, flow, corr, knn_indices):
         corr, flow = corr.float(), flow.float()
-        corr_feat = self.conv_c1(xyz, corr, knn_indices=knn_indices)
-        flow_feat = self.conv_f2(xyz, self.conv_f1(xyz, flow, knn_indices=knn_indices), knn_indices=knn_indices)
-        out = self.conv(xyz, torch.cat([corr_feat, flow_feat], dim=1), knn_indices=knn_indices)
-        return torch.cat([out, flow], dim=1)
+        from_corr = self.conv_c1(xyz, corr, knn_indices=knn_indices)
+        from_flow = self.conv_f1(xyz, flow, knn_indices=knn_indices)
+        from_flow = self.conv_f2(xyz, from_flow, knn_indices=knn_indices)
+        mixed = self.conv(xyz, torch.cat([from_corr, from_flow], dim=1), knn_indices=knn_indices)
+        return torch.cat([mixed, flow], dim=1)
 
 
 class CamLiRAFT_L_Core(nn.Module):
-    """Point-only model: pyramid -> encoders at levels 0..2 -> RAFT iterations on the 2048-point
-    level -> per-iteration interpolation back to the input cloud (camliraft_l_core.py:158-225)."""
+    """Point-only model (camliraft_l_core.py:158-225): FPS pyramid -> encoders on levels 0..2 ->
+    RAFT iterations on the 2048-point level -> every iterate interpolated back to the input cloud."""
 
     def __init__(self, cfgs):
         super().__init__()
         self.cfgs = cfgs
-        self.fnet = Encoder3D(n_channels=[64, 96, 128], norm='batch_norm', k=16)
-        self.cnet = Encoder3D(n_channels=[64, 96, 128], norm='batch_norm', k=16)
-        self.cnet_aligner = nn.Conv1d(128, 256, kernel_size=1)
+        widths = [64, 96, 128]
+        self.fnet = Encoder3D(n_channels=widths, norm='batch_norm', k=16)
+        self.cnet = Encoder3D(n_channels=widths, norm='batch_norm', k=16)
+        self.cnet_aligner = nn.Conv1d(128, 2 * HIDDEN, kernel_size=1)
         self.correlation = Correlation3D(out_channels=128, k=16)
         self.motion_encoder = MotionEncoder3D(corr_dim=128)
-        self.gru = GRU3D(input_dim=128 + 128, hidden_dim=128)
-        self.flow_head = FlowHead3D(input_dim=128)
+        self.gru = GRU3D(input_dim=128 + 128, hidden_dim=HIDDEN)
+        self.flow_head = FlowHead3D(input_dim=HIDDEN)
 
     def forward(self, pc1, pc2):
         with pass_cache():
-            return self._forward(pc1, pc2)
+            return self._run(pc1, pc2)
 
-    def _forward(self, pc1, pc2):
-        xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, PYRAMID_SIZES)
-        feat1 = self.fnet(xyzs1[:3])[2]
-        feat2 = self.fnet(xyzs2[:3])[2]
-        featc = self.cnet_aligner(self.cnet(xyzs1[:3])[2])
+    def _run(self, pc1, pc2):
+        pyramid1, pyramid2, _, _ = build_pc_pyramid(pc1, pc2, PYRAMID_SIZES)
+        top = 2                                                     # features come from pyramid level 2
+        feat1 = self.fnet(pyramid1[:top + 1])[top]
+        feat2 = self.fnet(pyramid2[:top + 1])[top]
+        context = self.cnet_aligner(self.cnet(pyramid1[:top + 1])[top])
 
-        xyzs1, xyzs2 = xyzs1[2:], xyzs2[2:]
-        xyz1, xyz2 = xyzs1[0], xyzs2[0]
-        self.correlation.build_cost_volume_pyramid(feat1, feat2, xyzs2)
-
-        h, x = torch.split(featc, [128, 128], dim=1)
-        h, x = torch.tanh(h), torch.relu(x)
-        knn_indices = _ops.k_nearest_neighbor(xyz1, xyz1, k=32)
+        work1, work2 = pyramid1[top:], pyramid2[top:]               # [2048, 1024, 512, 256]
+        xyz1 = work1[0]
+        self.correlation.build_cost_volume_pyramid(feat1, feat2, work2)
+        hidden, ctx = torch.split(context, [HIDDEN, HIDDEN], dim=1)
+        hidden, ctx = torch.tanh(hidden), torch.relu(ctx)
+        neighbours = _ops.k_nearest_neighbor(xyz1, xyz1, k=SELF_KNN)
         n_iters = self.cfgs.n_iters_train if self.training else self.cfgs.n_iters_eval
 
-        flow_preds = []
-        flow_pred = torch.zeros_like(xyz1)
-        xyzs2_warp = xyzs2
-        for it in range(n_iters):
-            if it > 0:
-                flow_pred = flow_pred.detach()
-                xyzs2_warp = [backwarp_3d(xyz1, level, flow_pred) for level in xyzs2]
-            corr = self.correlation(xyz1, xyzs2_warp)
-            motion_feat = self.motion_encoder(xyz1, flow_pred, corr, knn_indices=knn_indices)
-            h = self.gru(xyz1, h=h, x=torch.cat([x, motion_feat], dim=1), knn_indices=knn_indices)
-            flow_pred = flow_pred + self.flow_head(xyz1, h, knn_indices).float()
-            flow_preds.append(flow_pred)
-        return [knn_interpolation(xyz1, flow, pc1, k=3) for flow in flow_preds]
+        flow = torch.zeros_like(xyz1)
+        targets = work2
+        iterates = []
+        for step in range(n_iters):
+            if step:
+                flow = flow.detach()
+                targets = [backwarp_3d(xyz1, level, flow) for level in work2]
+            corr = self.correlation(xyz1, targets)
+            motion = self.motion_encoder(xyz1, flow, corr, knn_indices=neighbours)
+            hidden = self.gru(xyz1, h=hidden, x=torch.cat([ctx, motion], dim=1), knn_indices=neighbours)
+            flow = flow + self.flow_head(xyz1, hidden, neighbours).float()
+            iterates.append(flow)
+        return [knn_interpolation(xyz1, f, pc1, k=3) for f in iterates]

@@ -24,8 +24,9 @@ def hashed_fill_(module, scale=1.0):
     """Deterministic, name-keyed parameter fill: seed = crc32(name); weights ~ N(0, 1/fan_in);
     BatchNorm running stats are filled too.  No weights are ever shipped."""
     with torch.no_grad():
+        persistent = set(module.state_dict().keys())      # constants kept as non-persistent buffers stay as they are
         for name, t in list(module.named_parameters()) + list(module.named_buffers()):
-            if t.dtype not in (torch.float32, torch.float64):
+            if name not in persistent or t.dtype not in (torch.float32, torch.float64):
                 continue
             g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
             if name.endswith('running_var'):
