@@ -118,8 +118,14 @@ def backwarp_2d(x, flow12, padding_mode):
     return grid_sample(x, norm.permute(0, 2, 3, 1), padding_mode=padding_mode, align_corners=True)
 
 
-def convex_upsample(flow, mask, scale_factor=8):
-    """RAFT convex upsampling: softmax over the 3x3 neighbourhood (utils.py:191-204)."""
+def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0):
+    """RAFT convex upsampling: softmax over the 3x3 neighbourhood (utils.py:191-204).  ``mask_scale``
+    is the factor the caller would otherwise multiply the mask by (RAFT: 0.25)."""
+    if runtime.fused() and scale_factor in (4, 8):
+        from ..csrc import fused
+        return fused.convex_upsample(flow, mask, scale_factor, mask_scale)
+    if mask_scale != 1.0:
+        mask = mask_scale * mask
     batch_size, _, image_h, image_w = flow.shape
     mask = softmax(mask.float().view(batch_size, 1, 9, scale_factor, scale_factor, image_h, image_w), dim=2)
     patches = unfold(flow.float() * scale_factor, [3, 3], padding=1).view(batch_size, 2, 9, 1, 1, image_h, image_w)

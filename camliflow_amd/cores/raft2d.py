@@ -191,7 +191,7 @@ class ConvexUpsampler2D(nn.Module):
         self.mask = nn.Sequential(_conv(input_dim, 256, 3), nn.ReLU(inplace=True), _conv(256, 64 * 9, 1))
 
     def forward(self, h, flow):
-        return convex_upsample(flow, 0.25 * self.mask(h.float()))
+        return convex_upsample(flow, self.mask(h.float()), mask_scale=0.25)
 
 
 class RAFTCore(nn.Module):

@@ -416,3 +416,46 @@ def pointconv_mix(feat_cl, wgt, knn_indices, k):
     assert knn_indices.stride(0) == knn_indices.shape[1] * knn_indices.stride(1)
     assert wgt.shape[3] == k and wgt.shape[1] <= 16
     return _PointConvMix.apply(feat_cl.float().contiguous(), wgt.float().contiguous(), knn_indices, k)
+
+
+# ------------------------------------------------------------------------------------------------
+# convex flow up-sampling (models/utils.py:191-204, models/raft_core.py:183-197)
+# ------------------------------------------------------------------------------------------------
+class _ConvexUpsample(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, flow, mask, scale, mask_scale):
+        lib = _lib.load()
+        b, _, h, w = flow.shape
+        out = torch.empty((b, 2, h * scale, w * scale), dtype=torch.float32, device=flow.device)
+        with torch.cuda.device(flow.device):
+            _lib.launch('camli_convex_upsample_fwd', lib.camli_convex_upsample_fwd, flow.data_ptr(), mask.data_ptr(),
+                        out.data_ptr(), b, h, w, scale, float(mask_scale), _stream_ptr(flow),
+                        work=(4.0 * b * h * w * (9 * scale * scale + 2 * scale * scale + 2), 'B'))
+        ctx.save_for_backward(flow, mask)
+        ctx.scale, ctx.mask_scale = scale, mask_scale
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        lib = _lib.load()
+        flow, mask = ctx.saved_tensors
+        b, _, h, w = flow.shape
+        gout = gout.contiguous().float()
+        gflow = torch.zeros_like(flow)
+        gmask = torch.empty_like(mask)
+        with torch.cuda.device(flow.device):
+            _lib.launch('camli_convex_upsample_bwd', lib.camli_convex_upsample_bwd, gout.data_ptr(), flow.data_ptr(),
+                        mask.data_ptr(), gflow.data_ptr(), gmask.data_ptr(), b, h, w, ctx.scale,
+                        float(ctx.mask_scale), _stream_ptr(flow),
+                        work=(4.0 * b * h * w * (2 * 9 * ctx.scale ** 2 + 2 * ctx.scale ** 2 + 4), 'B'))
+        return gflow, gmask, None, None
+
+
+def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0):
+    """flow [B,2,h,w], raw mask [B,9*S*S,h,w] -> [B,2,h*S,w*S]; ``mask_scale`` multiplies the mask inside
+    the kernel (RAFT passes 0.25, raft_core.py:195)."""
+    _require_cuda('convex_upsample', flow, mask)
+    assert flow.shape[1] == 2 and mask.shape[1] == 9 * scale_factor * scale_factor
+    return _ConvexUpsample.apply(flow.float().contiguous(), mask.float().contiguous(), scale_factor, mask_scale)

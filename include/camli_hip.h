@@ -149,6 +149,18 @@ int camli_pointconv_mix_bwd(const float *gout, const float *feat_cl, const float
                             int idx_stride, float *gfeat_cl, float *gwgt,
                             int B, int M, int N, int CH, int Wn, int k, void *stream);
 
+/*
+ * Convex flow up-sampling and adjoint (internal composite op; the reference composes it from
+ * softmax / unfold / sum / permute, models/utils.py:191-204, with the mask pre-scaled at raft_core.py:195).
+ *   flow [B,2,h,w]; mask [B, 9*S*S, h, w] (raw: mask_scale is applied inside); out [B,2,h*S,w*S]; S in {4,8}
+ *   out[b,c,y*S+i,x*S+j] = sum_k softmax_k(mask_scale*mask[b,k*S*S+i*S+j,y,x]) * S * flow[b,c,y+dy_k,x+dx_k]
+ *   bwd: gmask fully written; gflow += (float atomics, caller zero-fills).
+ */
+int camli_convex_upsample_fwd(const float *flow, const float *mask, float *out,
+                              int B, int h, int w, int scale, float mask_scale, void *stream);
+int camli_convex_upsample_bwd(const float *gout, const float *flow, const float *mask, float *gflow, float *gmask,
+                              int B, int h, int w, int scale, float mask_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,3 +190,12 @@ def pointconv_mix_fwd(feat_cl, wgt, idx, k):
     _chk(_load().oracle_pointconv_mix_fwd(_p(feat_cl), _p(wgt), _p(idx), idx.shape[2], _p(out), B, M, N, CH, Wn, k),
          "pointconv_mix_fwd")
     return out
+
+
+def convex_upsample_fwd(flow, mask, scale):
+    """flow [B,2,h,w], mask [B,9*S*S,h,w] -> [B,2,h*S,w*S]"""
+    flow, mask = _f32(flow), _f32(mask)
+    B, _, h, w = flow.shape
+    out = np.zeros((B, 2, h * scale, w * scale), dtype=np.float32)
+    _chk(_load().oracle_convex_upsample_fwd(_p(flow), _p(mask), _p(out), B, h, w, scale), "convex_upsample_fwd")
+    return out

@@ -452,4 +452,36 @@ int oracle_pointconv_mix_fwd(const float *feat_cl, const float *wgt, const int64
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * convex up-sampling: follows models/utils.py:191-204 (softmax over the 9 taps of the 3x3 unfold)
+ *   flow [B,2,h,w], mask [B,9*S*S,h,w] (already scaled), out [B,2,h*S,w*S]
+ * ------------------------------------------------------------------------------------------ */
+int oracle_convex_upsample_fwd(const float *flow, const float *mask, float *out, int B, int h, int w, int S)
+{
+    size_t plane = (size_t)h * w;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x)
+                for (int i = 0; i < S; ++i)
+                    for (int j = 0; j < S; ++j) {
+                        float p[9], mx = -INFINITY, den = 0.0f;
+                        for (int k = 0; k < 9; ++k) {
+                            p[k] = mask[((size_t)b * 9 * S * S + (size_t)k * S * S + i * S + j) * plane + (size_t)y * w + x];
+                            if (p[k] > mx) mx = p[k];
+                        }
+                        for (int k = 0; k < 9; ++k) { p[k] = expf(p[k] - mx); den += p[k]; }
+                        for (int c = 0; c < 2; ++c) {
+                            float acc = 0.0f;
+                            for (int k = 0; k < 9; ++k) {
+                                int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+                                float f = (yy >= 0 && yy < h && xx >= 0 && xx < w)
+                                              ? flow[((size_t)b * 2 + c) * plane + (size_t)yy * w + xx] * (float)S : 0.0f;
+                                acc += (p[k] / den) * f;
+                            }
+                            out[(((size_t)b * 2 + c) * h * S + (size_t)y * S + i) * ((size_t)w * S) + (size_t)x * S + j] = acc;
+                        }
+                    }
+    return 0;
+}
+
 int oracle_version(void) { return 1; }
