@@ -122,14 +122,18 @@ def test_two_lane_stream_overlap_matches_single_stream():
         base_out, base_loss, base_grads = run()
         runtime.set_overlap(True)
         try:
-            for _ in range(3):
+            for rep in range(4):
                 out, loss, grads = run()
-                for key in ('flow_2d', 'flow_3d'):
-                    assert _epe(out[key], base_out[key]) <= 1e-5, key
-                assert abs(loss - base_loss) <= 1e-5 * max(1.0, abs(base_loss))
+                epes = {key: _epe(out[key], base_out[key]) for key in ('flow_2d', 'flow_3d')}
                 num = sum(((grads[n] - base_grads[n]).double() ** 2).sum().item() for n in grads) ** 0.5
                 den = sum((base_grads[n].double() ** 2).sum().item() for n in grads) ** 0.5
-                assert num / den < 1e-4, num / den
+                print('overlap rep %d: epe %s loss %.8f vs %.8f grad rel %.3e' % (rep, epes, loss, base_loss, num / den))
+                # the forward has no atomics: a stream race would show up here first
+                for key, epe in epes.items():
+                    assert epe <= 1e-6, (key, epe)
+                assert abs(loss - base_loss) <= 1e-6 * max(1.0, abs(base_loss))
+                # the backward accumulates with float atomics (order differs between the two schedules)
+                assert num / den < 1e-3, num / den
         finally:
             runtime.set_overlap(False)
 
