@@ -134,13 +134,24 @@ class GRU2D(nn.Module):
         return state
 
     def step(self, h, motion, state):
+        """One GRU update with the hoisted context terms; the elementwise halves run as two fused
+        kernels each way (camli_gru_gates / camli_gru_blend) when the channel plane allows 16-byte
+        accesses, otherwise as plain torch ops."""
+        from ..csrc import fused
+        conv2d = torch.nn.functional.conv2d
         hd = h.shape[1]
+        fusable = h.is_cuda and (hd * h.shape[2] * h.shape[3]) % 4 == 0
         for suffix in ('1', '2'):
             w_zr, w_q, ctx_zr, ctx_q, padding = state[suffix]
-            zr = torch.sigmoid(torch.nn.functional.conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding) + ctx_zr)
-            z, r = zr[:, :hd], zr[:, hd:]
-            q = torch.tanh(torch.nn.functional.conv2d(torch.cat([r * h, motion], dim=1), w_q, None, padding=padding) + ctx_q)
-            h = (1 - z) * h + z * q
+            pre_zr = conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding)
+            if fusable:
+                z, rh = fused.gru_gates(pre_zr, ctx_zr, h)
+                h = fused.gru_blend(conv2d(torch.cat([rh, motion], dim=1), w_q, None, padding=padding), ctx_q, z, h)
+            else:
+                zr = torch.sigmoid(pre_zr + ctx_zr)
+                z, r = zr[:, :hd], zr[:, hd:]
+                q = torch.tanh(conv2d(torch.cat([r * h, motion], dim=1), w_q, None, padding=padding) + ctx_q)
+                h = (1 - z) * h + z * q
         return torch.nan_to_num(h)
 
 

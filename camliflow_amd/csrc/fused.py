@@ -459,3 +459,84 @@ def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0):
     _require_cuda('convex_upsample', flow, mask)
     assert flow.shape[1] == 2 and mask.shape[1] == 9 * scale_factor * scale_factor
     return _ConvexUpsample.apply(flow.float().contiguous(), mask.float().contiguous(), scale_factor, mask_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# convolutional GRU, elementwise halves (models/raft_core.py:123-139)
+# ------------------------------------------------------------------------------------------------
+class _GruGates(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, pre_zr, ctx_zr, h):
+        lib = _lib.load()
+        pre_zr, ctx_zr, h = pre_zr.contiguous(), ctx_zr.contiguous(), h.contiguous()
+        b, c = h.shape[0], h.shape[1]
+        p = h[0, 0].numel()
+        z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            _lib.launch('camli_gru_gates_fwd', lib.camli_gru_gates_fwd, pre_zr.data_ptr(), ctx_zr.data_ptr(), h.data_ptr(),
+                        z.data_ptr(), r.data_ptr(), rh.data_ptr(), b, c, p, _stream_ptr(h), work=(32.0 * b * c * p, 'B'))
+        ctx.save_for_backward(z, r, h)
+        ctx.mark_non_differentiable(r)
+        return z, rh, r
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gz, grh, _gr):
+        lib = _lib.load()
+        z, r, h = ctx.saved_tensors
+        b, c = h.shape[0], h.shape[1]
+        p = h[0, 0].numel()
+        gz = gz.contiguous().float() if gz is not None else torch.zeros_like(h)
+        grh = grh.contiguous().float() if grh is not None else torch.zeros_like(h)
+        gpre = torch.empty((b, 2 * c) + tuple(h.shape[2:]), dtype=torch.float32, device=h.device)
+        gh = torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            _lib.launch('camli_gru_gates_bwd', lib.camli_gru_gates_bwd, gz.data_ptr(), grh.data_ptr(), z.data_ptr(),
+                        r.data_ptr(), h.data_ptr(), gpre.data_ptr(), gh.data_ptr(), b, c, p, _stream_ptr(h),
+                        work=(32.0 * b * c * p, 'B'))
+        return gpre, gpre, gh
+
+
+class _GruBlend(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, pre_q, ctx_q, z, h):
+        lib = _lib.load()
+        pre_q, ctx_q, z, h = pre_q.contiguous(), ctx_q.contiguous(), z.contiguous(), h.contiguous()
+        b, c = h.shape[0], h.shape[1]
+        p = h[0, 0].numel()
+        q, h_new = torch.empty_like(h), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            _lib.launch('camli_gru_blend_fwd', lib.camli_gru_blend_fwd, pre_q.data_ptr(), ctx_q.data_ptr(), z.data_ptr(),
+                        h.data_ptr(), q.data_ptr(), h_new.data_ptr(), b, c, p, _stream_ptr(h), work=(24.0 * b * c * p, 'B'))
+        ctx.save_for_backward(z, h, q)
+        return h_new
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, g):
+        lib = _lib.load()
+        z, h, q = ctx.saved_tensors
+        b, c = h.shape[0], h.shape[1]
+        p = h[0, 0].numel()
+        g = g.contiguous().float()
+        gpre, gz, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
+        with torch.cuda.device(h.device):
+            _lib.launch('camli_gru_blend_bwd', lib.camli_gru_blend_bwd, g.data_ptr(), z.data_ptr(), h.data_ptr(),
+                        q.data_ptr(), gpre.data_ptr(), gz.data_ptr(), gh.data_ptr(), b, c, p, _stream_ptr(h),
+                        work=(28.0 * b * c * p, 'B'))
+        return gpre, gpre, gz, gh
+
+
+def gru_gates(pre_zr, ctx_zr, h):
+    """(z, r*h) of one GRU half-step: z|r = sigmoid(pre_zr + ctx_zr) ([B,2C,...]), h [B,C,...]."""
+    _require_cuda('gru_gates', pre_zr, ctx_zr, h)
+    z, rh, _ = _GruGates.apply(pre_zr, ctx_zr, h)
+    return z, rh
+
+
+def gru_blend(pre_q, ctx_q, z, h):
+    """h' = (1 - z) * h + z * tanh(pre_q + ctx_q)."""
+    _require_cuda('gru_blend', pre_q, ctx_q, z, h)
+    return _GruBlend.apply(pre_q, ctx_q, z, h)

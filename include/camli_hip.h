@@ -161,6 +161,24 @@ int camli_convex_upsample_fwd(const float *flow, const float *mask, float *out,
 int camli_convex_upsample_bwd(const float *gout, const float *flow, const float *mask, float *gflow, float *gmask,
                               int B, int h, int w, int scale, float mask_scale, void *stream);
 
+/*
+ * Elementwise halves of the convolutional GRU (models/raft_core.py:123-139 composes them from ~9 torch
+ * kernels per half-step).  All tensors fp32 contiguous, P = h*w, C*P a multiple of 4.
+ *   gates: z = sigmoid(pre_zr[:, :C] + ctx_zr[:, :C]); r = sigmoid(pre_zr[:, C:] + ctx_zr[:, C:]); rh = r*h
+ *          pre_zr, ctx_zr [B,2C,P]; h, z, r, rh [B,C,P]
+ *   blend: q = tanh(pre_q + ctx_q); h_new = (1 - z)*h + z*q        all [B,C,P]
+ *   adjoints: gates_bwd(gz, grh, z, r, h) -> gpre_zr [B,2C,P] (= gradient of ctx_zr too), gh [B,C,P]
+ *             blend_bwd(g, z, h, q)       -> gpre_q (= gradient of ctx_q too), gz, gh   (all fully written)
+ */
+int camli_gru_gates_fwd(const float *pre_zr, const float *ctx_zr, const float *h, float *z, float *r, float *rh,
+                        int B, int C, int P, void *stream);
+int camli_gru_gates_bwd(const float *gz, const float *grh, const float *z, const float *r, const float *h,
+                        float *gpre_zr, float *gh, int B, int C, int P, void *stream);
+int camli_gru_blend_fwd(const float *pre_q, const float *ctx_q, const float *z, const float *h, float *q, float *h_new,
+                        int B, int C, int P, void *stream);
+int camli_gru_blend_bwd(const float *g, const float *z, const float *h, const float *q, float *gpre_q, float *gz,
+                        float *gh, int B, int C, int P, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

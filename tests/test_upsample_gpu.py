@@ -28,3 +28,37 @@ def test_convex_upsample(case, oracle_lib):
     assert torch.allclose(res['hip'][0], res['composed'][0], rtol=1e-5, atol=1e-5)
     assert torch.allclose(res['hip'][1], res['composed'][1], rtol=1e-4, atol=1e-4)
     assert torch.allclose(res['hip'][2], res['composed'][2], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 68, 120), (1, 128, 16, 20), (3, 8, 5, 6)], ids=str)
+def test_gru_step_fused_vs_literal(shape):
+    """GRU2D.step (hoisted context + fused gate / blend kernels) against the literal GRU2D.forward of
+    the reference formulation, values and all gradients (fp32, 1e-5 / 1e-4)."""
+    from camliflow_amd.cores.raft2d import GRU2D
+    b, c, hh, ww = shape
+    torch.manual_seed(c)
+    gru = GRU2D(hidden_dim=c, input_dim=2 * c).cuda()
+    h0 = torch.randn(b, c, hh, ww, device='cuda', requires_grad=True)
+    context = torch.randn(b, c, hh, ww, device='cuda', requires_grad=True)
+    motion = torch.randn(b, c, hh, ww, device='cuda', requires_grad=True)
+    gout = torch.randn(b, c, hh, ww, device='cuda')
+    res = []
+    for mode in ('fused', 'literal'):
+        for t in (h0, context, motion):
+            t.grad = None
+        gru.zero_grad()
+        if mode == 'fused':
+            state = gru.prepare(context)
+            out = gru.step(gru.step(h0, motion, state), motion, state)     # two iterations share the state
+        else:
+            x = torch.cat([context, motion], dim=1)
+            out = gru(gru(h0, x), x)
+        out.backward(gout)
+        res.append((out.detach(), h0.grad.clone(), context.grad.clone(), motion.grad.clone(),
+                    {n: p.grad.clone() for n, p in gru.named_parameters()}))
+    (o1, a1, b1, c1, p1), (o2, a2, b2, c2, p2) = res
+    assert torch.allclose(o1, o2, rtol=1e-5, atol=1e-5)
+    for x, y in ((a1, a2), (b1, b2), (c1, c2)):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-4)
+    for n in p1:
+        assert (p1[n] - p2[n]).norm() <= 1e-4 * p2[n].norm() + 1e-5, n
