@@ -6,6 +6,8 @@ checkpoints load; the classes are generated from one dimension-generic implement
 import torch
 import torch.nn as nn
 
+from . import runtime
+
 
 class _LayerNormCF(nn.Module):
     """LayerNorm over the channel axis of a channel-first tensor (mlp.py:5-40), eps inside sqrt."""
@@ -73,9 +75,28 @@ class _ConvNormAct(nn.Module):
                             dilation=dilation, groups=groups, bias=norm is None)
         self.norm_fn = _make_norm(norm, out_channels, self.dims)
         self.act_fn = make_activation(act)
+        self._epilogue = act if (norm is None and act in (None, 'relu', 'leaky_relu', 'sigmoid')) else False
 
     def forward(self, x):
+        if self._epilogue is not False and epilogue_ok(x):
+            return conv_bias_act(self.conv_fn, x, self._epilogue)
         return self.act_fn(self.norm_fn(self.conv_fn(x)))
+
+
+def epilogue_ok(x):
+    """The fused epilogue works in place on an fp32 convolution output: product path, GPU tensor, and
+    not under autocast (where the convolution itself yields bf16/fp16)."""
+    return runtime.fused() and x.is_cuda and not torch.is_autocast_enabled()
+
+
+def conv_bias_act(conv, x, act):
+    """``act(conv(x))`` with the bias add, the activation and (backward) the bias-gradient reduction
+    fused into one pass over the convolution output (camli_bias_act_fwd/bwd)."""
+    from ..csrc import fused
+    y = conv._conv_forward(x, conv.weight, None)
+    if conv.bias is None:
+        return y if act is None else fused.bias_act(y, torch.zeros(y.shape[1], device=y.device), act)
+    return fused.bias_act(y, conv.bias, act)
 
 
 class Conv1dNormRelu(_ConvNormAct):

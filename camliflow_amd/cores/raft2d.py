@@ -8,7 +8,7 @@ import torch.nn as nn
 from torch.nn.functional import avg_pool2d, grid_sample
 
 from . import runtime
-from .blocks import Conv2dNormRelu
+from .blocks import Conv2dNormRelu, conv_bias_act, epilogue_ok
 from .geometry import convex_upsample, mesh_grid
 from .resnet import ResNetTrunk
 
@@ -173,6 +173,11 @@ class MotionEncoder2D(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, flow, corr):
+        if epilogue_ok(corr):
+            c = conv_bias_act(self.conv_c2, conv_bias_act(self.conv_c1, corr, 'relu'), 'relu')
+            f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')
+            joint = torch.nan_to_num(conv_bias_act(self.conv, torch.cat([c, f], dim=1), 'relu'))
+            return torch.cat([joint, flow], dim=1)
         c = self.relu(self.conv_c1(corr))
         c = self.relu(self.conv_c2(c))
         f = self.relu(self.conv_f1(flow))
@@ -189,7 +194,10 @@ class FlowHead2D(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        delta = self.conv2(self.relu(self.conv1(x)))
+        if epilogue_ok(x):
+            delta = conv_bias_act(self.conv2, conv_bias_act(self.conv1, x, 'relu'), None)
+        else:
+            delta = self.conv2(self.relu(self.conv1(x)))
         return torch.nan_to_num(delta.float())
 
 
@@ -202,7 +210,11 @@ class ConvexUpsampler2D(nn.Module):
         self.mask = nn.Sequential(_conv(input_dim, 256, 3), nn.ReLU(inplace=True), _conv(256, 64 * 9, 1))
 
     def forward(self, h, flow):
-        return convex_upsample(flow, self.mask(h.float()), mask_scale=0.25)
+        if epilogue_ok(h):
+            mask = conv_bias_act(self.mask[2], conv_bias_act(self.mask[0], h.float(), 'relu'), None)
+        else:
+            mask = self.mask(h.float())
+        return convex_upsample(flow, mask, mask_scale=0.25)
 
 
 class RAFTCore(nn.Module):

@@ -49,6 +49,8 @@ PROTOTYPES = {
     "camli_gru_gates_bwd": (_int, [_c_float_p] * 7 + [_int, _int, _int, _stream]),
     "camli_gru_blend_fwd": (_int, [_c_float_p] * 6 + [_int, _int, _int, _stream]),
     "camli_gru_blend_bwd": (_int, [_c_float_p] * 7 + [_int, _int, _int, _stream]),
+    "camli_bias_act_fwd": (_int, [_c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_bias_act_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
 }
 
 _lib = None

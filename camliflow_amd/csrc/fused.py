@@ -540,3 +540,48 @@ def gru_blend(pre_q, ctx_q, z, h):
     """h' = (1 - z) * h + z * tanh(pre_q + ctx_q)."""
     _require_cuda('gru_blend', pre_q, ctx_q, z, h)
     return _GruBlend.apply(pre_q, ctx_q, z, h)
+
+
+# ------------------------------------------------------------------------------------------------
+# bias + activation epilogue (models/mlp.py:41-128, models/raft_core.py:155-197)
+# ------------------------------------------------------------------------------------------------
+ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh': 4}
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, bias, act):
+        lib = _lib.load()
+        if not x.is_contiguous():
+            x = x.contiguous()
+        b, c = x.shape[0], x.shape[1]
+        p = x[0, 0].numel()
+        with torch.cuda.device(x.device):
+            _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_fwd, x.data_ptr(), bias.data_ptr(), b, c, p, act,
+                        _stream_ptr(x), work=(8.0 * b * c * p, 'B'))
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return x
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        b, c = y.shape[0], y.shape[1]
+        p = y[0, 0].numel()
+        gy = gy.contiguous().float()
+        gx = torch.empty_like(y)
+        gbias = torch.zeros(c, dtype=torch.float32, device=y.device)
+        with torch.cuda.device(y.device):
+            _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gy.data_ptr(), y.data_ptr(), gx.data_ptr(),
+                        gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(y), work=(12.0 * b * c * p, 'B'))
+        return gx, gbias, None
+
+
+def bias_act(x, bias, act):
+    """act(x + bias[c]) in place on the (fresh) convolution output x [B,C,...]; ``act`` as in ACT_CODES."""
+    _require_cuda('bias_act', x, bias)
+    return _BiasAct.apply(x, bias.float(), ACT_CODES[act])

@@ -179,6 +179,17 @@ int camli_gru_blend_fwd(const float *pre_q, const float *ctx_q, const float *z, 
 int camli_gru_blend_bwd(const float *g, const float *z, const float *h, const float *q, float *gpre_q, float *gz,
                         float *gh, int B, int C, int P, void *stream);
 
+/*
+ * Bias + activation epilogue of a convolution and its adjoint (the reference runs conv -> bias add ->
+ * activation as separate passes: models/mlp.py:41-128, models/raft_core.py:155-197).
+ *   x_inout [B,C,P] updated IN PLACE to act(x + bias[c]); act: 0 identity, 1 relu, 2 leaky_relu(0.1),
+ *   3 sigmoid, 4 tanh.  bwd: gx = gy * act'(y) (fully written; may alias gy), gbias[c] += sum gx
+ *   (float atomics; caller zero-fills gbias).
+ */
+int camli_bias_act_fwd(float *x_inout, const float *bias, int B, int C, int P, int act, void *stream);
+int camli_bias_act_bwd(const float *gy, const float *y, float *gx, float *gbias, int B, int C, int P, int act,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,3 +62,25 @@ def test_gru_step_fused_vs_literal(shape):
         assert torch.allclose(x, y, rtol=1e-4, atol=1e-4)
     for n in p1:
         assert (p1[n] - p2[n]).norm() <= 1e-4 * p2[n].norm() + 1e-5, n
+
+
+@pytest.mark.parametrize('act', [None, 'relu', 'leaky_relu', 'sigmoid'])
+@pytest.mark.parametrize('shape', [(2, 37, 68, 120), (3, 16, 7, 9), (2, 8, 2048, 16), (1, 5, 1031)], ids=str)
+def test_conv_bias_act_vs_torch(act, shape):
+    """camli_bias_act_fwd/bwd through blocks.conv_bias_act vs conv -> activation in torch."""
+    import torch.nn as nn
+    from camliflow_amd.cores.blocks import conv_bias_act, make_activation
+    b, c = shape[0], shape[1]
+    torch.manual_seed(c)
+    conv = (nn.Conv1d(c, c + 3, 1) if len(shape) == 3 else nn.Conv2d(c, c + 3, 1)).cuda()
+    x = torch.randn(*shape, device='cuda', requires_grad=True)
+    res = []
+    for mode in ('fused', 'torch'):
+        x.grad = None
+        conv.zero_grad()
+        y = conv_bias_act(conv, x, act) if mode == 'fused' else make_activation(act)(conv(x))
+        g = torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
+        y.backward(g)
+        res.append((y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
+    for a, b_ in zip(*res):
+        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-5)
