@@ -82,5 +82,9 @@ def test_conv_bias_act_vs_torch(act, shape):
         g = torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1))
         y.backward(g)
         res.append((y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone()))
-    for a, b_ in zip(*res):
-        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-5)
+    (y1, gx1, gw1, gb1), (y2, gx2, gw2, gb2) = res
+    assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(gx1, gx2, rtol=1e-4, atol=1e-5)
+    # parameter gradients are long sums (library wrw kernels / float atomics): compare in norm
+    assert (gw1 - gw2).norm() <= 1e-5 * gw2.norm() + 1e-6
+    assert (gb1 - gb2).norm() <= 1e-5 * gb2.norm() + 1e-5
