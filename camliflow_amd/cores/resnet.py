@@ -10,7 +10,11 @@ checkpoints load.  Parity for this sub-module is UNPINNED (the dependency's sour
 the reference tree); it is plain conv/BN/ReLU/max-pool executed by MIOpen and is not a HIP-kernel
 target.
 """
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+from . import runtime
 
 _STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
@@ -36,11 +40,38 @@ class Bottleneck(nn.Module):
             )
 
     def forward(self, x):
+        if _foldable(self.bn1, x):
+            shortcut = x if self.downsample is None else _conv_bn(self.downsample[0], self.downsample[1], x, None)
+            y = _conv_bn(self.conv1, self.bn1, x, 'relu')
+            y = _conv_bn(self.conv2, self.bn2, y, 'relu')
+            y = _conv_bn(self.conv3, self.bn3, y, None)
+            return self.relu(y + shortcut)
         shortcut = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
         return self.relu(y + shortcut)
+
+
+def _foldable(bn, x):
+    """Frozen-statistics BatchNorm (norm_eval) on the product path: it is an affine map per channel
+    and can be folded into the preceding convolution."""
+    from .blocks import epilogue_ok
+    return (not bn.training) and epilogue_ok(x)
+
+
+def _conv_bn(conv, bn, x, act):
+    """conv -> BatchNorm(eval) -> act as ONE convolution with folded weights plus the fused bias /
+    activation epilogue:  y = conv(x, w * s) + (beta - mean * s),  s = gamma / sqrt(var + eps).
+    gamma / beta stay trainable (the fold is differentiated by autograd on the small tensors); no
+    BatchNorm pass over the activations remains, forward or backward.  Equal to the unfolded form up
+    to fp32 rounding."""
+    from ..csrc import fused
+    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    weight = conv.weight * scale.view(-1, 1, 1, 1)
+    bias = bn.bias - bn.running_mean * scale
+    y = F.conv2d(x, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return fused.bias_act(y, bias, act)
 
 
 class ResNetTrunk(nn.Module):
@@ -91,7 +122,10 @@ class ResNetTrunk(nn.Module):
         return self
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        if _foldable(self.bn1, x):
+            x = self.maxpool(_conv_bn(self.conv1, self.bn1, x, 'relu'))
+        else:
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         for name in self.res_layers:
             x = getattr(self, name)(x)
         return (x,)

@@ -88,3 +88,28 @@ def test_conv_bias_act_vs_torch(act, shape):
     # parameter gradients are long sums (library wrw kernels / float atomics): compare in norm
     assert (gw1 - gw2).norm() <= 1e-5 * gw2.norm() + 1e-6
     assert (gb1 - gb2).norm() <= 1e-5 * gb2.norm() + 1e-5
+
+
+def test_resnet_trunk_folded_batchnorm_vs_unfolded():
+    """Encoder2D on the product path (frozen BatchNorm folded into the convolutions + fused epilogue)
+    vs the plain conv -> BN -> ReLU form: features and parameter gradients, fp32."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.raft2d import Encoder2D
+    from modelutils import hashed_fill_
+    torch.manual_seed(0)
+    enc = hashed_fill_(Encoder2D()).cuda().train()       # norm_eval keeps the trunk's BN frozen in train mode
+    x = torch.randn(2, 3, 128, 160, device='cuda')
+    gout = torch.randn(2, 128, 16, 20, device='cuda')
+    res = {}
+    for backend in ('hip', 'composed'):
+        enc.zero_grad()
+        with runtime.use_backend(backend):
+            y = enc(x)
+        y.backward(gout)
+        res[backend] = (y.detach(), {n: p.grad.clone() for n, p in enc.named_parameters()})
+    (y1, g1), (y2, g2) = res['hip'], res['composed']
+    assert (y1 - y2).abs().max() <= 1e-4 * y2.abs().max()
+    assert g1.keys() == g2.keys()
+    num = sum(((g1[n] - g2[n]).double() ** 2).sum().item() for n in g1) ** 0.5
+    den = sum((g2[n].double() ** 2).sum().item() for n in g1) ** 0.5
+    assert num / den < 1e-4, num / den
