@@ -89,34 +89,11 @@ def epilogue_ok(x):
     return runtime.fused() and x.is_cuda and not torch.is_autocast_enabled()
 
 
-import os as _os
-_POINTWISE_AS_GEMM = _os.environ.get('CAMLI_POINTWISE_GEMM', '1') == '1'
-
-
-def _is_pointwise(conv):
-    return (all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride) and conv.groups == 1
-            and all(p == 0 for p in conv.padding))
-
-
-def pointwise_conv(conv, x):
-    """A 1x1 / kernel-size-1 convolution on a channel-first tensor is one GEMM per sample,
-    Y[b] = W @ X[b] ([Cout,Cin] @ [Cin,P]); issued as a strided-batched hipBLASLt GEMM it needs no
-    layout transposes and its backward is two more GEMMs (MIOpen's 1x1 solvers wrap the same GEMMs in
-    NCHW<->NHWC transposes and tensor-init kernels).  Bias-free: the epilogue kernel adds it."""
-    b, cin = x.shape[0], x.shape[1]
-    w = conv.weight.reshape(conv.weight.shape[0], cin)
-    y = torch.matmul(w, x.reshape(b, cin, -1))
-    return y.reshape((b, w.shape[0]) + tuple(x.shape[2:]))
-
-
 def conv_bias_act(conv, x, act):
     """``act(conv(x))`` with the bias add, the activation and (backward) the bias-gradient reduction
     fused into one pass over the convolution output (camli_bias_act_fwd/bwd)."""
     from ..csrc import fused
-    if _POINTWISE_AS_GEMM and _is_pointwise(conv) and x.is_contiguous():
-        y = pointwise_conv(conv, x)
-    else:
-        y = conv._conv_forward(x, conv.weight, None)
+    y = conv._conv_forward(x, conv.weight, None)
     if conv.bias is None:
         return y if act is None else fused.bias_act(y, torch.zeros(y.shape[1], device=y.device), act)
     return fused.bias_act(y, conv.bias, act)
