@@ -46,15 +46,15 @@ class FusionAwareInterp(nn.Module):
         base = (uv.data_ptr(), tuple(uv.shape), image_h, image_w, self.k, torch.is_grad_enabled())
         knn_key, score_key = ('knn2d',) + base, ('score2d', id(self)) + base
         if cache is not None and score_key in cache:
-            return cache[knn_key], cache[score_key]
-        knn_indices = cache.get(knn_key) if cache is not None else None
+            return cache[knn_key][0], cache[score_key][0]
+        knn_indices = cache[knn_key][0] if cache is not None and knn_key in cache else None
         if knn_indices is None:
             knn_indices = _ops.k_nearest_neighbor(uv, grid, self.k)
         knn_offset = batch_indexing(uv, knn_indices) - grid[..., None]
         knn_offset_norm = torch.linalg.norm(knn_offset, dim=1, keepdim=True)
         score = self.score_net(torch.cat([knn_offset, knn_offset_norm], dim=1))
-        if cache is not None:
-            cache[knn_key], cache[score_key] = knn_indices, score
+        if cache is not None:   # entries keep `uv` alive: the key is its address
+            cache[knn_key], cache[score_key] = (knn_indices, uv), (score, uv)
         return knn_indices, score
 
     def forward(self, uv, feat_2d, feat_3d):

@@ -108,10 +108,13 @@ class PointConvDW(nn.Module):
             knn_indices = _ops.k_nearest_neighbor(xyz, centres, self.k)
         key = (id(self), xyz.data_ptr(), centres.data_ptr(), knn_indices.data_ptr(), self.k,
                tuple(knn_indices.shape), torch.is_grad_enabled())
-        shared = _pass_cache.get(key) if _pass_cache is not None else None
-        if shared is None:
+        entry = _pass_cache.get(key) if _pass_cache is not None else None
+        if entry is None:
             _, _, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
             shared = fused.SharedSetConvWeights(self.weight_net(knn_offset))
             if _pass_cache is not None:
-                _pass_cache[key] = shared
+                # the key holds raw addresses: keep the keyed tensors alive so an address is never recycled
+                _pass_cache[key] = (shared, (xyz, centres, knn_indices))
+        else:
+            shared = entry[0]
         return fused.pointconv_dw(self.mlp(features), shared, knn_indices, self.k)
