@@ -19,70 +19,121 @@
 namespace {
 
 constexpr int CT_PX = 64;     // pixels per workgroup (one wave-width)
-constexpr int CT_CMAX = 256;  // channels staged per pass
+constexpr int CT_CMAX = 256;  // in1 channels resident in LDS per pass
+constexpr int CT_CH = 64;     // in2 channels staged per chunk
 
-// grid (ceil(W/64), H, B), block 256
-template <int MD>
+// grid (ceil(W/64), H, B), block 256.  VEC: C % 4 == 0 -> 16-byte global loads, ds_read_b128 in the
+// inner loop (row stride = channels + 4 dwords keeps the 16-lane b128 phases conflict-free).
+// LDS: in1 tile [64][cs+PAD] stays for all dy; per dy the in2 row tile is streamed in CT_CH-channel
+// chunks [64+2md][CT_CH+PAD]; red [4][Dd][64] combines the four waves' channel quarters.
+template <int MD, bool VEC>
 __global__ __launch_bounds__(256) void corr2d_fwd_kernel(const float* __restrict__ in1,
                                                           const float* __restrict__ in2,
                                                           float* __restrict__ out, int C, int H, int W) {
     constexpr int DD = 2 * MD + 1;
     constexpr int HALO = CT_PX + 2 * MD;
+    constexpr int PAD = VEC ? 4 : 1;
+    constexpr int LD2 = CT_CH + PAD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int px = tid & 63;
     const int cq = tid >> 6;
     const int x0 = blockIdx.x * CT_PX, y = blockIdx.y, n = blockIdx.z;
     const float inv_c = 1.0f / (float)C;
+    const int cs_max = min(C, CT_CMAX);
+    const int ld1 = cs_max + PAD;
+    float* s1 = smem;                      // [CT_PX][ld1]
+    float* s2 = s1 + CT_PX * ld1;          // [HALO][LD2]
+    float* red = s2 + HALO * LD2;          // [4][DD][CT_PX]
 
     for (int c0 = 0; c0 < C; c0 += CT_CMAX) {
-        const int cc = min(CT_CMAX, C - c0);
-        const int ld = cc + 1;
-        float* s1 = smem;                    // [CT_PX][ld]
-        float* s2 = s1 + CT_PX * ld;         // [HALO][ld]
-        float* red = s2 + HALO * ld;         // [4][DD][CT_PX]
-
-        // stage in1 tile: pixels x0..x0+63 of row y, channels c0..c0+cc
-        for (int e = tid; e < CT_PX * cc; e += 256) {
-            int p = e / cc, c = e - p * cc;
-            int x = x0 + p;
-            s1[p * ld + c] = (x < W) ? in1[(((size_t)n * H + y) * W + x) * C + c0 + c] : 0.0f;
+        const int cs = min(CT_CMAX, C - c0);
+        // ---- in1 tile: pixels x0..x0+63 of row y, channels c0..c0+cs ----
+        if (VEC) {
+            const int q4 = cs >> 2;
+            for (int e = tid; e < CT_PX * q4; e += 256) {
+                const int p = e / q4, c = (e - p * q4) << 2;
+                const int x = x0 + p;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (x < W) v = *reinterpret_cast<const float4*>(in1 + (((size_t)n * H + y) * W + x) * C + c0 + c);
+                *reinterpret_cast<float4*>(s1 + p * ld1 + c) = v;
+            }
+        } else {
+            for (int e = tid; e < CT_PX * cs; e += 256) {
+                const int p = e / cs, c = e - p * cs;
+                const int x = x0 + p;
+                s1[p * ld1 + c] = (x < W) ? in1[(((size_t)n * H + y) * W + x) * C + c0 + c] : 0.0f;
+            }
         }
-        const int cbeg = (cc * cq) / 4, cend = (cc * (cq + 1)) / 4;
 
         for (int dyi = 0; dyi < DD; ++dyi) {
             const int y2 = y + dyi - MD;
-            const bool row_ok = (y2 >= 0 && y2 < H);
-            __syncthreads();  // previous dy's consumers done with s2/red (and s1 staged)
-            if (row_ok) {
-                for (int e = tid; e < HALO * cc; e += 256) {
-                    int p = e / cc, c = e - p * cc;
-                    int x = x0 - MD + p;
-                    s2[p * ld + c] =
-                        (x >= 0 && x < W) ? in2[(((size_t)n * H + y2) * W + x) * C + c0 + c] : 0.0f;
-                }
+            if (y2 < 0 || y2 >= H) {   // whole displacement row is outside: zeros (block-uniform branch)
+                if (c0 == 0)
+                    for (int e = tid; e < DD * CT_PX; e += 256) {
+                        const int d = e >> 6, x = x0 + (e & 63);
+                        if (x < W) out[(((size_t)n * DD * DD + dyi * DD + d) * H + y) * W + x] = 0.0f;
+                    }
+                continue;
             }
-            __syncthreads();
             float acc[DD];
 #pragma unroll
             for (int d = 0; d < DD; ++d) acc[d] = 0.0f;
-            if (row_ok) {
-                for (int c = cbeg; c < cend; ++c) {
-                    float a = s1[px * ld + c];
+            for (int k0 = 0; k0 < cs; k0 += CT_CH) {
+                const int ck = min(CT_CH, cs - k0);
+                __syncthreads();   // consumers of the previous s2 chunk / red are done; s1 is staged
+                if (VEC) {
+                    const int q4 = ck >> 2;
+                    for (int e = tid; e < HALO * q4; e += 256) {
+                        const int p = e / q4, c = (e - p * q4) << 2;
+                        const int x = x0 - MD + p;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (x >= 0 && x < W)
+                            v = *reinterpret_cast<const float4*>(in2 + (((size_t)n * H + y2) * W + x) * C + c0 + k0 + c);
+                        *reinterpret_cast<float4*>(s2 + p * LD2 + c) = v;
+                    }
+                } else {
+                    for (int e = tid; e < HALO * ck; e += 256) {
+                        const int p = e / ck, c = e - p * ck;
+                        const int x = x0 - MD + p;
+                        s2[p * LD2 + c] =
+                            (x >= 0 && x < W) ? in2[(((size_t)n * H + y2) * W + x) * C + c0 + k0 + c] : 0.0f;
+                    }
+                }
+                __syncthreads();
+                if (VEC) {
+                    const int q4 = ck >> 2;
+                    const int qb = (q4 * cq) / 4, qe = (q4 * (cq + 1)) / 4;
+                    for (int q = qb; q < qe; ++q) {
+                        const float4 a = *reinterpret_cast<const float4*>(s1 + px * ld1 + k0 + 4 * q);
 #pragma unroll
-                    for (int d = 0; d < DD; ++d) acc[d] = __builtin_fmaf(a, s2[(px + d) * ld + c], acc[d]);
+                        for (int d = 0; d < DD; ++d) {
+                            const float4 b = *reinterpret_cast<const float4*>(s2 + (px + d) * LD2 + 4 * q);
+                            float t = __builtin_fmaf(a.x, b.x, acc[d]);
+                            t = __builtin_fmaf(a.y, b.y, t);
+                            t = __builtin_fmaf(a.z, b.z, t);
+                            acc[d] = __builtin_fmaf(a.w, b.w, t);
+                        }
+                    }
+                } else {
+                    const int cb = (ck * cq) / 4, ce = (ck * (cq + 1)) / 4;
+                    for (int c = cb; c < ce; ++c) {
+                        const float a = s1[px * ld1 + k0 + c];
+#pragma unroll
+                        for (int d = 0; d < DD; ++d) acc[d] = __builtin_fmaf(a, s2[(px + d) * LD2 + c], acc[d]);
+                    }
                 }
             }
 #pragma unroll
             for (int d = 0; d < DD; ++d) red[(cq * DD + d) * CT_PX + px] = acc[d];
             __syncthreads();
             for (int e = tid; e < DD * CT_PX; e += 256) {
-                int d = e >> 6, p = e & 63;
-                int x = x0 + p;
+                const int d = e >> 6, p = e & 63;
+                const int x = x0 + p;
                 if (x < W) {
                     float s = (red[(0 * DD + d) * CT_PX + p] + red[(1 * DD + d) * CT_PX + p]) +
                               (red[(2 * DD + d) * CT_PX + p] + red[(3 * DD + d) * CT_PX + p]);
-                    size_t o = (((size_t)n * DD * DD + dyi * DD + d) * H + y) * W + x;
+                    const size_t o = (((size_t)n * DD * DD + dyi * DD + d) * H + y) * W + x;
                     s *= inv_c;
                     out[o] = (c0 == 0) ? s : out[o] + s;
                 }
@@ -157,13 +208,105 @@ __global__ __launch_bounds__(256) void corr2d_bwd_kernel(const float* __restrict
     }
 }
 
+// Tiled backward for md <= 4.  WHICH = 0: grad wrt in1 (other = in2), 1: grad wrt in2 (other = in1).
+// With window position (r,q), other-pixel (y+r-md, x+q-md):
+//   WHICH 0: weight = gout[r*Dd+q][y][x]                      (gout at the output pixel)
+//   WHICH 1: weight = gout[Dd*Dd-1-(r*Dd+q)][y+r-md][x+q-md]  (gout at the other pixel)
+// grid (ceil(W/16), H, B), block = 64 * min(4, ceil(C/64)).  A wave owns 16 consecutive pixels x 64
+// channels: lanes run along the channels (coalesced NHWC loads and stores), the 16 accumulators and
+// the current window row (16 + 2md values) live in registers.  Each window row is 16+2md independent
+// 256-byte wave loads straight from L2/HBM (no staging barrier: the kernel is latency-bound, so
+// occupancy and loads in flight matter more than LDS reuse); each loaded value feeds up to Dd FMAs.
+// The Dd*Dd x 16 weight table gw[r*Dd+q][k] is staged once per workgroup in LDS, already shifted per
+// q and zeroed where the reference skips the displacement, and read as broadcast ds_read_b128.
+constexpr int CB_TW = 16;    // pixels per workgroup
+
+template <int MD, int WHICH>
+__global__ __launch_bounds__(256) void corr2d_bwd_tiled_kernel(const float* __restrict__ gout,
+                                                                const float* __restrict__ other,
+                                                                float* __restrict__ gdst, int C, int H, int W) {
+    constexpr int DD = 2 * MD + 1;
+    constexpr int HW = CB_TW + 2 * MD;
+    __shared__ __attribute__((aligned(16))) float gw[DD * DD * CB_TW];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6, nw = blockDim.x >> 6;
+    const int x0 = blockIdx.x * CB_TW, y = blockIdx.y, n = blockIdx.z;
+    const float inv_c = 1.0f / (float)C;
+    const size_t plane = (size_t)H * W;
+    const float* __restrict__ gn = gout + (size_t)n * DD * DD * plane;
+
+    for (int e = tid; e < DD * DD * CB_TW; e += blockDim.x) {
+        const int t = e / CB_TW, k = e - t * CB_TW;
+        const int r = t / DD, q = t - r * DD;
+        const int oy = y + r - MD, ox = x0 + k + q - MD;          // the other tensor's pixel
+        const bool ok = (x0 + k < W) & (oy >= 0) & (oy < H) & (ox >= 0) & (ox < W);
+        const int tc = WHICH == 0 ? t : DD * DD - 1 - t;
+        const int gy = WHICH == 0 ? y : oy, gx = WHICH == 0 ? x0 + k : ox;
+        gw[e] = ok ? gn[(size_t)tc * plane + (size_t)gy * W + gx] : 0.0f;
+    }
+    __syncthreads();
+
+    for (int cbase = w * 64; cbase < C; cbase += 64 * nw) {
+        const bool cok = cbase + lane < C;
+        float acc[CB_TW];
+#pragma unroll
+        for (int k = 0; k < CB_TW; ++k) acc[k] = 0.0f;
+#pragma unroll 1   // one window row in registers at a time (unrolling makes the compiler hoist all Dd rows)
+        for (int r = 0; r < DD; ++r) {
+            const int yy = y + r - MD;
+            if (yy < 0 || yy >= H) continue;   // block-uniform
+            const float* __restrict__ row = other + ((size_t)n * H + yy) * W * C + cbase + lane;
+            float v[HW];
+#pragma unroll
+            for (int i = 0; i < HW; ++i) {
+                const int xx = x0 + i - MD;
+                v[i] = (cok & (xx >= 0) & (xx < W)) ? row[(size_t)xx * C] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < DD; ++q) {
+#pragma unroll
+                for (int k4 = 0; k4 < CB_TW / 4; ++k4) {
+                    const float4 g = *reinterpret_cast<const float4*>(gw + (r * DD + q) * CB_TW + 4 * k4);
+                    acc[4 * k4 + 0] = __builtin_fmaf(g.x, v[q + 4 * k4 + 0], acc[4 * k4 + 0]);
+                    acc[4 * k4 + 1] = __builtin_fmaf(g.y, v[q + 4 * k4 + 1], acc[4 * k4 + 1]);
+                    acc[4 * k4 + 2] = __builtin_fmaf(g.z, v[q + 4 * k4 + 2], acc[4 * k4 + 2]);
+                    acc[4 * k4 + 3] = __builtin_fmaf(g.w, v[q + 4 * k4 + 3], acc[4 * k4 + 3]);
+                }
+            }
+        }
+        if (cok) {
+#pragma unroll
+            for (int k = 0; k < CB_TW; ++k) {
+                const int x = x0 + k;
+                if (x < W) gdst[(((size_t)n * H + y) * W + x) * C + cbase + lane] = acc[k] * inv_c;
+            }
+        }
+    }
+}
+
+template <int MD>
+int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1, float* g2, int B, int C, int H, int W,
+               hipStream_t stream) {
+    dim3 grid(camli_divup(W, CB_TW), H, B);
+    const int nw = camli_divup(C, 64) < 4 ? camli_divup(C, 64) : 4;
+    hipLaunchKernelGGL((corr2d_bwd_tiled_kernel<MD, 0>), grid, dim3(64 * nw), 0, stream, gout, in2, g1, C, H, W);
+    hipLaunchKernelGGL((corr2d_bwd_tiled_kernel<MD, 1>), grid, dim3(64 * nw), 0, stream, gout, in1, g2, C, H, W);
+    return camli_check_launch("camli_corr2d_bwd");
+}
+
 template <int MD>
 int launch_fwd(const float* in1, const float* in2, float* out, int B, int C, int H, int W, hipStream_t stream) {
     constexpr int DD = 2 * MD + 1;
-    const int cc = C < CT_CMAX ? C : CT_CMAX;
-    size_t lds = ((size_t)(CT_PX + CT_PX + 2 * MD) * (cc + 1) + 4 * DD * CT_PX) * sizeof(float);
+    const bool vec = (C % 4) == 0;
+    const int pad = vec ? 4 : 1;
+    const int cs = C < CT_CMAX ? C : CT_CMAX;
+    const size_t lds = ((size_t)CT_PX * (cs + pad) + (size_t)(CT_PX + 2 * MD) * (CT_CH + pad) + 4 * DD * CT_PX) * sizeof(float);
     dim3 grid(camli_divup(W, CT_PX), H, B);
-    hipLaunchKernelGGL((corr2d_fwd_kernel<MD>), grid, dim3(256), lds, stream, in1, in2, out, C, H, W);
+    if (vec)
+        hipLaunchKernelGGL((corr2d_fwd_kernel<MD, true>), grid, dim3(256), lds, stream, in1, in2, out, C, H, W);
+    else
+        hipLaunchKernelGGL((corr2d_fwd_kernel<MD, false>), grid, dim3(256), lds, stream, in1, in2, out, C, H, W);
     return camli_check_launch("camli_corr2d_fwd");
 }
 
@@ -208,9 +351,20 @@ extern "C" int camli_corr2d_bwd(const float* gout_nchw, const float* in1_nhwc, c
     }
     if (B == 0) return CAMLI_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (B > 65535 || H > 65535) {
+        camli_set_error("camli_corr2d_bwd: bad shape B=%d H=%d", B, H);
+        return CAMLI_EINVAL;
+    }
+    switch (md) {
+        case 1: return launch_bwd<1>(gout_nchw, in1_nhwc, in2_nhwc, g1_nhwc, g2_nhwc, B, C, H, W, s);
+        case 2: return launch_bwd<2>(gout_nchw, in1_nhwc, in2_nhwc, g1_nhwc, g2_nhwc, B, C, H, W, s);
+        case 3: return launch_bwd<3>(gout_nchw, in1_nhwc, in2_nhwc, g1_nhwc, g2_nhwc, B, C, H, W, s);
+        case 4: return launch_bwd<4>(gout_nchw, in1_nhwc, in2_nhwc, g1_nhwc, g2_nhwc, B, C, H, W, s);
+        default: break;
+    }
     const size_t total = (size_t)B * H * W * C;
     int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(corr2d_bwd_kernel, dim3(blocks, 2), dim3(256), 0, s, gout_nchw, in1_nhwc, in2_nhwc, g1_nhwc,
                        g2_nhwc, B, C, H, W, md);
-    return camli_check_launch("camli_corr2d_bwd");
+    return camli_check_launch("camli_corr2d_bwd(generic)");
 }
