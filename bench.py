@@ -86,13 +86,13 @@ def make_optimizer(model, capturable=False):
                              capturable=capturable)
 
 
-def allreduce_gradients(model, world):
+def allreduce_gradients(model, world, force=False):
     """Data-parallel gradient averaging as ONE flat bucket (33.5 MB for CamLiRAFT): a single RCCL
     all-reduce over xGMI after backward.  The payload is latency-, not bandwidth-bound, so
     there is nothing to gain from DDP's bucketed overlap -- and a plain collective issued after
     ``backward()`` (which joins every stream it used) stays correct when the point branch runs on
     its own HIP stream."""
-    if world <= 1:
+    if world <= 1 and not force:
         return
     grads = [p.grad for p in model.parameters() if p.grad is not None]
     flat = torch._utils._flatten_dense_tensors(grads)
@@ -102,11 +102,11 @@ def allreduce_gradients(model, world):
         g.copy_(f)
 
 
-def train_step(model, optimizer, batch, world=1):
+def train_step(model, optimizer, batch, world=1, force_dist=False):
     model(batch)
     loss = model.get_loss()
     loss.backward()
-    allreduce_gradients(model, world)
+    allreduce_gradients(model, world, force_dist)
     torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
@@ -216,7 +216,10 @@ def main():
         raise SystemExit('bench.py needs a GPU: the HIP path is the product, there is no CPU fallback')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    # CAMLI_FORCE_DIST=1 under a 1-rank torch.distributed.run exercises the whole multi-GPU path
+    # (RCCL init, broadcast, SyncBatchNorm, flat all-reduce) on a single-GPU box
+    dist_on = world > 1 or (os.environ.get('CAMLI_FORCE_DIST') == '1' and 'RANK' in os.environ)
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
 
@@ -229,10 +232,10 @@ def main():
 
     torch.manual_seed(0)
     raw_model = CamLiRAFT(model_cfg(args.iters))
-    if world > 1:
+    if dist_on:
         raw_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(raw_model)
     model = raw_model.to(device).train()
-    if world > 1:   # identical replicas: broadcast rank 0's parameters and buffers once
+    if dist_on:   # identical replicas: broadcast rank 0's parameters and buffers once
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
     use_graph = args.graph and world == 1
@@ -241,13 +244,13 @@ def main():
                                                          seed=100 + rank).items()}
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     graphed = GraphedStep(model, optimizer, batch) if use_graph else None
     for _ in range(args.warmup):
-        graphed() if graphed else train_step(model, optimizer, batch, world)
+        graphed() if graphed else train_step(model, optimizer, batch, world, dist_on)
     barrier()
     _lib.TIMER.reset()
     _lib.TIMER.only = None
@@ -256,12 +259,12 @@ def main():
     host_s = 0.0
     for _ in range(args.steps):
         h0 = time.perf_counter()
-        loss = graphed() if graphed else train_step(model, optimizer, batch, world)
+        loss = graphed() if graphed else train_step(model, optimizer, batch, world, dist_on)
         host_s += time.perf_counter() - h0
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.TIMER.enabled = False
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -289,7 +292,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

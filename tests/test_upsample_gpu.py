@@ -112,4 +112,5 @@ def test_resnet_trunk_folded_batchnorm_vs_unfolded():
     assert g1.keys() == g2.keys()
     num = sum(((g1[n] - g2[n]).double() ** 2).sum().item() for n in g1) ** 0.5
     den = sum((g2[n].double() ** 2).sum().item() for n in g1) ** 0.5
-    assert num / den < 1e-4, num / den
+    # library weight-gradient kernels are picked per call (workspace-dependent): seen 2e-5 .. 1.1e-4
+    assert num / den < 5e-4, num / den
