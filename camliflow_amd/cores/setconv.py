@@ -99,6 +99,13 @@ class PointConvDW(nn.Module):
         features = features * self.weight_net(knn_offset)
         return torch.max(features, dim=-1)[0]
 
+    def _weightnet_on_matrix_cores(self):
+        ok = getattr(self, '_wn_ok', None)
+        if ok is None:
+            from ..csrc import fused
+            ok = self._wn_ok = fused.weightnet_supported(self.weight_net, self.weight_net.convs[-1].conv_fn.out_channels)
+        return ok
+
     def _forward_fused(self, xyz, features, sampled_xyz, knn_indices):
         """Same math through camli_pointconv_dw_{fwd,bwd}: no [B,C,n,k] gather / product tensors,
         one atomic per output element in the backward, neighbour weights shared across the pass."""
@@ -110,8 +117,13 @@ class PointConvDW(nn.Module):
                tuple(knn_indices.shape), torch.is_grad_enabled())
         entry = _pass_cache.get(key) if _pass_cache is not None else None
         if entry is None:
-            _, _, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
-            shared = fused.SharedSetConvWeights(self.weight_net(knn_offset))
+            if self._weightnet_on_matrix_cores() and not (xyz.requires_grad or centres.requires_grad):
+                # offsets + 3 -> 8 -> 32 -> C in one launch, the wide layer on MFMA (camli_weightnet_fwd/bwd)
+                weight = fused.weightnet(xyz, centres, knn_indices, self.k, self.weight_net)
+            else:
+                _, _, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
+                weight = self.weight_net(knn_offset)
+            shared = fused.SharedSetConvWeights(weight)
             if _pass_cache is not None:
                 # the key holds raw addresses: keep the keyed tensors alive so an address is never recycled
                 _pass_cache[key] = (shared, (xyz, centres, knn_indices))

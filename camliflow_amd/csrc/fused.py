@@ -245,6 +245,78 @@ def pointconv_dw(feat, shared, knn_indices, k):
 
 
 # ------------------------------------------------------------------------------------------------
+# neighbour-weight network of PointConvDW on the matrix cores (models/point_conv.py:110-121)
+# ------------------------------------------------------------------------------------------------
+class _WeightNet(torch.autograd.Function):
+    """weight_net(knn_offset) in one launch; the backward is one launch as well: it recomputes the hidden
+    layers and produces the gradients of all six parameters (every contraction on the matrix cores)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, xyz, centres, knn_indices, k, w1, b1, w2, b2, w3, b3):
+        lib = _lib.load()
+        bs, _, m = xyz.shape
+        n, c = centres.shape[2], w3.shape[0]
+        params = [t.reshape(t.shape[0], -1).contiguous() for t in (w1, b1, w2, b2, w3, b3)]
+        out = torch.empty((bs, c, n, k), dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.launch('camli_weightnet_fwd', lib.camli_weightnet_fwd, xyz.data_ptr(), centres.data_ptr(),
+                        knn_indices.data_ptr(), knn_indices.stride(1), *[t.data_ptr() for t in params],
+                        out.data_ptr(), bs, c, m, n, k, _stream_ptr(xyz),
+                        work=(4.0 * bs * c * n * k + 8.0 * bs * n * k + 12.0 * bs * (m + n), 'B'))
+        ctx.save_for_backward(xyz, centres, knn_indices, *params)
+        ctx.k = k
+        ctx.shapes = [t.shape for t in (w1, b1, w2, b2, w3, b3)]
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        lib = _lib.load()
+        xyz, centres, knn_indices, *params = ctx.saved_tensors
+        k = ctx.k
+        bs, _, m = xyz.shape
+        n, c = centres.shape[2], params[4].shape[0]
+        gout = gout.contiguous().float()
+        sizes = [t.numel() for t in params]
+        grads = list(torch.split(torch.empty(sum(sizes), dtype=torch.float32, device=xyz.device), sizes))
+        ws_bytes = lib.camli_weightnet_bwd_workspace_bytes(c)
+        workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=xyz.device)
+        with torch.cuda.device(xyz.device):
+            _lib.launch('camli_weightnet_bwd', lib.camli_weightnet_bwd, xyz.data_ptr(), centres.data_ptr(),
+                        knn_indices.data_ptr(), knn_indices.stride(1), *[t.data_ptr() for t in params],
+                        gout.data_ptr(), *[g.data_ptr() for g in grads], workspace.data_ptr(), ws_bytes,
+                        bs, c, m, n, k, _stream_ptr(xyz),
+                        work=(4.0 * bs * c * n * k + 8.0 * bs * n * k + 12.0 * bs * (m + n), 'B'))
+        grads = [g.view(shape) for g, shape in zip(grads, ctx.shapes)]
+        return (None, None, None, None, *grads)
+
+
+def weightnet_supported(mlp, c_out):
+    """The fused kernel implements exactly MLP2d(3, [8, 32, C<=128], norm=None, act='relu')."""
+    convs = getattr(mlp, 'convs', None)
+    if convs is None or len(convs) != 3 or c_out > 128:
+        return False
+    dims = [(cv.conv_fn.in_channels, cv.conv_fn.out_channels) for cv in convs]
+    plain = all(isinstance(cv.norm_fn, torch.nn.Identity) and isinstance(cv.act_fn, torch.nn.ReLU)
+                and cv.conv_fn.bias is not None for cv in convs)
+    return plain and dims == [(3, 8), (8, 32), (32, c_out)]
+
+
+def weightnet(xyz, centres, knn_indices, k, mlp):
+    """xyz [B,3,M], centres [B,3,N], knn_indices int64 [B,N,>=k] -> weight_net(xyz[knn] - centre) [B,C,N,k]."""
+    _require_cuda('weightnet', xyz, centres, knn_indices)
+    assert knn_indices.dtype == torch.int64 and knn_indices.stride(2) == 1 and knn_indices.shape[2] >= k
+    assert knn_indices.stride(0) == knn_indices.shape[1] * knn_indices.stride(1)
+    assert not (xyz.requires_grad or centres.requires_grad), 'coordinates are constants of this path'
+    convs = mlp.convs
+    return _WeightNet.apply(xyz.float().contiguous(), centres.float().contiguous(), knn_indices, k,
+                            convs[0].conv_fn.weight, convs[0].conv_fn.bias, convs[1].conv_fn.weight,
+                            convs[1].conv_fn.bias, convs[2].conv_fn.weight, convs[2].conv_fn.bias)
+
+
+
+# ------------------------------------------------------------------------------------------------
 # gather / interpolation / point cost-volume lookup (models/utils.py, models/camliraft_l_core.py)
 # ------------------------------------------------------------------------------------------------
 class _GatherCF(torch.autograd.Function):

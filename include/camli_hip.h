@@ -190,6 +190,33 @@ int camli_bias_act_fwd(float *x_inout, const float *bias, int B, int C, int P, i
 int camli_bias_act_bwd(const float *gy, const float *y, float *gx, float *gbias, int B, int C, int P, int act,
                        void *stream);
 
+/*
+ * Neighbour-weight network of a depth-wise set-conv: weight_net = MLP2d(3 -> 8 -> 32 -> C, ReLU after
+ * every layer, bias, no norm) applied to the centred neighbour offsets (models/point_conv.py:102-121,
+ * models/mlp.py:100-162; the reference runs gather, subtract, 3x (1x1 conv, bias, ReLU)).  One launch:
+ * offsets and the two small layers on the VALU, the 32 -> C layer on the matrix cores
+ * (v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate), output written once.
+ *   xyz [B,3,M], centres [B,3,N] (channel-first), idx int64 rows of stride idx_stride (first k used),
+ *   w1 [8,3] b1 [8] w2 [32,8] b2 [32] w3 [C,32] b3 [C], out [B,C,N,k] (fully written), C <= 128.
+ * Every layer is bias-first followed by an input-ordered fmaf chain (bit-exact restatement:
+ * oracle_weightnet_fwd).
+ * bwd: gout [B,C,N,k] -> gradients of all six parameters, gw1 [8,3] gb1 [8] gw2 [32,8] gb2 [32] gw3 [C,32]
+ *   gb3 [C], fully written (an empty problem writes zeros).  Hidden layers and ReLU masks are recomputed
+ *   with the forward's arithmetic; every contraction runs on the matrix cores.  Workgroup partial sums go to
+ *   `workspace` (camli_weightnet_bwd_workspace_bytes(C) bytes, contents undefined afterwards) and are
+ *   added in a fixed order by a second kernel: no atomics, bit-reproducible.  The coordinates receive no
+ *   gradient (they are constants on this path: models/camliraft_core.py:105-106).
+ */
+int camli_weightnet_fwd(const float *xyz, const float *centres, const int64_t *idx, int idx_stride,
+                        const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                        const float *b3, float *out, int B, int C, int M, int N, int k, void *stream);
+int64_t camli_weightnet_bwd_workspace_bytes(int C);
+int camli_weightnet_bwd(const float *xyz, const float *centres, const int64_t *idx, int idx_stride,
+                        const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                        const float *b3, const float *gout, float *gw1, float *gb1, float *gw2, float *gb2,
+                        float *gw3, float *gb3, float *workspace, int64_t workspace_bytes,
+                        int B, int C, int M, int N, int k, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

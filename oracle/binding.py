@@ -199,3 +199,36 @@ def convex_upsample_fwd(flow, mask, scale):
     out = np.zeros((B, 2, h * scale, w * scale), dtype=np.float32)
     _chk(_load().oracle_convex_upsample_fwd(_p(flow), _p(mask), _p(out), B, h, w, scale), "convex_upsample_fwd")
     return out
+
+
+def weightnet_fwd(xyz, centres, idx, k, params, want_hidden=False):
+    """xyz [B,3,M], centres [B,3,N], idx int64 [B,N,kk>=k], params = (w1[8,3], b1, w2[32,8], b2, w3[C,32], b3)
+    -> out [B,C,N,k] (and h2 [B,32,N,k])"""
+    xyz, centres, idx = _f32(xyz), _f32(centres), _i64(idx)
+    w1, b1, w2, b2, w3, b3 = [_f32(t) for t in params]
+    B, _, M = xyz.shape
+    N, C = centres.shape[2], w3.shape[0]
+    out = np.zeros((B, C, N, k), dtype=np.float32)
+    h2 = np.zeros((B, 32, N, k), dtype=np.float32) if want_hidden else None
+    _chk(_load().oracle_weightnet_fwd(_p(xyz), _p(centres), _p(idx), idx.shape[2], _p(w1), _p(b1), _p(w2), _p(b2),
+                                      _p(w3), _p(b3), _p(out), _p(h2) if want_hidden else None, B, C, M, N, k),
+         "weightnet_fwd")
+    return (out, h2) if want_hidden else out
+
+
+def weightnet_bwd(xyz, centres, idx, k, params, gout):
+    """-> float64 gradients [gw1 [8,3], gb1 [8], gw2 [32,8], gb2 [32], gw3 [C,32], gb3 [C]]"""
+    xyz, centres, idx, gout = _f32(xyz), _f32(centres), _i64(idx), _f32(gout)
+    w1, b1, w2, b2, w3, b3 = [_f32(t) for t in params]
+    B, _, M = xyz.shape
+    N, C = centres.shape[2], w3.shape[0]
+    flat = np.zeros((24 + 8 + 256 + 32 + C * 33,), dtype=np.float64)
+    _chk(_load().oracle_weightnet_bwd(_p(xyz), _p(centres), _p(idx), idx.shape[2], _p(w1), _p(b1), _p(w2), _p(b2),
+                                      _p(w3), _p(b3), _p(gout), _p(flat), B, C, M, N, k), "weightnet_bwd")
+    sizes = [(8, 3), (8,), (32, 8), (32,), (C, 32), (C,)]
+    out, pos = [], 0
+    for shape in sizes:
+        n = int(np.prod(shape))
+        out.append(flat[pos:pos + n].reshape(shape))
+        pos += n
+    return out

@@ -484,4 +484,111 @@ int oracle_convex_upsample_fwd(const float *flow, const float *mask, float *out,
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * set-conv neighbour-weight network: follows models/point_conv.py:110-121 (knn_offset ->
+ * weight_net = MLP2d(3,[8,32,C], act='relu'), models/mlp.py:100-162: conv1x1 + bias, ReLU).
+ * Arithmetic order pinned for the HIP kernel: each layer = bias, then an input-ordered fmaf chain.
+ *   xyz [B,3,M], centres [B,3,N], idx rows of stride idx_stride; out [B,C,N,k]; h2_out [B,32,N,k] or NULL
+ * ------------------------------------------------------------------------------------------ */
+static void weightnet_hidden(const float *xyz, const float *centres, const int64_t *idx, int idx_stride,
+                             const float *w1, const float *b1, const float *w2, const float *b2,
+                             int b, int M, int N, int n, int j, float *h2)
+{
+    int64_t m = idx[((size_t)b * N + n) * idx_stride + j];
+    float off[3], h1[8];
+    for (int d = 0; d < 3; ++d) off[d] = xyz[((size_t)b * 3 + d) * M + m] - centres[((size_t)b * 3 + d) * N + n];
+    for (int i = 0; i < 8; ++i) {
+        float a = b1[i];
+        for (int d = 0; d < 3; ++d) a = fmaf(w1[i * 3 + d], off[d], a);
+        h1[i] = a > 0.0f ? a : 0.0f;
+    }
+    for (int q = 0; q < 32; ++q) {
+        float a = b2[q];
+        for (int i = 0; i < 8; ++i) a = fmaf(w2[q * 8 + i], h1[i], a);
+        h2[q] = a > 0.0f ? a : 0.0f;
+    }
+}
+
+int oracle_weightnet_fwd(const float *xyz, const float *centres, const int64_t *idx, int idx_stride,
+                         const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                         const float *b3, float *out, float *h2_out, int B, int C, int M, int N, int k)
+{
+    size_t NK = (size_t)N * k;
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n)
+            for (int j = 0; j < k; ++j) {
+                int64_t m = idx[((size_t)b * N + n) * idx_stride + j];
+                if (m < 0 || m >= M) return -1;
+                float h2[32];
+                weightnet_hidden(xyz, centres, idx, idx_stride, w1, b1, w2, b2, b, M, N, n, j, h2);
+                if (h2_out)
+                    for (int q = 0; q < 32; ++q) h2_out[((size_t)b * 32 + q) * NK + (size_t)n * k + j] = h2[q];
+                for (int c = 0; c < C; ++c) {
+                    float a = b3[c];
+                    for (int q = 0; q < 32; ++q) a = fmaf(w3[c * 32 + q], h2[q], a);
+                    out[((size_t)b * C + c) * NK + (size_t)n * k + j] = a > 0.0f ? a : 0.0f;
+                }
+            }
+    return 0;
+}
+
+/* backward of the whole network wrt its six parameters (double accumulation; masks from the fp32
+ * forward chains above):  g3 = gout*(pre3>0), gw3 += g3 h2^T, gb3 += g3, gh2 = W3^T g3, g2 = gh2*(h2>0),
+ * gw2 += g2 h1^T, gb2 += g2, gh1 = W2^T g2, g1 = gh1*(h1>0), gw1 += g1 d^T, gb1 += g1.
+ * grads = [gw1 (24), gb1 (8), gw2 (256), gb2 (32), gw3 (C*32), gb3 (C)] concatenated. */
+int oracle_weightnet_bwd(const float *xyz, const float *centres, const int64_t *idx, int idx_stride,
+                         const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                         const float *b3, const float *gout, double *grads, int B, int C, int M, int N, int k)
+{
+    size_t NK = (size_t)N * k;
+    double *gw1 = grads, *gb1 = gw1 + 24, *gw2 = gb1 + 8, *gb2 = gw2 + 256, *gw3 = gb2 + 32, *gb3 = gw3 + (size_t)C * 32;
+    for (size_t i = 0; i < (size_t)24 + 8 + 256 + 32 + (size_t)C * 33; ++i) grads[i] = 0.0;
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n)
+            for (int j = 0; j < k; ++j) {
+                int64_t m = idx[((size_t)b * N + n) * idx_stride + j];
+                if (m < 0 || m >= M) return -1;
+                float off[3], h1[8], h2[32];
+                for (int d = 0; d < 3; ++d) off[d] = xyz[((size_t)b * 3 + d) * M + m] - centres[((size_t)b * 3 + d) * N + n];
+                for (int i = 0; i < 8; ++i) {
+                    float a = b1[i];
+                    for (int d = 0; d < 3; ++d) a = fmaf(w1[i * 3 + d], off[d], a);
+                    h1[i] = a > 0.0f ? a : 0.0f;
+                }
+                for (int q = 0; q < 32; ++q) {
+                    float a = b2[q];
+                    for (int i = 0; i < 8; ++i) a = fmaf(w2[q * 8 + i], h1[i], a);
+                    h2[q] = a > 0.0f ? a : 0.0f;
+                }
+                double g2[32], g1[8];
+                for (int q = 0; q < 32; ++q) g2[q] = 0.0;
+                for (int c = 0; c < C; ++c) {
+                    float a = b3[c];
+                    for (int q = 0; q < 32; ++q) a = fmaf(w3[c * 32 + q], h2[q], a);
+                    if (!(a > 0.0f)) continue;
+                    double g = gout[((size_t)b * C + c) * NK + (size_t)n * k + j];
+                    gb3[c] += g;
+                    for (int q = 0; q < 32; ++q) {
+                        gw3[c * 32 + q] += g * h2[q];
+                        g2[q] += g * w3[c * 32 + q];
+                    }
+                }
+                for (int i = 0; i < 8; ++i) g1[i] = 0.0;
+                for (int q = 0; q < 32; ++q) {
+                    if (!(h2[q] > 0.0f)) continue;
+                    gb2[q] += g2[q];
+                    for (int i = 0; i < 8; ++i) {
+                        gw2[q * 8 + i] += g2[q] * h1[i];
+                        g1[i] += g2[q] * w2[q * 8 + i];
+                    }
+                }
+                for (int i = 0; i < 8; ++i) {
+                    if (!(h1[i] > 0.0f)) continue;
+                    gb1[i] += g1[i];
+                    for (int d = 0; d < 3; ++d) gw1[i * 3 + d] += g1[i] * off[d];
+                }
+            }
+    return 0;
+}
+
 int oracle_version(void) { return 1; }

@@ -138,6 +138,27 @@ def golden_allpairs():
              gfmap1=gf1, gfmap2=gf2, **extra)
 
 
+def golden_pointconv_dw():
+    """The reference's PointConvDW (models/point_conv.py:102-130) with the name-hashed fill: inputs,
+    the weight_net parameters and output (captured by a forward hook), and the module output."""
+    from models.point_conv import PointConvDW as RefPointConvDW
+    from modelutils import hashed_fill_
+    for tag, (cin, cout, k, n) in {'a': (24, 40, 16, 96), 'b': (6, 125, 4, 50)}.items():
+        g = gen(31 + ord(tag))
+        mod = hashed_fill_(RefPointConvDW(cin, cout, k=k)).eval()
+        xyz = torch.rand(2, 3, n, generator=g) * 4
+        feat = torch.randn(2, cin, n, generator=g)
+        knn = ref_ops.k_nearest_neighbor(xyz, xyz, 32, cpp_impl=False)
+        captured = {}
+        hook = mod.weight_net.register_forward_hook(lambda m, i, o: captured.update(offset=i[0], weight=o))
+        with torch.no_grad():
+            out = mod(xyz, feat, knn_indices=knn)
+        hook.remove()
+        sd = mod.state_dict()
+        save('pointconv_dw_' + tag, xyz=xyz, feat=feat, knn=knn, k=k, out=out, knn_offset=captured['offset'],
+             weight=captured['weight'], **{'p_' + name.replace('.', '__'): t for name, t in sd.items()})
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     golden_correlation()
@@ -145,3 +166,4 @@ if __name__ == '__main__':
     golden_knn()
     golden_indexing()
     golden_allpairs()
+    golden_pointconv_dw()

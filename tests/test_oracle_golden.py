@@ -121,3 +121,39 @@ def test_allpairs_lookup(name, golden, oracle_lib):
             total[l] = gl[l] + up
         for l in range(4):
             assert np.allclose(total[l], g['glevel%d' % l].reshape(gl[l].shape), rtol=1e-4, atol=1e-4)
+
+
+def _weightnet_params(g):
+    return [g['p_weight_net__convs__%d__conv_fn__%s' % (i, part)].reshape(
+        g['p_weight_net__convs__%d__conv_fn__weight' % i].shape[0], -1) for i in range(3) for part in ('weight', 'bias')]
+
+
+@pytest.mark.parametrize('name', ['pointconv_dw_a', 'pointconv_dw_b'])
+def test_weightnet_and_setconv_match_reference_module(name, golden, oracle_lib):
+    """oracle_weightnet_fwd (+ oracle_pointconv_dw_fwd) against the reference's PointConvDW: the
+    weight_net output captured by a forward hook, and the module output (fp32, different summation
+    order than the 1x1 convolutions: 1e-5)."""
+    g = golden(name)
+    k = int(g['k'])
+    params = _weightnet_params(g)
+    weight, h2 = oracle_lib.weightnet_fwd(g['xyz'], g['xyz'], g['knn'], k, params, want_hidden=True)
+    assert weight.shape == g['weight'].shape and h2.shape[1] == 32
+    assert np.allclose(weight, g['weight'], rtol=1e-5, atol=1e-6)
+    mlp_w = g['p_mlp__convs__0__conv_fn__weight'][:, :, 0]
+    pre = np.einsum('oi,bim->bom', mlp_w, g['feat']) + g['p_mlp__convs__0__conv_fn__bias'][None, :, None]
+    feat = np.where(pre > 0, pre, np.float32(0.1) * pre).astype(np.float32)            # leaky_relu(0.1)
+    out, _ = oracle_lib.pointconv_dw_fwd(feat, weight, g['knn'], k)
+    assert np.allclose(out, g['out'], rtol=1e-4, atol=1e-5)
+    # backward: against float64 autograd on the same formulas (composed from the golden offsets)
+    import torch
+    gout = np.random.default_rng(0).standard_normal(weight.shape).astype(np.float32)
+    grads = oracle_lib.weightnet_bwd(g['xyz'], g['xyz'], g['knn'], k, params, gout)
+    leaves = [torch.tensor(p if i % 2 == 0 else p[:, 0], dtype=torch.float64, requires_grad=True)
+              for i, p in enumerate(params)]
+    x = torch.tensor(g['knn_offset'], dtype=torch.float64)
+    for w, b in zip(leaves[0::2], leaves[1::2]):
+        x = torch.relu(torch.einsum('oi,binj->bonj', w, x) + b.view(1, -1, 1, 1))
+    x.backward(torch.tensor(gout, dtype=torch.float64))
+    for got, leaf in zip(grads, leaves):
+        ref = leaf.grad.numpy()
+        assert np.linalg.norm(got - ref) <= 1e-5 * np.linalg.norm(ref) + 1e-9
