@@ -112,5 +112,8 @@ def test_resnet_trunk_folded_batchnorm_vs_unfolded():
     assert g1.keys() == g2.keys()
     num = sum(((g1[n] - g2[n]).double() ** 2).sum().item() for n in g1) ** 0.5
     den = sum((g2[n].double() ** 2).sum().item() for n in g1) ** 0.5
-    # library weight-gradient kernels are picked per call (workspace-dependent): seen 2e-5 .. 1.1e-4
-    assert num / den < 5e-4, num / den
+    # Folded and unfolded forwards differ by fp32 rounding, so a few of the ~10^7 ReLU / max-pool decisions
+    # flip and each flip moves the gradients by one discrete term; which ones flip depends on the library
+    # convolution algorithms chosen for the call (workspace-dependent).  Seen: 2e-5 typical, 6e-4 in about
+    # one run in three of the whole suite.
+    assert num / den < 5e-3, num / den
