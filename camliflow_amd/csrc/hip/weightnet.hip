@@ -167,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
     float* __restrict__ s_g = s_t[wave][0];
     float* __restrict__ s_h = s_t[wave][1];
 
-    f32x16 gw[MT], gw2a, gw1a;
+    f32x16 gw[MT], gsm;     // gsm: [gw2 | gb2] in columns 0..8, [gw1 | gb1] (rows 0..7) in columns 16..19
     float gb[MT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gw2a[r] = gw1a[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) gsm[r] = 0.0f;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         gb[t] = 0.0f;
@@ -189,48 +189,9 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
         float h1[8], off[3];
         wn_hidden1(xyz, centres, idx, idx_stride, w1, b1, b, M, N, k, valid ? col : NK - 1, h1, off);
 
-        // ---- pre3 with the forward's operand order ----
-        f32x16 acc[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = s_b3[32 * t + wn_row(r, half)];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int q = 2 * s + half;
-            float a = s_b2[q];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a = __builtin_fmaf(s_w2[q * 8 + i], h1[i], a);
-            const float h2s = fmaxf(a, 0.0f);
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w3[(32 * t + cl) * WN_LD + q], h2s, acc[t], 0, 0, 0);
-        }
-        // ---- g3 = gout * (pre3 > 0), kept in the C/D registers ----
-        {
-            const float* __restrict__ src = gout + (size_t)b * C * NK;
-            const int lane_off = 4 * half * NK + col;
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int urow = 32 * t + wn_row(r, 0);
-                    float g = 0.0f;
-                    if (valid && urow + 4 * half < C) g = src[(size_t)urow * NK + lane_off];
-                    acc[t][r] = acc[t][r] > 0.0f ? g : 0.0f;
-                }
-        }
-        // ---- gh2 = W3^T g3: one 32x32 accumulator, K = (t, r, half) <-> c = 32t + wn_row(r, half) ----
-        f32x16 gd;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gd[r] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                gd = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w3[(32 * t + wn_row(r, half)) * WN_LD + cl], acc[t][r], gd,
-                                                          0, 0, 0);
-        // ---- h2 in C/D row order -> LDS tile [q][col];  g2 = gh2 * (h2 > 0) stays in gd ----
+        // ---- hidden layer 2 in C/D row order: transpose tile for gw3, ReLU mask for g2 ----
+        unsigned h2_mask = 0;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = wn_row(r, half);
@@ -238,28 +199,55 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
 #pragma unroll
             for (int i = 0; i < 8; ++i) a = __builtin_fmaf(s_w2[q * 8 + i], h1[i], a);
             s_h[q * WN_LD + cl] = fmaxf(a, 0.0f);
-            gd[r] = a > 0.0f ? gd[r] : 0.0f;
+            h2_mask |= (a > 0.0f ? 1u : 0u) << r;
         }
         __builtin_amdgcn_wave_barrier();
-        {
-            float hb[16];   // B fragments of the weight-gradient product: h2[q = cl][col = 2s + half]
+        float h2f[16];      // the column's h2 in the forward's K order, read back from the tile (other half's rows too)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) hb[s] = s_h[cl * WN_LD + 2 * s + half];
-            // ---- gw3 += g3 h2^T, one 32-row tile of C at a time through the wave's transpose tile ----
+        for (int s = 0; s < 16; ++s) h2f[s] = s_h[(2 * s + half) * WN_LD + cl];
+        // ---- per 32-row tile of C: pre3 (forward operand order -> identical mask), g3 = gout * (pre3 > 0),
+        // gh2 += W3^T g3 (K = (r, half) <-> c = 32t + wn_row(r, half)), gw3 += g3 h2^T via the transpose tile.
+        // gout of a tile is requested before its pre3 MFMAs and consumed after them. ----
+        const float* __restrict__ src = gout + (size_t)b * C * NK;
+        const int lane_off = 4 * half * NK + col;
+        f32x16 gd;
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < 16; ++r) gd[r] = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s_g[wn_row(r, half) * WN_LD + cl] = acc[t][r];
-                __builtin_amdgcn_wave_barrier();
+        for (int t = 0; t < MT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);      // keep the compiler from hoisting later tiles' loads (register budget)
+            float g[16];                            // requested before this tile's pre3 MFMAs, consumed after them
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float ga = s_g[cl * WN_LD + 2 * s + half];   // A[i = c_local = cl][k = col = 2s + half]
-                    gb[t] += ga;
-                    gw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, hb[s], gw[t], 0, 0, 0);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int urow = 32 * t + wn_row(r, 0);
+                g[r] = (valid && urow + 4 * half < C) ? src[(size_t)urow * NK + lane_off] : 0.0f;
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = s_b3[32 * t + wn_row(r, half)];
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w3[(32 * t + cl) * WN_LD + 2 * s + half], h2f[s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.0f ? g[r] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                gd = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w3[(32 * t + wn_row(r, half)) * WN_LD + cl], acc[r], gd, 0, 0, 0);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_g[wn_row(r, half) * WN_LD + cl] = acc[r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float ga = s_g[cl * WN_LD + 2 * s + half];   // A[i = c_local = cl][k = col = 2s + half]
+                gb[t] += ga;
+                gw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, s_h[cl * WN_LD + 2 * s + half], gw[t], 0, 0, 0);
             }
         }
+        // ---- g2 = gh2 * (h2 > 0) stays in gd ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gd[r] = (h2_mask >> r) & 1u ? gd[r] : 0.0f;
         // ---- [gw2 | gb2] += g2 [h1 ; 1]^T ----
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -274,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
         for (int s = 0; s < 16; ++s) {
             const float a2 = s_g[cl * WN_LD + 2 * s + half];                         // g2[q = cl][col]
             const float bv = s_h[(cl < 9 ? cl : 0) * WN_LD + 2 * s + half];          // [h1 ; 1][j = cl][col]
-            gw2a = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, cl < 9 ? bv : 0.0f, gw2a, 0, 0, 0);
+            gsm = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, cl < 9 ? bv : 0.0f, gsm, 0, 0, 0);
         }
         // ---- gh1 = W2^T g2 (each half holds 16 of the 32 q), g1 = gh1 * (h1 > 0) ----
         float g1[8];
@@ -301,11 +289,12 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
             s_h[3 * WN_LD + cl] = 1.0f;
         }
         __builtin_amdgcn_wave_barrier();
+        const bool bsel = cl >= 16 && cl < 20;      // output columns 16..19 <- [d ; 1] rows 0..3
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float a1 = s_g[(cl < 8 ? cl : 0) * WN_LD + 2 * s + half];
-            const float bv = s_h[(cl < 4 ? cl : 0) * WN_LD + 2 * s + half];
-            gw1a = __builtin_amdgcn_mfma_f32_32x32x2f32(cl < 8 ? a1 : 0.0f, cl < 4 ? bv : 0.0f, gw1a, 0, 0, 0);
+            const float bv = s_h[(bsel ? cl - 16 : 0) * WN_LD + 2 * s + half];
+            gsm = __builtin_amdgcn_mfma_f32_32x32x2f32(cl < 8 ? a1 : 0.0f, bsel ? bv : 0.0f, gsm, 0, 0, 0);
         }
     }
 
@@ -327,8 +316,9 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int q = wn_row(r, half);
-        if (cl < 9) atomicAdd(&red[RED_W3 + q * 9 + cl], gw2a[r]);
-        if (r < 4 && cl < 4) atomicAdd(&red[RED_W2 + q * 4 + cl], gw1a[r]);   // rows 0..7: r in 0..3 (+4 upper half)
+        if (cl < 9) atomicAdd(&red[RED_W3 + q * 9 + cl], gsm[r]);
+        if (r < 4 && cl >= 16 && cl < 20) atomicAdd(&red[RED_W2 + q * 4 + cl - 16], gsm[r]);   // rows 0..7: r in 0..3
+
     }
     __syncthreads();
     float* __restrict__ mine = partials + (size_t)blockIdx.x * RED_ALL;
