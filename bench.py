@@ -254,7 +254,7 @@ def main():
     barrier()
     _lib.TIMER.reset()
     _lib.TIMER.only = None
-    _lib.TIMER.enabled = graphed is None   # events cannot be recorded through a graph replay
+    _lib.TIMER.enabled = graphed is None and os.environ.get('CAMLI_NO_TIMER') != '1'   # events cannot be recorded through a graph replay
     t0 = time.perf_counter()
     host_s = 0.0
     for _ in range(args.steps):

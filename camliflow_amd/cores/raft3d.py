@@ -87,8 +87,25 @@ class Correlation3D(nn.Module):
         return self.cost_mlp(lookup).sum(dim=-1)
 
     def forward(self, xyz1, xyzs2):
+        if runtime.fused() and not (xyz1.requires_grad or any(x.requires_grad for x in xyzs2[:4])):
+            return self._forward_batched(xyz1, xyzs2)
         per_level = [self.calc_matching_cost(xyz1, xyzs2[lvl], self.cost_volume_pyramid[lvl]) for lvl in range(4)]
         return self.merge(torch.cat(per_level, dim=1))
+
+    def _forward_batched(self, xyz1, xyzs2):
+        """Same math with the four levels' (dxyz, cost) columns laid side by side, so ``cost_mlp`` (a
+        per-column MLP) runs once on [B,4,N,4k] instead of four times on [B,4,N,k]: a quarter of the
+        launches in both directions, one larger GEMM."""
+        from ..csrc import fused
+        bs, n_src = xyz1.shape[0], xyz1.shape[2]
+        columns = []
+        for lvl in range(4):
+            cross = _ops.k_nearest_neighbor(input_xyz=xyzs2[lvl], query_xyz=xyz1, k=self.k)
+            columns.append(fused.corr3d_lookup_input(self.cost_volume_pyramid[lvl], xyz1, xyzs2[lvl], cross))
+        cost = self.cost_mlp(torch.cat(columns, dim=3))                               # [B,C/4,N,4k]
+        cost = cost.view(bs, -1, n_src, 4, self.k).sum(dim=-1)                        # [B,C/4,N,4]
+        cost = cost.permute(0, 3, 1, 2).reshape(bs, -1, n_src)                        # level-major channels
+        return self.merge(cost)
 
 
 class FlowHead3D(nn.Module):

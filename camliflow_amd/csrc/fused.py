@@ -13,7 +13,7 @@ import torch
 from torch.nn.functional import avg_pool2d
 
 from . import _lib
-from .wrapper import _require_cuda, _stream_ptr
+from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_token
 
 
 # ------------------------------------------------------------------------------------------------
@@ -96,7 +96,7 @@ class _Lookup(torch.autograd.Function):
         n, ptrs, hs, ws = pyr._level_args(pyr.levels)
         d = 2 * radius + 1
         out = torch.empty((bs, n * d * d, h, w), dtype=torch.float32, device=coords.device)
-        with torch.cuda.device(coords.device):
+        with _on_device(coords):
             _lib.launch('camli_allpairs_lookup_fwd', lib.camli_allpairs_lookup_fwd, ptrs, hs, ws, n, coords.data_ptr(), out.data_ptr(),
                                                      bs, h, w, radius, _stream_ptr(coords),
                         work=(4.0 * bs * h * w * (n * d * d + n * (d + 1) ** 2 + 2), 'B'))
@@ -115,11 +115,11 @@ class _Lookup(torch.autograd.Function):
             pyr.grads = [torch.zeros_like(lvl) for lvl in pyr.levels]
         gout = gout.contiguous().float()
         n, ptrs, hs, ws = pyr._level_args(pyr.grads)
-        with torch.cuda.device(coords.device):
+        with _on_device(coords):
             _lib.launch('camli_allpairs_lookup_bwd', lib.camli_allpairs_lookup_bwd, ptrs, hs, ws, n, coords.data_ptr(), gout.data_ptr(),
                                                      bs, h, w, ctx.radius, _stream_ptr(coords),
                         work=(4.0 * bs * h * w * (n * (2 * ctx.radius + 1) ** 2 + 2 * n * (2 * ctx.radius + 2) ** 2 + 2), 'B'))
-        return gout.new_zeros(1), None, None, None
+        return _zero_token(gout), None, None, None
 
 
 def allpairs_pyramid(fmap1, fmap2, num_levels=4):
@@ -175,7 +175,7 @@ class _ShareWeights(torch.autograd.Function):
             return torch.zeros_like(weight), None
         b, c, n, k = weight.shape
         grad = torch.empty_like(weight)
-        with torch.cuda.device(weight.device):
+        with _on_device(weight):
             for start in range(0, len(records), 64):       # the kernel takes <= 64 calls at a time
                 chunk = records[start:start + 64]
                 part = grad if start == 0 else torch.empty_like(weight)
@@ -202,7 +202,7 @@ class _PointConvDW(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]   # grad mode is off inside forward()
         wsel = torch.empty((b, c, n), dtype=torch.float32, device=feat.device) if need_grad else None
         msel = torch.empty((b, c, n), dtype=torch.int32, device=feat.device) if need_grad else None
-        with torch.cuda.device(feat.device):
+        with _on_device(feat):
             _lib.launch('camli_pointconv_dw_fwd', lib.camli_pointconv_dw_fwd, feat.data_ptr(), weight.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), out.data_ptr(), arg.data_ptr(),
                         wsel.data_ptr() if need_grad else None, msel.data_ptr() if need_grad else None,
@@ -224,13 +224,13 @@ class _PointConvDW(torch.autograd.Function):
         gout = gout.contiguous().float()
         gfeat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None   # fully written by the kernel
         gwsel = torch.empty_like(wsel)
-        with torch.cuda.device(feat.device):
+        with _on_device(feat):
             _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd, gout.data_ptr(), feat.data_ptr(),
                         wsel.data_ptr(), msel.data_ptr(), gfeat.data_ptr() if gfeat is not None else None,
                         gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat),
                         work=(16.0 * b * c * n + 8.0 * b * c * m, 'B'))
         shared.records.append((gwsel, arg))
-        return gfeat, gout.new_zeros(1), None, None, None
+        return gfeat, _zero_token(gout), None, None, None
 
 
 def pointconv_dw(feat, shared, knn_indices, k):
@@ -259,7 +259,7 @@ class _WeightNet(torch.autograd.Function):
         n, c = centres.shape[2], w3.shape[0]
         params = [t.reshape(t.shape[0], -1).contiguous() for t in (w1, b1, w2, b2, w3, b3)]
         out = torch.empty((bs, c, n, k), dtype=torch.float32, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with _on_device(xyz):
             _lib.launch('camli_weightnet_fwd', lib.camli_weightnet_fwd, xyz.data_ptr(), centres.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), *[t.data_ptr() for t in params],
                         out.data_ptr(), bs, c, m, n, k, _stream_ptr(xyz),
@@ -282,7 +282,7 @@ class _WeightNet(torch.autograd.Function):
         grads = list(torch.split(torch.empty(sum(sizes), dtype=torch.float32, device=xyz.device), sizes))
         ws_bytes = lib.camli_weightnet_bwd_workspace_bytes(c)
         workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=xyz.device)
-        with torch.cuda.device(xyz.device):
+        with _on_device(xyz):
             _lib.launch('camli_weightnet_bwd', lib.camli_weightnet_bwd, xyz.data_ptr(), centres.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), *[t.data_ptr() for t in params],
                         gout.data_ptr(), *[g.data_ptr() for g in grads], workspace.data_ptr(), ws_bytes,
@@ -327,7 +327,7 @@ class _GatherCF(torch.autograd.Function):
         b, c, m = data.shape
         i = idx_flat.shape[1]
         out = torch.empty((b, c, i), dtype=torch.float32, device=data.device)
-        with torch.cuda.device(data.device):
+        with _on_device(data):
             _lib.launch('camli_gather_cf_fwd', lib.camli_gather_cf_fwd, data.data_ptr(), idx_flat.data_ptr(),
                         out.data_ptr(), b, c, m, i, _stream_ptr(data),
                         work=(8.0 * b * c * i + 8.0 * b * i, 'B'))
@@ -343,7 +343,7 @@ class _GatherCF(torch.autograd.Function):
         gout = gout.contiguous().float()
         b, c, i = gout.shape
         gdata = torch.zeros((b, c, ctx.m), dtype=torch.float32, device=gout.device)
-        with torch.cuda.device(gout.device):
+        with _on_device(gout):
             _lib.launch('camli_gather_cf_bwd', lib.camli_gather_cf_bwd, gout.data_ptr(), idx_flat.data_ptr(),
                         gdata.data_ptr(), b, c, ctx.m, i, _stream_ptr(gout),
                         work=(8.0 * b * c * i + 8.0 * b * i, 'B'))
@@ -367,7 +367,7 @@ class _KnnInterp(torch.autograd.Function):
         b, c, m = feat.shape
         nq = q_xyz.shape[2]
         out = torch.empty((b, c, nq), dtype=torch.float32, device=feat.device)
-        with torch.cuda.device(feat.device):
+        with _on_device(feat):
             _lib.launch('camli_knn_interp_fwd', lib.camli_knn_interp_fwd, in_xyz.data_ptr(), feat.data_ptr(),
                         q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), out.data_ptr(), b, c, m, nq, k,
                         _stream_ptr(feat),
@@ -384,7 +384,7 @@ class _KnnInterp(torch.autograd.Function):
         b, c, m, nq, k = ctx.dims
         gout = gout.contiguous().float()
         gfeat = torch.zeros((b, c, m), dtype=torch.float32, device=gout.device)
-        with torch.cuda.device(gout.device):
+        with _on_device(gout):
             _lib.launch('camli_knn_interp_bwd', lib.camli_knn_interp_bwd, in_xyz.data_ptr(), gout.data_ptr(),
                         q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), gfeat.data_ptr(), b, c, m, nq, k,
                         _stream_ptr(gout),
@@ -409,7 +409,7 @@ class _Corr3DGather(torch.autograd.Function):
         b, n, m = cost.shape
         k = knn.shape[2]
         out = torch.empty((b, 4, n, k), dtype=torch.float32, device=cost.device)
-        with torch.cuda.device(cost.device):
+        with _on_device(cost):
             _lib.launch('camli_corr3d_gather_fwd', lib.camli_corr3d_gather_fwd, xyz1.data_ptr(), xyz2.data_ptr(),
                         cost.data_ptr(), knn.data_ptr(), out.data_ptr(), b, n, m, k, _stream_ptr(cost),
                         work=(b * n * k * (8.0 + 16.0 + 4.0 + 12.0), 'B'))
@@ -425,7 +425,7 @@ class _Corr3DGather(torch.autograd.Function):
         b, n, m, k = ctx.dims
         gout = gout.contiguous().float()
         gcost = torch.zeros((b, n, m), dtype=torch.float32, device=gout.device)
-        with torch.cuda.device(gout.device):
+        with _on_device(gout):
             _lib.launch('camli_corr3d_gather_bwd', lib.camli_corr3d_gather_bwd, gout.data_ptr(), knn.data_ptr(),
                         gcost.data_ptr(), b, n, m, k, _stream_ptr(gout),
                         work=(b * n * k * (8.0 + 4.0 + 8.0), 'B'))
@@ -452,7 +452,7 @@ class _PointConvMix(torch.autograd.Function):
         b, m, ch = feat_cl.shape
         wn, n = wgt.shape[1], wgt.shape[2]
         out = torch.empty((b, n, wn, ch), dtype=torch.float32, device=feat_cl.device)
-        with torch.cuda.device(feat_cl.device):
+        with _on_device(feat_cl):
             _lib.launch('camli_pointconv_mix_fwd', lib.camli_pointconv_mix_fwd, feat_cl.data_ptr(), wgt.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), out.data_ptr(), b, m, n, ch, wn, k,
                         _stream_ptr(feat_cl), work=(4.0 * b * n * (k * ch + wn * k + wn * ch) + 8.0 * b * n * k, 'B'))
@@ -471,7 +471,7 @@ class _PointConvMix(torch.autograd.Function):
         gout = gout.contiguous().float()
         gfeat = torch.zeros_like(feat_cl) if ctx.needs_input_grad[0] else None
         gwgt = torch.empty_like(wgt) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device(feat_cl.device):
+        with _on_device(feat_cl):
             _lib.launch('camli_pointconv_mix_bwd', lib.camli_pointconv_mix_bwd, gout.data_ptr(), feat_cl.data_ptr(),
                         wgt.data_ptr(), knn_indices.data_ptr(), knn_indices.stride(1),
                         gfeat.data_ptr() if gfeat is not None else None, gwgt.data_ptr() if gwgt is not None else None,
@@ -500,7 +500,7 @@ class _ConvexUpsample(torch.autograd.Function):
         lib = _lib.load()
         b, _, h, w = flow.shape
         out = torch.empty((b, 2, h * scale, w * scale), dtype=torch.float32, device=flow.device)
-        with torch.cuda.device(flow.device):
+        with _on_device(flow):
             _lib.launch('camli_convex_upsample_fwd', lib.camli_convex_upsample_fwd, flow.data_ptr(), mask.data_ptr(),
                         out.data_ptr(), b, h, w, scale, float(mask_scale), _stream_ptr(flow),
                         work=(4.0 * b * h * w * (9 * scale * scale + 2 * scale * scale + 2), 'B'))
@@ -517,7 +517,7 @@ class _ConvexUpsample(torch.autograd.Function):
         gout = gout.contiguous().float()
         gflow = torch.zeros_like(flow)
         gmask = torch.empty_like(mask)
-        with torch.cuda.device(flow.device):
+        with _on_device(flow):
             _lib.launch('camli_convex_upsample_bwd', lib.camli_convex_upsample_bwd, gout.data_ptr(), flow.data_ptr(),
                         mask.data_ptr(), gflow.data_ptr(), gmask.data_ptr(), b, h, w, ctx.scale,
                         float(ctx.mask_scale), _stream_ptr(flow),
@@ -545,7 +545,7 @@ class _GruGates(torch.autograd.Function):
         b, c = h.shape[0], h.shape[1]
         p = h[0, 0].numel()
         z, r, rh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _on_device(h):
             _lib.launch('camli_gru_gates_fwd', lib.camli_gru_gates_fwd, pre_zr.data_ptr(), ctx_zr.data_ptr(), h.data_ptr(),
                         z.data_ptr(), r.data_ptr(), rh.data_ptr(), b, c, p, _stream_ptr(h), work=(32.0 * b * c * p, 'B'))
         ctx.save_for_backward(z, r, h)
@@ -563,7 +563,7 @@ class _GruGates(torch.autograd.Function):
         grh = grh.contiguous().float() if grh is not None else torch.zeros_like(h)
         gpre = torch.empty((b, 2 * c) + tuple(h.shape[2:]), dtype=torch.float32, device=h.device)
         gh = torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _on_device(h):
             _lib.launch('camli_gru_gates_bwd', lib.camli_gru_gates_bwd, gz.data_ptr(), grh.data_ptr(), z.data_ptr(),
                         r.data_ptr(), h.data_ptr(), gpre.data_ptr(), gh.data_ptr(), b, c, p, _stream_ptr(h),
                         work=(32.0 * b * c * p, 'B'))
@@ -579,7 +579,7 @@ class _GruBlend(torch.autograd.Function):
         b, c = h.shape[0], h.shape[1]
         p = h[0, 0].numel()
         q, h_new = torch.empty_like(h), torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _on_device(h):
             _lib.launch('camli_gru_blend_fwd', lib.camli_gru_blend_fwd, pre_q.data_ptr(), ctx_q.data_ptr(), z.data_ptr(),
                         h.data_ptr(), q.data_ptr(), h_new.data_ptr(), b, c, p, _stream_ptr(h), work=(24.0 * b * c * p, 'B'))
         ctx.save_for_backward(z, h, q)
@@ -594,7 +594,7 @@ class _GruBlend(torch.autograd.Function):
         p = h[0, 0].numel()
         g = g.contiguous().float()
         gpre, gz, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
-        with torch.cuda.device(h.device):
+        with _on_device(h):
             _lib.launch('camli_gru_blend_bwd', lib.camli_gru_blend_bwd, g.data_ptr(), z.data_ptr(), h.data_ptr(),
                         q.data_ptr(), gpre.data_ptr(), gz.data_ptr(), gh.data_ptr(), b, c, p, _stream_ptr(h),
                         work=(28.0 * b * c * p, 'B'))
@@ -629,7 +629,7 @@ class _BiasAct(torch.autograd.Function):
             x = x.contiguous()
         b, c = x.shape[0], x.shape[1]
         p = x[0, 0].numel()
-        with torch.cuda.device(x.device):
+        with _on_device(x):
             _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_fwd, x.data_ptr(), bias.data_ptr(), b, c, p, act,
                         _stream_ptr(x), work=(8.0 * b * c * p, 'B'))
         ctx.mark_dirty(x)
@@ -647,7 +647,7 @@ class _BiasAct(torch.autograd.Function):
         gy = gy.contiguous().float()
         gx = torch.empty_like(y)
         gbias = torch.zeros(c, dtype=torch.float32, device=y.device)
-        with torch.cuda.device(y.device):
+        with _on_device(y):
             _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gy.data_ptr(), y.data_ptr(), gx.data_ptr(),
                         gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(y), work=(12.0 * b * c * p, 'B'))
         return gx, gbias, None

@@ -20,8 +20,47 @@ import torch.nn.functional
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream_ptr(t):
+    """hipStream_t of torch's current stream on t's device (the raw getter skips the Stream object)."""
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on_device(t):
+    """Device guard for a launch: a no-op when t already lives on the current device (one process per
+    GPU: always, after the first torch.cuda.set_device), torch.cuda.device(t.device) otherwise."""
+    if t.device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(t.device)
+
+
+_zero_tokens = {}
+
+
+def _zero_token(t):
+    """A shared, never-written 1-element zero: the gradient handed to the token inputs of the
+    accumulate-outside-autograd Functions (saves one fill launch per backward call).  Created once per
+    device and synchronised then, so every stream may read it afterwards."""
+    z = _zero_tokens.get(t.device)
+    if z is None:
+        z = _zero_tokens[t.device] = torch.zeros(1, dtype=torch.float32, device=t.device)
+        torch.cuda.current_stream(t.device).synchronize()
+    return z
 
 
 def _require_cuda(name, *tensors):
@@ -46,7 +85,7 @@ class CorrelationFunction(torch.autograd.Function):
         b, h, w, c = input1.shape
         d = 2 * max_displacement + 1
         output = torch.empty((b, d * d, h, w), dtype=torch.float32, device=input1.device)
-        with torch.cuda.device(input1.device):
+        with _on_device(input1):
             _lib.launch('camli_corr2d_fwd', lib.camli_corr2d_fwd, input1.data_ptr(), input2.data_ptr(), output.data_ptr(),
                                             b, c, h, w, max_displacement, _stream_ptr(input1),
                         work=(4.0 * b * h * w * (2 * c + d * d), 'B'))
@@ -61,7 +100,7 @@ class CorrelationFunction(torch.autograd.Function):
         grad_output = grad_output.contiguous().float()
         grad_input1 = torch.empty_like(input1)
         grad_input2 = torch.empty_like(input2)
-        with torch.cuda.device(input1.device):
+        with _on_device(input1):
             _lib.launch('camli_corr2d_bwd', lib.camli_corr2d_bwd, grad_output.data_ptr(), input1.data_ptr(), input2.data_ptr(),
                                             grad_input1.data_ptr(), grad_input2.data_ptr(),
                                             b, c, h, w, ctx.max_displacement, _stream_ptr(input1),
@@ -119,7 +158,7 @@ def furthest_point_sampling(xyz: torch.Tensor, n_samples: int, cpp_impl=True):
     xyz = xyz.contiguous().float()
     b, n, _ = xyz.shape
     out = torch.empty((b, n_samples), dtype=torch.int64, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with _on_device(xyz):
         _lib.launch('camli_fps', lib.camli_fps, xyz.data_ptr(), out.data_ptr(), b, n, n_samples, _stream_ptr(xyz),
                         work=(float(b) * n * n_samples, 'point-updates'))
     return out
@@ -148,7 +187,7 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     nq = query_xyz.shape[1]
     assert query_xyz.shape[0] == b and query_xyz.shape[2] == d
     out = torch.empty((b, nq, k), dtype=torch.int64, device=query_xyz.device)
-    with torch.cuda.device(input_xyz.device):
+    with _on_device(input_xyz):
         _lib.launch('camli_knn', lib.camli_knn, input_xyz.data_ptr(), query_xyz.data_ptr(), out.data_ptr(),
                                  b, m, nq, d, k, _stream_ptr(input_xyz),
                         work=(float(b) * m * nq, 'pairs'))

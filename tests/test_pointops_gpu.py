@@ -84,3 +84,35 @@ def test_corr3d_lookup_input(case, oracle_lib):
     want = np.zeros_like(cost)
     np.add.at(want, (np.arange(b)[:, None, None], np.arange(n)[None, :, None], knn), g[:, 3])
     assert np.allclose(tc.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_correlation3d_module_batched_levels_vs_composed():
+    """raft3d.Correlation3D under the 'hip' backend (four levels through cost_mlp in one call) vs the
+    per-level composed formulation: output and parameter / feature gradients, fp32."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.geometry import build_pc_pyramid
+    from camliflow_amd.cores.raft3d import Correlation3D
+    from modelutils import hashed_fill_
+    torch.manual_seed(3)
+    corr = hashed_fill_(Correlation3D(out_channels=128, k=16)).cuda()
+    pc1 = torch.rand(2, 3, 4200, device='cuda') * 6
+    pc2 = pc1 + 0.05 * torch.randn_like(pc1)
+    xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, [4096, 2048, 1024, 512, 256])
+    xyz1, targets = xyzs1[2], xyzs2[2:]
+    gout = torch.randn(2, 128, 2048, device='cuda')
+    res = {}
+    for backend in ('hip', 'composed'):
+        f1 = torch.randn(2, 128, 2048, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5)).requires_grad_(True)
+        f2 = torch.randn(2, 128, 2048, device='cuda', generator=torch.Generator(device='cuda').manual_seed(6)).requires_grad_(True)
+        corr.zero_grad()
+        with runtime.use_backend(backend):
+            corr.build_cost_volume_pyramid(f1, f2, targets)
+            out = corr(xyz1, targets)
+        out.backward(gout)
+        res[backend] = (out.detach(), f1.grad, f2.grad, [p.grad.clone() for p in corr.parameters()])
+    a, b = res['hip'], res['composed']
+    assert torch.allclose(a[0], b[0], rtol=1e-4, atol=1e-5), (a[0] - b[0]).abs().max()
+    # gradients: a handful of the 4M ReLU decisions inside cost_mlp flip with the GEMM's summation order
+    # (one batched call vs four), each flip moves a gradient by one term -> norm-relative 5e-3
+    errs = [((x - y).norm() / y.norm()).item() for x, y in zip([a[1], a[2]] + a[3], [b[1], b[2]] + b[3])]
+    assert max(errs) <= 5e-3, errs
