@@ -180,6 +180,10 @@ def project_pc2image(pc, camera_info):
 
 def grid_sample_wrapper(feat_2d, uv):
     """Bilinear sample of [B,C,H,W] at pixel coordinates uv [B,2,N] -> [B,C,N], fp32 (utils.py:262-269)."""
+    if (runtime.fused() and feat_2d.is_cuda and min(feat_2d.shape[2:]) >= 2
+            and not (torch.is_grad_enabled() and (feat_2d.requires_grad or uv.requires_grad))):
+        from ..csrc import fused
+        return fused.bilinear_sample(feat_2d.detach(), uv.detach())       # one gather kernel (camli_bilinear_sample_fwd)
     with torch.autocast(device_type=feat_2d.device.type, enabled=False):
         image_h, image_w = feat_2d.shape[2:]
         new_x = 2.0 * uv[:, 0] / (image_w - 1) - 1.0

@@ -13,7 +13,7 @@ import torch
 from torch.nn.functional import avg_pool2d
 
 from . import _lib
-from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_token
+from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_slice, _zero_token
 
 
 # ------------------------------------------------------------------------------------------------
@@ -242,6 +242,26 @@ def pointconv_dw(feat, shared, knn_indices, k):
     assert shared.weight.shape[0] == feat.shape[0] and shared.weight.shape[1] == feat.shape[1]
     assert shared.weight.shape[3] == k
     return _PointConvDW.apply(feat.float().contiguous(), shared.token, knn_indices, k, shared)
+
+
+# ------------------------------------------------------------------------------------------------
+# bilinear sampling of image features at projected points (models/utils.py:262-269)
+# ------------------------------------------------------------------------------------------------
+def bilinear_sample(feat_2d, uv):
+    """feat_2d [B,C,H,W], uv [B,2,N] pixel coordinates -> [B,C,N] fp32, no autograd (the reference detaches
+    both the input and the output of this op on the fusion path, clfm.py:187-190)."""
+    _require_cuda('bilinear_sample', feat_2d, uv)
+    assert not (feat_2d.requires_grad or uv.requires_grad), 'forward-only op: detach the inputs'
+    lib = _lib.load()
+    feat_2d, uv = feat_2d.float().contiguous(), uv.float().contiguous()
+    bs, c, h, w = feat_2d.shape
+    n = uv.shape[2]
+    out = torch.empty((bs, c, n), dtype=torch.float32, device=feat_2d.device)
+    with _on_device(feat_2d):
+        _lib.launch('camli_bilinear_sample_fwd', lib.camli_bilinear_sample_fwd, feat_2d.data_ptr(), uv.data_ptr(),
+                    out.data_ptr(), bs, c, h, w, n, _stream_ptr(feat_2d),
+                    work=(4.0 * bs * c * n * 5 + 8.0 * bs * n, 'B'))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -628,7 +648,7 @@ class _BiasAct(torch.autograd.Function):
         if not x.is_contiguous():
             x = x.contiguous()
         b, c = x.shape[0], x.shape[1]
-        p = x[0, 0].numel()
+        p = x.numel() // (b * c)
         with _on_device(x):
             _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_fwd, x.data_ptr(), bias.data_ptr(), b, c, p, act,
                         _stream_ptr(x), work=(8.0 * b * c * p, 'B'))
@@ -643,10 +663,10 @@ class _BiasAct(torch.autograd.Function):
         lib = _lib.load()
         (y,) = ctx.saved_tensors
         b, c = y.shape[0], y.shape[1]
-        p = y[0, 0].numel()
+        p = y.numel() // (b * c)
         gy = gy.contiguous().float()
         gx = torch.empty_like(y)
-        gbias = torch.zeros(c, dtype=torch.float32, device=y.device)
+        gbias = _zero_slice(c, y)
         with _on_device(y):
             _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gy.data_ptr(), y.data_ptr(), gx.data_ptr(),
                         gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(y), work=(12.0 * b * c * p, 'B'))

@@ -63,6 +63,25 @@ def _zero_token(t):
     return z
 
 
+_zero_arena = {}            # device -> [chunk, used]
+_ARENA_FLOATS = 1 << 20
+
+
+def _zero_slice(n, like):
+    """n zero floats for a kernel that ACCUMULATES into its (small) output: carved from a pre-zeroed
+    4 MB chunk instead of one fill launch per call; every slice is handed out once, a fresh chunk is
+    zeroed (and synchronised, so any stream may use it) when the current one is used up."""
+    if n > 4096 or torch.cuda.is_current_stream_capturing():
+        return torch.zeros(n, dtype=torch.float32, device=like.device)
+    state = _zero_arena.get(like.device)
+    if state is None or state[1] + n > _ARENA_FLOATS:
+        state = _zero_arena[like.device] = [torch.zeros(_ARENA_FLOATS, dtype=torch.float32, device=like.device), 0]
+        torch.cuda.current_stream(like.device).synchronize()
+    start = state[1]
+    state[1] = start + ((n + 31) // 32) * 32          # 128-byte aligned slices
+    return state[0][start:start + n]
+
+
 def _require_cuda(name, *tensors):
     for t in tensors:
         if not t.is_cuda:

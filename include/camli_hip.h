@@ -217,6 +217,16 @@ int camli_weightnet_bwd(const float *xyz, const float *centres, const int64_t *i
                         float *gw3, float *gb3, float *workspace, int64_t workspace_bytes,
                         int B, int C, int M, int N, int k, void *stream);
 
+/*
+ * Bilinear sampling of a feature map at pixel positions (2-D -> 3-D half of the CLFM fusion).
+ * Replaces grid_sample_wrapper: models/utils.py:262-269 (normalise, F.grid_sample(bilinear,
+ * align_corners=True, padding zeros)); its output is detached at the only call site on this path
+ * (models/clfm.py:187-190), hence no adjoint.
+ *   feat [B,C,H,W], uv [B,2,N] (x,y in pixels), out [B,C,N] (fully written); H, W >= 2.
+ */
+int camli_bilinear_sample_fwd(const float *feat, const float *uv, float *out, int B, int C, int H, int W, int N,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -232,3 +232,13 @@ def weightnet_bwd(xyz, centres, idx, k, params, gout):
         out.append(flat[pos:pos + n].reshape(shape))
         pos += n
     return out
+
+
+def bilinear_sample_fwd(feat, uv):
+    """feat [B,C,H,W], uv [B,2,N] pixel coordinates -> [B,C,N]"""
+    feat, uv = _f32(feat), _f32(uv)
+    B, C, H, W = feat.shape
+    N = uv.shape[2]
+    out = np.zeros((B, C, N), dtype=np.float32)
+    _chk(_load().oracle_bilinear_sample_fwd(_p(feat), _p(uv), _p(out), B, C, H, W, N), "bilinear_sample_fwd")
+    return out

@@ -591,4 +591,35 @@ int oracle_weightnet_bwd(const float *xyz, const float *centres, const int64_t *
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * bilinear sampling at pixel positions: follows models/utils.py:262-269 (normalise to [-1,1]) and
+ * F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=True): un-normalise, the four
+ * corners nw/ne/sw/se with weights (x1-x)(y1-y) ..., out-of-image corners skipped.
+ *   feat [B,C,H,W], uv [B,2,N], out [B,C,N]
+ * ------------------------------------------------------------------------------------------ */
+int oracle_bilinear_sample_fwd(const float *feat, const float *uv, float *out, int B, int C, int H, int W, int N)
+{
+    size_t plane = (size_t)H * W;
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            float gx = 2.0f * uv[((size_t)b * 2 + 0) * N + n] / (float)(W - 1) - 1.0f;
+            float gy = 2.0f * uv[((size_t)b * 2 + 1) * N + n] / (float)(H - 1) - 1.0f;
+            float x = ((gx + 1.0f) / 2.0f) * (float)(W - 1), y = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+            float x0 = floorf(x), y0 = floorf(y);
+            float wx1 = x - x0, wy1 = y - y0, wx0 = (x0 + 1.0f) - x, wy0 = (y0 + 1.0f) - y;
+            for (int c = 0; c < C; ++c) {
+                const float *p = feat + ((size_t)b * C + c) * plane;
+                float acc = 0.0f;
+                for (int t = 0; t < 4; ++t) {
+                    float fx = x0 + (float)(t & 1), fy = y0 + (float)(t >> 1);
+                    if (!(fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H)) continue;
+                    float w = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
+                    acc += p[(size_t)fy * W + (size_t)fx] * w;
+                }
+                out[((size_t)b * C + c) * N + n] = acc;
+            }
+        }
+    return 0;
+}
+
 int oracle_version(void) { return 1; }

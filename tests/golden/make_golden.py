@@ -159,6 +159,17 @@ def golden_pointconv_dw():
              weight=captured['weight'], **{'p_' + name.replace('.', '__'): t for name, t in sd.items()})
 
 
+def golden_grid_sample():
+    """grid_sample_wrapper of the reference (models/utils.py:262-269): interior, border-crossing, far-out
+    and exactly-integer positions."""
+    g = gen(41)
+    feat = torch.randn(2, 5, 9, 13, generator=g)
+    uv = torch.rand(2, 2, 64, generator=g) * torch.tensor([16.0, 12.0]).view(1, 2, 1) - 2.0
+    uv[:, :, :8] = torch.randint(0, 9, (2, 2, 8), generator=g).float()          # exact pixel centres
+    uv[:, :, 8:12] = torch.tensor([[-50.0, 1e6, 12.0, 11.999], [3.0, -1e6, 8.0, 7.5]]).unsqueeze(0)
+    save('grid_sample', feat=feat, uv=uv, out=ref_utils.grid_sample_wrapper(feat, uv))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     golden_correlation()
@@ -167,3 +178,4 @@ if __name__ == '__main__':
     golden_indexing()
     golden_allpairs()
     golden_pointconv_dw()
+    golden_grid_sample()

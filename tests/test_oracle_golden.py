@@ -157,3 +157,10 @@ def test_weightnet_and_setconv_match_reference_module(name, golden, oracle_lib):
     for got, leaf in zip(grads, leaves):
         ref = leaf.grad.numpy()
         assert np.linalg.norm(got - ref) <= 1e-5 * np.linalg.norm(ref) + 1e-9
+
+
+def test_bilinear_sample_matches_reference_grid_sample_wrapper(golden, oracle_lib):
+    g = golden('grid_sample')
+    out = oracle_lib.bilinear_sample_fwd(g['feat'], g['uv'])
+    assert out.shape == g['out'].shape
+    assert np.allclose(out, g['out'], rtol=1e-5, atol=1e-6)

@@ -44,9 +44,21 @@ def main():
         a[2] = min(a[2], e - s)
         a[3] = max(a[3], e - s)
     total = sum(a[1] for a in agg.values())
+    # union of the kernel intervals = time with at least one kernel executing (both streams together)
+    busy, cur_s, cur_e = 0, None, None
+    for s_, e_, _ in sel:
+        if cur_e is None or s_ > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    busy += (cur_e - cur_s) if cur_e is not None else 0
     w = csv.writer(sys.stdout)
-    w.writerow(['# steady-state window: %d steps, %.3f ms wall per step, %.3f ms summed kernel time per step, %d launches per step'
-                % (args.steps, span / args.steps / 1e6, total / args.steps / 1e6, len(sel) // args.steps)])
+    w.writerow(['# steady-state window: %d steps, %.3f ms wall per step, %.3f ms summed kernel time per step, '
+                '%.3f ms with at least one kernel running (GPU idle %.1f %%), %d launches per step'
+                % (args.steps, span / args.steps / 1e6, total / args.steps / 1e6, busy / args.steps / 1e6,
+                   100.0 * (1 - busy / span), len(sel) // args.steps)])
     w.writerow(['Name', 'CallsPerStep', 'TotalMsPerStep', 'AverageUs', 'Percentage', 'MinUs', 'MaxUs'])
     for n, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.top]:
         w.writerow([short(n), '%.1f' % (a[0] / args.steps), '%.3f' % (a[1] / args.steps / 1e6), '%.2f' % (a[1] / a[0] / 1e3),
