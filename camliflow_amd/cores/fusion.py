@@ -129,6 +129,13 @@ class SKFusion(nn.Module):
     def forward(self, feat_2d, feat_3d):
         bs = feat_2d.shape[0]
         feat_2d, feat_3d = self.align1(feat_2d), self.align2(feat_3d)
+        if runtime.fused() and feat_2d.is_cuda and bs * feat_2d.shape[1] <= 65535:
+            # pooled sum, mix and both adjoints as four streaming kernels (camli_sk_*); the gate stays in torch
+            from ..csrc import fused
+            state = fused.SkState()
+            squeezed = fused.sk_pool(feat_2d, feat_3d, state)
+            weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
+            return fused.sk_mix(feat_2d, feat_3d, weight, state)
         squeezed = self.avg_pool(feat_2d + feat_3d).reshape(bs, -1)
         weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
         bshape = [bs, -1] + [1] * (feat_2d.dim() - 2)

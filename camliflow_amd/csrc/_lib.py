@@ -54,6 +54,10 @@ PROTOTYPES = {
     "camli_weightnet_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int] + [_c_float_p] * 7
                             + [_int, _int, _int, _int, _int, _stream]),
     "camli_bilinear_sample_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
+    "camli_sk_pool_fwd": (_int, [_c_float_p] * 3 + [_int, _int, _int, _stream]),
+    "camli_sk_mix_fwd": (_int, [_c_float_p] * 4 + [_int, _int, _int, _stream]),
+    "camli_sk_mix_bwd_w": (_int, [_c_float_p] * 4 + [_int, _int, _int, _stream]),
+    "camli_sk_mix_bwd_x": (_int, [_c_float_p] * 5 + [_int, _int, _int, _stream]),
     "camli_weightnet_bwd_workspace_bytes": (ctypes.c_int64, [_int]),
     "camli_weightnet_bwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int] + [_c_float_p] * 14
                             + [ctypes.c_int64, _int, _int, _int, _int, _int, _stream]),

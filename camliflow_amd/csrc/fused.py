@@ -245,6 +245,115 @@ def pointconv_dw(feat, shared, knn_indices, k):
 
 
 # ------------------------------------------------------------------------------------------------
+# selective-kernel fusion, full-size part (models/clfm.py:170-213)
+# ------------------------------------------------------------------------------------------------
+class SkState:
+    """Links the two autograd nodes of one SKFusion call: the mix node leaves (g, w) here and returns no
+    gradient for a / b; the pool node -- which autograd necessarily runs later, because the gate that
+    produced w hangs off its output -- then writes ga = g*w0 + gs/P and gb = g*w1 + gs/P in ONE pass."""
+    __slots__ = ('g', 'w', 'deferred')
+
+    def __init__(self):
+        self.g = self.w = None
+        self.deferred = False
+
+
+def _rows(t):
+    b, c = t.shape[0], t.shape[1]
+    return b, c, t.numel() // max(b * c, 1)
+
+
+class _SkPool(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, a, b, state):
+        lib = _lib.load()
+        bs, c, p = _rows(a)
+        s = torch.empty((bs, c), dtype=torch.float32, device=a.device)
+        with _on_device(a):
+            _lib.launch('camli_sk_pool_fwd', lib.camli_sk_pool_fwd, a.data_ptr(), b.data_ptr(), s.data_ptr(), bs, c, p,
+                        _stream_ptr(a), work=(8.0 * bs * c * p, 'B'))
+        ctx.state, ctx.shape = state, a.shape
+        return s
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gs):
+        lib = _lib.load()
+        st = ctx.state
+        bs, c = ctx.shape[0], ctx.shape[1]
+        p = 1
+        for d in ctx.shape[2:]:
+            p *= d
+        gs = gs.contiguous().float()
+        if st.g is None:        # the mixed output took no part in the loss: only the pooled term
+            ga = (gs / p).view(bs, c, *([1] * (len(ctx.shape) - 2))).expand(ctx.shape).contiguous()
+            return ga, ga.clone(), None
+        g, w = st.g, st.w
+        st.g = st.w = None
+        ga = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        gb = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        with _on_device(g):
+            _lib.launch('camli_sk_mix_bwd_x', lib.camli_sk_mix_bwd_x, g.data_ptr(), w.data_ptr(), gs.data_ptr(),
+                        ga.data_ptr(), gb.data_ptr(), bs, c, p, _stream_ptr(g), work=(12.0 * bs * c * p, 'B'))
+        return ga, gb, None
+
+
+class _SkMix(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, a, b, w, state):
+        lib = _lib.load()
+        bs, c, p = _rows(a)
+        w = w.contiguous()
+        out = torch.empty_like(a)
+        with _on_device(a):
+            _lib.launch('camli_sk_mix_fwd', lib.camli_sk_mix_fwd, a.data_ptr(), b.data_ptr(), w.data_ptr(),
+                        out.data_ptr(), bs, c, p, _stream_ptr(a), work=(12.0 * bs * c * p, 'B'))
+        # a / b gradients are deferred to the pool node only if that node is certain to run: w is
+        # differentiable (so the gate, hence the pooled vector, is on the backward path)
+        state.deferred = bool(ctx.needs_input_grad[2] and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
+        ctx.state = state
+        ctx.save_for_backward(a, b, w)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b, w = ctx.saved_tensors
+        bs, c, p = _rows(a)
+        g = g.contiguous().float()
+        gw = None
+        with _on_device(g):
+            if ctx.needs_input_grad[2]:
+                gw = torch.empty_like(w)
+                _lib.launch('camli_sk_mix_bwd_w', lib.camli_sk_mix_bwd_w, g.data_ptr(), a.data_ptr(), b.data_ptr(),
+                            gw.data_ptr(), bs, c, p, _stream_ptr(g), work=(12.0 * bs * c * p, 'B'))
+            if ctx.state.deferred:
+                ctx.state.g, ctx.state.w = g, w
+                return None, None, gw, None
+            ga, gb = torch.empty_like(a), torch.empty_like(b)
+            _lib.launch('camli_sk_mix_bwd_x', lib.camli_sk_mix_bwd_x, g.data_ptr(), w.data_ptr(), None,
+                        ga.data_ptr(), gb.data_ptr(), bs, c, p, _stream_ptr(g), work=(12.0 * bs * c * p, 'B'))
+        return ga, gb, gw, None
+
+
+def sk_pool(a, b, state):
+    """mean over the positions of (a + b): [B,C,...] x2 -> [B,C]"""
+    _require_cuda('sk_pool', a, b)
+    assert a.shape == b.shape and a.dim() >= 3
+    return _SkPool.apply(a.float().contiguous(), b.float().contiguous(), state)
+
+
+def sk_mix(a, b, w, state):
+    """a * w[...,0] + b * w[...,1] with per-(batch, channel) weights w [B,C,2]"""
+    _require_cuda('sk_mix', a, b, w)
+    assert a.shape == b.shape and w.shape == (a.shape[0], a.shape[1], 2)
+    return _SkMix.apply(a.float().contiguous(), b.float().contiguous(), w.float(), state)
+
+
+# ------------------------------------------------------------------------------------------------
 # bilinear sampling of image features at projected points (models/utils.py:262-269)
 # ------------------------------------------------------------------------------------------------
 def bilinear_sample(feat_2d, uv):

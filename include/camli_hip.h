@@ -227,6 +227,21 @@ int camli_weightnet_bwd(const float *xyz, const float *centres, const int64_t *i
 int camli_bilinear_sample_fwd(const float *feat, const float *uv, float *out, int B, int C, int H, int W, int N,
                               void *stream);
 
+/*
+ * Selective-kernel fusion of the image and point branches, full-size part (models/clfm.py:170-213:
+ * squeezed = avg_pool(a + b); out = a * w[...,0] + b * w[...,1], w = softmax(gate(squeezed))).
+ *   a, b, out, g, ga, gb [B,C,P];  s, gs [B,C];  w, gw [B,C,2];  B*C <= 65535 for the mix kernels.
+ *   pool_fwd : s = mean_p(a + b)
+ *   mix_fwd  : out = a * w0 + b * w1
+ *   mix_bwd_w: gw0 = sum_p g * a, gw1 = sum_p g * b                      (fully written)
+ *   mix_bwd_x: ga = g * w0 + gs / P, gb = g * w1 + gs / P  (gs may be NULL: no pooled term; fully written)
+ */
+int camli_sk_pool_fwd(const float *a, const float *b, float *s, int B, int C, int P, void *stream);
+int camli_sk_mix_fwd(const float *a, const float *b, const float *w, float *out, int B, int C, int P, void *stream);
+int camli_sk_mix_bwd_w(const float *g, const float *a, const float *b, float *gw, int B, int C, int P, void *stream);
+int camli_sk_mix_bwd_x(const float *g, const float *w, const float *gs, float *ga, float *gb, int B, int C, int P,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif
