@@ -11,7 +11,7 @@ import torch.nn as nn
 from ..csrc import wrapper as _ops
 from . import runtime
 from .fusion import CLFM
-from .geometry import (InputPadder, backwarp_3d, build_pc_pyramid, knn_interpolation, mesh_grid, paral2persp,
+from .geometry import (InputPadder, backwarp_3d, backwarp_3d_levels, build_pc_pyramid, knn_interpolation, mesh_grid, paral2persp,
                        persp2paral, project_pc2image)
 from .objectives import FlowModel, calc_sequence_loss_2d, calc_sequence_loss_3d
 from .raft2d import RAFTCore
@@ -110,7 +110,7 @@ class CamLiRAFT_Core(nn.Module):
             with lanes.side():
                 if it > 0:
                     flow_3d_pred = flow_3d_pred.detach()
-                    xyzs2_warp = [backwarp_3d(xyz1, level, flow_3d_pred) for level in xyzs2]
+                    xyzs2_warp = backwarp_3d_levels(xyz1, xyzs2, flow_3d_pred)
                 corr3d = b3d.correlation(xyz1, xyzs2_warp)
             if it > 0:
                 flow_2d_pred = flow_2d_pred.detach()
@@ -144,7 +144,7 @@ class CamLiRAFT_Core(nn.Module):
             # ---- flow heads --------------------------------------------------------------------
             with lanes.side():
                 flow_3d_pred = flow_3d_pred + b3d.flow_head(xyz1, h_3d, knn_indices)
-                flow_3d_preds.append(knn_interpolation(xyz1, flow_3d_pred, pc1, k=3))
+                flow_3d_preds.append(knn_interpolation(xyz1, flow_3d_pred, pc1, k=3, invariant_input=True, invariant_query=True))
             flow_2d_pred = flow_2d_pred + b2d.flow_head(h_2d)
             flow_2d_preds.append(b2d.convex_upsampler(h_2d, flow_2d_pred))
 

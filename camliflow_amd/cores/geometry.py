@@ -69,10 +69,44 @@ def build_pc_pyramid(pc1, pc2, n_samples_list):
     return xyzs1, xyzs2, sample_indices1, sample_indices2
 
 
-def knn_interpolation(input_xyz, input_features, query_xyz, k=3):
+def _channel_last(xyz, invariant):
+    """[B,3,N] -> contiguous [B,N,3] for the KNN kernel; an operand that is the same tensor in every GRU
+    iteration (``invariant``) takes its copy from the pass cache instead of a transpose kernel per call."""
+    from . import setconv
+    cache = setconv._pass_cache if invariant else None
+    if cache is None or xyz.requires_grad:
+        return xyz.transpose(1, 2).contiguous()
+    key = ('channel_last', xyz.data_ptr(), tuple(xyz.shape))
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = (xyz.detach().transpose(1, 2).contiguous(), xyz)     # keeps xyz alive: the key is its address
+    return hit[0]
+
+
+def knn_channel_first(input_xyz, query_xyz, k, invariant_input=False, invariant_query=False):
+    """k_nearest_neighbor on channel-first clouds [B,3,*] with cached layout conversion (and, when BOTH
+    operands are iteration-invariant, a cached result: the reference recomputes e.g. the up-sampling
+    neighbours of every iterate, camliraft_core.py:142-143 -> utils.py:132)."""
+    from . import setconv
+    cache = setconv._pass_cache
+    if not (runtime.fused() and input_xyz.is_cuda and input_xyz.shape[1] <= 3):
+        return _ops.k_nearest_neighbor(input_xyz, query_xyz, k)
+    both = invariant_input and invariant_query and cache is not None
+    if both:
+        key = ('knn', input_xyz.data_ptr(), query_xyz.data_ptr(), tuple(input_xyz.shape), tuple(query_xyz.shape), k)
+        hit = cache.get(key)
+        if hit is not None:
+            return hit[0]
+    indices = _ops.k_nearest_neighbor(_channel_last(input_xyz, invariant_input), _channel_last(query_xyz, invariant_query), k)
+    if both:
+        cache[key] = (indices, input_xyz, query_xyz)
+    return indices
+
+
+def knn_interpolation(input_xyz, input_features, query_xyz, k=3, invariant_input=False, invariant_query=False):
     """Inverse-distance interpolation from the k nearest inputs (utils.py:130-146).
     [B,3,M] x [B,C,M] x [B,3,Nq] -> [B,C,Nq]; gradients flow to features AND coordinates."""
-    knn_indices = _ops.k_nearest_neighbor(input_xyz, query_xyz, k)
+    knn_indices = knn_channel_first(input_xyz, query_xyz, k, invariant_input, invariant_query)
     if runtime.fused() and k <= 8 and not input_xyz.requires_grad and not query_xyz.requires_grad:
         from ..csrc import fused
         return fused.knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
@@ -86,8 +120,23 @@ def knn_interpolation(input_xyz, input_features, query_xyz, k=3):
 
 def backwarp_3d(xyz1, xyz2, flow12, k=3):
     """Warp cloud 2 towards cloud 1 with the interpolated inverse flow (utils.py:149-159)."""
-    flow21 = knn_interpolation(xyz1 + flow12, -flow12, query_xyz=xyz2, k=k)
+    flow21 = knn_interpolation(xyz1 + flow12, -flow12, query_xyz=xyz2, k=k, invariant_query=True)
     return xyz2 + flow21
+
+
+def backwarp_3d_levels(xyz1, xyz2_levels, flow12, k=3):
+    """``[backwarp_3d(xyz1, level, flow12) for level in xyz2_levels]`` with the level-independent parts
+    (warped source cloud, negated flow, their layout conversion) evaluated once."""
+    if not (runtime.fused() and xyz1.is_cuda) or xyz1.requires_grad or flow12.requires_grad:
+        return [backwarp_3d(xyz1, level, flow12, k) for level in xyz2_levels]
+    from ..csrc import fused
+    warped, inverse = xyz1 + flow12, -flow12
+    warped_cl = warped.transpose(1, 2).contiguous()
+    out = []
+    for level in xyz2_levels:
+        knn_indices = _ops.k_nearest_neighbor(warped_cl, _channel_last(level, True), k)
+        out.append(level + fused.knn_interpolate(warped, inverse, level, knn_indices, k))
+    return out
 
 
 _grid_cache = {}

@@ -130,7 +130,9 @@ class GRU2D(nn.Module):
             bias = torch.cat([g.bias for g in gates], dim=0)
             ctx = torch.nn.functional.conv2d(context, w_ctx, bias, padding=padding)
             keep = [torch.cat([g.weight[:, :hd], g.weight[:, hd + cd:]], dim=1) for g in gates]
-            state[suffix] = (torch.cat(keep[:2], dim=0), keep[2], ctx[:, :2 * hd], ctx[:, 2 * hd:], padding)
+            # contiguous once per pass: the gate kernels would otherwise copy these channel slices every iteration
+            state[suffix] = (torch.cat(keep[:2], dim=0), keep[2], ctx[:, :2 * hd].contiguous(),
+                             ctx[:, 2 * hd:].contiguous(), padding)
         return state
 
     def step(self, h, motion, state):

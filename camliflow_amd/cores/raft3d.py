@@ -15,7 +15,8 @@ import torch.nn as nn
 from ..csrc import wrapper as _ops
 from . import runtime
 from .blocks import Conv1dNormRelu, MLP1d, MLP2d
-from .geometry import backwarp_3d, batch_indexing, build_pc_pyramid, knn_interpolation
+from .geometry import (backwarp_3d, backwarp_3d_levels, batch_indexing, build_pc_pyramid, knn_channel_first,
+                       knn_interpolation)
 from .setconv import PointConv, PointConvDW, pass_cache
 
 # number of points kept at each pyramid level; every CamLi* model hard-codes it
@@ -100,7 +101,7 @@ class Correlation3D(nn.Module):
         bs, n_src = xyz1.shape[0], xyz1.shape[2]
         columns = []
         for lvl in range(4):
-            cross = _ops.k_nearest_neighbor(input_xyz=xyzs2[lvl], query_xyz=xyz1, k=self.k)
+            cross = knn_channel_first(xyzs2[lvl], xyz1, self.k, invariant_query=True)
             columns.append(fused.corr3d_lookup_input(self.cost_volume_pyramid[lvl], xyz1, xyzs2[lvl], cross))
         cost = self.cost_mlp(torch.cat(columns, dim=3))                               # [B,C/4,N,4k]
         cost = cost.view(bs, -1, n_src, 4, self.k).sum(dim=-1)                        # [B,C/4,N,4]
@@ -200,10 +201,10 @@ class CamLiRAFT_L_Core(nn.Module):
         for step in range(n_iters):
             if step:
                 flow = flow.detach()
-                targets = [backwarp_3d(xyz1, level, flow) for level in work2]
+                targets = backwarp_3d_levels(xyz1, work2, flow)
             corr = self.correlation(xyz1, targets)
             motion = self.motion_encoder(xyz1, flow, corr, knn_indices=neighbours)
             hidden = self.gru(xyz1, h=hidden, x=torch.cat([ctx, motion], dim=1), knn_indices=neighbours)
             flow = flow + self.flow_head(xyz1, hidden, neighbours).float()
             iterates.append(flow)
-        return [knn_interpolation(xyz1, f, pc1, k=3) for f in iterates]
+        return [knn_interpolation(xyz1, f, pc1, k=3, invariant_input=True, invariant_query=True) for f in iterates]
