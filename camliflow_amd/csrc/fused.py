@@ -758,27 +758,36 @@ class _BiasAct(torch.autograd.Function):
             x = x.contiguous()
         b, c = x.shape[0], x.shape[1]
         p = x.numel() // (b * c)
+        # relu / leaky_relu: keep one sign bit per element for the backward instead of re-reading y
+        mask = None
+        if act in (1, 2) and p % 4 == 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            mask = torch.empty(lib.camli_bias_act_mask_bytes(b, c, p) // 8, dtype=torch.int64, device=x.device)
         with _on_device(x):
-            _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_fwd, x.data_ptr(), bias.data_ptr(), b, c, p, act,
-                        _stream_ptr(x), work=(8.0 * b * c * p, 'B'))
+            _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_fwd, x.data_ptr(), bias.data_ptr(),
+                        mask.data_ptr() if mask is not None else None, b, c, p, act,
+                        _stream_ptr(x), work=(8.0 * b * c * p + (b * c * p / 8.0 if mask is not None else 0.0), 'B'))
         ctx.mark_dirty(x)
-        ctx.save_for_backward(x)
-        ctx.act = act
+        if mask is not None:
+            ctx.save_for_backward(mask)
+        else:
+            ctx.save_for_backward(x)
+        ctx.act, ctx.masked, ctx.dims = act, mask is not None, (b, c, p)
         return x
 
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gy):
         lib = _lib.load()
-        (y,) = ctx.saved_tensors
-        b, c = y.shape[0], y.shape[1]
-        p = y.numel() // (b * c)
+        (saved,) = ctx.saved_tensors
+        b, c, p = ctx.dims
         gy = gy.contiguous().float()
-        gx = torch.empty_like(y)
-        gbias = _zero_slice(c, y)
-        with _on_device(y):
-            _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gy.data_ptr(), y.data_ptr(), gx.data_ptr(),
-                        gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(y), work=(12.0 * b * c * p, 'B'))
+        gx = torch.empty_like(gy)
+        gbias = _zero_slice(c, gy)
+        with _on_device(gy):
+            _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gy.data_ptr(),
+                        None if ctx.masked else saved.data_ptr(), saved.data_ptr() if ctx.masked else None,
+                        gx.data_ptr(), gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(gy),
+                        work=((8.125 if ctx.masked else 12.0) * b * c * p, 'B'))
         return gx, gbias, None
 
 

@@ -31,28 +31,47 @@ __device__ __forceinline__ float act_grad(float y) {
     return 1.0f;
 }
 
+// Sign mask of the output (ACT 1 / 2 only): one bit per element, so that the backward reads 1/32 byte per
+// element instead of y (4 bytes).  Word w of plane (b,c) holds, for the 64 float4 groups 64w .. 64w+63 of
+// the plane, the ballots of their x, y, z, w components: mask[((b*C + c) * words(P) + w) * 4 + comp], bit =
+// lane.  fwd and bwd walk the plane identically (chunks are multiples of 1024 elements), so a wave
+// iteration always covers one whole word.
+__host__ __device__ __forceinline__ int mask_words(int P) { return (P / 4 + 63) / 64; }
+
 // grid (chunks, C, B), block 256; each block walks its chunk of one (b, c) plane
-template <int ACT>
-__global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x, const float* __restrict__ bias, int C,
-                                                            int P, int chunk) {
+template <int ACT, bool MASK>
+__global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                            unsigned long long* __restrict__ mask, int C, int P,
+                                                            int chunk) {
     const int c = blockIdx.y, b = blockIdx.z;
     const float bv = bias[c];
     float* __restrict__ plane = x + ((size_t)b * C + c) * P;
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
     if ((P & 3) == 0 && (chunk & 3) == 0) {
         float4* __restrict__ p4 = reinterpret_cast<float4*>(plane);
+        unsigned long long* __restrict__ mrow = MASK ? mask + ((size_t)b * C + c) * mask_words(P) * 4 : nullptr;
         for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
             float4 v = p4[e];
             v.x = act_fwd<ACT>(v.x + bv); v.y = act_fwd<ACT>(v.y + bv); v.z = act_fwd<ACT>(v.z + bv); v.w = act_fwd<ACT>(v.w + bv);
             p4[e] = v;
+            if (MASK) {
+                const unsigned long long mx = __ballot(v.x > 0.0f), my = __ballot(v.y > 0.0f);
+                const unsigned long long mz = __ballot(v.z > 0.0f), mw = __ballot(v.w > 0.0f);
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long* w = mrow + (size_t)(e >> 6) * 4;
+                    w[0] = mx; w[1] = my; w[2] = mz; w[3] = mw;
+                }
+            }
         }
     } else {
         for (int e = beg + threadIdx.x; e < end; e += 256) plane[e] = act_fwd<ACT>(plane[e] + bv);
     }
 }
 
-template <int ACT>
+// MASK: the activation derivative comes from the sign mask (ACT 1 / 2, P % 4 == 0) and y is not read
+template <int ACT, bool MASK>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                            const unsigned long long* __restrict__ mask,
                                                             float* __restrict__ gx, float* __restrict__ gbias, int C,
                                                             int P, int chunk) {
     __shared__ float partial[4];
@@ -62,15 +81,30 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
     float acc = 0.0f;
     if ((P & 3) == 0 && (chunk & 3) == 0) {
         const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gy + base);
-        const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y + base);
         float4* __restrict__ o4 = reinterpret_cast<float4*>(gx + base);
-        for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
-            const float4 g = g4[e], yy = y4[e];
-            float4 o;
-            o.x = g.x * act_grad<ACT>(yy.x); o.y = g.y * act_grad<ACT>(yy.y);
-            o.z = g.z * act_grad<ACT>(yy.z); o.w = g.w * act_grad<ACT>(yy.w);
-            o4[e] = o;
-            acc += (o.x + o.y) + (o.z + o.w);
+        if (MASK) {
+            const unsigned long long* __restrict__ mrow = mask + ((size_t)b * C + c) * mask_words(P) * 4;
+            const int lane = threadIdx.x & 63;
+            constexpr float neg = ACT == 1 ? 0.0f : 0.1f;
+            for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
+                const float4 g = g4[e];
+                const unsigned long long* w = mrow + (size_t)(e >> 6) * 4;
+                float4 o;
+                o.x = g.x * (((w[0] >> lane) & 1ull) ? 1.0f : neg); o.y = g.y * (((w[1] >> lane) & 1ull) ? 1.0f : neg);
+                o.z = g.z * (((w[2] >> lane) & 1ull) ? 1.0f : neg); o.w = g.w * (((w[3] >> lane) & 1ull) ? 1.0f : neg);
+                o4[e] = o;
+                acc += (o.x + o.y) + (o.z + o.w);
+            }
+        } else {
+            const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y + base);
+            for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
+                const float4 g = g4[e], yy = y4[e];
+                float4 o;
+                o.x = g.x * act_grad<ACT>(yy.x); o.y = g.y * act_grad<ACT>(yy.y);
+                o.z = g.z * act_grad<ACT>(yy.z); o.w = g.w * act_grad<ACT>(yy.w);
+                o4[e] = o;
+                acc += (o.x + o.y) + (o.z + o.w);
+            }
         }
     } else {
         for (int e = beg + threadIdx.x; e < end; e += 256) {
@@ -101,29 +135,57 @@ bool shape_ok(const char* what, int B, int C, int P, int act) {
 
 }  // namespace
 
-extern "C" int camli_bias_act_fwd(float* x_inout, const float* bias, int B, int C, int P, int act, void* stream) {
+extern "C" int64_t camli_bias_act_mask_bytes(int B, int C, int P) {
+    if (B < 0 || C < 1 || P < 4 || (P & 3)) return 0;     // 0: no mask form for this shape (scalar path)
+    return (int64_t)B * C * mask_words(P) * 4 * (int64_t)sizeof(unsigned long long);
+}
+
+extern "C" int camli_bias_act_fwd(float* x_inout, const float* bias, void* sign_mask, int B, int C, int P, int act,
+                                  void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!x_inout || !bias) { camli_set_error("camli_bias_act_fwd: null pointer"); return CAMLI_EINVAL; }
     if (!shape_ok("camli_bias_act_fwd", B, C, P, act)) return CAMLI_EINVAL;
+    if (sign_mask && !((act == 1 || act == 2) && (P & 3) == 0)) {
+        camli_set_error("camli_bias_act_fwd: a sign mask needs act 1 or 2 and P %% 4 == 0 (act=%d P=%d)", act, P);
+        return CAMLI_EINVAL;
+    }
     const int chunk = pick_chunk(P);
     dim3 grid(camli_divup(P, chunk), C, B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define L(A) hipLaunchKernelGGL((bias_act_fwd_kernel<A>), grid, dim3(256), 0, s, x_inout, bias, C, P, chunk)
-    switch (act) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; default: L(4); break; }
+    unsigned long long* m = static_cast<unsigned long long*>(sign_mask);
+#define L(A, M) hipLaunchKernelGGL((bias_act_fwd_kernel<A, M>), grid, dim3(256), 0, s, x_inout, bias, m, C, P, chunk)
+    switch (act) {
+        case 0: L(0, false); break;
+        case 1: if (m) L(1, true); else L(1, false); break;
+        case 2: if (m) L(2, true); else L(2, false); break;
+        case 3: L(3, false); break;
+        default: L(4, false); break;
+    }
 #undef L
     return camli_check_launch("camli_bias_act_fwd");
 }
 
-extern "C" int camli_bias_act_bwd(const float* gy, const float* y, float* gx, float* gbias, int B, int C, int P, int act,
-                                  void* stream) {
+extern "C" int camli_bias_act_bwd(const float* gy, const float* y, const void* sign_mask, float* gx, float* gbias,
+                                  int B, int C, int P, int act, void* stream) {
     if (B == 0) return CAMLI_OK;
-    if (!gy || !y || !gx || !gbias) { camli_set_error("camli_bias_act_bwd: null pointer"); return CAMLI_EINVAL; }
+    if (!gy || (!y && !sign_mask) || !gx || !gbias) { camli_set_error("camli_bias_act_bwd: null pointer"); return CAMLI_EINVAL; }
     if (!shape_ok("camli_bias_act_bwd", B, C, P, act)) return CAMLI_EINVAL;
+    if (sign_mask && !((act == 1 || act == 2) && (P & 3) == 0)) {
+        camli_set_error("camli_bias_act_bwd: a sign mask needs act 1 or 2 and P %% 4 == 0 (act=%d P=%d)", act, P);
+        return CAMLI_EINVAL;
+    }
     const int chunk = pick_chunk(P);
     dim3 grid(camli_divup(P, chunk), C, B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-#define L(A) hipLaunchKernelGGL((bias_act_bwd_kernel<A>), grid, dim3(256), 0, s, gy, y, gx, gbias, C, P, chunk)
-    switch (act) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; default: L(4); break; }
+    const unsigned long long* m = static_cast<const unsigned long long*>(sign_mask);
+#define L(A, M) hipLaunchKernelGGL((bias_act_bwd_kernel<A, M>), grid, dim3(256), 0, s, gy, y, m, gx, gbias, C, P, chunk)
+    switch (act) {
+        case 0: L(0, false); break;
+        case 1: if (m) L(1, true); else L(1, false); break;
+        case 2: if (m) L(2, true); else L(2, false); break;
+        case 3: L(3, false); break;
+        default: L(4, false); break;
+    }
 #undef L
     return camli_check_launch("camli_bias_act_bwd");
 }

@@ -185,10 +185,14 @@ int camli_gru_blend_bwd(const float *g, const float *z, const float *h, const fl
  *   x_inout [B,C,P] updated IN PLACE to act(x + bias[c]); act: 0 identity, 1 relu, 2 leaky_relu(0.1),
  *   3 sigmoid, 4 tanh.  bwd: gx = gy * act'(y) (fully written; may alias gy), gbias[c] += sum gx
  *   (float atomics; caller zero-fills gbias).
+ *   sign_mask (optional, act 1 / 2 with P % 4 == 0, camli_bias_act_mask_bytes(B,C,P) bytes): the forward
+ *   also records one bit per element (y > 0); a backward given the mask does not read y at all
+ *   (8.1 instead of 12 bytes per element).  Pass NULL for the y-based form.
  */
-int camli_bias_act_fwd(float *x_inout, const float *bias, int B, int C, int P, int act, void *stream);
-int camli_bias_act_bwd(const float *gy, const float *y, float *gx, float *gbias, int B, int C, int P, int act,
-                       void *stream);
+int64_t camli_bias_act_mask_bytes(int B, int C, int P);
+int camli_bias_act_fwd(float *x_inout, const float *bias, void *sign_mask, int B, int C, int P, int act, void *stream);
+int camli_bias_act_bwd(const float *gy, const float *y, const void *sign_mask, float *gx, float *gbias,
+                       int B, int C, int P, int act, void *stream);
 
 /*
  * Neighbour-weight network of a depth-wise set-conv: weight_net = MLP2d(3 -> 8 -> 32 -> C, ReLU after
