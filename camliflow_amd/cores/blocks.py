@@ -89,11 +89,46 @@ def epilogue_ok(x):
     return runtime.fused() and x.is_cuda and not torch.is_autocast_enabled()
 
 
+class _PointwiseConv(torch.autograd.Function):
+    """1x1, stride-1 convolution without bias.  Forward and data gradient stay on the library (a GEMM,
+    no layout change); the WEIGHT gradient is taken as a batched GEMM over the positions
+    (dW = sum_b gy_b x_b^T), because the library's weight-gradient path for these shapes is an NHWC
+    implicit-GEMM kernel wrapped in three layout transposes and a zero-fill (measured, B8 128->128 at
+    68x120: 137 us for dx+dW against 55 + 39 us)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        nd = x.dim() - 2
+        ctx.conv_args = ([1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1)
+        return torch.ops.aten.convolution(x, w, None, *ctx.conv_args)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, *ctx.conv_args, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(gy.flatten(2), x.flatten(2).transpose(1, 2)).sum(0).view_as(w)
+        return gx, gw
+
+
+def _is_pointwise(conv):
+    return (all(k == 1 for k in conv.kernel_size) and all(s == 1 for s in conv.stride)
+            and all(p == 0 for p in conv.padding) and all(d == 1 for d in conv.dilation) and conv.groups == 1
+            and not isinstance(conv.padding, str))
+
+
 def conv_bias_act(conv, x, act):
     """``act(conv(x))`` with the bias add, the activation and (backward) the bias-gradient reduction
     fused into one pass over the convolution output (camli_bias_act_fwd/bwd)."""
     from ..csrc import fused
-    y = conv._conv_forward(x, conv.weight, None)
+    if _is_pointwise(conv) and x.dtype == torch.float32 and x.is_contiguous():
+        y = _PointwiseConv.apply(x, conv.weight)
+    else:
+        y = conv._conv_forward(x, conv.weight, None)
     if conv.bias is None:
         return y if act is None else fused.bias_act(y, torch.zeros(y.shape[1], device=y.device), act)
     return fused.bias_act(y, conv.bias, act)
