@@ -99,6 +99,7 @@ class _PointwiseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
+        ctx.param = w if (w.is_leaf and w.requires_grad) else None      # identity of the Parameter, for deferral
         nd = x.dim() - 2
         ctx.conv_args = ([1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1)
         return torch.ops.aten.convolution(x, w, None, *ctx.conv_args)
@@ -111,7 +112,15 @@ class _PointwiseConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.ops.aten.convolution_backward(gy, x, w, None, *ctx.conv_args, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            gw = torch.bmm(gy.flatten(2), x.flatten(2).transpose(1, 2)).sum(0).view_as(w)
+            gy3, xt3 = gy.flatten(2), x.flatten(2).transpose(1, 2)
+            if ctx.param is not None and runtime.deferred_param_grads():
+                # one [B,Co,Ci] accumulator per parameter and pass, GEMM with beta = 1; summed over the batch and
+                # moved into .grad once, at the end of backward()
+                acc = runtime.PARAM_GRADS.slot(ctx.param, lambda: torch.zeros(gy3.shape[0], gy3.shape[1], xt3.shape[2],
+                                                                            dtype=torch.float32, device=gy.device), True)
+                acc.baddbmm_(gy3, xt3)
+            else:
+                gw = torch.bmm(gy3, xt3).sum(0).view_as(w)
         return gx, gw
 
 

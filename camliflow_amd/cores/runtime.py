@@ -41,6 +41,61 @@ def fused():
 
 
 # ------------------------------------------------------------------------------------------------
+# deferred parameter gradients: the 12 GRU iterations share their parameters, so autograd adds a
+# fresh weight / bias gradient into .grad after every call (~1,200 small add + sum launches per
+# step).  With this switch on, the fused 1x1-convolution and bias/activation nodes accumulate into
+# one buffer per parameter inside their own kernels (GEMM with beta = 1, float atomics) and a
+# callback at the end of backward() moves the totals into .grad.  Opt-in because it bypasses the
+# functional API: torch.autograd.grad(...) would not see these gradients (training loops call
+# .backward()).
+# ------------------------------------------------------------------------------------------------
+_DEFER_PARAM_GRADS = False
+
+
+def set_deferred_param_grads(enabled):
+    global _DEFER_PARAM_GRADS
+    _DEFER_PARAM_GRADS = bool(enabled)
+
+
+def deferred_param_grads():
+    return _DEFER_PARAM_GRADS
+
+
+class _ParamGradSink:
+    """Per-parameter accumulators of one backward pass (see set_deferred_param_grads)."""
+
+    def __init__(self):
+        self.entries = {}
+        self.armed = False
+
+    def slot(self, param, make, reduce_batch):
+        import torch
+        entry = self.entries.get(id(param))
+        if entry is None:
+            if not self.armed:
+                torch.autograd.variable.Variable._execution_engine.queue_callback(self.flush)
+                self.armed = True
+            entry = self.entries[id(param)] = [param, make(), reduce_batch, None]
+        entry[3] = torch.cuda.current_stream(param.device)
+        return entry[1]
+
+    def flush(self):
+        import torch
+        entries, self.entries, self.armed = self.entries, {}, False
+        with torch.no_grad():
+            for param, acc, reduce_batch, stream in entries.values():
+                current = torch.cuda.current_stream(param.device)
+                if stream is not None and stream != current:
+                    current.wait_stream(stream)          # the accumulator was last written on another lane
+                    acc.record_stream(current)
+                grad = (acc.sum(0) if reduce_batch else acc).view_as(param)
+                param.grad = grad if param.grad is None else param.grad + grad
+
+
+PARAM_GRADS = _ParamGradSink()
+
+
+# ------------------------------------------------------------------------------------------------
 # two-lane execution: point branch on a side HIP stream next to the image branch
 # ------------------------------------------------------------------------------------------------
 _OVERLAP = False

@@ -13,6 +13,7 @@ import torch
 from torch.nn.functional import avg_pool2d
 
 from . import _lib
+from ..cores import runtime as _runtime
 from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_slice, _zero_token
 
 
@@ -772,6 +773,7 @@ class _BiasAct(torch.autograd.Function):
         else:
             ctx.save_for_backward(x)
         ctx.act, ctx.masked, ctx.dims = act, mask is not None, (b, c, p)
+        ctx.bias_param = bias if (bias.is_leaf and bias.requires_grad) else None
         return x
 
     @staticmethod
@@ -782,13 +784,17 @@ class _BiasAct(torch.autograd.Function):
         b, c, p = ctx.dims
         gy = gy.contiguous().float()
         gx = torch.empty_like(gy)
-        gbias = _zero_slice(c, gy)
+        deferred = ctx.bias_param is not None and _runtime.deferred_param_grads()
+        if deferred:      # the kernel's atomics accumulate straight into the parameter's per-pass buffer
+            gbias = _runtime.PARAM_GRADS.slot(ctx.bias_param, lambda: _zero_slice(c, gy), False)
+        else:
+            gbias = _zero_slice(c, gy)
         with _on_device(gy):
             _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gy.data_ptr(),
                         None if ctx.masked else saved.data_ptr(), saved.data_ptr() if ctx.masked else None,
                         gx.data_ptr(), gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(gy),
                         work=((8.125 if ctx.masked else 12.0) * b * c * p, 'B'))
-        return gx, gbias, None
+        return gx, (None if deferred else gbias), None
 
 
 def bias_act(x, bias, act):

@@ -181,3 +181,45 @@ def test_camlipwc_config2_shape_runs():
         model.get_loss().backward()
     assert out['flow_2d'].shape == (1, 2, 540, 960) and out['flow_3d'].shape == (1, 3, 8192)
     assert torch.isfinite(out['flow_2d']).all() and torch.isfinite(out['flow_3d']).all()
+
+
+@pytest.mark.parametrize('overlap', [False, True], ids=['one_lane', 'two_lanes'])
+def test_deferred_parameter_gradients_match_autograd_accumulation(overlap):
+    """runtime.set_deferred_param_grads(True): the 1x1-convolution weights and the fused biases accumulate
+    inside their kernels and are moved into .grad by one callback at the end of backward().  Every
+    parameter's gradient must equal the per-call autograd accumulation (same forward, same adjoint
+    kernels, different summation order -> 1e-5 per tensor in norm; whole model 1e-3 like the overlap
+    test, float atomics)."""
+    from camliflow_amd.cores import runtime
+    _, model = _models(3, 'train')
+    inputs = _to(synthetic_inputs(2, 128, 160, 4608), 'cuda')
+
+    def run():
+        model.zero_grad()
+        model(inputs)
+        loss = model.get_loss()
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    runtime.set_overlap(overlap)
+    try:
+        with runtime.use_backend('hip'):
+            base_loss, base = run()
+            runtime.set_deferred_param_grads(True)
+            try:
+                for _ in range(2):
+                    loss, grads = run()
+                    assert not runtime.PARAM_GRADS.entries and not runtime.PARAM_GRADS.armed
+                    assert grads.keys() == base.keys()
+                    assert abs(loss - base_loss) <= 1e-5 * max(1.0, abs(base_loss))
+                    num = sum(((grads[n] - base[n]).double() ** 2).sum().item() for n in grads) ** 0.5
+                    den = sum((base[n].double() ** 2).sum().item() for n in grads) ** 0.5
+                    assert num / den < 1e-3, num / den
+                    worst = max(((grads[n] - base[n]).norm() / (base[n].norm() + 1e-12)).item() for n in grads
+                                if base[n].norm() > 1e-6)
+                    print('deferred grads: whole-model rel %.2e, worst tensor %.2e' % (num / den, worst))
+            finally:
+                runtime.set_deferred_param_grads(False)
+    finally:
+        runtime.set_overlap(False)
