@@ -228,9 +228,10 @@ def main():
     _lib.load()
     runtime.set_backend('hip')
     runtime.set_overlap(os.environ.get('CAMLI_OVERLAP', '1') == '1')
-    # optional: parameter gradients of the iteration-shared 1x1 convolutions / biases accumulate inside their
-    # kernels and reach .grad once per backward() (cores/runtime.py).  Measured neutral (305 vs 306.5 ms), so off.
-    runtime.set_deferred_param_grads(os.environ.get('CAMLI_DEFER_GRADS', '0') == '1')
+    # parameter gradients of the iteration-shared 1x1 convolutions / biases accumulate inside their kernels and
+    # reach .grad once per backward() (cores/runtime.py): 119 parameters, ~1,200 fewer add / sum launches per
+    # step; same-box A/B at batch 8: 306.0 vs 308.0 ms (3 runs each), 162 vs 180 ms at batch 2
+    runtime.set_deferred_param_grads(os.environ.get('CAMLI_DEFER_GRADS', '1') == '1')
     torch.backends.cudnn.benchmark = os.environ.get('CAMLI_MIOPEN_FIND', '0') == '1'
 
     torch.manual_seed(0)
