@@ -134,7 +134,11 @@ class SKFusion(nn.Module):
             from ..csrc import fused
             state = fused.SkState()
             squeezed = fused.sk_pool(feat_2d, feat_3d, state)
-            weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
+            w_mid, w_out = self.fc_mid[0].weight, self.fc_out[0].weight
+            if w_mid.shape[1] <= 256 and w_mid.shape[0] <= 128 and not torch.is_autocast_enabled():
+                weight = fused.sk_gate(squeezed, w_mid, w_out)           # the whole gate in one launch each way
+            else:
+                weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
             return fused.sk_mix(feat_2d, feat_3d, weight, state)
         squeezed = self.avg_pool(feat_2d + feat_3d).reshape(bs, -1)
         weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)

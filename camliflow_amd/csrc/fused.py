@@ -340,6 +340,58 @@ class _SkMix(torch.autograd.Function):
         return ga, gb, gw, None
 
 
+class _SkGate(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, s, wmid, wout):
+        lib = _lib.load()
+        bs, c = s.shape
+        r = wmid.shape[0]
+        s = s.contiguous()
+        m = torch.empty((bs, r), dtype=torch.float32, device=s.device)
+        z = torch.empty((bs, 2 * c), dtype=torch.float32, device=s.device)
+        w = torch.empty((bs, c, 2), dtype=torch.float32, device=s.device)
+        with _on_device(s):
+            _lib.launch('camli_sk_gate_fwd', lib.camli_sk_gate_fwd, s.data_ptr(), wmid.data_ptr(), wout.data_ptr(),
+                        m.data_ptr(), z.data_ptr(), w.data_ptr(), bs, c, r, _stream_ptr(s),
+                        work=(4.0 * (bs * (4 * c + r) + 3 * c * r), 'B'))
+        ctx.save_for_backward(s, m, z, w, wmid, wout)
+        ctx.params = [t if (t.is_leaf and t.requires_grad) else None for t in (wmid, wout)]
+        return w
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gw):
+        lib = _lib.load()
+        s, m, z, w, wmid, wout = ctx.saved_tensors
+        bs, c = s.shape
+        r = wmid.shape[0]
+        gw = gw.contiguous().float()
+        gs = torch.empty_like(s)
+        grads = []
+        deferred = []
+        for param, like in zip(ctx.params, (wmid, wout)):
+            if param is not None and _runtime.deferred_param_grads():
+                grads.append(_runtime.PARAM_GRADS.slot(param, lambda like=like: torch.zeros_like(like), False))
+                deferred.append(True)
+            else:
+                grads.append(torch.zeros_like(like))
+                deferred.append(False)
+        with _on_device(s):
+            _lib.launch('camli_sk_gate_bwd', lib.camli_sk_gate_bwd, gw.data_ptr(), s.data_ptr(), m.data_ptr(), z.data_ptr(),
+                        w.data_ptr(), wmid.data_ptr(), wout.data_ptr(), gs.data_ptr(), grads[0].data_ptr(),
+                        grads[1].data_ptr(), bs, c, r, _stream_ptr(s), work=(4.0 * (bs * (7 * c + r) + 9 * c * r), 'B'))
+        return gs, (None if deferred[0] else grads[0]), (None if deferred[1] else grads[1])
+
+
+def sk_gate(s, wmid, wout):
+    """[B,C] pooled vector -> [B,C,2] branch weights (two bias-free Linear layers, ReLU, Sigmoid, softmax over
+    the pair) in one launch each way."""
+    _require_cuda('sk_gate', s, wmid, wout)
+    assert s.dim() == 2 and wmid.shape[1] == s.shape[1] and wout.shape == (2 * s.shape[1], wmid.shape[0])
+    return _SkGate.apply(s.float(), wmid.float().contiguous(), wout.float().contiguous())
+
+
 def sk_pool(a, b, state):
     """mean over the positions of (a + b): [B,C,...] x2 -> [B,C]"""
     _require_cuda('sk_pool', a, b)

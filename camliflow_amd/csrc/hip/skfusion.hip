@@ -123,6 +123,89 @@ __global__ __launch_bounds__(256) void sk_mix_bwd_x_kernel(const float* __restri
     }
 }
 
+
+// ---- the gate: w = softmax_pairs(sigmoid(relu(s Wmid^T) Wout^T)) on [B,C] vectors (clfm.py:183-184,
+// 199-203: two bias-free Linear layers, ReLU, Sigmoid, reshape [B,C,2], softmax over the pair).  In torch
+// this is ~5 launches forward and ~9 backward per SKFusion call, all on kilobyte-sized tensors. ----
+constexpr int SKG_MAXC = 256, SKG_MAXR = 128;
+
+// grid B, block 256
+__global__ __launch_bounds__(256) void sk_gate_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wmid,
+                                                          const float* __restrict__ wout, float* __restrict__ m,
+                                                          float* __restrict__ z, float* __restrict__ w, int C, int R) {
+    __shared__ float ss[SKG_MAXC], sm[SKG_MAXR], sz[2 * SKG_MAXC];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) ss[c] = s[(size_t)b * C + c];
+    __syncthreads();
+    for (int r = tid; r < R; r += 256) {
+        float a = 0.0f;
+        for (int c = 0; c < C; ++c) a = __builtin_fmaf(wmid[r * C + c], ss[c], a);
+        a = fmaxf(a, 0.0f);
+        sm[r] = a;
+        m[(size_t)b * R + r] = a;
+    }
+    __syncthreads();
+    for (int o = tid; o < 2 * C; o += 256) {
+        float a = 0.0f;
+        for (int r = 0; r < R; ++r) a = __builtin_fmaf(wout[o * R + r], sm[r], a);
+        a = 1.0f / (1.0f + __expf(-a));
+        sz[o] = a;
+        z[(size_t)b * 2 * C + o] = a;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float z0 = sz[2 * c], z1 = sz[2 * c + 1];
+        const float mx = fmaxf(z0, z1);
+        const float e0 = __expf(z0 - mx), e1 = __expf(z1 - mx);
+        const float inv = 1.0f / (e0 + e1);
+        w[((size_t)b * C + c) * 2] = e0 * inv;
+        w[((size_t)b * C + c) * 2 + 1] = e1 * inv;
+    }
+}
+
+// grid B, block 256: one workgroup per batch row; the weight gradients are added into the callers'
+// accumulators with float atomics (8 x 24k of them: a single workgroup walking the batch serially took
+// ~270 us, 25x longer).  gs is fully written.
+__global__ __launch_bounds__(256) void sk_gate_bwd_kernel(const float* __restrict__ gw, const float* __restrict__ s,
+                                                          const float* __restrict__ m, const float* __restrict__ z,
+                                                          const float* __restrict__ w, const float* __restrict__ wmid,
+                                                          const float* __restrict__ wout, float* __restrict__ gs,
+                                                          float* __restrict__ gwmid, float* __restrict__ gwout, int C,
+                                                          int R) {
+    __shared__ float ss[SKG_MAXC], sm[SKG_MAXR], gp[2 * SKG_MAXC], gm[SKG_MAXR];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        ss[c] = s[(size_t)b * C + c];
+        const size_t e = ((size_t)b * C + c) * 2;
+        const float w0 = w[e], w1 = w[e + 1], g0 = gw[e], g1 = gw[e + 1];
+        const float dot = g0 * w0 + g1 * w1;                       // softmax over the pair
+        const float z0 = z[(size_t)b * 2 * C + 2 * c], z1 = z[(size_t)b * 2 * C + 2 * c + 1];
+        gp[2 * c] = w0 * (g0 - dot) * z0 * (1.0f - z0);            // ... then the sigmoid
+        gp[2 * c + 1] = w1 * (g1 - dot) * z1 * (1.0f - z1);
+    }
+    for (int r = tid; r < R; r += 256) sm[r] = m[(size_t)b * R + r];
+    __syncthreads();
+    for (int e = tid; e < 2 * C * R; e += 256) {                    // gWout[o,r] += gpre[o] * m[r]
+        const int o = e / R, r = e - o * R;
+        unsafeAtomicAdd(&gwout[e], gp[o] * sm[r]);
+    }
+    for (int r = tid; r < R; r += 256) {                            // gm = Wout^T gpre, through the ReLU
+        float a = 0.0f;
+        for (int o = 0; o < 2 * C; ++o) a = __builtin_fmaf(wout[o * R + r], gp[o], a);
+        gm[r] = sm[r] > 0.0f ? a : 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < R * C; e += 256) {                        // gWmid[r,c] += gm[r] * s[c]
+        const int r = e / C, c = e - r * C;
+        unsafeAtomicAdd(&gwmid[e], gm[r] * ss[c]);
+    }
+    for (int c = tid; c < C; c += 256) {                            // gs = Wmid^T gm
+        float a = 0.0f;
+        for (int r = 0; r < R; ++r) a = __builtin_fmaf(wmid[r * C + c], gm[r], a);
+        gs[(size_t)b * C + c] = a;
+    }
+}
+
 bool sk_args_ok(const char* what, int B, int C, int P) {
     if (B < 0 || C < 1 || P < 1 || (long long)B * C > 0x7fffffffLL || (long long)B * C > 65535LL * 65535LL) {
         camli_set_error("%s: bad shape B=%d C=%d P=%d", what, B, C, P);
@@ -174,4 +257,34 @@ extern "C" int camli_sk_mix_bwd_x(const float* g, const float* w, const float* g
     hipLaunchKernelGGL(sk_mix_bwd_x_kernel, dim3(camli_divup(P, 1024), B * C), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), g, w, gs, ga, gb, P);
     return camli_check_launch("camli_sk_mix_bwd_x");
+}
+
+extern "C" int camli_sk_gate_fwd(const float* s, const float* wmid, const float* wout, float* m, float* z, float* w,
+                                 int B, int C, int R, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
+    if (!s || !wmid || !wout || !m || !z || !w) { camli_set_error("camli_sk_gate_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || C < 1 || R < 1 || C > SKG_MAXC || R > SKG_MAXR) {
+        camli_set_error("camli_sk_gate_fwd: bad shape B=%d C=%d (<= %d) R=%d (<= %d)", B, C, SKG_MAXC, R, SKG_MAXR);
+        return C > SKG_MAXC || R > SKG_MAXR ? CAMLI_ENOTSUP : CAMLI_EINVAL;
+    }
+    hipLaunchKernelGGL(sk_gate_fwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, wmid, wout, m, z,
+                       w, C, R);
+    return camli_check_launch("camli_sk_gate_fwd");
+}
+
+extern "C" int camli_sk_gate_bwd(const float* gw, const float* s, const float* m, const float* z, const float* w,
+                                 const float* wmid, const float* wout, float* gs, float* gwmid, float* gwout, int B,
+                                 int C, int R, void* stream) {
+    if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
+    if (!gw || !s || !m || !z || !w || !wmid || !wout || !gs || !gwmid || !gwout) {
+        camli_set_error("camli_sk_gate_bwd: null pointer");
+        return CAMLI_EINVAL;
+    }
+    if (B < 0 || C < 1 || R < 1 || C > SKG_MAXC || R > SKG_MAXR) {
+        camli_set_error("camli_sk_gate_bwd: bad shape B=%d C=%d (<= %d) R=%d (<= %d)", B, C, SKG_MAXC, R, SKG_MAXR);
+        return C > SKG_MAXC || R > SKG_MAXR ? CAMLI_ENOTSUP : CAMLI_EINVAL;
+    }
+    hipLaunchKernelGGL(sk_gate_bwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gw, s, m, z, w,
+                       wmid, wout, gs, gwmid, gwout, C, R);
+    return camli_check_launch("camli_sk_gate_bwd");
 }

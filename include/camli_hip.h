@@ -246,6 +246,20 @@ int camli_sk_mix_bwd_w(const float *g, const float *a, const float *b, float *gw
 int camli_sk_mix_bwd_x(const float *g, const float *w, const float *gs, float *ga, float *gb, int B, int C, int P,
                        void *stream);
 
+/*
+ * The SKFusion gate on [B,C] vectors (models/clfm.py:183-184,199-203): m = relu(s Wmid^T),
+ * z = sigmoid(m Wout^T), w[b,c,:] = softmax(z[b,2c], z[b,2c+1]).  C <= 256, R <= 128.
+ *   s [B,C], wmid [R,C], wout [2C,R];  m [B,R], z [B,2C], w [B,C,2] (all fully written; m and z are kept
+ *   for the backward).
+ *   bwd: gw [B,C,2] -> gs [B,C] (fully written), gwmid [R,C] += , gwout [2C,R] += (float atomics, one
+ *   workgroup per batch row; caller zero-fills or passes its running accumulators).
+ */
+int camli_sk_gate_fwd(const float *s, const float *wmid, const float *wout, float *m, float *z, float *w,
+                      int B, int C, int R, void *stream);
+int camli_sk_gate_bwd(const float *gw, const float *s, const float *m, const float *z, const float *w,
+                      const float *wmid, const float *wout, float *gs, float *gwmid, float *gwout,
+                      int B, int C, int R, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

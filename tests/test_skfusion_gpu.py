@@ -63,3 +63,26 @@ def test_skfusion_module_hip_vs_composed(fmt):
     assert torch.allclose(a[0], b[0], rtol=1e-4, atol=1e-5)
     for u, v in zip([a[1], a[2]] + a[3], [b[1], b[2]] + b[3]):
         assert (u - v).norm() <= 2e-4 * v.norm() + 1e-6, ((u - v).norm() / v.norm()).item()
+
+
+@pytest.mark.parametrize('dims', [(8, 128, 64), (3, 20, 7), (1, 256, 128)], ids=lambda d: 'B%d_C%d_R%d' % d)
+def test_gate_vs_torch(dims):
+    from camliflow_amd.csrc import fused
+    b, c, r = dims
+    torch.manual_seed(sum(dims))
+    s0 = torch.randn(b, c, device='cuda')
+    wmid = (torch.randn(r, c, device='cuda') * c ** -0.5).requires_grad_(True)
+    wout = (torch.randn(2 * c, r, device='cuda') * r ** -0.5).requires_grad_(True)
+    gw = torch.randn(b, c, 2, device='cuda')
+    res = []
+    for impl in ('hip', 'torch'):
+        s = s0.clone().requires_grad_(True)
+        wmid.grad = wout.grad = None
+        if impl == 'hip':
+            w = fused.sk_gate(s, wmid, wout)
+        else:
+            w = torch.softmax(torch.sigmoid(torch.relu(s @ wmid.t()) @ wout.t()).reshape(b, c, 2), dim=-1)
+        w.backward(gw)
+        res.append((w.detach(), s.grad, wmid.grad.clone(), wout.grad.clone()))
+    for x, y in zip(*res):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-6), (x - y).abs().max()
