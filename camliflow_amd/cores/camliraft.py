@@ -11,7 +11,8 @@ import torch.nn as nn
 from ..csrc import wrapper as _ops
 from . import runtime
 from .fusion import CLFM
-from .geometry import (InputPadder, backwarp_3d, backwarp_3d_levels, build_pc_pyramid, knn_interpolation, mesh_grid, paral2persp,
+from .geometry import (InputPadder, backwarp_3d, backwarp_3d_levels, build_pc_pyramid, flows_paral2persp, knn_interpolation,
+                       mesh_grid, paral2persp,
                        persp2paral, project_pc2image)
 from .objectives import FlowModel, calc_sequence_loss_2d, calc_sequence_loss_3d
 from .raft2d import RAFTCore
@@ -206,8 +207,7 @@ class CamLiRAFT(_FreezableBN, FlowModel):
 
         flow_2d_preds, flow_3d_preds = self.core(image1, image2, pc1, pc2, paral)
         flow_2d_preds = [padder.unpad(f) for f in flow_2d_preds]
-        origin = paral2persp(pc1, persp, paral)
-        flow_3d_preds = [paral2persp(pc1 + f, persp, paral) - origin for f in flow_3d_preds]
+        flow_3d_preds = flows_paral2persp(pc1, flow_3d_preds, persp, paral)
 
         final_flow_2d, final_flow_3d = flow_2d_preds[-1], flow_3d_preds[-1]
         outputs = {'flow_2d': final_flow_2d, 'flow_3d': final_flow_3d}
@@ -269,8 +269,7 @@ class CamLiRAFT_L(FlowModel):
             flow_preds = [to_src(pc1 + f) - to_src(pc1) for f in flow_preds]
             pc1 = to_src(pc1)
         if use_ids:
-            origin = paral2persp(pc1, persp, paral)
-            flow_preds = [paral2persp(pc1 + f, persp, paral) - origin for f in flow_preds]
+            flow_preds = flows_paral2persp(pc1, flow_preds, persp, paral)
 
         final_flow_3d = flow_preds[-1]
         if 'flow_3d' not in inputs:

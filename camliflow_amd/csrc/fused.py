@@ -407,6 +407,54 @@ def sk_mix(a, b, w, state):
 
 
 # ------------------------------------------------------------------------------------------------
+# flow read-out of the inverse-depth-scaling wrapper (models/ids.py:36-67, camliraft.py:108-110)
+# ------------------------------------------------------------------------------------------------
+class _IdsFlow(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, flow, pc1, origin, f, cx, cy, consts):
+        lib = _lib.load()
+        bs, _, n = pc1.shape
+        flow = flow.contiguous()
+        out = torch.empty_like(pc1)
+        with _on_device(pc1):
+            _lib.launch('camli_ids_flow_fwd', lib.camli_ids_flow_fwd, pc1.data_ptr(), flow.data_ptr(), origin.data_ptr(),
+                        f.data_ptr(), cx.data_ptr(), cy.data_ptr(), out.data_ptr(), *consts, bs, n, _stream_ptr(pc1),
+                        work=(48.0 * bs * n, 'B'))
+        ctx.save_for_backward(flow, pc1, f, cx, cy)
+        ctx.consts = consts
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        lib = _lib.load()
+        flow, pc1, f, cx, cy = ctx.saved_tensors
+        bs, _, n = pc1.shape
+        gout = gout.contiguous().float()
+        gflow = torch.empty_like(flow)
+        with _on_device(pc1):
+            _lib.launch('camli_ids_flow_bwd', lib.camli_ids_flow_bwd, pc1.data_ptr(), flow.data_ptr(), gout.data_ptr(),
+                        f.data_ptr(), cx.data_ptr(), cy.data_ptr(), gflow.data_ptr(), *ctx.consts, bs, n,
+                        _stream_ptr(pc1), work=(48.0 * bs * n, 'B'))
+        return gflow, None, None, None, None, None, None
+
+
+def ids_flow(flow, pc1, origin, persp, paral):
+    """paral2persp(pc1 + flow) - origin in one launch (differentiable wrt flow); persp / paral as in
+    cores.geometry.paral2persp."""
+    _require_cuda('ids_flow', flow, pc1, origin)
+    assert not (pc1.requires_grad or origin.requires_grad)
+    ratio_w = (paral['sensor_w'] - 1) / (persp['sensor_w'] - 1)
+    ratio_h = (paral['sensor_h'] - 1) / (persp['sensor_h'] - 1)
+    consts = (float(ratio_w), float(ratio_h), float(min(ratio_w, ratio_h)), float((paral['sensor_w'] - 1) / 2),
+              float((paral['sensor_h'] - 1) / 2))
+    return _IdsFlow.apply(flow.float(), pc1.float().contiguous(), origin.float().contiguous(),
+                          persp['f'].float().contiguous(), persp['cx'].float().contiguous(),
+                          persp['cy'].float().contiguous(), consts)
+
+
+# ------------------------------------------------------------------------------------------------
 # bilinear sampling of image features at projected points (models/utils.py:262-269)
 # ------------------------------------------------------------------------------------------------
 def bilinear_sample(feat_2d, uv):

@@ -260,6 +260,21 @@ int camli_sk_gate_bwd(const float *gw, const float *s, const float *m, const flo
                       const float *wmid, const float *wout, float *gs, float *gwmid, float *gwout,
                       int B, int C, int R, void *stream);
 
+/*
+ * Flow read-out of the inverse-depth-scaling wrapper: out = paral2persp(pc1 + flow) - origin
+ * (models/ids.py:36-67 applied per flow iterate at models/camliraft.py:108-110 / camlipwc.py / *_l.py).
+ *   pc1, flow, origin, out [B,3,N]; f, cx, cy [B] (perspective intrinsics);
+ *   ratio_w / ratio_h = (paral sensor - 1) / (persp sensor - 1), ratio_min = min of the two,
+ *   half_w / half_h = (paral sensor - 1) / 2.
+ *   bwd: gflow = d out / d flow applied to gout (pc1, origin constant); fully written.
+ */
+int camli_ids_flow_fwd(const float *pc1, const float *flow, const float *origin, const float *f, const float *cx,
+                       const float *cy, float *out, float ratio_w, float ratio_h, float ratio_min,
+                       float half_w, float half_h, int B, int N, void *stream);
+int camli_ids_flow_bwd(const float *pc1, const float *flow, const float *gout, const float *f, const float *cx,
+                       const float *cy, float *gflow, float ratio_w, float ratio_h, float ratio_min,
+                       float half_w, float half_h, int B, int N, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

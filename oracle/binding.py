@@ -242,3 +242,14 @@ def bilinear_sample_fwd(feat, uv):
     out = np.zeros((B, C, N), dtype=np.float32)
     _chk(_load().oracle_bilinear_sample_fwd(_p(feat), _p(uv), _p(out), B, C, H, W, N), "bilinear_sample_fwd")
     return out
+
+
+def ids_flow_fwd(pc1, flow, origin, f, cx, cy, rw, rh, rm, aw, ah):
+    """paral2persp(pc1 + flow) - origin on [B,3,N] arrays; f, cx, cy [B]"""
+    pc1, flow, origin, f, cx, cy = [_f32(t) for t in (pc1, flow, origin, f, cx, cy)]
+    B, _, N = pc1.shape
+    out = np.zeros_like(pc1)
+    c = ctypes.c_float
+    _chk(_load().oracle_ids_flow_fwd(_p(pc1), _p(flow), _p(origin), _p(f), _p(cx), _p(cy), _p(out), c(rw), c(rh), c(rm),
+                                     c(aw), c(ah), B, N), "ids_flow_fwd")
+    return out

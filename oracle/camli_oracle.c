@@ -622,4 +622,23 @@ int oracle_bilinear_sample_fwd(const float *feat, const float *uv, float *out, i
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * flow read-out of the IDS wrapper: follows models/ids.py:36-67 (paral2persp) as used at
+ * models/camliraft.py:108-110:  out = paral2persp(pc1 + flow) - origin;  [B,3,N] tensors, f/cx/cy [B]
+ * ------------------------------------------------------------------------------------------ */
+int oracle_ids_flow_fwd(const float *pc1, const float *flow, const float *origin, const float *f, const float *cx,
+                        const float *cy, float *out, float rw, float rh, float rm, float aw, float ah, int B, int N)
+{
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            size_t i0 = ((size_t)b * 3 + 0) * N + n, i1 = ((size_t)b * 3 + 1) * N + n, i2 = ((size_t)b * 3 + 2) * N + n;
+            float u = ((pc1[i0] + flow[i0]) + aw) / rw, v = ((pc1[i1] + flow[i1]) + ah) / rh, d = (pc1[i2] + flow[i2]) / rm;
+            float z = expf((d - 1.0f) / f[b]);
+            out[i0] = (u - cx[b]) * z / f[b] - origin[i0];
+            out[i1] = (v - cy[b]) * z / f[b] - origin[i1];
+            out[i2] = z - origin[i2];
+        }
+    return 0;
+}
+
 int oracle_version(void) { return 1; }

@@ -170,6 +170,25 @@ def golden_grid_sample():
     save('grid_sample', feat=feat, uv=uv, out=ref_utils.grid_sample_wrapper(feat, uv))
 
 
+def golden_ids_flow():
+    """paral2persp(pc1 + flow) - paral2persp(pc1) with the reference's models/ids.py (camliraft.py:108-110)."""
+    from models.ids import paral2persp as ref_paral2persp, persp2paral as ref_persp2paral
+    g = gen(53)
+    b, n = 2, 300
+    intr = torch.tensor([[1050.0, 479.5, 269.5], [721.5, 609.6, 172.9]])
+    persp = {'projection_mode': 'perspective', 'sensor_h': 544, 'sensor_w': 960, 'f': intr[:, 0], 'cx': intr[:, 1], 'cy': intr[:, 2]}
+    paral = {'projection_mode': 'parallel', 'sensor_h': 17, 'sensor_w': 30, 'cx': 14.5, 'cy': 8.0}
+    z = torch.rand(b, n, generator=g) * 30 + 5
+    u = torch.rand(b, n, generator=g) * 959
+    v = torch.rand(b, n, generator=g) * 543
+    pc = torch.stack([(u - intr[:, 1:2]) * z / intr[:, 0:1], (v - intr[:, 2:3]) * z / intr[:, 0:1], z], dim=1)
+    pc1 = ref_persp2paral(pc, persp, paral)
+    flow = torch.randn(b, 3, n, generator=g) * 0.3
+    origin = ref_paral2persp(pc1, persp, paral)
+    out = ref_paral2persp(pc1 + flow, persp, paral) - origin
+    save('ids_flow', pc1=pc1, flow=flow, origin=origin, out=out, intrinsics=intr, persp_hw=[544, 960], paral_hw=[17, 30])
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     golden_correlation()
@@ -179,3 +198,4 @@ if __name__ == '__main__':
     golden_allpairs()
     golden_pointconv_dw()
     golden_grid_sample()
+    golden_ids_flow()

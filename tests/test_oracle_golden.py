@@ -164,3 +164,16 @@ def test_bilinear_sample_matches_reference_grid_sample_wrapper(golden, oracle_li
     out = oracle_lib.bilinear_sample_fwd(g['feat'], g['uv'])
     assert out.shape == g['out'].shape
     assert np.allclose(out, g['out'], rtol=1e-5, atol=1e-6)
+
+
+def _ids_consts(g):
+    (ph, pw), (qh, qw) = g['persp_hw'], g['paral_hw']
+    rw, rh = (qw - 1) / (pw - 1), (qh - 1) / (ph - 1)
+    return float(rw), float(rh), float(min(rw, rh)), float((qw - 1) / 2), float((qh - 1) / 2)
+
+
+def test_ids_flow_matches_reference_paral2persp(golden, oracle_lib):
+    g = golden('ids_flow')
+    intr = g['intrinsics']
+    out = oracle_lib.ids_flow_fwd(g['pc1'], g['flow'], g['origin'], intr[:, 0], intr[:, 1], intr[:, 2], *_ids_consts(g))
+    assert np.allclose(out, g['out'], rtol=1e-5, atol=1e-5)

@@ -146,3 +146,43 @@ def test_bilinear_sample_golden_and_wrapper_dispatch(golden):
     with runtime.use_backend('hip'):
         out = grid_sample_wrapper(feat.clone().requires_grad_(True), uv)
     assert out.requires_grad
+
+
+def test_ids_flow_vs_oracle_golden_and_autograd(golden, oracle_lib):
+    """camli_ids_flow_fwd/bwd: the reference's paral2persp read-out (golden), the oracle at a larger size, and
+    the adjoint against autograd through geometry.paral2persp."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.geometry import flows_paral2persp, paral2persp
+    from test_oracle_golden import _ids_consts
+    g = golden('ids_flow')
+    intr = torch.from_numpy(g['intrinsics']).cuda()
+    (ph, pw), (qh, qw) = g['persp_hw'], g['paral_hw']
+    persp = {'sensor_h': int(ph), 'sensor_w': int(pw), 'f': intr[:, 0], 'cx': intr[:, 1], 'cy': intr[:, 2]}
+    paral = {'sensor_h': int(qh), 'sensor_w': int(qw)}
+    pc1 = torch.from_numpy(g['pc1']).cuda()
+    with runtime.use_backend('hip'):
+        got = flows_paral2persp(pc1, [torch.from_numpy(g['flow']).cuda()], persp, paral)[0]
+    # z = exp(.) is 5..35 and the flow is the DIFFERENCE of two such values: one ulp of exp is ~4e-6 here
+    assert np.allclose(got.cpu().numpy(), g['out'], rtol=1e-5, atol=5e-5)
+    # larger, with gradients
+    rng = np.random.default_rng(9)
+    b, n = 8, 8192
+    big_pc1 = np.concatenate([rng.uniform(-14, 14, (b, 1, n)), rng.uniform(-8, 8, (b, 1, n)), rng.uniform(30, 120, (b, 1, n))], 1).astype(np.float32)
+    flow0 = (rng.standard_normal((b, 3, n)) * 0.2).astype(np.float32)
+    intr8 = intr[:1].expand(b, -1).contiguous()
+    persp8 = dict(persp, f=intr8[:, 0], cx=intr8[:, 1], cy=intr8[:, 2])
+    t_pc1 = torch.from_numpy(big_pc1).cuda()
+    gout = torch.randn(b, 3, n, device='cuda')
+    res = []
+    for backend in ('hip', 'composed'):
+        flow = torch.from_numpy(flow0).cuda().requires_grad_(True)
+        with runtime.use_backend(backend):
+            out = flows_paral2persp(t_pc1, [flow], persp8, paral)[0]
+        out.backward(gout)
+        res.append((out.detach(), flow.grad))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=5e-5)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-4, atol=1e-6)
+    origin = paral2persp(t_pc1, persp8, paral).cpu().numpy()
+    f = intr8.cpu().numpy()
+    want = oracle_lib.ids_flow_fwd(big_pc1, flow0, origin, f[:, 0], f[:, 1], f[:, 2], *_ids_consts(g))
+    assert np.allclose(res[0][0].cpu().numpy(), want, rtol=1e-6, atol=5e-5)
