@@ -9,7 +9,8 @@ from ..csrc import wrapper as _ops
 from .blocks import Conv1dNormRelu, Conv2dNormRelu
 from .camliraft import _FreezableBN, _camera_pair
 from .fusion import CLFM
-from .geometry import (InputPadder, backwarp_2d, backwarp_3d, build_pc_pyramid, knn_interpolation, paral2persp,
+from .geometry import (InputPadder, backwarp_2d, backwarp_3d, build_pc_pyramid, flows_paral2persp, knn_interpolation,
+                       paral2persp,
                        persp2paral, project_pc2image, resize_flow2d, resize_to_64x)
 from .objectives import (FlowModel, calc_pyramid_loss_2d, calc_pyramid_loss_3d, calc_sequence_loss_2d)
 from .pwc2d import (PYRAMID_CHANNELS_2D, ContextNetwork2D, FeaturePyramid2D, FlowEstimatorDense2D,
@@ -165,8 +166,7 @@ class CamLiPWC(_FreezableBN, FlowModel):
         feats1_2d, feats1_3d = self.core.encode(image1, xyzs1)
         feats2_2d, feats2_3d = self.core.encode(image2, xyzs2)
         flows_2d, flows_3d = self.core.decode(xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, paral)
-        flows_3d = [paral2persp(xyz1 + f, persp, paral) - paral2persp(xyz1, persp, paral)
-                    for xyz1, f in zip(xyzs1, flows_3d)]
+        flows_3d = [flows_paral2persp(xyz1, [f], persp, paral)[0] for xyz1, f in zip(xyzs1, flows_3d)]
 
         final_flow_2d = resize_flow2d(flows_2d[0], origin_h, origin_w)
         final_flow_3d = flows_3d[0]
@@ -210,8 +210,7 @@ class CamLiPWC_L(FlowModel):
         xyzs1, xyzs2, sample_indices1, _ = build_pc_pyramid(pc1, pc2, n_samples_list=PYRAMID_SIZES)
         flows_3d = self.core.decode(xyzs1, xyzs2, self.core.encode(xyzs1), self.core.encode(xyzs2))
         if use_ids:
-            flows_3d = [paral2persp(xyz1 + f, persp, paral) - paral2persp(xyz1, persp, paral)
-                        for xyz1, f in zip(xyzs1, flows_3d)]
+            flows_3d = [flows_paral2persp(xyz1, [f], persp, paral)[0] for xyz1, f in zip(xyzs1, flows_3d)]
         final_flow_3d = flows_3d[0]
         if 'flow_3d' not in inputs:
             return {'flow_3d': final_flow_3d}

@@ -39,12 +39,12 @@ class Bottleneck(nn.Module):
                 nn.BatchNorm2d(out_planes),
             )
 
-    def forward(self, x):
+    def forward(self, x, folded=None):
         if _foldable(self.bn1, x):
-            shortcut = x if self.downsample is None else _conv_bn(self.downsample[0], self.downsample[1], x, None)
-            y = _conv_bn(self.conv1, self.bn1, x, 'relu')
-            y = _conv_bn(self.conv2, self.bn2, y, 'relu')
-            y = _conv_bn(self.conv3, self.bn3, y, None)
+            shortcut = x if self.downsample is None else _conv_bn(self.downsample[0], self.downsample[1], x, None, folded)
+            y = _conv_bn(self.conv1, self.bn1, x, 'relu', folded)
+            y = _conv_bn(self.conv2, self.bn2, y, 'relu', folded)
+            y = _conv_bn(self.conv3, self.bn3, y, None, folded)
             return self.relu(y + shortcut)
         shortcut = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
@@ -60,16 +60,20 @@ def _foldable(bn, x):
     return (not bn.training) and epilogue_ok(x)
 
 
-def _conv_bn(conv, bn, x, act):
+def _conv_bn(conv, bn, x, act, folded=None):
     """conv -> BatchNorm(eval) -> act as ONE convolution with folded weights plus the fused bias /
     activation epilogue:  y = conv(x, w * s) + (beta - mean * s),  s = gamma / sqrt(var + eps).
     gamma / beta stay trainable (the fold is differentiated by autograd on the small tensors); no
     BatchNorm pass over the activations remains, forward or backward.  Equal to the unfolded form up
-    to fp32 rounding."""
+    to fp32 rounding.  ``folded`` = the trunk's table of (s, beta - mean * s) per BatchNorm, computed
+    for all layers at once (ResNetTrunk._fold_table): same values, 5 launches instead of 5 per layer."""
     from ..csrc import fused
-    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    if folded is not None and id(bn) in folded:
+        scale, bias = folded[id(bn)]
+    else:
+        scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        bias = bn.bias - bn.running_mean * scale
     weight = conv.weight * scale.view(-1, 1, 1, 1)
-    bias = bn.bias - bn.running_mean * scale
     y = F.conv2d(x, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     return fused.bias_act(y, bias, act)
 
@@ -121,11 +125,34 @@ class ResNetTrunk(nn.Module):
                     m.eval()
         return self
 
+    def _fold_table(self):
+        """{id(bn): (scale, bias)} for every BatchNorm of the trunk from ONE vectorised evaluation:
+        gamma and beta are concatenated (autograd splits the gradient back), the frozen statistics
+        (rsqrt(var + eps), mean) are concatenated once and reused until a buffer is written again."""
+        bns = getattr(self, '_bn_list', None)
+        if bns is None:
+            bns = self._bn_list = [m for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        versions = tuple(t._version for bn in bns for t in (bn.running_var, bn.running_mean))
+        stats = getattr(self, '_frozen_stats', None)
+        if stats is None or stats[0] != versions or stats[1].device != bns[0].weight.device:
+            with torch.no_grad():
+                inv_std = torch.cat([torch.rsqrt(bn.running_var + bn.eps) for bn in bns])
+                mean = torch.cat([bn.running_mean for bn in bns])
+            stats = self._frozen_stats = (versions, inv_std, mean)
+        scale = torch.cat([bn.weight for bn in bns]) * stats[1]
+        bias = torch.cat([bn.bias for bn in bns]) - stats[2] * scale
+        sizes = [bn.num_features for bn in bns]
+        return {id(bn): pair for bn, pair in zip(bns, zip(torch.split(scale, sizes), torch.split(bias, sizes)))}
+
     def forward(self, x):
         if _foldable(self.bn1, x):
-            x = self.maxpool(_conv_bn(self.conv1, self.bn1, x, 'relu'))
-        else:
-            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+            folded = self._fold_table()
+            x = self.maxpool(_conv_bn(self.conv1, self.bn1, x, 'relu', folded))
+            for name in self.res_layers:
+                for block in getattr(self, name):
+                    x = block(x, folded)
+            return (x,)
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         for name in self.res_layers:
             x = getattr(self, name)(x)
         return (x,)
