@@ -7,7 +7,10 @@ stay on the device as [sum, count] pairs; ``get_metrics()`` does ONE packed all-
 import torch
 import torch.nn as nn
 
+from . import runtime
 from .geometry import batch_indexing, resize_flow2d
+
+_GAMMA_WEIGHTS = {}
 
 
 def _masked_mean_error(diff, mask, order):
@@ -32,6 +35,17 @@ def _sequence_loss(flow_preds, target, cfgs, n_flow_channels):
         mask = target[:, n_flow_channels] > 0
     else:
         mask = torch.ones_like(target)[:, 0] > 0
+    if (cfgs.order == 'l2-norm' and runtime.fused() and target.is_cuda and n_flow_channels in (2, 3)
+            and not target.requires_grad):
+        # one kernel per iterate (camli_masked_l2_fwd/bwd) instead of nine pointwise / reduction launches
+        from ..csrc import fused
+        sums = fused.masked_l2_sums(list(flow_preds), target, n_flow_channels)
+        key = (n_preds, float(cfgs.gamma), target.device)
+        weights = _GAMMA_WEIGHTS.get(key)
+        if weights is None:
+            weights = _GAMMA_WEIGHTS[key] = torch.tensor([cfgs.gamma ** (n_preds - i - 1) for i in range(n_preds)],
+                                                         dtype=torch.float32, device=target.device)
+        return (sums * weights).sum() / mask.sum()
     total = 0
     for i, pred in enumerate(flow_preds):
         loss = _masked_mean_error(pred - target[:, :n_flow_channels], mask, cfgs.order)

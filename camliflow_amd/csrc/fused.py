@@ -407,6 +407,59 @@ def sk_mix(a, b, w, state):
 
 
 # ------------------------------------------------------------------------------------------------
+# masked end-point-error sums of the sequence losses (models/losses.py:64-119)
+# ------------------------------------------------------------------------------------------------
+class _MaskedL2Sums(torch.autograd.Function):
+    """[sum over the mask of ||pred_i - target||_2 for every iterate i]: one kernel per iterate each way."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, target, n_channels, *preds):
+        lib = _lib.load()
+        bs, tc = target.shape[0], target.shape[1]
+        p = target.numel() // (bs * tc)
+        preds = [q.contiguous() for q in preds]
+        sums = torch.zeros(len(preds), dtype=torch.float32, device=target.device)
+        with _on_device(target):
+            for i, q in enumerate(preds):
+                _lib.launch('camli_masked_l2_fwd', lib.camli_masked_l2_fwd, q.data_ptr(), target.data_ptr(), tc,
+                            sums.data_ptr() + 4 * i, bs, n_channels, p, _stream_ptr(target),
+                            work=(4.0 * bs * p * (n_channels + tc), 'B'))
+        ctx.save_for_backward(target, *preds)
+        ctx.n_channels = n_channels
+        return sums
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gsums):
+        lib = _lib.load()
+        target, *preds = ctx.saved_tensors
+        bs, tc = target.shape[0], target.shape[1]
+        p = target.numel() // (bs * tc)
+        gsums = gsums.contiguous().float()
+        grads = []
+        with _on_device(target):
+            for i, q in enumerate(preds):
+                if not ctx.needs_input_grad[2 + i]:
+                    grads.append(None)
+                    continue
+                gq = torch.empty_like(q)
+                _lib.launch('camli_masked_l2_bwd', lib.camli_masked_l2_bwd, q.data_ptr(), target.data_ptr(), tc,
+                            gsums.data_ptr() + 4 * i, gq.data_ptr(), bs, ctx.n_channels, p, _stream_ptr(target),
+                            work=(4.0 * bs * p * (2 * ctx.n_channels + tc), 'B'))
+                grads.append(gq)
+        return (None, None, *grads)
+
+
+def masked_l2_sums(preds, target, n_channels):
+    """preds: list of [B,C,...], target [B,C or C+1,...] -> [len(preds)] masked sums of the per-position L2 error."""
+    _require_cuda('masked_l2_sums', target, *preds)
+    assert n_channels in (2, 3) and target.shape[1] in (n_channels, n_channels + 1) and not target.requires_grad
+    assert all(q.shape[1] == n_channels and q.shape[2:] == target.shape[2:] for q in preds)
+    return _MaskedL2Sums.apply(target.float().contiguous(), n_channels, *[q.float() for q in preds])
+
+
+# ------------------------------------------------------------------------------------------------
 # flow read-out of the inverse-depth-scaling wrapper (models/ids.py:36-67, camliraft.py:108-110)
 # ------------------------------------------------------------------------------------------------
 class _IdsFlow(torch.autograd.Function):

@@ -275,6 +275,21 @@ int camli_ids_flow_bwd(const float *pc1, const float *flow, const float *gout, c
                        const float *cy, float *gflow, float ratio_w, float ratio_h, float ratio_min,
                        float half_w, float half_h, int B, int N, void *stream);
 
+/*
+ * Masked end-point-error sum of one flow iterate and its adjoint (sequence losses, order 'l2-norm':
+ * models/losses.py:64-119 -- err = ||pred - target[:, :C]||_2 over the channels, averaged over the mask).
+ *   pred [B,C,P] (C = 2 or 3), target [B,target_channels,P] with target_channels = C (no mask) or C + 1
+ *   (mask = last channel > 0).
+ *   fwd: *sum_out += sum over the masked (b,p) of err  (float atomics; caller zero-fills; the caller
+ *        divides by the mask count and applies the iterate's weight).
+ *   bwd: gpred = coef[0] * (pred - target) / err on the mask, 0 elsewhere and where err == 0
+ *        (fully written); coef is a DEVICE scalar.
+ */
+int camli_masked_l2_fwd(const float *pred, const float *target, int target_channels, float *sum_out,
+                        int B, int C, int P, void *stream);
+int camli_masked_l2_bwd(const float *pred, const float *target, int target_channels, const float *coef,
+                        float *gpred, int B, int C, int P, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,3 +186,30 @@ def test_ids_flow_vs_oracle_golden_and_autograd(golden, oracle_lib):
     f = intr8.cpu().numpy()
     want = oracle_lib.ids_flow_fwd(big_pc1, flow0, origin, f[:, 0], f[:, 1], f[:, 2], *_ids_consts(g))
     assert np.allclose(res[0][0].cpu().numpy(), want, rtol=1e-6, atol=5e-5)
+
+
+@pytest.mark.parametrize('case', [(2, 2, (64, 81), True), (8, 2, (540, 960), True), (3, 3, (4097,), False), (2, 3, (2048,), True)],
+                         ids=lambda c: 'B%d_C%d_%s_%s' % (c[0], c[1], 'x'.join(map(str, c[2])), 'mask' if c[3] else 'nomask'))
+def test_sequence_loss_l2_hip_vs_composed(case):
+    """objectives._sequence_loss (order l2-norm) through camli_masked_l2_fwd/bwd vs the torch formulation of
+    models/losses.py:64-119: value and the gradient of every iterate."""
+    from types import SimpleNamespace
+    from camliflow_amd.cores import objectives, runtime
+    b, c, sp, masked = case
+    torch.manual_seed(sum(sp) + b)
+    target = torch.randn(b, c + (1 if masked else 0), *sp, device='cuda')
+    if masked:
+        target[:, c] = (torch.rand(b, *sp, device='cuda') > 0.3).float()
+    preds0 = [torch.randn(b, c, *sp, device='cuda') for _ in range(4)]
+    preds0[1][0, :, ..., :3] = target[0, :c, ..., :3]          # exact hits: zero error, zero gradient
+    cfgs = SimpleNamespace(gamma=0.8, order='l2-norm')
+    res = []
+    for backend in ('hip', 'composed'):
+        preds = [q.clone().requires_grad_(True) for q in preds0]
+        with runtime.use_backend(backend):
+            loss = objectives._sequence_loss(preds, target, cfgs, c)
+        loss.backward()
+        res.append((loss.item(), [q.grad for q in preds]))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    for g1, g2 in zip(res[0][1], res[1][1]):
+        assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-9), (g1 - g2).abs().max()
