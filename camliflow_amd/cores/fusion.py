@@ -65,6 +65,10 @@ class FusionAwareInterp(nn.Module):
             # the pixel -> nearest-point assignment and the score it induces depend only on
             # (uv, grid size), not on the features: one evaluation per pass (see _geometry)
             knn_indices, score = self._geometry(uv, grid, image_h, image_w)
+            if self.k == 1 and feat_3d.is_cuda and not feat_3d.requires_grad:
+                from ..csrc import fused          # gather * score in one launch (its own adjoint wrt the score)
+                final = fused.gather_scale(feat_3d, score[..., 0], knn_indices[..., 0])
+                return self.out_conv(final.reshape(bs, -1, image_h, image_w))
             knn_feat3d = batch_indexing(feat_3d, knn_indices)                       # [B,C,HW,k]
         else:
             knn_indices = _ops.k_nearest_neighbor(uv, grid, self.k)                 # [B,HW,k]

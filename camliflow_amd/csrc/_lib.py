@@ -55,6 +55,7 @@ PROTOTYPES = {
     "camli_weightnet_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int] + [_c_float_p] * 7
                             + [_int, _int, _int, _int, _int, _stream]),
     "camli_bilinear_sample_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
+    "camli_gather_scale_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_masked_l2_fwd": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _int, _int, _int, _stream]),
     "camli_masked_l2_bwd": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _int, _int, _int, _stream]),
     "camli_ids_flow_fwd": (_int, [_c_float_p] * 7 + [ctypes.c_float] * 5 + [_int, _int, _stream]),

@@ -407,6 +407,44 @@ def sk_mix(a, b, w, state):
 
 
 # ------------------------------------------------------------------------------------------------
+# nearest-point feature x score of FusionAwareInterp (models/clfm.py:70-76, k = 1)
+# ------------------------------------------------------------------------------------------------
+class _GatherScale(torch.autograd.Function):
+    @staticmethod
+    def _run(data, scale, idx):
+        lib = _lib.load()
+        bs, c, m = data.shape
+        p = scale.shape[2]
+        out = torch.empty_like(scale)
+        with _on_device(data):
+            _lib.launch('camli_gather_scale_fwd', lib.camli_gather_scale_fwd, data.data_ptr(), scale.data_ptr(),
+                        idx.data_ptr(), out.data_ptr(), bs, c, m, p, _stream_ptr(data),
+                        work=(12.0 * bs * c * p + 8.0 * bs * p, 'B'))
+        return out
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, scale, data, idx):
+        scale = scale.contiguous()
+        ctx.save_for_backward(data, idx)
+        return _GatherScale._run(data, scale, idx)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        data, idx = ctx.saved_tensors
+        return _GatherScale._run(data, gout.contiguous().float(), idx), None, None
+
+
+def gather_scale(data, scale, idx):
+    """scale [B,C,P] * data[B,C,M] gathered at idx [B,P] -> [B,C,P]; differentiable wrt scale only."""
+    _require_cuda('gather_scale', data, scale, idx)
+    assert not data.requires_grad and idx.dtype == torch.int64 and idx.shape == (scale.shape[0], scale.shape[2])
+    assert data.shape[:2] == scale.shape[:2]
+    return _GatherScale.apply(scale.float(), data.float().contiguous(), idx.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
 # masked end-point-error sums of the sequence losses (models/losses.py:64-119)
 # ------------------------------------------------------------------------------------------------
 class _MaskedL2Sums(torch.autograd.Function):

@@ -121,6 +121,28 @@ __global__ __launch_bounds__(256) void corr3d_gather_kernel(const float* __restr
 
 int grid_y_for(int C) { return C < 64 ? C : 64; }
 
+// out[b,c,p] = scale[b,c,p] * data[b,c,idx[b,p]]  -- the nearest-point feature of every pixel times its score
+// (FusionAwareInterp with k = 1, models/clfm.py:70-76: batch_indexing, multiply, sum over the singleton k axis:
+// three launches and two [B,C,HW] intermediates).  The same kernel is its own adjoint wrt `scale`
+// (gscale = gout * data[idx]); `data` is detached on this path (clfm.py:186).
+// grid (ceil(P/256), ceil(C/4), B), block 256: lanes along p, four channels per thread share the index.
+__global__ __launch_bounds__(256) void gather_scale_kernel(const float* __restrict__ data, const float* __restrict__ scale,
+                                                           const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                           int C, int M, int P) {
+    const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.z;
+    if (p >= P) return;
+    const int m = (int)idx[(size_t)b * P + p];
+    const int c0 = blockIdx.y * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + j;
+        if (c < C) {
+            const size_t row = (size_t)b * C + c;
+            out[row * P + p] = scale[row * P + p] * data[row * M + m];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int camli_gather_cf_fwd(const float* data, const int64_t* idx, float* out, int B, int C, int M, int I,
@@ -215,4 +237,17 @@ extern "C" int camli_corr3d_gather_bwd(const float* gout, const int64_t* knn, fl
     hipLaunchKernelGGL((corr3d_gather_kernel<true>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        nullptr, nullptr, gcost, knn, const_cast<float*>(gout), B, N, M, k);
     return camli_check_launch("camli_corr3d_gather_bwd");
+}
+
+extern "C" int camli_gather_scale_fwd(const float* data, const float* scale, const int64_t* idx, float* out, int B, int C,
+                                      int M, int P, void* stream) {
+    if (B == 0 || P == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
+    if (!data || !scale || !idx || !out) { camli_set_error("camli_gather_scale_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || C < 1 || M < 1 || P < 0 || B > 65535 || C > 4 * 65535) {
+        camli_set_error("camli_gather_scale_fwd: bad shape B=%d C=%d M=%d P=%d", B, C, M, P);
+        return CAMLI_EINVAL;
+    }
+    hipLaunchKernelGGL(gather_scale_kernel, dim3(camli_divup(P, 256), camli_divup(C, 4), B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), data, scale, idx, out, C, M, P);
+    return camli_check_launch("camli_gather_scale_fwd");
 }

@@ -290,6 +290,15 @@ int camli_masked_l2_fwd(const float *pred, const float *target, int target_chann
 int camli_masked_l2_bwd(const float *pred, const float *target, int target_channels, const float *coef,
                         float *gpred, int B, int C, int P, void *stream);
 
+/*
+ * out[b,c,p] = scale[b,c,p] * data[b,c,idx[b,p]]: nearest-point feature of every pixel times its score
+ * (FusionAwareInterp with k = 1, models/clfm.py:70-76).  data [B,C,M], scale/out [B,C,P], idx int64 [B,P]
+ * (values in [0,M)).  Linear in `scale` with the same kernel as adjoint (gscale = gout * data[idx]);
+ * `data` is detached at the call site (clfm.py:186).
+ */
+int camli_gather_scale_fwd(const float *data, const float *scale, const int64_t *idx, float *out,
+                           int B, int C, int M, int P, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,3 +213,20 @@ def test_sequence_loss_l2_hip_vs_composed(case):
     assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
     for g1, g2 in zip(res[0][1], res[1][1]):
         assert torch.allclose(g1, g2, rtol=1e-4, atol=1e-9), (g1 - g2).abs().max()
+
+
+@pytest.mark.parametrize('case', [(8, 128, 2048, 8160), (2, 7, 50, 301), (1, 64, 16384, 7332)], ids=lambda c: 'B%d_C%d_M%d_P%d' % c)
+def test_gather_scale_vs_torch(case):
+    """camli_gather_scale_fwd and its use as the score adjoint vs gather * score in torch (exact: one product)."""
+    from camliflow_amd.csrc import fused
+    b, c, m, p = case
+    torch.manual_seed(sum(case))
+    data = torch.randn(b, c, m, device='cuda')
+    score = torch.rand(b, c, p, device='cuda').requires_grad_(True)
+    idx = torch.randint(0, m, (b, p), device='cuda')
+    gout = torch.randn(b, c, p, device='cuda')
+    out = fused.gather_scale(data, score, idx)
+    out.backward(gout)
+    gathered = torch.gather(data, 2, idx[:, None, :].expand(-1, c, -1))
+    assert torch.equal(out.detach(), score.detach() * gathered)
+    assert torch.equal(score.grad, gout * gathered)
