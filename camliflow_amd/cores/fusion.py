@@ -139,7 +139,7 @@ class SKFusion(nn.Module):
             state = fused.SkState()
             squeezed = fused.sk_pool(feat_2d, feat_3d, state)
             w_mid, w_out = self.fc_mid[0].weight, self.fc_out[0].weight
-            if w_mid.shape[1] <= 256 and w_mid.shape[0] <= 128 and not torch.is_autocast_enabled():
+            if w_mid.shape[1] <= 512 and w_mid.shape[0] <= 256 and not torch.is_autocast_enabled():
                 weight = fused.sk_gate(squeezed, w_mid, w_out)           # the whole gate in one launch each way
             else:
                 weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)

@@ -248,7 +248,7 @@ int camli_sk_mix_bwd_x(const float *g, const float *w, const float *gs, float *g
 
 /*
  * The SKFusion gate on [B,C] vectors (models/clfm.py:183-184,199-203): m = relu(s Wmid^T),
- * z = sigmoid(m Wout^T), w[b,c,:] = softmax(z[b,2c], z[b,2c+1]).  C <= 256, R <= 128.
+ * z = sigmoid(m Wout^T), w[b,c,:] = softmax(z[b,2c], z[b,2c+1]).  C <= 512, R <= 256.
  *   s [B,C], wmid [R,C], wout [2C,R];  m [B,R], z [B,2C], w [B,C,2] (all fully written; m and z are kept
  *   for the backward).
  *   bwd: gw [B,C,2] -> gs [B,C] (fully written), gwmid [R,C] += , gwout [2C,R] += (float atomics, one
