@@ -29,10 +29,10 @@ for name in SCOPES:
     m.forward = wrapped
 
 for _ in range(2):
-    bench.train_step(model, model, opt, batch)
+    bench.train_step(model, opt, batch)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    bench.train_step(model, model, opt, batch)
+    bench.train_step(model, opt, batch)
     torch.cuda.synchronize()
 
 # attribute each kernel to the innermost enclosing SCOPE range of its launching op (forward) ; backward ops carry
