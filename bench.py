@@ -1,17 +1,31 @@
 """Headline benchmark: CamLiRAFT training step (forward + sequence losses + backward + clip + AdamW)
 on synthetic FlyingThings3D-shaped inputs, 960x540 images + 8192 points (BASELINE.json configs[2]).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config camliraft|camlipwc|kitti|eval]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-One process per GPU, batch-dimension data parallel (SyncBatchNorm + one flat-bucket gradient
-all-reduce over RCCL/xGMI per step); per-GPU batch is fixed, so the scaling is weak.  Rank 0 prints ONE JSON line.  `value` = global frame-pairs per second with the
-inputs resident in HBM before the timed region.
+One process per GPU, batch-dimension data parallel (SyncBatchNorm + one flat-bucket gradient all-reduce over
+RCCL/xGMI per step); per-GPU batch is fixed, so the scaling is weak.  Rank 0 prints ONE JSON line.  `value` =
+global frame-pairs per second with the inputs resident in HBM before the timed region.
+
+Besides the driver contract the line carries (N = 1, default config only):
+  parity        EPE2D / EPE3D of the HIP path against the CPU port (this repo's cores driven by the C oracle
+                operators) on one sample of the SAME workload with shared post-IDS core inputs, plus bit-equality
+                of the FPS / KNN indices; the run FAILS when |dEPE| > 1e-4 or an index differs
+  roofline      the lowest-fraction north-star kernel with >= 1 % of the step's time, in situ (HIP events on the
+                launch stream over the timed region)
+  roofline_rows one row per north-star kernel measured alone on the idle GPU (tools/kernel_bench.py)
+  cpu_baseline  the CPU port timed on the host cores: 1 warm-up + 2 repetitions at all cores, 1 at 8 threads
+  census        fused launches vs composed fall-backs under the 'hip' backend (cores/runtime.py)
+
+Other configurations (own bench lines, not the headline): --config camlipwc (configs[1]), kitti (configs[4],
+bf16 autocast, 32 iterations), eval (batch 8, 20 iterations, inference).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,14 +35,37 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 from types import SimpleNamespace as NS  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
-# Every C-ABI launch of the timed region is bracketed by HIP events on its launch stream and carries
-# its algorithmic work.  The roofline object reports the HBM-bound entry point
-# with the largest total time; KNN (VALU-bound) and FPS (latency-bound) are listed beside it.
+# entry point -> roofline kind, for the kernels north_star names.  Glue kernels either side of the path
+# (bias_act, gru_*, sk_*, ids_*, masked_l2, convex_upsample) are listed in `hip_kernels` but never selected.
+NORTH_STAR = {
+    'camli_corr2d_fwd': 'hbm', 'camli_corr2d_bwd': 'hbm',
+    'camli_allpairs_build_fwd': 'mfma', 'camli_allpairs_build_bwd': 'mfma', 'camli_allpairs_fold_bwd': 'hbm',
+    'camli_allpairs_lookup_fwd': 'hbm', 'camli_allpairs_lookup_bwd': 'hbm',
+    'camli_knn': 'valu', 'camli_fps': 'fps',
+    'camli_gather_cf_fwd': 'hbm', 'camli_gather_cf_bwd': 'hbm',
+    'camli_pointconv_mix_fwd': 'hbm', 'camli_pointconv_mix_bwd': 'hbm',
+    'camli_pointconv_dw_fwd': 'hbm', 'camli_pointconv_dw_bwd': 'hbm', 'camli_pointconv_dw_expand': 'hbm',
+    'camli_weightnet_fwd': 'hbm', 'camli_weightnet_bwd': 'mfma',
+    'camli_knn_interp_fwd': 'hbm', 'camli_knn_interp_bwd': 'hbm', 'camli_knn_interp_bwd_xyz': 'hbm',
+    'camli_corr3d_gather_fwd': 'hbm', 'camli_corr3d_gather_bwd': 'hbm',
+    'camli_pwc3d_pair_fwd': 'hbm', 'camli_pwc3d_pair_bwd': 'hbm', 'camli_gather_wsum_fwd': 'hbm', 'camli_gather_wsum_bwd': 'hbm',
+}
+MFMA_F32_PEAK_TFLOPS = 157.3
+VALU_PAIR_PEAK_G = 7865.0
+
+CONFIGS = {
+    # name: (model, height, width, points, iters, batch, mode, autocast dtype, BASELINE config it stands for)
+    'camliraft': ('camliraft', 540, 960, 8192, 12, 8, 'train', None, 'configs[2]'),
+    'camlipwc': ('camlipwc', 540, 960, 8192, 0, 1, 'train', None, 'configs[1]'),
+    'kitti': ('camliraft', 375, 1242, 16384, 32, 1, 'train', torch.bfloat16, 'configs[4]'),
+    'eval': ('camliraft', 540, 960, 8192, 20, 8, 'eval', None, 'SURVEY 8f rank 1 (eval_things.py: batch 8, n_iters_eval 20)'),
+}
 
 
 def model_cfg(n_iters):
@@ -38,12 +75,20 @@ def model_cfg(n_iters):
               loss3d=NS(gamma=0.8, order='l2-norm'))
 
 
-def synthetic_batch(b, h, w, n_points, seed):
+def build_model(args):
+    from camliflow_amd.cores import CamLiPWC, CamLiRAFT
+    if args.model == 'camlipwc':
+        from modelutils import camlipwc_cfg
+        return CamLiPWC(camlipwc_cfg())
+    return CamLiRAFT(model_cfg(args.iters))
+
+
+def synthetic_batch(b, h, w, n_points, seed, kitti=False):
     """uint8-valued images, points whose projections land inside the image, small flows."""
     g = torch.Generator().manual_seed(seed)
-    f, cx, cy = 1050.0, 479.5, 269.5
+    f, cx, cy, zmax = (721.5, 609.6, 172.9, 90.0) if kitti else (1050.0, 479.5, 269.5, 35.0)
     images = torch.randint(0, 256, (b, 6, h, w), generator=g).float()
-    z = torch.rand(b, n_points, generator=g) * 30.0 + 5.0
+    z = torch.rand(b, n_points, generator=g) * (zmax - 5.0) + 5.0
     u = torch.rand(b, n_points, generator=g) * (w - 1)
     v = torch.rand(b, n_points, generator=g) * (h - 1)
     pc1 = torch.stack([(u - cx) * z / f, (v - cy) * z / f, z], dim=1)
@@ -56,21 +101,20 @@ def synthetic_batch(b, h, w, n_points, seed):
 
 class GraphedStep:
     """The whole training step (forward, losses, backward, clip, AdamW) captured once into a HIP graph
-    and replayed: removes the ~16k kernel launches per step from the host.  Both HIP streams of the
-    two-lane execution are captured (the side stream forks from and joins the capture stream).
-    Single GPU only (collectives stay outside graphs here)."""
+    and replayed.  Both HIP streams of the two-lane execution are captured (the side stream forks from and joins
+    the capture stream).  Single GPU only (collectives stay outside graphs here)."""
 
-    def __init__(self, model, optimizer, batch, warmup=3):
+    def __init__(self, step_fn, warmup=3):
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                train_step(model, optimizer, batch)
+                step_fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.cuda.graph(self.graph):
-            self.loss = train_step(model, optimizer, batch)
+            self.loss = step_fn()
 
     def __call__(self):
         self.graph.replay()
@@ -102,9 +146,14 @@ def allreduce_gradients(model, world, force=False):
         g.copy_(f)
 
 
-def train_step(model, optimizer, batch, world=1, force_dist=False):
-    model(batch)
-    loss = model.get_loss()
+def train_step(model, optimizer, batch, world=1, force_dist=False, autocast=None):
+    if autocast is not None:
+        with torch.autocast('cuda', dtype=autocast):
+            model(batch)
+            loss = model.get_loss()
+    else:
+        model(batch)
+        loss = model.get_loss()
     loss.backward()
     allreduce_gradients(model, world, force_dist)
     torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
@@ -114,23 +163,124 @@ def train_step(model, optimizer, batch, world=1, force_dist=False):
     return loss
 
 
-def cpu_baseline(args):
-    """The CPU restatement path (this repo's cores driven by the C oracle operators) timed on the
-    host cores: ONE training step at batch 1 of the same workload.  Reported, not the target."""
+def eval_step(model, batch, autocast=None):
+    with torch.no_grad():
+        if autocast is not None:
+            with torch.autocast('cuda', dtype=autocast):
+                out = model({k: v for k, v in batch.items() if k not in ('flow_2d', 'flow_3d')})
+        else:
+            out = model({k: v for k, v in batch.items() if k not in ('flow_2d', 'flow_3d')})
+    return out['flow_2d'].sum()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU port: timing (cpu_baseline) and the parity reference
+# ------------------------------------------------------------------------------------------------------------
+def _epe(pred, target):
+    return torch.linalg.norm(pred - target, dim=1).mean().item()
+
+
+def _cpu_model_name():
+    try:
+        out = subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            if line.startswith('Model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline_and_reference(args, state_dict):
+    """The CPU restatement path (this repo's cores driven by the C oracle operators) on the host cores: one
+    sample (batch 1) of the same workload.  1 warm-up + 2 timed training steps at all cores, then 1 at 8 threads
+    (the thread count of the in-container reference timing).  The warm-up step's forward is also
+    the parity reference: it returns the final flows of that sample.  Reported, not the target."""
     from modelutils import oracle_boundary
-    from camliflow_amd.cores import CamLiRAFT
-    threads = torch.get_num_threads()
-    torch.manual_seed(0)
-    model = CamLiRAFT(model_cfg(args.iters)).train()
+    all_threads = torch.get_num_threads()
+    model = build_model(args).train()
+    model.load_state_dict(state_dict)
     opt = make_optimizer(model)
-    batch = synthetic_batch(1, args.height, args.width, args.points, seed=1)
+    batch = synthetic_batch(1, args.height, args.width, args.points, seed=1, kitti=args.config == 'kitti')
+    times = {}
+    ref = None
     with oracle_boundary():
-        t0 = time.perf_counter()
-        train_step(model, opt, batch)
-        dt = time.perf_counter() - t0
-    return {'value': 1.0 / dt, 'unit': 'frame-pairs/s', 'cores': threads, 'kind': 'port',
-            'sample': '1 training step (fwd+bwd+AdamW), batch 1, %dx%d + %d pts, %d iters, %.1f s, cold'
-                      % (args.width, args.height, args.points, args.iters, dt)}
+        for label, threads, reps in (('warmup', all_threads, 1), ('all', all_threads, 2), ('t8', min(8, all_threads), 1)):
+            torch.set_num_threads(threads)
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                if ref is None:       # the very first step: weights == state_dict, keep its forward as the reference
+                    out = model(batch)
+                    ref = {k: v.detach().clone() for k, v in out.items()}
+                    loss = model.get_loss()
+                    loss.backward()
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+                    opt.step()
+                    opt.zero_grad(set_to_none=True)
+                    model.clear_metrics()
+                else:
+                    train_step(model, opt, batch)
+                times.setdefault(label, []).append(time.perf_counter() - t0)
+    torch.set_num_threads(all_threads)
+    best = min(times['all'])
+    base = {'value': round(1.0 / best, 5), 'unit': 'frame-pairs/s', 'cores': all_threads, 'kind': 'port',
+            'sample': '1 sample (batch 1) of the same training step (fwd+bwd+clip+AdamW), %dx%d + %d pts, %d iters: '
+                      '1 warm-up (%.1f s) + 2 timed steps at %d threads (%.1f / %.1f s, best taken), 1 at 8 threads'
+                      % (args.width, args.height, args.points, args.iters, times['warmup'][0], all_threads,
+                         times['all'][0], times['all'][1]),
+            'value_8_threads': round(1.0 / times['t8'][0], 5), 'cpu_model': _cpu_model_name(),
+            'os_cpu_count': os.cpu_count()}
+    return base, batch, ref
+
+
+def parity_check(args, state_dict, batch, ref, device):
+    """The HIP path on the sample the CPU port just ran, with SHARED post-IDS core inputs (the IDS transform uses
+    log / divide, which differ in the last ulp between CPU and GPU, and FPS -- 4096 chained arg-max decisions -- is
+    only reproducible on bit-identical inputs; tests/test_model_gpu.py does the same).  EPE as in eval_things.py:62,88."""
+    import numpy as np
+    import oracle
+    from camliflow_amd import csrc
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.camliraft import _IMAGENET_MEAN, _IMAGENET_STD, _camera_pair
+    from camliflow_amd.cores.geometry import InputPadder, flows_paral2persp, persp2paral
+    model = build_model(args)
+    model.load_state_dict(state_dict)
+    model = model.to(device).train()
+    images = batch['images'].float()
+    padder = InputPadder(images.shape, x=8)
+    image1, image2 = padder.pad(images[:, :3], images[:, 3:])
+    mean = torch.tensor(_IMAGENET_MEAN).reshape(1, 3, 1, 1)
+    std = torch.tensor(_IMAGENET_STD).reshape(1, 3, 1, 1)
+    persp, paral = _camera_pair(image1.shape[-2], image1.shape[-1], batch['intrinsics'])
+    pc1 = persp2paral(batch['pcs'][:, :3], persp, paral)          # on the CPU: identical to what the CPU port saw
+    pc2 = persp2paral(batch['pcs'][:, 3:], persp, paral)
+    with torch.no_grad(), runtime.use_backend('hip'):
+        f2d, f3d = model.core(((image1 - mean) / std).to(device), ((image2 - mean) / std).to(device),
+                              pc1.to(device), pc2.to(device), paral)
+        flow_2d = padder.unpad(f2d[-1]).cpu()
+        persp_cpu = {k: v for k, v in persp.items()}
+        flow_3d = flows_paral2persp(pc1, [f3d[-1].cpu()], persp_cpu, paral)[0]
+    tgt2d, tgt3d = batch['flow_2d'][:, :2], batch['flow_3d'][:, :3]
+    epe2d_cpu, epe2d_gpu = _epe(ref['flow_2d'], tgt2d), _epe(flow_2d, tgt2d)
+    epe3d_cpu, epe3d_gpu = _epe(ref['flow_3d'], tgt3d), _epe(flow_3d, tgt3d)
+    # index parity on the sample's own (IDS-transformed) clouds
+    both = torch.cat([pc1, pc2], dim=0).transpose(1, 2).contiguous()
+    picks = csrc.furthest_point_sampling(both.to(device), 4096).cpu().numpy()
+    fps_equal = bool(np.array_equal(picks, oracle.fps(both.numpy(), 4096)))
+    lvl1 = torch.gather(both, 1, torch.from_numpy(picks)[:, :, None].expand(-1, -1, 3)).contiguous()
+    lvl2 = lvl1[:, :2048].contiguous()
+    knn_equal = True
+    for inp, qry, k in ((both, lvl1, 16), (lvl1, lvl2, 16), (lvl2, lvl2, 32), (lvl2, both, 3)):
+        got = csrc.k_nearest_neighbor(inp.to(device), qry.to(device), k).cpu().numpy()
+        knn_equal = knn_equal and bool(np.array_equal(got, oracle.knn(inp.numpy(), qry.numpy(), k)))
+    res = {'epe2d_cpu': round(epe2d_cpu, 6), 'epe2d_gpu': round(epe2d_gpu, 6), 'epe2d_abs_diff': abs(epe2d_cpu - epe2d_gpu),
+           'epe3d_cpu': round(epe3d_cpu, 6), 'epe3d_gpu': round(epe3d_gpu, 6), 'epe3d_abs_diff': abs(epe3d_cpu - epe3d_gpu),
+           'flow2d_mean_diff_px': _epe(flow_2d, ref['flow_2d']), 'flow3d_mean_diff': _epe(flow_3d, ref['flow_3d']),
+           'fps_equal': fps_equal, 'knn_equal': knn_equal, 'tolerance': 1e-4,
+           'sample': 'batch 1, %dx%d + %d pts, %d iters, train-mode forward, fp32, shared post-IDS core inputs; '
+                     'reference = CPU port (cores + C oracle operators)' % (args.width, args.height, args.points, args.iters)}
+    res['ok'] = bool(res['epe2d_abs_diff'] <= 1e-4 and res['epe3d_abs_diff'] <= 1e-4 and fps_equal and knn_equal)
+    return res
 
 
 def pmc_traffic(entry_point, args):
@@ -147,48 +297,42 @@ def pmc_traffic(entry_point, args):
     return None
 
 
-def isolated_dw_fwd(batch, device):
-    """The roofline kernel alone on an idle GPU (its largest shape in the step: C=128, k=32,
-    2048 points): context for the in-situ figure, which is measured while the image branch's
-    convolutions share the chip with it on another stream."""
-    from camliflow_amd.csrc import fused
-    c, n, k = 128, 2048, 32
-    feat = torch.randn(batch, c, n, device=device)
-    shared = fused.SharedSetConvWeights(torch.rand(batch, c, n, k, device=device))
-    idx = torch.randint(0, n, (batch, n, 32), device=device)
-    for _ in range(3):
-        fused.pointconv_dw(feat, shared, idx, k)
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    start.record()
-    for _ in range(reps):
-        fused.pointconv_dw(feat, shared, idx, k)
-    end.record()
-    torch.cuda.synchronize()
-    us = start.elapsed_time(end) / reps * 1e3
-    byt = 4.0 * batch * c * n * k + 4.0 * batch * c * n + 8.0 * batch * n * k + 5.0 * batch * c * n
-    return {'shape': 'B%d C%d N%d k%d, inference form' % (batch, c, n, k), 'avg_launch_us': round(us, 2),
-            'achieved': round(byt / us / 1e3, 1), 'frac': round(byt / us / 1e3 / HBM_PEAK_GBS, 4)}
-
-
-def roofline_report(summary, steps, args):
-    """summary: _lib.TIMER.summary().  Returns (roofline object, per-kernel table)."""
+def roofline_report(summary, steps, args, step_ms):
+    """summary: _lib.TIMER.summary().  Returns (roofline object, per-kernel table).  The roofline kernel is the
+    north-star entry point with the LOWEST fraction of its bound among those holding >= 1 % of the step's time."""
     table = {}
+    fracs = {}
     for name, rec in sorted(summary.items(), key=lambda kv: -kv[1]['total_ms']):
-        rate = rec['work'] / (rec['total_ms'] * 1e-3) if rec['total_ms'] > 0 else 0.0
-        table[name] = {'launches_per_step': round(rec['launches'] / steps, 1),
-                       'ms_per_step': round(rec['total_ms'] / steps, 3),
-                       'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
-                       'rate': round(rate / 1e9, 2), 'rate_unit': 'G' + rec['unit'] + '/s'}
-    hbm = [(n, r) for n, r in summary.items() if r['unit'] == 'B' and r['total_ms'] > 0]
-    if not hbm:
+        secs = rec['total_ms'] * 1e-3
+        rate = rec['work'] / secs if secs > 0 else 0.0
+        entry = {'launches_per_step': round(rec['launches'] / steps, 1), 'ms_per_step': round(rec['total_ms'] / steps, 3),
+                 'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
+                 'rate': round(rate / 1e9, 2), 'rate_unit': 'G' + rec['unit'] + '/s'}
+        kind = NORTH_STAR.get(name)
+        if kind == 'hbm':
+            entry['frac'] = round(rate / 1e9 / HBM_PEAK_GBS, 4)
+        elif kind == 'mfma' and rec.get('flop', 0) > 0:
+            entry['tflops'] = round(rec['flop'] / secs / 1e12, 2)
+            entry['frac'] = round(entry['tflops'] / MFMA_F32_PEAK_TFLOPS, 4)
+        elif kind == 'valu':
+            entry['frac'] = round(rate / 1e9 / VALU_PAIR_PEAK_G, 4)
+        if 'frac' in entry and kind in ('hbm', 'mfma') and entry['ms_per_step'] >= 0.01 * step_ms:
+            fracs[name] = entry['frac']
+        table[name] = entry
+    if not fracs:
         return None, table
-    name, rec = max(hbm, key=lambda kv: kv[1]['total_ms'])
-    achieved = rec['work'] / (rec['total_ms'] * 1e-3) / 1e9
-    roofline = {'kernel': name, 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(name, args),
-                'launches': rec['launches'], 'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
-                'algorithmic_bytes_per_launch': round(rec['work'] / rec['launches'])}
+    name = min(fracs, key=fracs.get)
+    rec = summary[name]
+    secs = rec['total_ms'] * 1e-3
+    if NORTH_STAR[name] == 'hbm':
+        achieved, peak, unit, per_launch = rec['work'] / secs / 1e9, HBM_PEAK_GBS, 'GB/s', rec['work'] / rec['launches']
+    else:
+        achieved, peak, unit, per_launch = rec['flop'] / secs / 1e12, MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', rec['flop'] / rec['launches']
+    roofline = {'kernel': name, 'bound': NORTH_STAR[name], 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
+                'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(name, args), 'launches': rec['launches'],
+                'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
+                'algorithmic_work_per_launch': round(per_launch), 'measured': 'in situ, HIP events on the launch stream over the timed region',
+                'selection': 'lowest fraction among the north-star kernels with >= 1 % of the step time'}
     return roofline, table
 
 
@@ -197,14 +341,23 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=8, help='per-GPU batch (configs[2]: 8)')
-    ap.add_argument('--iters', type=int, default=12)
-    ap.add_argument('--height', type=int, default=540)
-    ap.add_argument('--width', type=int, default=960)
-    ap.add_argument('--points', type=int, default=8192)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='camliraft')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (configs[2]: 8; configs[3] would be 4)')
+    ap.add_argument('--iters', type=int, default=None)
+    ap.add_argument('--height', type=int, default=None)
+    ap.add_argument('--width', type=int, default=None)
+    ap.add_argument('--points', type=int, default=None)
+    ap.add_argument('--mode', choices=['train', 'eval'], default=None)
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU port (cpu_baseline AND parity)')
+    ap.add_argument('--no-isolated', action='store_true', help='skip the isolated per-kernel rows (roofline_rows)')
     ap.add_argument('--graph', action='store_true', help='capture the whole training step in one HIP graph (single GPU)')
     args = ap.parse_args()
+    model_name, h, w, pts, iters, batch, mode, autocast, stands_for = CONFIGS[args.config]
+    args.model = model_name
+    args.height, args.width = args.height or h, args.width or w
+    args.points, args.mode = args.points or pts, args.mode or mode
+    args.iters = iters if args.iters is None else args.iters
+    args.batch = args.batch or batch
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -223,39 +376,47 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
 
-    from camliflow_amd.cores import CamLiRAFT, runtime
+    from camliflow_amd.cores import runtime
     from camliflow_amd.csrc import _lib
     _lib.load()
     runtime.set_backend('hip')
     runtime.set_overlap(os.environ.get('CAMLI_OVERLAP', '1') == '1')
     # parameter gradients of the iteration-shared 1x1 convolutions / biases accumulate inside their kernels and
-    # reach .grad once per backward() (cores/runtime.py): 119 parameters, ~1,200 fewer add / sum launches per
-    # step; same-box A/B at batch 8: 306.0 vs 308.0 ms (3 runs each), 162 vs 180 ms at batch 2
+    # reach .grad once per backward() (cores/runtime.py)
     runtime.set_deferred_param_grads(os.environ.get('CAMLI_DEFER_GRADS', '1') == '1')
     torch.backends.cudnn.benchmark = os.environ.get('CAMLI_MIOPEN_FIND', '0') == '1'
 
     torch.manual_seed(0)
-    raw_model = CamLiRAFT(model_cfg(args.iters))
-    if dist_on:
+    raw_model = build_model(args)
+    state_dict = {k: v.clone() for k, v in raw_model.state_dict().items()}      # the parity legs start from these weights
+    if dist_on and args.mode == 'train':
         raw_model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(raw_model)
-    model = raw_model.to(device).train()
+    model = raw_model.to(device)
+    model = model.train() if args.mode == 'train' else model.eval()
     if dist_on:   # identical replicas: broadcast rank 0's parameters and buffers once
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
     use_graph = args.graph and world == 1
-    optimizer = make_optimizer(model, capturable=use_graph)
+    optimizer = make_optimizer(model, capturable=use_graph) if args.mode == 'train' else None
     batch = {k: v.to(device) for k, v in synthetic_batch(args.batch, args.height, args.width, args.points,
-                                                         seed=100 + rank).items()}
+                                                         seed=100 + rank, kitti=args.config == 'kitti').items()}
+
+    def step():
+        if args.mode == 'train':
+            return train_step(model, optimizer, batch, world, dist_on, autocast)
+        return eval_step(model, batch, autocast)
 
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    graphed = GraphedStep(model, optimizer, batch) if use_graph else None
+    graphed = GraphedStep(step) if use_graph else None
     for _ in range(args.warmup):
-        graphed() if graphed else train_step(model, optimizer, batch, world, dist_on)
+        graphed() if graphed else step()
     barrier()
+    runtime.set_census(True)
+    runtime.reset_census()
     _lib.TIMER.reset()
     _lib.TIMER.only = None
     _lib.TIMER.enabled = graphed is None and os.environ.get('CAMLI_NO_TIMER') != '1'   # events cannot be recorded through a graph replay
@@ -263,42 +424,62 @@ def main():
     host_s = 0.0
     for _ in range(args.steps):
         h0 = time.perf_counter()
-        loss = graphed() if graphed else train_step(model, optimizer, batch, world, dist_on)
+        loss = graphed() if graphed else step()
         host_s += time.perf_counter() - h0
     barrier()
     elapsed = time.perf_counter() - t0
     _lib.TIMER.enabled = False
+    census = runtime.census()
+    runtime.set_census(False)
     if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    failed = False
     if rank == 0:
         global_batch = args.batch * world
-        roofline, kernel_table = roofline_report(_lib.TIMER.summary(), args.steps, args)
-        if roofline and roofline['kernel'] == 'camli_pointconv_dw_fwd':
-            roofline['isolated'] = isolated_dw_fwd(args.batch, device)
+        step_ms = elapsed / args.steps * 1e3
+        roofline, kernel_table = roofline_report(_lib.TIMER.summary(), args.steps, args, step_ms)
+        what = {'train': 'training step (fwd + losses + bwd + clip + AdamW)', 'eval': 'inference forward'}[args.mode]
+        metric = 'frame-pairs/sec (fwd+bwd) 960x540 + 8192 pts, CamLiRAFT' if args.config == 'camliraft' else \
+                 'frame-pairs/sec, %s %s, %dx%d + %d pts' % (args.model, args.mode, args.width, args.height, args.points)
         line = {
-            'metric': 'frame-pairs/sec (fwd+bwd) 960x540 + 8192 pts, CamLiRAFT',
+            'metric': metric,
             'value': round(global_batch * args.steps / elapsed, 4),
             'unit': 'frame-pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'CamLiRAFT training step (fwd + sequence losses + bwd + clip + AdamW), '
-                                   '%dx%d + %d pts, %d GRU iters, batch %d per GPU (BASELINE configs[2])'
-                                   % (args.width, args.height, args.points, args.iters, args.batch),
+            'ms_per_step': round(step_ms, 2), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16' if autocast is not None else 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s %s, %dx%d + %d pts, %s, batch %d per GPU (BASELINE %s)'
+                                   % (args.model, what, args.width, args.height, args.points,
+                                      ('%d GRU iters' % args.iters) if args.iters else 'coarse-to-fine pyramid',
+                                      args.batch, stands_for),
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hip_graph': bool(graphed),
                        'loss': round(float(loss.detach()), 4),
-                       'host_enqueue_ms_per_step': round(host_s / args.steps * 1e3, 1)},
+                       'host_enqueue_ms_per_step': round(host_s / args.steps * 1e3, 1),
+                       'hip_launches_per_step': round(sum(census['fused'].values()) / args.steps, 1)},
             'roofline': roofline,
             'hip_kernels': kernel_table,
+            'census': {'fused_launches_per_step': {k: round(v / args.steps, 1) for k, v in sorted(census['fused'].items())},
+                       'composed_calls_per_step': {k: round(v / args.steps, 1) for k, v in sorted(census['composed'].items())}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args)
+        if world == 1 and not args.no_isolated and args.config == 'camliraft':
+            import kernel_bench
+            line['roofline_rows'] = kernel_bench.run(batch=args.batch, reps=5)
+        if world == 1 and not args.no_cpu_baseline and args.model == 'camliraft':
+            # free the bench model before the parity model is built
+            del optimizer, graphed
+            base, sample, ref = cpu_baseline_and_reference(args, state_dict)
+            line['cpu_baseline'] = base
+            if autocast is None:
+                line['parity'] = parity_check(args, state_dict, sample, ref, device)
+                failed = not line['parity']['ok']
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit('parity check FAILED: %s' % json.dumps(line['parity']))
 
 
 if __name__ == '__main__':

@@ -84,9 +84,10 @@ class _ConvNormAct(nn.Module):
 
 
 def epilogue_ok(x):
-    """The fused epilogue works in place on an fp32 convolution output: product path, GPU tensor, and
-    not under autocast (where the convolution itself yields bf16/fp16)."""
-    return runtime.fused() and x.is_cuda and not torch.is_autocast_enabled()
+    """The fused epilogue runs on the product path for GPU tensors.  Under autocast the convolution
+    yields bf16 / fp16: ``conv_bias_act`` then widens its output to fp32 first (the reference's
+    activations stay in the low precision there; this path is at least as precise)."""
+    return runtime.fused() and x.is_cuda
 
 
 class _PointwiseConv(torch.autograd.Function):
@@ -138,6 +139,8 @@ def conv_bias_act(conv, x, act):
         y = _PointwiseConv.apply(x, conv.weight)
     else:
         y = conv._conv_forward(x, conv.weight, None)
+    if y.dtype != torch.float32:      # autocast: a fresh fp32 copy the epilogue may overwrite in place
+        y = y.float()
     if conv.bias is None:
         return y if act is None else fused.bias_act(y, torch.zeros(y.shape[1], device=y.device), act)
     return fused.bias_act(y, conv.bias, act)

@@ -133,15 +133,18 @@ class SKFusion(nn.Module):
     def forward(self, feat_2d, feat_3d):
         bs = feat_2d.shape[0]
         feat_2d, feat_3d = self.align1(feat_2d), self.align2(feat_3d)
+        if runtime.fused() and feat_2d.is_cuda and bs * feat_2d.shape[1] > 65535:
+            runtime.fallback('SKFusion', 'B*C = %d exceeds the kernels\' grid limit 65535' % (bs * feat_2d.shape[1]))
         if runtime.fused() and feat_2d.is_cuda and bs * feat_2d.shape[1] <= 65535:
             # pooled sum, mix and both adjoints as four streaming kernels (camli_sk_*); the gate stays in torch
             from ..csrc import fused
             state = fused.SkState()
             squeezed = fused.sk_pool(feat_2d, feat_3d, state)
             w_mid, w_out = self.fc_mid[0].weight, self.fc_out[0].weight
-            if w_mid.shape[1] <= 512 and w_mid.shape[0] <= 256 and not torch.is_autocast_enabled():
+            if w_mid.shape[1] <= 512 and w_mid.shape[0] <= 256:
                 weight = fused.sk_gate(squeezed, w_mid, w_out)           # the whole gate in one launch each way
             else:
+                runtime.fallback('sk_gate', 'C=%d R=%d outside the gate kernel (C<=512, R<=256)' % (w_mid.shape[1], w_mid.shape[0]))
                 weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
             return fused.sk_mix(feat_2d, feat_3d, weight, state)
         squeezed = self.avg_pool(feat_2d + feat_3d).reshape(bs, -1)

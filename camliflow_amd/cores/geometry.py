@@ -37,13 +37,17 @@ def batch_indexing(batched_data, batched_indices, layout='channel_first'):
     bs = batched_data.shape[0]
     idx_shape = list(batched_indices.shape[1:])
     if layout == 'channel_first':
-        if runtime.fused() and batched_data.dim() == 3 and batched_data.dtype == torch.float32:
-            from ..csrc import fused
-            return fused.gather_points(batched_data, batched_indices)
+        if runtime.fused() and batched_data.is_cuda:
+            if batched_data.dim() == 3 and batched_data.is_floating_point():
+                from ..csrc import fused
+                return fused.gather_points(batched_data, batched_indices)
+            runtime.fallback('batch_indexing', 'channel-first data of rank %d / dtype %s' % (batched_data.dim(), batched_data.dtype))
         n_channels = batched_data.shape[1]
         flat = batched_indices.reshape(bs, 1, -1).expand(bs, n_channels, -1).to(torch.int64)
         return torch.gather(batched_data, 2, flat).view([bs, n_channels] + idx_shape)
     if layout == 'channel_last':
+        if batched_data.is_cuda:
+            runtime.fallback('batch_indexing', 'channel-last layout (its only product-path user, PointConv, is fused)')
         rows = torch.arange(bs, dtype=torch.long, device=batched_data.device)
         rows = rows.view([bs] + [1] * len(idx_shape)).expand([bs] + idx_shape)
         if batched_data.dim() == 2:
@@ -107,9 +111,11 @@ def knn_interpolation(input_xyz, input_features, query_xyz, k=3, invariant_input
     """Inverse-distance interpolation from the k nearest inputs (utils.py:130-146).
     [B,3,M] x [B,C,M] x [B,3,Nq] -> [B,C,Nq]; gradients flow to features AND coordinates."""
     knn_indices = knn_channel_first(input_xyz, query_xyz, k, invariant_input, invariant_query)
-    if runtime.fused() and k <= 8 and not input_xyz.requires_grad and not query_xyz.requires_grad:
-        from ..csrc import fused
-        return fused.knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
+    if runtime.fused() and input_xyz.is_cuda:
+        if k <= 8:
+            from ..csrc import fused
+            return fused.knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
+        runtime.fallback('knn_interpolation', 'k = %d > 8' % k)
     knn_xyz = batch_indexing(input_xyz, knn_indices)
     knn_dists = torch.linalg.norm(knn_xyz - query_xyz[..., None], dim=1).clamp(1e-8)
     knn_weights = 1.0 / knn_dists
@@ -127,11 +133,11 @@ def backwarp_3d(xyz1, xyz2, flow12, k=3):
 def backwarp_3d_levels(xyz1, xyz2_levels, flow12, k=3):
     """``[backwarp_3d(xyz1, level, flow12) for level in xyz2_levels]`` with the level-independent parts
     (warped source cloud, negated flow, their layout conversion) evaluated once."""
-    if not (runtime.fused() and xyz1.is_cuda) or xyz1.requires_grad or flow12.requires_grad:
+    if not (runtime.fused() and xyz1.is_cuda):
         return [backwarp_3d(xyz1, level, flow12, k) for level in xyz2_levels]
     from ..csrc import fused
     warped, inverse = xyz1 + flow12, -flow12
-    warped_cl = warped.transpose(1, 2).contiguous()
+    warped_cl = warped.detach().transpose(1, 2).contiguous()
     out = []
     for level in xyz2_levels:
         knn_indices = _ops.k_nearest_neighbor(warped_cl, _channel_last(level, True), k)
@@ -170,9 +176,11 @@ def backwarp_2d(x, flow12, padding_mode):
 def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0):
     """RAFT convex upsampling: softmax over the 3x3 neighbourhood (utils.py:191-204).  ``mask_scale``
     is the factor the caller would otherwise multiply the mask by (RAFT: 0.25)."""
-    if runtime.fused() and scale_factor in (4, 8):
-        from ..csrc import fused
-        return fused.convex_upsample(flow, mask, scale_factor, mask_scale)
+    if runtime.fused() and flow.is_cuda:
+        if scale_factor in (4, 8):
+            from ..csrc import fused
+            return fused.convex_upsample(flow, mask, scale_factor, mask_scale)
+        runtime.fallback('convex_upsample', 'scale factor %d (kernels exist for 4 and 8)' % scale_factor)
     if mask_scale != 1.0:
         mask = mask_scale * mask
     batch_size, _, image_h, image_w = flow.shape
@@ -229,10 +237,14 @@ def project_pc2image(pc, camera_info):
 
 def grid_sample_wrapper(feat_2d, uv):
     """Bilinear sample of [B,C,H,W] at pixel coordinates uv [B,2,N] -> [B,C,N], fp32 (utils.py:262-269)."""
-    if (runtime.fused() and feat_2d.is_cuda and min(feat_2d.shape[2:]) >= 2
-            and not (torch.is_grad_enabled() and (feat_2d.requires_grad or uv.requires_grad))):
-        from ..csrc import fused
-        return fused.bilinear_sample(feat_2d.detach(), uv.detach())       # one gather kernel (camli_bilinear_sample_fwd)
+    if runtime.fused() and feat_2d.is_cuda:
+        if min(feat_2d.shape[2:]) < 2:
+            runtime.fallback('grid_sample_wrapper', 'degenerate %dx%d feature map' % tuple(feat_2d.shape[2:]))
+        elif torch.is_grad_enabled() and (feat_2d.requires_grad or uv.requires_grad):
+            runtime.fallback('grid_sample_wrapper', 'differentiable inputs (the fusion path detaches them)')
+        else:
+            from ..csrc import fused
+            return fused.bilinear_sample(feat_2d.detach(), uv.detach())       # one gather kernel (camli_bilinear_sample_fwd)
     with torch.autocast(device_type=feat_2d.device.type, enabled=False):
         image_h, image_w = feat_2d.shape[2:]
         new_x = 2.0 * uv[:, 0] / (image_w - 1) - 1.0
@@ -295,4 +307,6 @@ def flows_paral2persp(pc1, flows, perspect_camera_info, parallel_camera_info):
             and all(torch.is_tensor(perspect_camera_info[k]) for k in ('cx', 'cy'))):
         from ..csrc import fused
         return [fused.ids_flow(flow, pc1, origin, perspect_camera_info, parallel_camera_info) for flow in flows]
+    if pc1.is_cuda:
+        runtime.fallback('flows_paral2persp', 'non-tensor intrinsics or differentiable pc1')
     return [paral2persp(pc1 + flow, perspect_camera_info, parallel_camera_info) - origin for flow in flows]

@@ -46,6 +46,8 @@ def _sequence_loss(flow_preds, target, cfgs, n_flow_channels):
             weights = _GAMMA_WEIGHTS[key] = torch.tensor([cfgs.gamma ** (n_preds - i - 1) for i in range(n_preds)],
                                                          dtype=torch.float32, device=target.device)
         return (sums * weights).sum() / mask.sum()
+    if target.is_cuda and cfgs.order == 'l2-norm':
+        runtime.fallback('sequence_loss', 'differentiable target or %d flow channels' % n_flow_channels)
     total = 0
     for i, pred in enumerate(flow_preds):
         loss = _masked_mean_error(pred - target[:, :n_flow_channels], mask, cfgs.order)

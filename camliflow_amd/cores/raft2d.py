@@ -146,6 +146,8 @@ class GRU2D(nn.Module):
         for suffix in ('1', '2'):
             w_zr, w_q, ctx_zr, ctx_q, padding = state[suffix]
             pre_zr = conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding)
+            if not fusable and h.is_cuda:
+                runtime.fallback('GRU2D', 'hidden plane is not a multiple of 4 elements')
             if fusable:
                 z, rh = fused.gru_gates(pre_zr, ctx_zr, h)
                 h = fused.gru_blend(conv2d(torch.cat([rh, motion], dim=1), w_q, None, padding=padding), ctx_q, z, h)

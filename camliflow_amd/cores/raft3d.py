@@ -88,8 +88,10 @@ class Correlation3D(nn.Module):
         return self.cost_mlp(lookup).sum(dim=-1)
 
     def forward(self, xyz1, xyzs2):
-        if runtime.fused() and not (xyz1.requires_grad or any(x.requires_grad for x in xyzs2[:4])):
-            return self._forward_batched(xyz1, xyzs2)
+        if runtime.fused() and xyz1.is_cuda:
+            if not (xyz1.requires_grad or any(x.requires_grad for x in xyzs2[:4])):
+                return self._forward_batched(xyz1, xyzs2)
+            runtime.fallback('Correlation3D(RAFT)', 'differentiable coordinates')
         per_level = [self.calc_matching_cost(xyz1, xyzs2[lvl], self.cost_volume_pyramid[lvl]) for lvl in range(4)]
         return self.merge(torch.cat(per_level, dim=1))
 
@@ -145,7 +147,9 @@ class GRU3D(nn.Module):
     def forward(self, xyz, h, x, knn_indices=None):
         h, x = h.float(), x.float()
         joint = torch.cat([h, x], dim=1)
-        if runtime.fused() and h.is_cuda and (h.shape[1] * h.shape[2]) % 4 == 0 and not torch.is_autocast_enabled():
+        if runtime.fused() and h.is_cuda and (h.shape[1] * h.shape[2]) % 4 != 0:
+            runtime.fallback('GRU3D', 'plane of %d elements is not a multiple of 4' % (h.shape[1] * h.shape[2]))
+        if runtime.fused() and h.is_cuda and (h.shape[1] * h.shape[2]) % 4 == 0:
             # the elementwise halves through the GRU kernels of the image branch (camli_gru_gates / _blend) with a
             # zero context term: 3 launches instead of 8 forward, 2 instead of ~14 backward
             from ..csrc import fused

@@ -8,9 +8,17 @@
                 it is the fp32 torch reference the fused kernels are tested against, and what the
                 CPU tests / the cpu_baseline leg of bench.py select explicitly.
 
-There is no automatic switching: a CPU tensor under 'hip' is an error, not a fallback.
+A CPU tensor under 'hip' is an error, not a fallback.  A handful of call sites DO take the composed
+formulation under 'hip' when a precondition of their kernel fails (autocast active, a shape outside the
+kernel's range, an op variant without a kernel); every one of them reports through ``fallback()`` below,
+so that
+  * ``CAMLI_STRICT=1`` / ``set_strict(True)`` turns each such switch into an error, and
+  * ``census()`` lists, per op, how many calls ran fused and how many composed (bench.py and the
+    full-size tests print it, so it is known which ops of a configuration actually hit HIP).
 """
+import collections
 import contextlib
+import os
 
 _BACKEND = 'hip'
 
@@ -41,6 +49,60 @@ def fused():
 
 
 # ------------------------------------------------------------------------------------------------
+# strict mode + census of fused vs composed calls under the 'hip' backend
+# ------------------------------------------------------------------------------------------------
+_STRICT = os.environ.get('CAMLI_STRICT', '0') == '1'
+_CENSUS = {'fused': collections.Counter(), 'composed': collections.Counter()}
+_CENSUS_ON = os.environ.get('CAMLI_CENSUS', '0') == '1'
+
+
+class CamliStrictError(RuntimeError):
+    pass
+
+
+def set_strict(enabled):
+    global _STRICT
+    _STRICT = bool(enabled)
+
+
+def strict():
+    return _STRICT
+
+
+def set_census(enabled):
+    global _CENSUS_ON
+    _CENSUS_ON = bool(enabled)
+    from ..csrc import _lib
+    _lib._CENSUS = _CENSUS['fused'] if _CENSUS_ON else None
+
+
+def census_on():
+    return _CENSUS_ON
+
+
+def reset_census():
+    _CENSUS['fused'].clear()
+    _CENSUS['composed'].clear()
+
+
+def census():
+    """{'fused': {entry point: launches}, 'composed': {'op: reason': calls}} since the last reset."""
+    return {'fused': dict(_CENSUS['fused']), 'composed': dict(_CENSUS['composed'])}
+
+
+def fallback(op, reason):
+    """Called by a core op that has a fused kernel but is about to run the torch-composed formulation
+    although the backend is 'hip'.  Raises in strict mode, otherwise records the event."""
+    if _BACKEND != 'hip':
+        return
+    if _STRICT:
+        raise CamliStrictError("%s: would run the torch-composed formulation under the 'hip' backend (%s); "
+                               "CAMLI_STRICT=1 forbids it" % (op, reason))
+    if _CENSUS_ON:
+        _CENSUS['composed']['%s: %s' % (op, reason)] += 1
+
+
+# ------------------------------------------------------------------------------------------------
 # deferred parameter gradients: the 12 GRU iterations share their parameters, so autograd adds a
 # fresh weight / bias gradient into .grad after every call (~1,200 small add + sum launches per
 # step).  With this switch on, the fused 1x1-convolution and bias/activation nodes accumulate into
@@ -67,9 +129,19 @@ class _ParamGradSink:
     def __init__(self):
         self.entries = {}
         self.armed = False
+        self.task = None
 
     def slot(self, param, make, reduce_batch):
         import torch
+        # tie the sink to the running backward: accumulators that survived a failed backward (its queued
+        # callbacks are skipped when the engine raises) must not leak into the next one
+        task = torch._C._current_graph_task_id()
+        if task != self.task:
+            self.entries, self.armed, self.task = {}, False, task
+        if getattr(param, '_backward_hooks', None):
+            raise RuntimeError('deferred parameter gradients bypass AccumulateGrad: a parameter with backward hooks '
+                               '(e.g. under DistributedDataParallel) cannot use them; call '
+                               'runtime.set_deferred_param_grads(False)')
         entry = self.entries.get(id(param))
         if entry is None:
             if not self.armed:
@@ -81,7 +153,7 @@ class _ParamGradSink:
 
     def flush(self):
         import torch
-        entries, self.entries, self.armed = self.entries, {}, False
+        entries, self.entries, self.armed, self.task = self.entries, {}, False, None
         with torch.no_grad():
             for param, acc, reduce_batch, stream in entries.values():
                 current = torch.cuda.current_stream(param.device)
@@ -154,3 +226,6 @@ class Lanes:
             self.main.wait_stream(self.side_stream)
             for t in _flatten(tensors):
                 t.record_stream(self.main)
+
+if _CENSUS_ON:
+    set_census(True)

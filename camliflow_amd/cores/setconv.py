@@ -121,6 +121,7 @@ class PointConvDW(nn.Module):
                 # offsets + 3 -> 8 -> 32 -> C in one launch, the wide layer on MFMA (camli_weightnet_fwd/bwd)
                 weight = fused.weightnet(xyz, centres, knn_indices, self.k, self.weight_net)
             else:
+                runtime.fallback('weightnet', 'weight_net is not MLP2d(3,[8,32,C<=128],relu) or the coordinates are differentiable')
                 _, _, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
                 weight = self.weight_net(knn_offset)
             shared = fused.SharedSetConvWeights(weight)

@@ -34,6 +34,8 @@ PROTOTYPES = {
                                     _int, _int, _int, _int, _int, _stream]),
     "camli_knn_interp_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p,
                                     _int, _int, _int, _int, _int, _stream]),
+    "camli_knn_interp_bwd_xyz": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p,
+                                        _c_float_p, _int, _int, _int, _int, _int, _stream]),
     "camli_corr3d_gather_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _c_float_p,
                                        _int, _int, _int, _int, _stream]),
     "camli_corr3d_gather_bwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
@@ -123,17 +125,24 @@ class KernelTimer:
         """name -> dict(launches, total_ms, work, unit).  Call after torch.cuda.synchronize()."""
         out = {}
         for name, recs in self.records.items():
-            out[name] = {'launches': len(recs), 'total_ms': sum(s.elapsed_time(e) for s, e, _, _ in recs),
-                         'work': float(sum(w for _, _, w, _ in recs)), 'unit': recs[0][3]}
+            out[name] = {'launches': len(recs), 'total_ms': sum(r[0].elapsed_time(r[1]) for r in recs),
+                         'work': float(sum(r[2] for r in recs)), 'unit': recs[0][3],
+                         'flop': float(sum(r[4] for r in recs))}
         return out
 
 
 TIMER = KernelTimer()
 
 
-def launch(name, fn, *args, work=None):
+_CENSUS = None      # set by cores.runtime when the census is on (avoids an import cycle here)
+
+
+def launch(name, fn, *args, work=None, flop=0.0):
     """Call a C-ABI entry point, check its status, optionally time it.  ``work`` = (amount, unit) of
-    algorithmic work of this launch, only evaluated bookkeeping-wise."""
+    algorithmic work of this launch, ``flop`` its floating-point work for the
+    matrix-core kernels; both only evaluated bookkeeping-wise."""
+    if _CENSUS is not None:
+        _CENSUS[name] += 1
     if TIMER.enabled and (TIMER.only is None or name in TIMER.only):
         import torch
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -141,7 +150,7 @@ def launch(name, fn, *args, work=None):
         code = fn(*args)
         end.record()
         amount, unit = work if work is not None else (0.0, 'B')
-        TIMER.records.setdefault(name, []).append((start, end, amount, unit))
+        TIMER.records.setdefault(name, []).append((start, end, amount, unit, flop))
     else:
         code = fn(*args)
     check(code, name)

@@ -27,19 +27,44 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """Compile every .hip source into camliflow_amd/csrc/libcamli_hip.so.  Returns the path."""
+    """Compile every .hip source into camliflow_amd/csrc/libcamli_hip.so.  Returns the path.
+    One object per source (compiled in parallel, rebuilt only when the source or a header is newer), then one
+    link: a kernel edit costs one file's compile time."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libcamli_hip.so")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-I", HIP_DIR, "-I", INCLUDE_DIR] + sources() + ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
+    obj_dir = os.path.join(HERE, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(HIP_DIR, f) for f in os.listdir(HIP_DIR) if f.endswith(".h")]
+    headers += [os.path.join(INCLUDE_DIR, f) for f in os.listdir(INCLUDE_DIR) if f.endswith(".h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > newest_header):
+            return obj, None
+        cmd = [hipcc] + compile_flags + ["-c", "-I", HIP_DIR, "-I", INCLUDE_DIR, src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, (res.stdout + res.stderr if res.returncode != 0 else None)
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_one, sources()))
+    errors = [err for _, err in results if err]
+    if errors:
+        sys.stderr.write("\n".join(errors))
+        raise RuntimeError("hipcc failed building libcamli_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for obj, _ in results] + ["-o", LIB_PATH + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
-        raise RuntimeError("hipcc failed building libcamli_hip.so")
+        raise RuntimeError("hipcc failed linking libcamli_hip.so")
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

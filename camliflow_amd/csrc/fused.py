@@ -8,6 +8,7 @@ fp32 under AMP as well (``.float()`` at raft_core.py:53-54, clfm.py:31-32, camli
 """
 import ctypes
 import math
+import weakref
 
 import torch
 from torch.nn.functional import avg_pool2d
@@ -60,17 +61,22 @@ class _BuildPyramid(torch.autograd.Function):
         pyr.levels = [lvl.reshape(bs * h * w, lvl.shape[-2], lvl.shape[-1]) for lvl in levels]
         pyr.shape = (bs, h, w)
         ctx.save_for_backward(f1, f2)
-        ctx.pyr = pyr
+        # weak: pyr.token is this node's output, a strong link would close a reference cycle
+        # (pyr -> token -> grad_fn -> ctx -> pyr) and keep the 2.8 GB pyramid alive until the cyclic GC runs.
+        # Every lookup node holds pyr strongly, so it lives exactly as long as the graph needs it.
+        ctx.pyr = weakref.ref(pyr)
         ctx.dims = (bs, dim, h, w)
         return fmap1.new_zeros(1)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, _gtoken):
-        pyr = ctx.pyr
+        pyr = ctx.pyr()
         f1, f2 = ctx.saved_tensors
         bs, dim, h, w = ctx.dims
-        grads, pyr.grads = pyr.grads, None
+        grads = None
+        if pyr is not None:
+            grads, pyr.grads = pyr.grads, None
         if grads is None:
             return torch.zeros(bs, dim, h, w, device=f1.device), torch.zeros(bs, dim, h, w, device=f1.device), None, None
         # adjoint of the avg_pool2d chain: fold coarse levels into level 0
@@ -134,6 +140,11 @@ def allpairs_pyramid(fmap1, fmap2, num_levels=4):
 def allpairs_lookup(pyr, coords, radius=4):
     """coords [B,2,h,w] -> [B, L*(2r+1)^2, h, w] (raft_core.py:70-94 in one launch)."""
     _require_cuda('allpairs_lookup', coords)
+    if coords.requires_grad and torch.is_grad_enabled():
+        # the reference's grid_sample is differentiable wrt the coordinates; its RAFT loops detach the flow first
+        # (raft_core.py:248, camliraft_core.py:105-106), and this kernel has no coordinate adjoint
+        raise _lib.CamliHipError('allpairs_lookup: coordinates that require grad are not supported (detach the flow '
+                                 'as the reference loops do, or select the composed backend)')
     return _Lookup.apply(pyr.token, coords.detach().float().contiguous(), radius, pyr)
 
 
@@ -162,18 +173,21 @@ class _ShareWeights(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, weight, shared):
-        ctx.shared = shared
+        # weak for the same reason as _BuildPyramid: shared.token is this node's output; the fused set-conv
+        # nodes of the pass hold `shared` strongly
+        ctx.shared = weakref.ref(shared)
+        ctx.wshape, ctx.wdevice = tuple(weight.shape), weight.device
         return weight.new_zeros(1)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, _gtoken):
         lib = _lib.load()
-        shared = ctx.shared
+        shared = ctx.shared()
+        if shared is None or not shared.records:
+            return torch.zeros(ctx.wshape, dtype=torch.float32, device=ctx.wdevice), None
         records, shared.records = shared.records, []
         weight = shared.weight
-        if not records:
-            return torch.zeros_like(weight), None
         b, c, n, k = weight.shape
         grad = torch.empty_like(weight)
         with _on_device(weight):
@@ -584,7 +598,8 @@ class _WeightNet(torch.autograd.Function):
             _lib.launch('camli_weightnet_fwd', lib.camli_weightnet_fwd, xyz.data_ptr(), centres.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), *[t.data_ptr() for t in params],
                         out.data_ptr(), bs, c, m, n, k, _stream_ptr(xyz),
-                        work=(4.0 * bs * c * n * k + 8.0 * bs * n * k + 12.0 * bs * (m + n), 'B'))
+                        work=(4.0 * bs * c * n * k + 8.0 * bs * n * k + 12.0 * bs * (m + n), 'B'),
+                        flop=2.0 * bs * n * k * (24 + 256 + 32 * c))
         ctx.save_for_backward(xyz, centres, knn_indices, *params)
         ctx.k = k
         ctx.shapes = [t.shape for t in (w1, b1, w2, b2, w3, b3)]
@@ -608,7 +623,8 @@ class _WeightNet(torch.autograd.Function):
                         knn_indices.data_ptr(), knn_indices.stride(1), *[t.data_ptr() for t in params],
                         gout.data_ptr(), *[g.data_ptr() for g in grads], workspace.data_ptr(), ws_bytes,
                         bs, c, m, n, k, _stream_ptr(xyz),
-                        work=(4.0 * bs * c * n * k + 8.0 * bs * n * k + 12.0 * bs * (m + n), 'B'))
+                        work=(4.0 * bs * c * n * k + 8.0 * bs * n * k + 12.0 * bs * (m + n), 'B'),
+                        flop=2.0 * bs * n * k * (3 * 32 * c + 2 * 32 * 32))
         grads = [g.view(shape) for g, shape in zip(grads, ctx.shapes)]
         return (None, None, None, None, *grads)
 
@@ -693,7 +709,8 @@ class _KnnInterp(torch.autograd.Function):
                         q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), out.data_ptr(), b, c, m, nq, k,
                         _stream_ptr(feat),
                         work=(4.0 * b * c * nq * (1 + k) + 8.0 * b * nq * k + 12.0 * b * nq * (1 + k), 'B'))
-        ctx.save_for_backward(in_xyz, q_xyz, knn)
+        coords = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
+        ctx.save_for_backward(in_xyz, q_xyz, knn, *([feat] if coords else []))
         ctx.dims = (b, c, m, nq, k)
         return out
 
@@ -701,23 +718,34 @@ class _KnnInterp(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gout):
         lib = _lib.load()
-        in_xyz, q_xyz, knn = ctx.saved_tensors
+        in_xyz, q_xyz, knn = ctx.saved_tensors[:3]
         b, c, m, nq, k = ctx.dims
         gout = gout.contiguous().float()
-        gfeat = torch.zeros((b, c, m), dtype=torch.float32, device=gout.device)
+        gfeat = g_in = g_q = None
         with _on_device(gout):
-            _lib.launch('camli_knn_interp_bwd', lib.camli_knn_interp_bwd, in_xyz.data_ptr(), gout.data_ptr(),
-                        q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), gfeat.data_ptr(), b, c, m, nq, k,
-                        _stream_ptr(gout),
-                        work=(4.0 * b * c * nq * (1 + 2 * k) + 8.0 * b * nq * k + 12.0 * b * nq * (1 + k), 'B'))
-        return None, gfeat, None, None, None
+            if ctx.needs_input_grad[1]:
+                gfeat = torch.zeros((b, c, m), dtype=torch.float32, device=gout.device)
+                _lib.launch('camli_knn_interp_bwd', lib.camli_knn_interp_bwd, in_xyz.data_ptr(), gout.data_ptr(),
+                            q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), gfeat.data_ptr(), b, c, m, nq, k,
+                            _stream_ptr(gout),
+                            work=(4.0 * b * c * nq * (1 + 2 * k) + 8.0 * b * nq * k + 12.0 * b * nq * (1 + k), 'B'))
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+                # CamLiPWC back-warps with a live flow (camlipwc_core.py:172-179): the coordinates carry a gradient
+                feat = ctx.saved_tensors[3]
+                g_in = torch.zeros_like(in_xyz) if ctx.needs_input_grad[0] else None
+                g_q = torch.empty_like(q_xyz) if ctx.needs_input_grad[2] else None
+                _lib.launch('camli_knn_interp_bwd_xyz', lib.camli_knn_interp_bwd_xyz, in_xyz.data_ptr(), feat.data_ptr(),
+                            gout.data_ptr(), q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1),
+                            g_in.data_ptr() if g_in is not None else None, g_q.data_ptr() if g_q is not None else None,
+                            b, c, m, nq, k, _stream_ptr(gout),
+                            work=(4.0 * b * c * nq * (1 + k) + 8.0 * b * nq * k + 12.0 * b * nq * (2 + 2 * k), 'B'))
+        return g_in, gfeat, g_q, None, None
 
 
 def knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k):
-    """IDW interpolation given the k nearest inputs per query (utils.py:138-146).  Gradient flows to
-    the features only; callers route coordinate-differentiable cases to the composed formulation."""
+    """IDW interpolation given the k nearest inputs per query (utils.py:138-146); differentiable wrt the
+    features and, when they require it, both coordinate sets."""
     _require_cuda('knn_interpolate', input_xyz, input_features, query_xyz, knn_indices)
-    assert not input_xyz.requires_grad and not query_xyz.requires_grad
     return _KnnInterp.apply(input_xyz.float().contiguous(), input_features.float().contiguous(),
                             query_xyz.float().contiguous(), knn_indices, k)
 
@@ -961,7 +989,7 @@ class _BiasAct(torch.autograd.Function):
         ctx.mark_dirty(x)
         if mask is not None:
             ctx.save_for_backward(mask)
-        else:
+        elif act != 0:
             ctx.save_for_backward(x)
         ctx.act, ctx.masked, ctx.dims = act, mask is not None, (b, c, p)
         ctx.bias_param = bias if (bias.is_leaf and bias.requires_grad) else None
@@ -971,20 +999,23 @@ class _BiasAct(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gy):
         lib = _lib.load()
-        (saved,) = ctx.saved_tensors
+        saved = ctx.saved_tensors[0] if ctx.saved_tensors else None
         b, c, p = ctx.dims
         gy = gy.contiguous().float()
-        gx = torch.empty_like(gy)
+        identity = ctx.act == 0
+        gx = gy if identity else torch.empty_like(gy)       # identity: the input gradient IS gy, only the bias sums are reduced
         deferred = ctx.bias_param is not None and _runtime.deferred_param_grads()
+        if identity and not (deferred or ctx.needs_input_grad[1]):
+            return gx, None, None
         if deferred:      # the kernel's atomics accumulate straight into the parameter's per-pass buffer
             gbias = _runtime.PARAM_GRADS.slot(ctx.bias_param, lambda: _zero_slice(c, gy), False)
         else:
             gbias = _zero_slice(c, gy)
         with _on_device(gy):
             _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gy.data_ptr(),
-                        None if ctx.masked else saved.data_ptr(), saved.data_ptr() if ctx.masked else None,
-                        gx.data_ptr(), gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(gy),
-                        work=((8.125 if ctx.masked else 12.0) * b * c * p, 'B'))
+                        None if (ctx.masked or identity) else saved.data_ptr(), saved.data_ptr() if ctx.masked else None,
+                        None if identity else gx.data_ptr(), gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(gy),
+                        work=((4.0 if identity else (8.125 if ctx.masked else 12.0)) * b * c * p, 'B'))
         return gx, (None if deferred else gbias), None
 
 

@@ -120,6 +120,31 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
     if (threadIdx.x == 0) unsafeAtomicAdd(gbias + c, (partial[0] + partial[1]) + (partial[2] + partial[3]));
 }
 
+// Identity activation: gx == gy, so the adjoint only needs the per-channel sum of gy (4 B/elem read, nothing
+// written but the C bias sums).  Same grid / reduction as the general kernel.
+__global__ __launch_bounds__(256) void bias_sum_kernel(const float* __restrict__ gy, float* __restrict__ gbias, int C,
+                                                        int P, int chunk) {
+    __shared__ float partial[4];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const size_t base = ((size_t)b * C + c) * P;
+    const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
+    float acc = 0.0f;
+    if ((P & 3) == 0 && (chunk & 3) == 0) {
+        const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gy + base);
+        for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
+            const float4 g = g4[e];
+            acc += (g.x + g.y) + (g.z + g.w);
+        }
+    } else {
+        for (int e = beg + threadIdx.x; e < end; e += 256) acc += gy[base + e];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(gbias + c, (partial[0] + partial[1]) + (partial[2] + partial[3]));
+}
+
 int pick_chunk(int P) {
     // ~8K elements per block, multiple of 1024 so float4 groups never straddle chunks
     return P <= 8192 ? ((P + 1023) / 1024) * 1024 : 8192;
@@ -168,8 +193,15 @@ extern "C" int camli_bias_act_fwd(float* x_inout, const float* bias, void* sign_
 extern "C" int camli_bias_act_bwd(const float* gy, const float* y, const void* sign_mask, float* gx, float* gbias,
                                   int B, int C, int P, int act, void* stream) {
     if (B == 0) return CAMLI_OK;
-    if (!gy || (!y && !sign_mask) || !gx || !gbias) { camli_set_error("camli_bias_act_bwd: null pointer"); return CAMLI_EINVAL; }
     if (!shape_ok("camli_bias_act_bwd", B, C, P, act)) return CAMLI_EINVAL;
+    if (act == 0 && !gx) {   // identity: the caller aliases gx to gy, only the bias sums are produced
+        if (!gy || !gbias) { camli_set_error("camli_bias_act_bwd: null pointer"); return CAMLI_EINVAL; }
+        const int chunk0 = pick_chunk(P);
+        hipLaunchKernelGGL(bias_sum_kernel, dim3(camli_divup(P, chunk0), C, B), dim3(256), 0,
+                           reinterpret_cast<hipStream_t>(stream), gy, gbias, C, P, chunk0);
+        return camli_check_launch("camli_bias_act_bwd(identity)");
+    }
+    if (!gy || (!y && !sign_mask && act != 0) || !gx || !gbias) { camli_set_error("camli_bias_act_bwd: null pointer"); return CAMLI_EINVAL; }
     if (sign_mask && !((act == 1 || act == 2) && (P & 3) == 0)) {
         camli_set_error("camli_bias_act_bwd: a sign mask needs act 1 or 2 and P %% 4 == 0 (act=%d P=%d)", act, P);
         return CAMLI_EINVAL;

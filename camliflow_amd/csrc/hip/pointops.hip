@@ -90,6 +90,78 @@ __global__ __launch_bounds__(256) void knn_interp_kernel(const float* __restrict
     }
 }
 
+// Coordinate adjoint of the interpolation (models/utils.py:138-146 differentiated: norm -> clamp(1e-8) ->
+// reciprocal -> normalise -> weighted sum).  With p_j = w_j / W the normalised weights, a_j = sum_c g_c f_cj and
+// S = sum_c g_c out_c:   dL/dw_j = (a_j - S) / W,   dw_j/ddist_j = -w_j^2 (where the clamp is inactive),
+// ddist_j/dx_j = (x_j - q) / dist_j  (0 at dist_j = 0, as torch.linalg.norm's backward defines it).
+// thread = query; the k neighbour rows are re-read per channel (L2-resident, C <= ~200), g_q is written
+// directly, the input-cloud gradient by one float atomic per (neighbour, axis).
+__global__ __launch_bounds__(256) void knn_interp_bwd_xyz_kernel(const float* __restrict__ in_xyz,
+                                                                  const float* __restrict__ feat,
+                                                                  const float* __restrict__ gout,
+                                                                  const float* __restrict__ q_xyz,
+                                                                  const int64_t* __restrict__ knn, int knn_stride,
+                                                                  float* __restrict__ g_in, float* __restrict__ g_q,
+                                                                  int C, int M, int Nq, int k) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (q >= Nq) return;
+    const float qx = q_xyz[((size_t)b * 3 + 0) * Nq + q];
+    const float qy = q_xyz[((size_t)b * 3 + 1) * Nq + q];
+    const float qz = q_xyz[((size_t)b * 3 + 2) * Nq + q];
+    int m[KI_MAXK];
+    float w[KI_MAXK], raw[KI_MAXK], dx[KI_MAXK], dy[KI_MAXK], dz[KI_MAXK], a[KI_MAXK];
+    float wsum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KI_MAXK; ++j) {
+        a[j] = 0.0f;
+        if (j < k) {
+            m[j] = (int)knn[((size_t)b * Nq + q) * knn_stride + j];
+            dx[j] = in_xyz[((size_t)b * 3 + 0) * M + m[j]] - qx;
+            dy[j] = in_xyz[((size_t)b * 3 + 1) * M + m[j]] - qy;
+            dz[j] = in_xyz[((size_t)b * 3 + 2) * M + m[j]] - qz;
+            raw[j] = sqrtf(dx[j] * dx[j] + dy[j] * dy[j] + dz[j] * dz[j]);
+            w[j] = 1.0f / fmaxf(raw[j], 1e-8f);
+            wsum += w[j];
+        } else {
+            m[j] = 0;
+            w[j] = raw[j] = dx[j] = dy[j] = dz[j] = 0.0f;
+        }
+    }
+    float s_tot = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const size_t row = ((size_t)b * C + c) * M;
+        const float g = gout[((size_t)b * C + c) * Nq + q];
+        float o = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KI_MAXK; ++j)
+            if (j < k) {
+                const float f = feat[row + m[j]];
+                o += f * (w[j] / wsum);
+                a[j] += g * f;
+            }
+        s_tot += g * o;
+    }
+    float gqx = 0.0f, gqy = 0.0f, gqz = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KI_MAXK; ++j)
+        if (j < k && raw[j] >= 1e-8f) {
+            const float gd = -((a[j] - s_tot) / wsum) * (w[j] * w[j]);     // dL/ddist_j
+            const float sx = gd * (dx[j] / raw[j]), sy = gd * (dy[j] / raw[j]), sz = gd * (dz[j] / raw[j]);
+            if (g_in) {
+                unsafeAtomicAdd(g_in + ((size_t)b * 3 + 0) * M + m[j], sx);
+                unsafeAtomicAdd(g_in + ((size_t)b * 3 + 1) * M + m[j], sy);
+                unsafeAtomicAdd(g_in + ((size_t)b * 3 + 2) * M + m[j], sz);
+            }
+            gqx -= sx; gqy -= sy; gqz -= sz;
+        }
+    if (g_q) {
+        g_q[((size_t)b * 3 + 0) * Nq + q] = gqx;
+        g_q[((size_t)b * 3 + 1) * Nq + q] = gqy;
+        g_q[((size_t)b * 3 + 2) * Nq + q] = gqz;
+    }
+}
+
 // ---- point cost-volume lookup gather ---------------------------------------------------------------
 // out[b,0:3,n,j] = xyz2[b,:,idx[b,n,j]] - xyz1[b,:,n];  out[b,3,n,j] = cost[b,n,idx[b,n,j]]
 // thread = (b, n, j), j fastest (k contiguous outputs per point)
@@ -205,6 +277,19 @@ extern "C" int camli_knn_interp_bwd(const float* in_xyz, const float* gout, cons
                        dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in_xyz, q_xyz, knn, knn_stride, gout, gfeat,
                        C, M, Nq, k);
     return camli_check_launch("camli_knn_interp_bwd");
+}
+
+extern "C" int camli_knn_interp_bwd_xyz(const float* in_xyz, const float* feat, const float* gout, const float* q_xyz,
+                                        const int64_t* knn, int knn_stride, float* g_in_xyz, float* g_q_xyz, int B, int C,
+                                        int M, int Nq, int k, void* stream) {
+    if (B == 0 || Nq == 0) return CAMLI_OK;
+    if (!knn_interp_args_ok("camli_knn_interp_bwd_xyz", in_xyz, feat, q_xyz, knn, gout, B, C, M, Nq, k, knn_stride))
+        return CAMLI_EINVAL;
+    if (!g_in_xyz && !g_q_xyz) return CAMLI_OK;
+    hipLaunchKernelGGL(knn_interp_bwd_xyz_kernel, dim3(camli_divup(Nq, 256), B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), in_xyz, feat, gout, q_xyz, knn, knn_stride, g_in_xyz,
+                       g_q_xyz, C, M, Nq, k);
+    return camli_check_launch("camli_knn_interp_bwd_xyz");
 }
 
 extern "C" int camli_corr3d_gather_fwd(const float* xyz1, const float* xyz2, const float* cost, const int64_t* knn,

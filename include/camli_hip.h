@@ -115,13 +115,20 @@ int camli_gather_cf_bwd(const float *gout, const int64_t *idx, float *gdata, int
  * knn_interpolation tail (models/utils.py:138-146) given the k <= 8 nearest inputs of every query:
  *   w_j = (1/max(|in_xyz[:,knn_j] - q|, 1e-8)) / sum_j(...);  out[b,c,q] = sum_j feat[b,c,knn_j] * w_j
  *   in_xyz [B,3,M], feat [B,C,M], q_xyz [B,3,Nq] channel-first; knn int64 rows of stride knn_stride.
- *   bwd: gradient w.r.t. feat only (gfeat += with atomics, caller zero-fills); the coordinate
- *   gradient is never needed on the path (coordinates come from inputs / detached flow).
+ *   bwd: gradient w.r.t. feat (gfeat += with atomics, caller zero-fills).
+ *   bwd_xyz: gradient w.r.t. the coordinates -- CamLiPWC back-warps with a live flow
+ *   (models/camlipwc_core.py:172-179 -> models/utils.py:149-159), so both in_xyz and q_xyz can carry a
+ *   gradient there: g_in_xyz [B,3,M] += (atomics, caller zero-fills; may be NULL), g_q_xyz [B,3,Nq] is
+ *   written (may be NULL).  Follows torch's subgradients: the clamp passes where |.| >= 1e-8, the norm's
+ *   gradient is 0 at 0.
  */
 int camli_knn_interp_fwd(const float *in_xyz, const float *feat, const float *q_xyz, const int64_t *knn,
                          int knn_stride, float *out, int B, int C, int M, int Nq, int k, void *stream);
 int camli_knn_interp_bwd(const float *in_xyz, const float *gout, const float *q_xyz, const int64_t *knn,
                          int knn_stride, float *gfeat, int B, int C, int M, int Nq, int k, void *stream);
+int camli_knn_interp_bwd_xyz(const float *in_xyz, const float *feat, const float *gout, const float *q_xyz,
+                             const int64_t *knn, int knn_stride, float *g_in_xyz, float *g_q_xyz,
+                             int B, int C, int M, int Nq, int k, void *stream);
 
 /*
  * input tensor of the point cost-volume lookup (models/camliraft_l_core.py:62-76):
@@ -188,6 +195,8 @@ int camli_gru_blend_bwd(const float *g, const float *z, const float *h, const fl
  *   sign_mask (optional, act 1 / 2 with P % 4 == 0, camli_bias_act_mask_bytes(B,C,P) bytes): the forward
  *   also records one bit per element (y > 0); a backward given the mask does not read y at all
  *   (8.1 instead of 12 bytes per element).  Pass NULL for the y-based form.
+ *   act 0 (identity): gx equals gy, so pass gx = NULL (and y = NULL): the call then only reduces the bias
+ *   sums, 4 bytes per element read and nothing written; the caller hands gy on as the input gradient.
  */
 int64_t camli_bias_act_mask_bytes(int B, int C, int P);
 int camli_bias_act_fwd(float *x_inout, const float *bias, void *sign_mask, int B, int C, int P, int act, void *stream);

@@ -171,6 +171,18 @@ def knn_interp_bwd(in_xyz, gout, q_xyz, knn_idx, M):
     return gfeat
 
 
+def knn_interp_bwd_xyz(in_xyz, feat, gout, q_xyz, knn_idx):
+    """-> (g_in_xyz [B,3,M], g_q_xyz [B,3,Nq])"""
+    in_xyz, feat, gout, q_xyz, knn_idx = _f32(in_xyz), _f32(feat), _f32(gout), _f32(q_xyz), _i64(knn_idx)
+    B, C, M = feat.shape
+    Nq, k = knn_idx.shape[1], knn_idx.shape[2]
+    g_in = np.zeros((B, 3, M), dtype=np.float32)
+    g_q = np.zeros((B, 3, Nq), dtype=np.float32)
+    _chk(_load().oracle_knn_interp_bwd_xyz(_p(in_xyz), _p(feat), _p(gout), _p(q_xyz), _p(knn_idx), _p(g_in), _p(g_q),
+                                           B, C, M, Nq, k), "knn_interp_bwd_xyz")
+    return g_in, g_q
+
+
 def corr3d_gather_fwd(xyz1, xyz2, cost, knn_idx):
     xyz1, xyz2, cost, knn_idx = _f32(xyz1), _f32(xyz2), _f32(cost), _i64(knn_idx)
     B, N, M = cost.shape

@@ -409,6 +409,53 @@ int oracle_knn_interp_bwd(const float *in_xyz, const float *gout, const float *q
     return 0;
 }
 
+/* adjoint of oracle_knn_interp_fwd w.r.t. the coordinates: models/utils.py:138-146 differentiated the way
+ * torch.autograd does it (linalg.norm: 0 at 0; clamp(1e-8): passes where the norm >= 1e-8).
+ * g_in [B,3,M] accumulates (caller zero-fills), g_q [B,3,Nq] is written. */
+int oracle_knn_interp_bwd_xyz(const float *in_xyz, const float *feat, const float *gout, const float *q_xyz,
+                              const int64_t *knn, float *g_in, float *g_q, int B, int C, int M, int Nq, int k)
+{
+    if (k > ORACLE_MAX_K) return -1;
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < Nq; ++q) {
+            double w[ORACLE_MAX_K], raw[ORACLE_MAX_K], d[ORACLE_MAX_K][3], a[ORACLE_MAX_K], wsum = 0.0, s_tot = 0.0;
+            const int64_t *ix = knn + ((size_t)b * Nq + q) * k;
+            for (int j = 0; j < k; ++j) {
+                float s = 0.0f;
+                for (int ax = 0; ax < 3; ++ax) {
+                    float df = in_xyz[((size_t)b * 3 + ax) * M + ix[j]] - q_xyz[((size_t)b * 3 + ax) * Nq + q];
+                    d[j][ax] = df;
+                    s += df * df;
+                }
+                raw[j] = sqrtf(s);
+                w[j] = 1.0 / (raw[j] < 1e-8f ? 1e-8f : (float)raw[j]);
+                wsum += w[j];
+                a[j] = 0.0;
+            }
+            for (int c = 0; c < C; ++c) {
+                double g = gout[((size_t)b * C + c) * Nq + q], o = 0.0;
+                for (int j = 0; j < k; ++j) {
+                    double f = feat[((size_t)b * C + c) * M + ix[j]];
+                    o += f * (w[j] / wsum);
+                    a[j] += g * f;
+                }
+                s_tot += g * o;
+            }
+            double gq[3] = {0.0, 0.0, 0.0};
+            for (int j = 0; j < k; ++j) {
+                if (!(raw[j] >= 1e-8f)) continue;
+                double gd = -((a[j] - s_tot) / wsum) * (w[j] * w[j]);
+                for (int ax = 0; ax < 3; ++ax) {
+                    double v = gd * (d[j][ax] / raw[j]);
+                    g_in[((size_t)b * 3 + ax) * M + ix[j]] += (float)v;
+                    gq[ax] -= v;
+                }
+            }
+            for (int ax = 0; ax < 3; ++ax) g_q[((size_t)b * 3 + ax) * Nq + q] = (float)gq[ax];
+        }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * input of the point cost-volume lookup: follows models/camliraft_l_core.py:62-76
  *   out[b,0:3,n,j] = xyz2[b,:,knn[b,n,j]] - xyz1[b,:,n];  out[b,3,n,j] = cost[b,n,knn[b,n,j]]

@@ -58,6 +58,53 @@ def test_knn_interpolate(case, oracle_lib):
                        rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('case', [(2, 3, 2048, 1024, 3), (1, 67, 512, 1024, 3), (2, 7, 200, 90, 5)], ids=str)
+def test_knn_interpolate_coordinate_adjoint(case, oracle_lib):
+    """CamLiPWC back-warps with a live flow (camlipwc_core.py:172-179): gradients reach both coordinate sets.
+    Checked against the oracle's adjoint (itself pinned on the reference's autograd, tests/test_oracle_golden.py);
+    coincident points exercise the clamp / norm-at-zero subgradients."""
+    from camliflow_amd.csrc import fused, k_nearest_neighbor
+    b, c, m, nq, k = case
+    rng = np.random.default_rng(nq + 1)
+    in_xyz = rng.standard_normal((b, 3, m)).astype(np.float32)
+    q_xyz = rng.standard_normal((b, 3, nq)).astype(np.float32)
+    q_xyz[:, :, :4] = in_xyz[:, :, :4]
+    feat = rng.standard_normal((b, c, m)).astype(np.float32)
+    knn = k_nearest_neighbor(dev(in_xyz), dev(q_xyz), k)
+    ti, tf, tq = dev(in_xyz).requires_grad_(True), dev(feat).requires_grad_(True), dev(q_xyz).requires_grad_(True)
+    out = fused.knn_interpolate(ti, tf, tq, knn, k)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(g))
+    want_in, want_q = oracle_lib.knn_interp_bwd_xyz(in_xyz, feat, g, q_xyz, knn.cpu().numpy())
+    scale = max(np.abs(want_in).max(), np.abs(want_q).max())
+    assert np.abs(ti.grad.cpu().numpy() - want_in).max() <= 2e-4 * scale
+    assert np.abs(tq.grad.cpu().numpy() - want_q).max() <= 2e-4 * scale
+    assert np.allclose(tf.grad.cpu().numpy(), oracle_lib.knn_interp_bwd(in_xyz, g, q_xyz, knn.cpu().numpy(), m),
+                       rtol=1e-4, atol=1e-5)
+
+
+def test_backwarp_3d_with_live_flow_stays_on_hip():
+    """the CamLiPWC call pattern: backwarp_3d(xyz1, xyz2, flow) with flow requiring grad -- under CAMLI strict mode
+    nothing may drop to the composed formulation, and the flow gradient must match the composed one"""
+    from camliflow_amd.cores import geometry, runtime
+    torch.manual_seed(0)
+    xyz1, xyz2 = torch.rand(2, 3, 512, device='cuda') * 4, torch.rand(2, 3, 512, device='cuda') * 4
+    flow = (torch.randn(2, 3, 512, device='cuda') * 0.1).requires_grad_(True)
+    g = torch.randn(2, 3, 512, device='cuda')
+    res = {}
+    for backend in ('hip', 'composed'):
+        with runtime.use_backend(backend):
+            runtime.set_strict(backend == 'hip')
+            try:
+                out = geometry.backwarp_3d(xyz1, xyz2, flow)
+                res[backend] = (out.detach(), torch.autograd.grad(out, flow, g)[0])
+            finally:
+                runtime.set_strict(False)
+    assert torch.allclose(res['hip'][0], res['composed'][0], rtol=1e-5, atol=1e-5)
+    err = (res['hip'][1] - res['composed'][1]).abs().max() / res['composed'][1].abs().max()
+    assert err < 1e-3, err
+
+
 def test_knn_interpolation_golden_through_the_core_function(golden):
     from camliflow_amd.cores import runtime
     from camliflow_amd.cores.geometry import knn_interpolation

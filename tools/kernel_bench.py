@@ -1,0 +1,222 @@
+"""Isolated per-kernel roofline rows of the north-star operators at the shapes of the headline step
+(BASELINE configs[2]: CamLiRAFT 960x540 + 8192 points, batch 8) plus the PWC correlation shapes of configs[1].
+
+Every case drives the C-ABI entry point through the same Python wrappers the cores use; each launch is bracketed
+by HIP events on its launch stream (csrc/_lib.KernelTimer) and carries its ALGORITHMIC work,
+so a row is   achieved = algorithmic work / average launch duration   on an otherwise idle GPU (no second lane).
+
+  python tools/kernel_bench.py [--batch 8] [--reps 20] [--only substr] [--json out.json]
+
+bench.py imports ``run()`` for its ``roofline_rows``; the committed rocprofv3 --kernel-trace --stats summary of
+THIS command (profiles/r02_kernel_bench_*) is what the per-row durations are checked against.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8000.0          # GB/s, MI355X_MICROARCH.md (spec; ~6.3 TB/s is the measured copy ceiling)
+MFMA_F32_PEAK = 157.3      # TFLOP/s, fp32-input MFMA = the fp32 vector rate
+VALU_PAIR_PEAK = 7865.0    # Gpairs/s: 157.3 TFLOP/s / 2 flop per lane-op / ~10 lane-ops per candidate pair (3-D)
+LDS_STEP_IDEAL_US = 0.35   # FPS: one dependent step with the cloud resident in registers (update + arg-max + 1 barrier)
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.rand(*shape, generator=g) * scale).cuda()
+
+
+def _randn(g, *shape):
+    return torch.randn(*shape, generator=g).cuda()
+
+
+def cases(batch):
+    """yield (row name, callable running the op once, {entry point: bound kind})"""
+    from camliflow_amd import csrc
+    from camliflow_amd.csrc import fused, wrapper
+    g = torch.Generator(device='cpu').manual_seed(0)
+    b = batch
+
+    # ---- A1 correlation2d, PWC pyramid shapes (configs[1], batch 1) + the reference self-check shape -------------
+    for (cb, c, h, w) in [(1, 32, 144, 240), (1, 64, 72, 120), (1, 96, 36, 60), (1, 128, 18, 30), (1, 192, 9, 15),
+                          (32, 128, 144, 240)]:
+        in1 = _randn(g, cb, h, w, c).requires_grad_(True)
+        in2 = _randn(g, cb, h, w, c).requires_grad_(True)
+        go = _randn(g, cb, 81, h, w)
+
+        def corr(in1=in1, in2=in2, go=go):
+            out = wrapper.CorrelationFunction.apply(in1, in2, 4)
+            torch.autograd.grad(out, [in1, in2], go)
+        yield 'corr2d B%d C%d %dx%d' % (cb, c, h, w), corr, {'camli_corr2d_fwd': 'hbm', 'camli_corr2d_bwd': 'hbm'}
+
+    # ---- A2 / A3 all-pairs volume: build (+ adjoint) and the radius-4 lookup (+ adjoint) --------------------------
+    h, w = 68, 120
+    f1 = _randn(g, b, 256, h, w).requires_grad_(True)
+    f2 = _randn(g, b, 256, h, w).requires_grad_(True)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    coords = (torch.stack([xs, ys])[None].repeat(b, 1, 1, 1) + torch.randn(b, 2, h, w, generator=g) * 3).cuda()
+    go_lookup = _randn(g, b, 324, h, w)
+
+    def allpairs():
+        pyr = fused.allpairs_pyramid(f1, f2, 4)
+        out = fused.allpairs_lookup(pyr, coords, 4)
+        torch.autograd.grad(out, [f1, f2], go_lookup)
+    yield 'allpairs B%d 68x120' % b, allpairs, {'camli_allpairs_build_fwd': 'mfma', 'camli_allpairs_build_bwd': 'mfma',
+                                                'camli_allpairs_fold_bwd': 'hbm',
+                                                'camli_allpairs_lookup_fwd': 'hbm', 'camli_allpairs_lookup_bwd': 'hbm'}
+
+    # ---- A4 furthest point sampling ---------------------------------------------------------------------------
+    xyz = _rand(g, 2 * b, 8192, 3, scale=10.0)
+    yield 'fps B%d 8192->4096' % (2 * b), (lambda: csrc.furthest_point_sampling(xyz, 4096)), {'camli_fps': 'fps'}
+
+    # ---- A6 KNN at every shape of the step -----------------------------------------------------------------------
+    for (m, nq, d, k) in [(8192, 4096, 3, 16), (4096, 2048, 3, 16), (2048, 2048, 3, 32), (2048, 2048, 3, 16),
+                          (1024, 2048, 3, 16), (512, 2048, 3, 16), (256, 2048, 3, 16), (2048, 2048, 3, 3),
+                          (2048, 1024, 3, 3), (2048, 8192, 3, 3), (2048, 8160, 2, 1)]:
+        inp, qry = _rand(g, b, m, d, scale=10.0), _rand(g, b, nq, d, scale=10.0)
+        yield ('knn B%d M%d Nq%d D%d k%d' % (b, m, nq, d, k),
+               (lambda inp=inp, qry=qry, k=k: csrc.k_nearest_neighbor(inp, qry, k)), {'camli_knn': 'valu'})
+
+    # ---- A8 gather / scatter (the cost-volume pooling gathers of Correlation3D.build) ---------------------------
+    for (c, m, i) in [(2048, 2048, 3072), (128, 2048, 2048 * 16)]:
+        data = _randn(g, b, c, m).requires_grad_(True)
+        idx = torch.randint(0, m, (b, i), generator=g).cuda()
+        go = _randn(g, b, c, i)
+
+        def gather(data=data, idx=idx, go=go):
+            out = fused.gather_points(data, idx)
+            torch.autograd.grad(out, data, go)
+        yield 'gather_cf B%d C%d M%d I%d' % (b, c, m, i), gather, {'camli_gather_cf_fwd': 'hbm', 'camli_gather_cf_bwd': 'hbm'}
+
+    # ---- A9 PointConv mixing (Encoder3D) -------------------------------------------------------------------------
+    for (m, n, ch) in [(8192, 4096, 99), (4096, 2048, 131)]:
+        feat = _randn(g, b, m, ch).requires_grad_(True)
+        wgt = _rand(g, b, 16, n, 16).requires_grad_(True)
+        idx = torch.randint(0, m, (b, n, 16), generator=g).cuda()
+        go = _randn(g, b, n, 16, ch)
+
+        def mix(feat=feat, wgt=wgt, idx=idx, go=go):
+            out = fused.pointconv_mix(feat, wgt, idx, 16)
+            torch.autograd.grad(out, [feat, wgt], go)
+        yield 'pointconv_mix B%d M%d n%d CH%d' % (b, m, n, ch), mix, {'camli_pointconv_mix_fwd': 'hbm', 'camli_pointconv_mix_bwd': 'hbm'}
+
+    # ---- A10 PointConvDW: fused gather * weight -> max, and the weight network on the matrix cores ---------------
+    n = 2048
+    for (c, k) in [(128, 32), (128, 16), (128, 4)]:
+        feat = _randn(g, b, c, n).requires_grad_(True)
+        wgt = _rand(g, b, c, n, k).requires_grad_(True)
+        idx = torch.randint(0, n, (b, n, 32), generator=g).cuda()
+        go = _randn(g, b, c, n)
+
+        def dw(feat=feat, wgt=wgt, idx=idx, go=go, k=k):
+            shared = fused.SharedSetConvWeights(wgt)
+            out = fused.pointconv_dw(feat, shared, idx, k)
+            torch.autograd.grad(out, [feat, wgt], go)
+        yield 'pointconv_dw B%d C%d k%d' % (b, c, k), dw, {'camli_pointconv_dw_fwd': 'hbm', 'camli_pointconv_dw_bwd': 'hbm',
+                                                           'camli_pointconv_dw_expand': 'hbm'}
+    from camliflow_amd.cores.blocks import MLP2d
+    xyzc = _rand(g, b, 3, n, scale=10.0)
+    for k in (16, 32):
+        mlp = MLP2d(3, [8, 32, 128], act='relu').cuda()
+        idx = torch.randint(0, n, (b, n, 32), generator=g).cuda()
+        go = _randn(g, b, 128, n, k)
+
+        def wn(mlp=mlp, idx=idx, go=go, k=k):
+            out = fused.weightnet(xyzc, xyzc, idx, k, mlp)
+            torch.autograd.grad(out, list(mlp.parameters()), go)
+        yield 'weightnet B%d C128 k%d' % (b, k), wn, {'camli_weightnet_fwd': 'hbm', 'camli_weightnet_bwd': 'mfma_wn'}
+
+    # ---- A11 / A12 interpolation and the point cost-volume gather ------------------------------------------------
+    in_xyz, q_xyz = _rand(g, b, 3, 2048, scale=10.0), _rand(g, b, 3, 8192, scale=10.0)
+    feat = _randn(g, b, 3, 2048).requires_grad_(True)
+    knn3 = torch.randint(0, 2048, (b, 8192, 3), generator=g).cuda()
+    go = _randn(g, b, 3, 8192)
+
+    def interp():
+        out = fused.knn_interpolate(in_xyz, feat, q_xyz, knn3, 3)
+        torch.autograd.grad(out, feat, go)
+    yield 'knn_interp B%d C3 M2048 Nq8192' % b, interp, {'camli_knn_interp_fwd': 'hbm', 'camli_knn_interp_bwd': 'hbm'}
+
+    cost = _randn(g, b, 2048, 2048).requires_grad_(True)
+    x1, x2 = _rand(g, b, 3, 2048), _rand(g, b, 3, 2048)
+    knn16 = torch.randint(0, 2048, (b, 2048, 16), generator=g).cuda()
+    go4 = _randn(g, b, 4, 2048, 16)
+
+    def c3d():
+        out = fused.corr3d_lookup_input(cost, x1, x2, knn16)
+        torch.autograd.grad(out, cost, go4)
+    yield 'corr3d_gather B%d N2048 k16' % b, c3d, {'camli_corr3d_gather_fwd': 'hbm', 'camli_corr3d_gather_bwd': 'hbm'}
+
+
+def _row(case, name, kind, rec, fps_steps=None):
+    us = rec['total_ms'] / rec['launches'] * 1e3
+    work = rec['work'] / rec['launches']
+    row = {'case': case, 'kernel': name, 'avg_launch_us': round(us, 2), 'launches': rec['launches'],
+           'algorithmic_work_per_launch': work, 'work_unit': rec['unit']}
+    if kind == 'hbm':
+        ach = work / us / 1e3
+        row.update(bound='hbm', achieved=round(ach, 1), peak=HBM_PEAK, unit='GB/s', frac=round(ach / HBM_PEAK, 4))
+    elif kind in ('mfma', 'mfma_wn'):
+        flop = rec.get('flop', 0.0) / rec['launches']
+        ach = flop / us / 1e6
+        row.update(bound='mfma', achieved=round(ach, 2), peak=MFMA_F32_PEAK, unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK, 4),
+                   flop_per_launch=flop)
+    elif kind == 'valu':
+        ach = work / us / 1e3
+        row.update(bound='valu', achieved=round(ach, 1), peak=VALU_PAIR_PEAK, unit='Gpairs/s', frac=round(ach / VALU_PAIR_PEAK, 4))
+    elif kind == 'fps':
+        steps = fps_steps or 4096
+        row.update(bound='latency', achieved=round(us / steps, 3), peak=LDS_STEP_IDEAL_US, unit='us/dependent-step',
+                   frac=round(LDS_STEP_IDEAL_US / (us / steps), 4))
+    return row
+
+
+def run(batch=8, reps=10, only=None):
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.csrc import _lib
+    _lib.load()
+    runtime.set_backend('hip')
+    rows = []
+    for case, fn, kinds in cases(batch):
+        if only and only not in case:
+            continue
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        _lib.TIMER.reset()
+        _lib.TIMER.only = None
+        _lib.TIMER.enabled = True
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        _lib.TIMER.enabled = False
+        summary = _lib.TIMER.summary()
+        for name, rec in summary.items():
+            if name in kinds:
+                rows.append(_row(case, name, kinds[name], rec))
+    _lib.TIMER.reset()
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--only', default=None)
+    ap.add_argument('--json', default=None)
+    args = ap.parse_args()
+    rows = run(args.batch, args.reps, args.only)
+    print('%-34s %-28s %10s %12s %-18s %6s' % ('case', 'kernel', 'us', 'achieved', 'unit', 'frac'))
+    for r in rows:
+        print('%-34s %-28s %10.1f %12.1f %-18s %6.3f' % (r['case'], r['kernel'], r['avg_launch_us'], r['achieved'], r['unit'], r['frac']))
+    if args.json:
+        with open(args.json, 'w') as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
