@@ -37,7 +37,10 @@ def _neighbourhood(xyz, sampled_xyz, knn_indices, k):
     if sampled_xyz is None:
         sampled_xyz = xyz
     if knn_indices is None:
-        knn_indices = _ops.k_nearest_neighbor(xyz, sampled_xyz, k)
+        # inside a pass the pyramid clouds are fixed tensors: the feature and context encoders of frame 1 ask for the
+        # same neighbour table (camliraft_core.py:45-47), which the pass cache then serves once
+        from .geometry import knn_channel_first
+        knn_indices = knn_channel_first(xyz, sampled_xyz, k, invariant_input=True, invariant_query=True)
     else:
         bs, n_samples = sampled_xyz.shape[0], sampled_xyz.shape[-1]
         assert knn_indices.shape[:2] == torch.Size([bs, n_samples])

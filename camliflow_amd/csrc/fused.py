@@ -654,6 +654,33 @@ def weightnet(xyz, centres, knn_indices, k, mlp):
 
 
 # ------------------------------------------------------------------------------------------------
+# inverse index maps: the adjoint of a gather without atomics
+# ------------------------------------------------------------------------------------------------
+_inverse_maps = {}      # key -> (index tensor kept alive so its address cannot be recycled, order, offsets); small LRU
+
+
+def inverse_map(idx_flat, m):
+    """idx_flat int64 [B, I] with values in [0, m) -> (order int32 [B*I], offsets int32 [B*m + 1]): the flat
+    positions b*I + i sorted (stably) by (b, idx) and the CSR bounds of every (b, source) segment.  This is what
+    torch's index_put_(accumulate=True) recomputes with a device-wide sort on EVERY backward call; here it is
+    built once per index tensor (neighbour tables are shared by the modules and iterations of a pass) and turns
+    scatter-adds into coalesced segment sums."""
+    key = (idx_flat.data_ptr(), tuple(idx_flat.shape), tuple(idx_flat.stride()), m, idx_flat._version)
+    hit = _inverse_maps.pop(key, None)
+    if hit is None:
+        b, i = idx_flat.shape
+        assert b * i < 2 ** 31 and b * m < 2 ** 31
+        keys = (idx_flat + torch.arange(b, device=idx_flat.device).view(b, 1) * m).reshape(-1)
+        sorted_keys, order = torch.sort(keys, stable=True)
+        offsets = torch.searchsorted(sorted_keys, torch.arange(b * m + 1, device=idx_flat.device))
+        hit = (idx_flat, order.to(torch.int32), offsets.to(torch.int32))
+        while len(_inverse_maps) >= 16:
+            _inverse_maps.pop(next(iter(_inverse_maps)))
+    _inverse_maps[key] = hit          # (re)insert as most recent
+    return hit[1], hit[2]
+
+
+# ------------------------------------------------------------------------------------------------
 # gather / interpolation / point cost-volume lookup (models/utils.py, models/camliraft_l_core.py)
 # ------------------------------------------------------------------------------------------------
 class _GatherCF(torch.autograd.Function):
@@ -679,11 +706,13 @@ class _GatherCF(torch.autograd.Function):
         (idx_flat,) = ctx.saved_tensors
         gout = gout.contiguous().float()
         b, c, i = gout.shape
-        gdata = torch.zeros((b, c, ctx.m), dtype=torch.float32, device=gout.device)
+        # gather-side adjoint through the inverse map: no atomics, every output written once
+        order, offsets = inverse_map(idx_flat, ctx.m)
+        gdata = torch.empty((b, c, ctx.m), dtype=torch.float32, device=gout.device)
         with _on_device(gout):
-            _lib.launch('camli_gather_cf_bwd', lib.camli_gather_cf_bwd, gout.data_ptr(), idx_flat.data_ptr(),
-                        gdata.data_ptr(), b, c, ctx.m, i, _stream_ptr(gout),
-                        work=(8.0 * b * c * i + 8.0 * b * i, 'B'))
+            _lib.launch('camli_gather_cf_bwd', lib.camli_gather_cf_bwd_sorted, gout.data_ptr(), order.data_ptr(),
+                        offsets.data_ptr(), gdata.data_ptr(), b, c, ctx.m, i, _stream_ptr(gout),
+                        work=(4.0 * b * c * (i + ctx.m) + 4.0 * b * (i + ctx.m), 'B'))
         return gdata, None
 
 
@@ -818,8 +847,28 @@ class _PointConvMix(torch.autograd.Function):
         wn, n = wgt.shape[1], wgt.shape[2]
         k = ctx.k
         gout = gout.contiguous().float()
-        gfeat = torch.zeros_like(feat_cl) if ctx.needs_input_grad[0] else None
         gwgt = torch.empty_like(wgt) if ctx.needs_input_grad[1] else None
+        if k == 16 and wn == 16:
+            # atomic-free: per-point row gradients into a scratch tensor, then a segment sum through the inverse
+            # neighbour map (built once per neighbour table)
+            gfeat = scratch = order = offsets = None
+            if ctx.needs_input_grad[0]:
+                flat = knn_indices[:, :, :k].reshape(b, n * k) if knn_indices.shape[2] != k else knn_indices.view(b, n * k)
+                order, offsets = inverse_map(flat, m)
+                gfeat = torch.empty_like(feat_cl)
+                scratch = torch.empty(lib.camli_pointconv_mix_bwd_scratch_bytes(b, n, ch, k) // 4, dtype=torch.float32,
+                                      device=gout.device)
+            with _on_device(feat_cl):
+                _lib.launch('camli_pointconv_mix_bwd', lib.camli_pointconv_mix_bwd_sorted, gout.data_ptr(), feat_cl.data_ptr(),
+                            wgt.data_ptr(), knn_indices.data_ptr(), knn_indices.stride(1),
+                            order.data_ptr() if order is not None else None,
+                            offsets.data_ptr() if offsets is not None else None,
+                            scratch.data_ptr() if scratch is not None else None,
+                            gfeat.data_ptr() if gfeat is not None else None, gwgt.data_ptr() if gwgt is not None else None,
+                            b, m, n, ch, wn, k, _stream_ptr(feat_cl),
+                            work=(4.0 * b * n * (wn * ch + 2 * k * ch + 2 * wn * k) + 8.0 * b * n * k, 'B'))
+            return gfeat, gwgt, None, None
+        gfeat = torch.zeros_like(feat_cl) if ctx.needs_input_grad[0] else None
         with _on_device(feat_cl):
             _lib.launch('camli_pointconv_mix_bwd', lib.camli_pointconv_mix_bwd, gout.data_ptr(), feat_cl.data_ptr(),
                         wgt.data_ptr(), knn_indices.data_ptr(), knn_indices.stride(1),

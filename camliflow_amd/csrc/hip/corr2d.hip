@@ -16,7 +16,15 @@
 // axis (coalesced), the grad_output scalar is wave-uniform per pixel.
 #include "camli_common.h"
 
+#include <stdlib.h>
+
 namespace {
+
+// CAMLI_CORR2D_TILE=0 selects the one-row forward kernel (A/B measurements); default: the 2-D tile kernel
+bool camli_corr2d_use_tile() {
+    static const bool on = [] { const char* e = getenv("CAMLI_CORR2D_TILE"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 constexpr int CT_PX = 64;     // pixels per workgroup (one wave-width)
 constexpr int CT_CMAX = 256;  // in1 channels resident in LDS per pass
@@ -285,6 +293,169 @@ __global__ __launch_bounds__(256) void corr2d_bwd_tiled_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Forward, md = 4, C % 4 == 0: 2-D output tile per workgroup.
+//
+// The one-row kernel above re-streams every in2 row for each of the 9 dy that use it (9x the L2 -> LDS bytes) and
+// synchronises twice per (dy, 64-channel chunk) with nothing in flight: at the reference's self-check shape it sat
+// at 0.65 TB/s, bound by exposed load latency and by LDS read bandwidth (3.6 FMA per ds_read_b128).  Here a
+// 512-thread workgroup owns TH = 8 rows x TW = 64 columns of output pixels:
+//   * per 16-channel pass the in1 tile [8][64] and the in2 halo tile [16][72] are staged ONCE into LDS as channel
+//     planes (x contiguous): an in2 row is fetched once per tile instead of once per (row, dy) -- 2.25x the
+//     algorithmic in2 bytes instead of 9x.  A pass covers 64 contiguous bytes of every pixel (half an L2 line;
+//     narrower passes multiply the L2 -> L1 line traffic), the next pass's global loads are issued before the
+//     current pass's math and land in registers while it runs (one barrier pair per pass)
+//   * a thread owns 2 adjacent pixels of one row and half of the dy range (5 or 4 of the 9; wave = (2-row block,
+//     dy half), one heavy and one light wave per SIMD): 90 / 72 accumulators live in VGPRs across the whole
+//     channel loop.  Per channel it reads its 2 in1 values (one ds_read_b64) and, per dy, the 10-wide in2 window
+//     (five ds_read_b64) for 18 FMAs; lanes run along x, so every 32-lane read group covers 64 distinct banks
+//   * plane stride == 2 (mod 32) floats makes the transposing staging stores (4 lanes = 4 channel quads of one
+//     pixel) hit 32 distinct banks; cost-volume rows are written as contiguous float2 per lane.
+// grid (ceil(W/64), ceil(H/8), B), block 512, 108 KB of LDS (one workgroup = 2 waves per SIMD).
+struct CorrTile {
+    static constexpr int XG = 32, TW = 64, TH = 8, CC = 16, Q = CC / 4, NT = 512;
+    static constexpr int XS1 = TW, XS2 = TW + 8;
+    static constexpr int PS1 = TH * XS1 + 2;                  // == 2 (mod 32)
+    static constexpr int PS2 = (TH + 8) * XS2 + 2;            // 1154 == 2 (mod 32)
+    static constexpr int N1 = TH * TW * Q, N2 = (TH + 8) * (TW + 8) * Q;
+    static constexpr int L1 = (N1 + NT - 1) / NT, L2 = (N2 + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = (size_t)CC * (PS1 + PS2) * sizeof(float);
+};
+
+__global__ __launch_bounds__(512) void corr2d_fwd_tile_kernel(const float* __restrict__ in1,
+                                                               const float* __restrict__ in2,
+                                                               float* __restrict__ out, int C, int H, int W) {
+    using T = CorrTile;
+    constexpr int MD = 4, DD = 9, Q = T::Q;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s1 = smem;                       // [CC][PS1]  rows of XS1
+    float* s2 = smem + T::CC * T::PS1;      // [CC][PS2]  rows of XS2
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane & 31;
+    const int half = wave >> 2;                       // waves 0-3: dy 0..4, waves 4-7: dy 5..8
+    const int r = (wave & 3) * 2 + (lane >> 5);       // row of the tile
+    const int d0 = half * 5, nd = 5 - half;
+    const int x0t = blockIdx.x * T::TW, y0t = blockIdx.y * T::TH, n = blockIdx.z;
+    const size_t img = (size_t)n * H * W;
+
+    float acc[5][2][DD];
+#pragma unroll
+    for (int d = 0; d < 5; ++d)
+#pragma unroll
+        for (int k = 0; k < DD; ++k) acc[d][0][k] = acc[d][1][k] = 0.0f;
+
+    float4 pre1[T::L1], pre2[T::L2];
+    auto gload = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < T::L1; ++i) {
+            const int e = tid + i * T::NT;
+            const int q = e % Q, px = (e / Q) % T::TW, row = e / (Q * T::TW);
+            const int y = y0t + row, x = x0t + px, c = c0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < T::N1 && y < H && x < W && c < C) v = *reinterpret_cast<const float4*>(in1 + (img + (size_t)y * W + x) * C + c);
+            pre1[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < T::L2; ++i) {
+            const int e = tid + i * T::NT;
+            const int q = e % Q, px = (e / Q) % (T::TW + 8), row = e / (Q * (T::TW + 8));
+            const int y = y0t - MD + row, x = x0t - MD + px, c = c0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < T::N2 && y >= 0 && y < H && x >= 0 && x < W && c < C)
+                v = *reinterpret_cast<const float4*>(in2 + (img + (size_t)y * W + x) * C + c);
+            pre2[i] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < T::L1; ++i) {
+            const int e = tid + i * T::NT;
+            if (e < T::N1) {
+                const int q = e % Q, px = (e / Q) % T::TW, row = e / (Q * T::TW);
+                float* d = s1 + (4 * q) * T::PS1 + row * T::XS1 + px;
+                d[0] = pre1[i].x; d[T::PS1] = pre1[i].y; d[2 * T::PS1] = pre1[i].z; d[3 * T::PS1] = pre1[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < T::L2; ++i) {
+            const int e = tid + i * T::NT;
+            if (e < T::N2) {
+                const int q = e % Q, px = (e / Q) % (T::TW + 8), row = e / (Q * (T::TW + 8));
+                float* d = s2 + (4 * q) * T::PS2 + row * T::XS2 + px;
+                d[0] = pre2[i].x; d[T::PS2] = pre2[i].y; d[2 * T::PS2] = pre2[i].z; d[3 * T::PS2] = pre2[i].w;
+            }
+        }
+    };
+
+    gload(0);
+    for (int c0 = 0; c0 < C; c0 += T::CC) {
+        __syncthreads();          // every wave is done reading the previous pass
+        lstore();
+        __syncthreads();
+        if (c0 + T::CC < C) gload(c0 + T::CC);      // in flight while this pass is consumed
+        const float* a_row = s1 + r * T::XS1 + 2 * g;
+        const float* b_row = s2 + (r + d0) * T::XS2 + 2 * g;
+#pragma unroll 1
+        for (int c = 0; c < T::CC; ++c) {
+            const float2 a = *reinterpret_cast<const float2*>(a_row + c * T::PS1);
+#pragma unroll
+            for (int d = 0; d < 5; ++d) {
+                if (d < nd) {          // wave-uniform
+                    const float* bp = b_row + c * T::PS2 + d * T::XS2;
+                    float b[10];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const float2 t = *reinterpret_cast<const float2*>(bp + 2 * j);
+                        b[2 * j] = t.x;
+                        b[2 * j + 1] = t.y;
+                    }
+#pragma unroll
+                    for (int k = 0; k < DD; ++k) {
+                        acc[d][0][k] = __builtin_fmaf(a.x, b[k], acc[d][0][k]);
+                        acc[d][1][k] = __builtin_fmaf(a.y, b[k + 1], acc[d][1][k]);
+                    }
+                }
+            }
+        }
+    }
+
+    const int y = y0t + r, x = x0t + 2 * g;
+    if (y < H && x < W) {
+        const float inv_c = 1.0f / (float)C;
+        const size_t plane = (size_t)H * W;
+        float* o = out + (size_t)n * DD * DD * plane + (size_t)y * W + x;
+        const bool vec = ((W & 1) == 0);      // x is even: a float2 store stays inside the row and aligned
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+            if (d < nd) {
+#pragma unroll
+                for (int k = 0; k < DD; ++k) {
+                    float* op = o + (size_t)((d0 + d) * DD + k) * plane;
+                    if (vec) {
+                        *reinterpret_cast<float2*>(op) = make_float2(acc[d][0][k] * inv_c, acc[d][1][k] * inv_c);
+                    } else {
+                        op[0] = acc[d][0][k] * inv_c;
+                        if (x + 1 < W) op[1] = acc[d][1][k] * inv_c;
+                    }
+                }
+            }
+    }
+}
+
+int launch_fwd_tile(const float* in1, const float* in2, float* out, int B, int C, int H, int W, hipStream_t stream) {
+    using T = CorrTile;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr2d_fwd_tile_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid(camli_divup(W, T::TW), camli_divup(H, T::TH), B);
+    hipLaunchKernelGGL(corr2d_fwd_tile_kernel, grid, dim3(T::NT), T::LDS_BYTES, stream, in1, in2, out, C, H, W);
+    return camli_check_launch("camli_corr2d_fwd(tile)");
+}
+
 template <int MD>
 int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1, float* g2, int B, int C, int H, int W,
                hipStream_t stream) {
@@ -329,7 +500,11 @@ extern "C" int camli_corr2d_fwd(const float* in1_nhwc, const float* in2_nhwc, fl
         case 1: return launch_fwd<1>(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
         case 2: return launch_fwd<2>(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
         case 3: return launch_fwd<3>(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
-        case 4: return launch_fwd<4>(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
+        case 4:
+            if ((C & 3) == 0 && camli_corr2d_use_tile()) {
+                return launch_fwd_tile(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
+            }
+            return launch_fwd<4>(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
         default: {
             hipLaunchKernelGGL(corr2d_fwd_generic_kernel, dim3(2048), dim3(256), 0, s, in1_nhwc, in2_nhwc, out_nchw,
                                B, C, H, W, md);

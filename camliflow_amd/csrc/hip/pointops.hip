@@ -36,6 +36,28 @@ __global__ __launch_bounds__(256) void gather_cf_bwd_kernel(const float* __restr
         unsafeAtomicAdd(gdata + ((size_t)b * C + c) * M + m, gout[((size_t)b * C + c) * I + i]);
 }
 
+// Gather-side adjoint: gdata[b,c,m] = sum over the positions i with idx[b,i] == m of gout[b,c,i], walked through the
+// inverse map (CSR over (b, m): `order` holds the GLOBAL flat positions b*I + i sorted by (b, idx), `offsets` the
+// segment bounds).  No atomics (the scatter form above manages 26 G atomics/s = 0.03 of the HBM roofline), every output
+// written once, fixed summation order.  Lanes run along m; the 4-byte reads of one (b, c) row stay inside I*4 bytes
+// (L2-resident), the writes are coalesced.  grid (ceil(M/256), min(C,64), B).
+__global__ __launch_bounds__(256) void gather_cf_bwd_sorted_kernel(const float* __restrict__ gout,
+                                                                    const int32_t* __restrict__ order,
+                                                                    const int32_t* __restrict__ offsets,
+                                                                    float* __restrict__ gdata, int C, int M, int I) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    if (m >= M) return;
+    const int beg = offsets[(size_t)b * M + m], end = offsets[(size_t)b * M + m + 1];
+    const int base = b * I;
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        const float* __restrict__ row = gout + ((size_t)b * C + c) * I - base;
+        float acc = 0.0f;
+        for (int e = beg; e < end; ++e) acc += row[order[e]];
+        gdata[((size_t)b * C + c) * M + m] = acc;
+    }
+}
+
 // ---- inverse-distance interpolation from precomputed k nearest neighbours -------------------------
 // dist_j = max(||in_xyz[:,idx_j] - q||, 1e-8); w_j = (1/dist_j) / sum_j(1/dist_j)
 constexpr int KI_MAXK = 8;
@@ -243,6 +265,19 @@ extern "C" int camli_gather_cf_bwd(const float* gout, const int64_t* idx, float*
     hipLaunchKernelGGL(gather_cf_bwd_kernel, dim3(camli_divup(I, 256), grid_y_for(C), B), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), gout, idx, gdata, C, M, I);
     return camli_check_launch("camli_gather_cf_bwd");
+}
+
+extern "C" int camli_gather_cf_bwd_sorted(const float* gout, const int32_t* inv_order, const int32_t* inv_offsets,
+                                          float* gdata, int B, int C, int M, int I, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!gout || !inv_order || !inv_offsets || !gdata) { camli_set_error("camli_gather_cf_bwd_sorted: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || C < 1 || M < 1 || I < 0 || B > 65535 || (int64_t)B * I > 2147483647LL) {
+        camli_set_error("camli_gather_cf_bwd_sorted: bad shape B=%d C=%d M=%d I=%d", B, C, M, I);
+        return CAMLI_EINVAL;
+    }
+    hipLaunchKernelGGL(gather_cf_bwd_sorted_kernel, dim3(camli_divup(M, 256), grid_y_for(C), B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gout, inv_order, inv_offsets, gdata, C, M, I);
+    return camli_check_launch("camli_gather_cf_bwd_sorted");
 }
 
 static int knn_interp_args_ok(const char* what, const void* a, const void* b, const void* c, const void* d,

@@ -110,6 +110,15 @@ int camli_pointconv_dw_expand(const float *const *gwsel_list, const unsigned cha
  */
 int camli_gather_cf_fwd(const float *data, const int64_t *idx, float *out, int B, int C, int M, int I, void *stream);
 int camli_gather_cf_bwd(const float *gout, const int64_t *idx, float *gdata, int B, int C, int M, int I, void *stream);
+/*
+ * The same adjoint without atomics, through the INVERSE map of idx (what torch's index_put_(accumulate=True)
+ * derives with a device-wide sort on every call; here the host builds it once per index tensor):
+ *   inv_order int32 [B*I]: the flat positions b*I + i sorted by (b, idx[b,i]) (stable);
+ *   inv_offsets int32 [B*M + 1]: segment s = b*M + m covers inv_order[inv_offsets[s] .. inv_offsets[s+1]).
+ * gdata is fully written (no zero-fill needed), fixed summation order.
+ */
+int camli_gather_cf_bwd_sorted(const float *gout, const int32_t *inv_order, const int32_t *inv_offsets, float *gdata,
+                               int B, int C, int M, int I, void *stream);
 
 /*
  * knn_interpolation tail (models/utils.py:138-146) given the k <= 8 nearest inputs of every query:
@@ -155,6 +164,17 @@ int camli_pointconv_mix_fwd(const float *feat_cl, const float *wgt, const int64_
 int camli_pointconv_mix_bwd(const float *gout, const float *feat_cl, const float *wgt, const int64_t *idx,
                             int idx_stride, float *gfeat_cl, float *gwgt,
                             int B, int M, int N, int CH, int Wn, int k, void *stream);
+/*
+ * Atomic-free adjoint for k = 16, Wn = 16 (every PointConv of the reference): the per-neighbour row gradients
+ * T[b,n,j,:] = sum_w wgt[b,w,n,j] * gout[b,n,w,:] go to `scratch` (camli_pointconv_mix_bwd_scratch_bytes), then
+ * gfeat_cl[b,m,:] = sum of the T rows whose neighbour index is m, walked through the inverse map of idx
+ * (inv_order int32 [B*N*k]: flat positions (b*N + n)*k + j sorted by (b, idx); inv_offsets int32 [B*M + 1]).
+ * gfeat_cl is fully written (no zero-fill), gwgt as above; either may be NULL.  Bit-reproducible.
+ */
+int64_t camli_pointconv_mix_bwd_scratch_bytes(int B, int N, int CH, int k);
+int camli_pointconv_mix_bwd_sorted(const float *gout, const float *feat_cl, const float *wgt, const int64_t *idx,
+                                   int idx_stride, const int32_t *inv_order, const int32_t *inv_offsets, float *scratch,
+                                   float *gfeat_cl, float *gwgt, int B, int M, int N, int CH, int Wn, int k, void *stream);
 
 /*
  * Convex flow up-sampling and adjoint (internal composite op; the reference composes it from
