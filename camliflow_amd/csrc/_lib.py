@@ -18,6 +18,10 @@ PROTOTYPES = {
     "camli_corr2d_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
     "camli_corr2d_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                 _int, _int, _int, _int, _int, _stream]),
+    "camli_allpairs_build_fwd": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _int, _int, _int,
+                                        ctypes.c_float, _stream]),
+    "camli_allpairs_build_bwd": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
+                                        ctypes.c_void_p, _int, _int, _int, ctypes.c_float, _stream]),
     "camli_allpairs_lookup_fwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                          _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_allpairs_lookup_bwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,

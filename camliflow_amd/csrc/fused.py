@@ -46,49 +46,75 @@ class AllPairsPyramid:
         return n, ptrs, hs, ws
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class _BuildPyramid(torch.autograd.Function):
+    """All levels straight from the feature maps on the fp32 matrix cores (camli_allpairs_build_fwd/bwd):
+    avg_pool2d acts on the target pixel only and is linear, so level l = f1^T . pool_l(f2) / sqrt(C) -- every volume
+    element is written once and never re-read, and the adjoint needs no volume-sized fold (csrc/hip/allpairs.hip)."""
+
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, fmap1, fmap2, num_levels, pyr):
+        lib = _lib.load()
         bs, dim, h, w = fmap1.shape
-        f1 = fmap1.reshape(bs, dim, h * w)
-        f2 = fmap2.reshape(bs, dim, h * w)
-        volume = torch.matmul(f1.transpose(1, 2), f2)
-        volume = (volume / math.sqrt(dim)).reshape(bs * h * w, 1, h, w)
-        levels = [volume]
+        p = h * w
+        f2_levels = [fmap2]
         for _ in range(num_levels - 1):
-            levels.append(avg_pool2d(levels[-1], 2, stride=2))
-        pyr.levels = [lvl.reshape(bs * h * w, lvl.shape[-2], lvl.shape[-1]) for lvl in levels]
+            if min(f2_levels[-1].shape[-2:]) < 2:
+                break
+            f2_levels.append(avg_pool2d(f2_levels[-1], 2, stride=2))     # tiny: [B,C,h_l,w_l]
+        sizes = [(t.shape[-2], t.shape[-1]) for t in f2_levels]
+        p_levels = (ctypes.c_int * len(sizes))(*[a * b for a, b in sizes])
+        levels = [torch.empty((bs * p, a, b), dtype=torch.float32, device=fmap1.device) for a, b in sizes]
+        total = sum(a * b for a, b in sizes)
+        with _on_device(fmap1):
+            _lib.launch('camli_allpairs_build_fwd', lib.camli_allpairs_build_fwd, fmap1.data_ptr(), _ptr_array(f2_levels),
+                        _ptr_array(levels), p_levels, len(sizes), bs, dim, p, 1.0 / math.sqrt(dim), _stream_ptr(fmap1),
+                        work=(4.0 * bs * p * total + 4.0 * bs * dim * (p + total), 'B'), flop=2.0 * bs * p * total * dim)
+        pyr.levels = levels
         pyr.shape = (bs, h, w)
-        ctx.save_for_backward(f1, f2)
+        ctx.save_for_backward(fmap1, *f2_levels)
         # weak: pyr.token is this node's output, a strong link would close a reference cycle
         # (pyr -> token -> grad_fn -> ctx -> pyr) and keep the 2.8 GB pyramid alive until the cyclic GC runs.
         # Every lookup node holds pyr strongly, so it lives exactly as long as the graph needs it.
         ctx.pyr = weakref.ref(pyr)
         ctx.dims = (bs, dim, h, w)
+        ctx.sizes = sizes
         return fmap1.new_zeros(1)
 
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, _gtoken):
+        lib = _lib.load()
         pyr = ctx.pyr()
-        f1, f2 = ctx.saved_tensors
+        fmap1, *f2_levels = ctx.saved_tensors
         bs, dim, h, w = ctx.dims
+        p = h * w
         grads = None
         if pyr is not None:
             grads, pyr.grads = pyr.grads, None
         if grads is None:
-            return torch.zeros(bs, dim, h, w, device=f1.device), torch.zeros(bs, dim, h, w, device=f1.device), None, None
-        # adjoint of the avg_pool2d chain: fold coarse levels into level 0
-        total = grads[-1]
-        for lvl in range(len(grads) - 2, -1, -1):
-            h2, w2 = total.shape[-2:]
-            up = total.repeat_interleave(2, dim=-2).repeat_interleave(2, dim=-1)
-            grads[lvl][:, :2 * h2, :2 * w2] += up * 0.25
-            total = grads[lvl]
-        gvol = total.reshape(bs, h * w, h * w) / math.sqrt(dim)
-        g1 = torch.matmul(f2, gvol.transpose(1, 2)).reshape(bs, dim, h, w)   # [B,C,P2] x [B,P2,P1]
-        g2 = torch.matmul(f1, gvol).reshape(bs, dim, h, w)                   # [B,C,P1] x [B,P1,P2]
+            return torch.zeros_like(fmap1), torch.zeros_like(fmap1), None, None
+        sizes = ctx.sizes
+        p_levels = (ctypes.c_int * len(sizes))(*[a * b for a, b in sizes])
+        total = sum(a * b for a, b in sizes)
+        g1 = torch.empty_like(fmap1)
+        g2_levels = [torch.empty_like(t) for t in f2_levels]
+        with _on_device(fmap1):
+            _lib.launch('camli_allpairs_build_bwd', lib.camli_allpairs_build_bwd, fmap1.data_ptr(), _ptr_array(f2_levels),
+                        _ptr_array(grads), p_levels, len(sizes), g1.data_ptr(), _ptr_array(g2_levels), bs, dim, p,
+                        1.0 / math.sqrt(dim), _stream_ptr(fmap1),
+                        work=(4.0 * bs * p * total + 4.0 * bs * dim * 2 * (p + total), 'B'), flop=4.0 * bs * p * total * dim)
+        # adjoint of the avg_pool2d chain on the SMALL maps ([B,C,h_l,w_l]): fold the coarse levels into level 0
+        g2 = g2_levels[-1]
+        for lvl in range(len(g2_levels) - 2, -1, -1):
+            h2, w2 = g2.shape[-2:]
+            up = g2.repeat_interleave(2, dim=-2).repeat_interleave(2, dim=-1)
+            g2_levels[lvl][:, :, :2 * h2, :2 * w2] += up * 0.25
+            g2 = g2_levels[lvl]
         return g1, g2, None, None
 
 

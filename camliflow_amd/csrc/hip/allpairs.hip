@@ -1,0 +1,250 @@
+// All-pairs cost-volume pyramid: build and adjoint on the fp32 matrix cores, gfx950.
+//
+// Replaces Correlation2D.build_cost_volume_pyramid of the reference (models/raft_core.py:52-68):
+//     corr = matmul(f1^T, f2) / sqrt(C)          [B, P, P]      (P = h*w source / target pixels, C = 256)
+//     pyramid = [corr, avg_pool2d(corr), avg_pool2d(avg_pool2d(corr)), ...]     over the TARGET dims
+// i.e. one library GEMM, one elementwise pass for the scale and three pooling passes that re-read the 2.1 GB volume
+// (batch 8, 68x120), and in the backward a volume-sized fold per level before two more GEMMs.
+//
+// avg_pool2d is linear and acts on the target pixel only, so level l of the pyramid IS a GEMM against the l-times
+// pooled target features:   V_l = f1^T . pool_l(f2) / sqrt(C)    (equal to the reference up to fp32 summation order;
+// the floor-cropping of odd sizes, 17x30 -> 8x15, is inherited from pool_l).  Every level is therefore produced by
+// the same kernel straight from the feature maps, with the 1/sqrt(C) scale in the epilogue: each volume element is
+// written exactly once and never re-read.  The adjoint needs no fold over volume-sized tensors either:
+//     g_f1           = sum_l  pool_l(f2) . gV_l^T / sqrt(C)          [C, P]
+//     g_pool_l(f2)   =        f1 . gV_l        / sqrt(C)             [C, P_l]     (un-pooled on the small maps)
+//
+// Kernel: 128x128 output tile per 256-thread workgroup, 2x2 tiles of v_mfma_f32_32x32x2_f32 per wave (exact fp32,
+// a k-ordered fmaf chain), K walked in steps of 32 through a double-buffered LDS image that is always k-major
+// ([k][m]: the MFMA fragment of a lane is then one ds_read_b32 and the 32 lanes of a half-wave read 32 consecutive
+// floats, conflict-free); the next step's global loads are in flight in registers while the current one is on the
+// matrix cores.  Operands may be m-contiguous ([K][M], staged with 16-byte loads / ds_write_b128) or k-contiguous
+// ([M][K], transposed by the staging stores; row stride 130 floats keeps those stores on 32 distinct banks).
+#include "camli_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GB_T = 128;      // tile edge (M and N)
+constexpr int GB_K = 32;       // K step
+
+// One operand tile [GB_K][GB_T] from global memory into registers (4 float4 per thread) and on to LDS.
+//   KC = false: element (k, m) at base[k * ld + m]   (m contiguous)
+//   KC = true : element (k, m) at base[m * ld + k]   (k contiguous)
+// Out-of-range elements read as zero.  `vec` = base and ld allow aligned 16-byte loads.
+template <bool KC>
+struct OperandTile {
+    static constexpr int LD = KC ? 130 : 132;      // LDS row stride in floats
+    float4 r[4];
+
+    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int m0, int k0, int M, int K,
+                                         bool vec, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256;
+            int k, m;
+            if (KC) { k = 4 * (f & 7); m = f >> 3; } else { k = f >> 5; m = 4 * (f & 31); }
+            const int gk = k0 + k, gm = m0 + m;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                if (gm < M) {
+                    const float* p = base + (int64_t)gm * ld + gk;
+                    if (vec && gk + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (gk < K) v.x = p[0];
+                        if (gk + 1 < K) v.y = p[1];
+                        if (gk + 2 < K) v.z = p[2];
+                        if (gk + 3 < K) v.w = p[3];
+                    }
+                }
+            } else {
+                if (gk < K) {
+                    const float* p = base + (int64_t)gk * ld + gm;
+                    if (vec && gm + 3 < M) v = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (gm < M) v.x = p[0];
+                        if (gm + 1 < M) v.y = p[1];
+                        if (gm + 2 < M) v.z = p[2];
+                        if (gm + 3 < M) v.w = p[3];
+                    }
+                }
+            }
+            r[i] = v;
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ s, int tid) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + i * 256;
+            if (KC) {
+                const int k = 4 * (f & 7), m = f >> 3;
+                float* d = s + k * LD + m;
+                d[0] = r[i].x; d[LD] = r[i].y; d[2 * LD] = r[i].z; d[3 * LD] = r[i].w;
+            } else {
+                const int k = f >> 5, m = 4 * (f & 31);
+                *reinterpret_cast<float4*>(s + k * LD + m) = r[i];
+            }
+        }
+    }
+};
+
+// C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
+// grid (ceil(N/128), ceil(M/128), batch), block 256
+template <bool A_KC, bool B_KC, bool ACC>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                             float* __restrict__ C, int M, int N, int K, int64_t lda,
+                                                             int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc,
+                                                             float alpha, int vec_a, int vec_b) {
+    constexpr int LDA = OperandTile<A_KC>::LD, LDB = OperandTile<B_KC>::LD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 * GB_K * (LDA + LDB) floats (> 64 KB: dynamic)
+    float* const sA = lds;                          // two buffers of [GB_K][LDA]
+    float* const sB = lds + 2 * GB_K * LDA;         // two buffers of [GB_K][LDB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.y * GB_T, n0 = blockIdx.x * GB_T;
+    const float* __restrict__ Ab = A + (int64_t)blockIdx.z * sa;
+    const float* __restrict__ Bb = Bm + (int64_t)blockIdx.z * sb;
+    float* __restrict__ Cb = C + (int64_t)blockIdx.z * sc;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    OperandTile<A_KC> ta;
+    OperandTile<B_KC> tb;
+    ta.load(Ab, lda, m0, 0, M, K, vec_a != 0, tid);
+    tb.load(Bb, ldb, n0, 0, N, K, vec_b != 0, tid);
+    ta.store(sA, tid);
+    tb.store(sB, tid);
+    __syncthreads();
+
+    const int fk = lane >> 5, fm = lane & 31;
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += GB_K) {
+        const bool more = k0 + GB_K < K;
+        if (more) {     // next step's operands: in flight while this step runs on the matrix cores
+            ta.load(Ab, lda, m0, k0 + GB_K, M, K, vec_a != 0, tid);
+            tb.load(Bb, ldb, n0, k0 + GB_K, N, K, vec_b != 0, tid);
+        }
+        const float* a = sA + buf * (GB_K * LDA) + fk * LDA + wm + fm;
+        const float* b = sB + buf * (GB_K * LDB) + fk * LDB + wn + fm;
+#pragma unroll
+        for (int kk = 0; kk < GB_K; kk += 2) {
+            const float a0 = a[kk * LDA], a1 = a[kk * LDA + 32];
+            const float b0 = b[kk * LDB], b1 = b[kk * LDB + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            ta.store(sA + (buf ^ 1) * (GB_K * LDA), tid);     // the other buffer: its readers finished one barrier ago
+            tb.store(sB + (buf ^ 1) * (GB_K * LDB), tid);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 32 + fm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < M && col < N) {
+                    float* c = Cb + (int64_t)row * ldc + col;
+                    const float v = alpha * acc[i][j][r];
+                    *c = ACC ? (*c + v) : v;
+                }
+            }
+        }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <bool A_KC, bool B_KC>
+void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                 int64_t sa, int64_t sb, int64_t sc, int batch, float alpha, bool accumulate, hipStream_t stream) {
+    const int vec_a = aligned16(A) && (lda % 4 == 0) && (sa % 4 == 0);
+    const int vec_b = aligned16(Bm) && (ldb % 4 == 0) && (sb % 4 == 0);
+    dim3 grid(camli_divup(N, GB_T), camli_divup(M, GB_T), batch);
+    constexpr size_t lds = (size_t)2 * GB_K * (OperandTile<A_KC>::LD + OperandTile<B_KC>::LD) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<A_KC, B_KC, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<A_KC, B_KC, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (accumulate)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, true>), grid, dim3(256), lds, stream, A, Bm, C, M, N, K, lda, ldb,
+                           ldc, sa, sb, sc, alpha, vec_a, vec_b);
+    else
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, false>), grid, dim3(256), lds, stream, A, Bm, C, M, N, K, lda, ldb,
+                           ldc, sa, sb, sc, alpha, vec_a, vec_b);
+}
+
+int build_args_ok(const char* what, const void* f1, const void* a, const void* b, const int* p_levels, int L, int B, int C,
+                  int P) {
+    if (!f1 || !a || !b || !p_levels) { camli_set_error("%s: null pointer", what); return 0; }
+    if (L < 1 || L > 8 || B < 0 || C < 1 || P < 1 || B > 65535) {
+        camli_set_error("%s: bad shape L=%d B=%d C=%d P=%d", what, L, B, C, P);
+        return 0;
+    }
+    for (int l = 0; l < L; ++l)
+        if (p_levels[l] < 1) { camli_set_error("%s: level %d has %d target pixels", what, l, p_levels[l]); return 0; }
+    return 1;
+}
+
+}  // namespace
+
+// V_l[b, p, q] = scale * sum_c f1[b, c, p] * f2_l[b, c, q]       f1 [B,C,P], f2_l [B,C,P_l], V_l [B,P,P_l]
+extern "C" int camli_allpairs_build_fwd(const float* f1, const float* const* f2_levels, float* const* vol_levels,
+                                        const int* p_levels, int L, int B, int C, int P, float scale, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!build_args_ok("camli_allpairs_build_fwd", f1, f2_levels, vol_levels, p_levels, L, B, C, P)) return CAMLI_EINVAL;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int l = 0; l < L; ++l) {
+        if (!f2_levels[l] || !vol_levels[l]) { camli_set_error("camli_allpairs_build_fwd: null level pointer"); return CAMLI_EINVAL; }
+        const int Pl = p_levels[l];
+        // M = P (source pixel), N = P_l (target pixel), K = C;  A = f1 [K][M], B = f2_l [K][N]
+        launch_gemm<false, false>(f1, f2_levels[l], vol_levels[l], P, Pl, C, P, Pl, Pl, (int64_t)C * P, (int64_t)C * Pl,
+                                  (int64_t)P * Pl, B, scale, false, s);
+    }
+    return camli_check_launch("camli_allpairs_build_fwd");
+}
+
+// g_f1[b, c, p]   = scale * sum_l sum_q gV_l[b, p, q] * f2_l[b, c, q]         (fully written)
+// g_f2_l[b, c, q] = scale * sum_p f1[b, c, p] * gV_l[b, p, q]                 (fully written, per level)
+extern "C" int camli_allpairs_build_bwd(const float* f1, const float* const* f2_levels, const float* const* gvol_levels,
+                                        const int* p_levels, int L, float* g_f1, float* const* g_f2_levels, int B, int C,
+                                        int P, float scale, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!build_args_ok("camli_allpairs_build_bwd", f1, f2_levels, gvol_levels, p_levels, L, B, C, P)) return CAMLI_EINVAL;
+    if (!g_f1 || !g_f2_levels) { camli_set_error("camli_allpairs_build_bwd: null pointer"); return CAMLI_EINVAL; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int l = 0; l < L; ++l) {
+        if (!f2_levels[l] || !gvol_levels[l] || !g_f2_levels[l]) {
+            camli_set_error("camli_allpairs_build_bwd: null level pointer");
+            return CAMLI_EINVAL;
+        }
+        const int Pl = p_levels[l];
+        // g_f1: M = C, N = P, K = P_l;  A = f2_l [M][K] (k contiguous), B = gV_l [N][K] (k contiguous); accumulate over levels
+        launch_gemm<true, true>(f2_levels[l], gvol_levels[l], g_f1, C, P, Pl, Pl, Pl, P, (int64_t)C * Pl, (int64_t)P * Pl,
+                                (int64_t)C * P, B, scale, l > 0, s);
+        // g_f2_l: M = C, N = P_l, K = P;  A = f1 [M][K] (k contiguous), B = gV_l [K][N] (n contiguous)
+        launch_gemm<true, false>(f1, gvol_levels[l], g_f2_levels[l], C, Pl, P, P, Pl, Pl, (int64_t)C * P, (int64_t)P * Pl,
+                                 (int64_t)C * Pl, B, scale, false, s);
+    }
+    return camli_check_launch("camli_allpairs_build_bwd");
+}

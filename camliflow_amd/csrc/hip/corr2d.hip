@@ -447,7 +447,7 @@ int launch_fwd_tile(const float* in1, const float* in2, float* out, int B, int C
     using T = CorrTile;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&corr2d_fwd_tile_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&corr2d_fwd_tile_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
         attr_set = true;
     }

@@ -355,7 +355,7 @@ extern "C" int camli_pointconv_mix_bwd_sorted(const float* gout, const float* fe
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&pointconv_mix_bwd_point_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointconv_mix_bwd_point_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }

@@ -67,6 +67,21 @@ int camli_corr2d_bwd(const float *gout_nchw, const float *in1_nhwc, const float 
                      int B, int C, int H, int W, int md, void *stream);
 
 /*
+ * All-pairs cost-volume pyramid, build and adjoint (internal composite op; the reference composes it from
+ * torch.matmul, a division and three avg_pool2d passes over the volume: models/raft_core.py:52-68).
+ *   f1 [B,C,P] source features, f2_levels[l] [B,C,P_l] the target features pooled l times (avg_pool2d(2,2) acts
+ *   on the target pixel only and is linear, so level l = f1^T . pool_l(f2) * scale; HOST arrays of DEVICE pointers),
+ *   vol_levels[l] [B,P,P_l] fully written, scale = 1/sqrt(C).  fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ *   bwd: g_f1 [B,C,P] = scale * sum_l gV_l . f2_l^T and g_f2_levels[l] [B,C,P_l] = scale * f1 . gV_l, both fully
+ *   written; the caller un-pools g_f2_levels on the small maps.
+ */
+int camli_allpairs_build_fwd(const float *f1, const float *const *f2_levels, float *const *vol_levels,
+                             const int *p_levels, int L, int B, int C, int P, float scale, void *stream);
+int camli_allpairs_build_bwd(const float *f1, const float *const *f2_levels, const float *const *gvol_levels,
+                             const int *p_levels, int L, float *g_f1, float *const *g_f2_levels,
+                             int B, int C, int P, float scale, void *stream);
+
+/*
  * All-pairs cost-volume pyramid lookup and its adjoint (internal composite op of the cores; the
  * reference composes it from grid_sample/cat/permute: models/raft_core.py:70-107, and its
  * backward from grid_sampler_2d_backward).

@@ -103,3 +103,34 @@ def test_correlation2d_module_vs_reference_golden(name, golden):
         scale = np.abs(g['gfmap1']).max()
         assert np.abs(gf1 - g['gfmap1']).max() < 1e-4 * scale + 1e-4, backend
         assert np.abs(gf2 - g['gfmap2']).max() < 1e-4 * scale + 1e-4, backend
+
+
+@pytest.mark.parametrize('shape', [(2, 256, 20, 24), (1, 64, 17, 30), (1, 256, 9, 13)], ids=str)
+def test_allpairs_build_on_the_matrix_cores_vs_torch(shape):
+    """camli_allpairs_build_fwd/bwd (fp32 MFMA, every level straight from the feature maps, pooled target features)
+    against the reference composition matmul -> /sqrt(C) -> avg_pool2d chain (raft_core.py:52-68) in torch, fp32:
+    levels to 1e-5 relative, feature gradients (random gradient on every level) to 1e-4."""
+    import math
+    from torch.nn.functional import avg_pool2d
+    from camliflow_amd.csrc import fused
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(h * w)
+    f1 = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+    f2 = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+    pyr = fused.allpairs_pyramid(f1, f2, 4)
+    vol = torch.matmul(f1.view(b, c, h * w).transpose(1, 2), f2.view(b, c, h * w)) / math.sqrt(c)
+    want = [vol.reshape(b * h * w, 1, h, w)]
+    for _ in range(3):
+        want.append(avg_pool2d(want[-1], 2, stride=2))
+    assert len(pyr.levels) == 4
+    grads = []
+    for lvl, ref in zip(pyr.levels, want):
+        ref = ref[:, 0]
+        assert lvl.shape == ref.shape
+        assert (lvl - ref.detach()).abs().max() <= 1e-5 * ref.detach().abs().max() + 1e-6
+        grads.append(torch.randn(ref.shape, generator=g).cuda())
+    want_g1, want_g2 = torch.autograd.grad([r[:, 0] for r in want], [f1, f2], grads)
+    pyr.grads = [x.clone() for x in grads]
+    g1, g2 = torch.autograd.grad(pyr.token, [f1, f2], torch.zeros(1, device='cuda'))
+    for got, ref in ((g1, want_g1), (g2, want_g2)):
+        assert (got - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-5
