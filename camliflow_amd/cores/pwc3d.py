@@ -5,8 +5,9 @@ import torch
 import torch.nn as nn
 
 from ..csrc import wrapper as _ops
+from . import runtime
 from .blocks import Conv1dNormRelu, MLP1d, MLP2d
-from .geometry import backwarp_3d, batch_indexing, knn_interpolation
+from .geometry import backwarp_3d, batch_indexing, knn_channel_first, knn_interpolation
 from .pwc2d import pyramid_aligners
 from .setconv import PointConv
 
@@ -54,6 +55,10 @@ class Correlation3D(nn.Module):
         return given[:, :, :self.k]
 
     def forward(self, xyz1, feat1, xyz2, feat2, knn_indices_1in1=None):
+        if runtime.fused() and xyz1.is_cuda:
+            if (self.k & (self.k - 1)) == 0 and self.k <= 64 and not xyz1.requires_grad and len(self.cost_mlp.convs) == 2:
+                return self._forward_fused(xyz1, feat1, xyz2, feat2, knn_indices_1in1)
+            runtime.fallback('Correlation3D(PWC)', 'k = %d is not a power of two <= 64, or differentiable xyz1' % self.k)
         bs, channels, n = feat1.shape
         origin = xyz1.view(bs, 3, n, 1)
 
@@ -69,6 +74,37 @@ class Correlation3D(nn.Module):
         d_own = batch_indexing(xyz1, own) - origin
         patch = (self.weight_net1(d_own) * batch_indexing(to_patch, own)).sum(dim=3)
         return self.feat_aligner(patch)
+
+
+    def _forward_fused(self, xyz1, feat1, xyz2, feat2, knn_indices_1in1):
+        """Same math without the [B, 2C+3, N, k] tensor (csrc/hip/pwc3d.hip): the first cost-MLP layer is linear in
+        the concatenated channels, so its f1 / f2 blocks become per-POINT 1x1 convolutions and only the offset block
+        is evaluated per pair; gather + add + leaky run as one kernel, the two weighted neighbour sums as one kernel
+        each.  xyz2 may carry a gradient (CamLiPWC warps it with a live flow, camlipwc_core.py:179): the offsets and
+        weight_net2 stay differentiable; weight_net1 sees constant coordinates and runs on the matrix cores."""
+        from ..csrc import fused
+        from torch.nn.functional import conv1d, conv2d
+        bs, channels, n = feat1.shape
+        k = self.k
+        cross = knn_channel_first(xyz2.detach(), xyz1, k, invariant_query=True).contiguous()
+        d_cross = batch_indexing(xyz2, cross) - xyz1.view(bs, 3, n, 1)                   # [B,3,N,k], grad -> xyz2
+        first = self.cost_mlp.convs[0].conv_fn
+        w = first.weight.reshape(first.weight.shape[0], -1).float()
+        w_f1, w_f2, w_d = w[:, :channels], w[:, channels:2 * channels], w[:, 2 * channels:]
+        a = conv1d(feat1.float(), w_f1[:, :, None])                                         # [B,C,N]
+        bm = conv1d(feat2.float(), w_f2[:, :, None])                                        # [B,C,M]
+        e = conv2d(d_cross, w_d[:, :, None, None], first.bias)                              # [B,C,N,k]
+        h1 = fused.pwc3d_pair(a, bm, e, cross, slope=0.1)
+        h2 = self.cost_mlp.convs[1](h1)
+        to_patch = fused.ksum(self.weight_net2(d_cross), h2)                                # [B,C,N]
+
+        own = self._self_neighbours(xyz1, knn_indices_1in1).contiguous()
+        if fused.weightnet_hidden8_supported(self.weight_net1):
+            w1 = fused.weightnet_hidden8(xyz1, xyz1, own, k, self.weight_net1)
+        else:
+            runtime.fallback('weight_net1', 'not MLP2d(3,[8,8,C<=256],relu)')
+            w1 = self.weight_net1(batch_indexing(xyz1, own) - xyz1.view(bs, 3, n, 1))
+        return self.feat_aligner(fused.gather_wsum(w1, to_patch, own))
 
 
 class FlowEstimator3D(nn.Module):

@@ -47,6 +47,14 @@ PROTOTYPES = {
     "camli_corr3d_gather_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _c_float_p,
                                        _int, _int, _int, _int, _stream]),
     "camli_corr3d_gather_bwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_pwc3d_pair_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _int,
+                                    ctypes.c_float, _stream]),
+    "camli_pwc3d_pair_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, ctypes.c_float, _stream]),
+    "camli_ksum_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_ksum_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_gather_wsum_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
+    "camli_gather_wsum_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _c_float_p, _c_float_p,
+                                     _int, _int, _int, _int, _int, _stream]),
     "camli_pointconv_mix_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p,
                                        _int, _int, _int, _int, _int, _int, _stream]),
     "camli_pointconv_mix_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p, _c_float_p,

@@ -666,6 +666,40 @@ def weightnet_supported(mlp, c_out):
     return plain and dims == [(3, 8), (8, 32), (32, c_out)]
 
 
+def weightnet_hidden8(xyz, centres, knn_indices, k, mlp):
+    """weight_net = MLP2d(3, [8, 8, C], relu) of the PointPWC cost volume (camlipwc_l_core.py:45-46) through the same
+    matrix-core kernel: the 8-wide second layer is zero-padded to the kernel's 32 hidden units (padded units are
+    relu(0) = 0 and meet zero columns of the last layer, so values and gradients are unchanged; torch differentiates
+    the padding).  C > 128 is evaluated in two channel halves."""
+    _require_cuda('weightnet_hidden8', xyz, centres, knn_indices)
+    convs = mlp.convs
+    w1, b1 = convs[0].conv_fn.weight, convs[0].conv_fn.bias
+    w2, b2 = convs[1].conv_fn.weight, convs[1].conv_fn.bias
+    w3, b3 = convs[2].conv_fn.weight, convs[2].conv_fn.bias
+    assert w1.shape[:2] == (8, 3) and w2.shape[:2] == (8, 8) and w3.shape[1] == 8
+    pad = torch.nn.functional.pad
+    w2p = pad(w2.reshape(8, 8), (0, 0, 0, 24))            # [32, 8]
+    b2p = pad(b2, (0, 24))                                # [32]
+    w3p = pad(w3.reshape(w3.shape[0], 8), (0, 24))        # [C, 32]
+    args = (xyz.float().contiguous(), centres.float().contiguous(), knn_indices, k)
+    c = w3.shape[0]
+    if c <= 128:
+        return _WeightNet.apply(*args, w1, b1, w2p, b2p, w3p, b3)
+    half = c // 2
+    return torch.cat([_WeightNet.apply(*args, w1, b1, w2p, b2p, w3p[:half], b3[:half]),
+                      _WeightNet.apply(*args, w1, b1, w2p, b2p, w3p[half:], b3[half:])], dim=1)
+
+
+def weightnet_hidden8_supported(mlp):
+    convs = getattr(mlp, 'convs', None)
+    if convs is None or len(convs) != 3:
+        return False
+    dims = [(cv.conv_fn.in_channels, cv.conv_fn.out_channels) for cv in convs]
+    plain = all(isinstance(cv.norm_fn, torch.nn.Identity) and isinstance(cv.act_fn, torch.nn.ReLU)
+                and cv.conv_fn.bias is not None for cv in convs)
+    return plain and dims[0] == (3, 8) and dims[1] == (8, 8) and dims[2][0] == 8 and dims[2][1] <= 256
+
+
 def weightnet(xyz, centres, knn_indices, k, mlp):
     """xyz [B,3,M], centres [B,3,N], knn_indices int64 [B,N,>=k] -> weight_net(xyz[knn] - centre) [B,C,N,k]."""
     _require_cuda('weightnet', xyz, centres, knn_indices)
@@ -843,6 +877,138 @@ def corr3d_lookup_input(cost_volume, xyz1, xyz2, knn_indices):
     assert not xyz1.requires_grad and not xyz2.requires_grad
     return _Corr3DGather.apply(cost_volume.float().contiguous(), xyz1.float().contiguous(),
                                xyz2.float().contiguous(), knn_indices.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+# PointPWC learnable cost volume (models/camlipwc_l_core.py:53-106), see csrc/hip/pwc3d.hip
+# ------------------------------------------------------------------------------------------------
+def _gather_adjoint_sorted(lib, grad_nk, idx_flat, m):
+    """grad_nk [B,C,I] -> sum into [B,C,m] through the inverse map of idx_flat [B,I] (no atomics)."""
+    b, c, i = grad_nk.shape
+    order, offsets = inverse_map(idx_flat, m)
+    out = torch.empty((b, c, m), dtype=torch.float32, device=grad_nk.device)
+    _lib.launch('camli_gather_cf_bwd', lib.camli_gather_cf_bwd_sorted, grad_nk.data_ptr(), order.data_ptr(),
+                offsets.data_ptr(), out.data_ptr(), b, c, m, i, _stream_ptr(grad_nk),
+                work=(4.0 * b * c * (i + m) + 4.0 * b * (i + m), 'B'))
+    return out
+
+
+class _Pwc3dPair(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, a, bm, e, idx, slope):
+        lib = _lib.load()
+        b, c, n = a.shape
+        m, k = bm.shape[2], idx.shape[2]
+        h1 = torch.empty((b, c, n, k), dtype=torch.float32, device=a.device)
+        with _on_device(a):
+            _lib.launch('camli_pwc3d_pair_fwd', lib.camli_pwc3d_pair_fwd, a.data_ptr(), bm.data_ptr(), e.data_ptr(),
+                        idx.data_ptr(), h1.data_ptr(), b, c, m, n, k, slope, _stream_ptr(a),
+                        work=(4.0 * b * c * n * (3 * k + 1) + 8.0 * b * n * k, 'B'))
+        ctx.save_for_backward(h1, idx)
+        ctx.slope, ctx.m = slope, m
+        return h1
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gh1):
+        lib = _lib.load()
+        h1, idx = ctx.saved_tensors
+        b, c, n, k = h1.shape
+        gh1 = gh1.contiguous().float()
+        gpre = torch.empty_like(h1)
+        ga = torch.empty((b, c, n), dtype=torch.float32, device=h1.device)
+        with _on_device(h1):
+            _lib.launch('camli_pwc3d_pair_bwd', lib.camli_pwc3d_pair_bwd, gh1.data_ptr(), h1.data_ptr(), gpre.data_ptr(),
+                        ga.data_ptr(), b, c, n, k, ctx.slope, _stream_ptr(h1), work=(4.0 * b * c * n * (3 * k + 1), 'B'))
+            gbm = _gather_adjoint_sorted(lib, gpre.view(b, c, n * k), idx.view(b, n * k), ctx.m) if ctx.needs_input_grad[1] else None
+        return ga, gbm, gpre, None, None
+
+
+def pwc3d_pair(a, bm, e, idx, slope=0.1):
+    """leaky_relu(a[:, :, n] + bm[:, :, idx[n, j]] + e[:, :, n, j]): the first cost-MLP layer of the PointPWC cost
+    volume with the concatenation [f1 | f2_knn | dxyz] split by input block (a = W1a.f1, bm = W1b.f2, e = W1c.d + b1)."""
+    _require_cuda('pwc3d_pair', a, bm, e, idx)
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.shape[:2] == (a.shape[0], a.shape[2])
+    assert e.shape == (a.shape[0], a.shape[1], a.shape[2], idx.shape[2]) and bm.shape[:2] == a.shape[:2]
+    return _Pwc3dPair.apply(a.float().contiguous(), bm.float().contiguous(), e.float().contiguous(), idx, float(slope))
+
+
+class _KSum(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, w, h):
+        lib = _lib.load()
+        b, c, n, k = w.shape
+        out = torch.empty((b, c, n), dtype=torch.float32, device=w.device)
+        with _on_device(w):
+            _lib.launch('camli_ksum_fwd', lib.camli_ksum_fwd, w.data_ptr(), h.data_ptr(), out.data_ptr(), b, c, n, k,
+                        _stream_ptr(w), work=(4.0 * b * c * n * (2 * k + 1), 'B'))
+        ctx.save_for_backward(w, h)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, g):
+        lib = _lib.load()
+        w, h = ctx.saved_tensors
+        b, c, n, k = w.shape
+        g = g.contiguous().float()
+        gw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        gh = torch.empty_like(h) if ctx.needs_input_grad[1] else None
+        with _on_device(w):
+            _lib.launch('camli_ksum_bwd', lib.camli_ksum_bwd, g.data_ptr(), w.data_ptr(), h.data_ptr(),
+                        gw.data_ptr() if gw is not None else None, gh.data_ptr() if gh is not None else None,
+                        b, c, n, k, _stream_ptr(w), work=(4.0 * b * c * n * (4 * k + 1), 'B'))
+        return gw, gh
+
+
+def ksum(w, h):
+    """sum over the neighbour axis of w * h: [B,C,N,k] x [B,C,N,k] -> [B,C,N] (one pass each way)."""
+    _require_cuda('ksum', w, h)
+    assert w.shape == h.shape and w.dim() == 4
+    return _KSum.apply(w.float().contiguous(), h.float().contiguous())
+
+
+class _GatherWSum(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, w, feat, idx):
+        lib = _lib.load()
+        b, c, n, k = w.shape
+        m = feat.shape[2]
+        out = torch.empty((b, c, n), dtype=torch.float32, device=w.device)
+        with _on_device(w):
+            _lib.launch('camli_gather_wsum_fwd', lib.camli_gather_wsum_fwd, w.data_ptr(), feat.data_ptr(), idx.data_ptr(),
+                        out.data_ptr(), b, c, m, n, k, _stream_ptr(w), work=(4.0 * b * c * n * (2 * k + 1) + 8.0 * b * n * k, 'B'))
+        ctx.save_for_backward(w, feat, idx)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, g):
+        lib = _lib.load()
+        w, feat, idx = ctx.saved_tensors
+        b, c, n, k = w.shape
+        m = feat.shape[2]
+        g = g.contiguous().float()
+        gw = torch.empty_like(w) if ctx.needs_input_grad[0] else None
+        t = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        gfeat = None
+        with _on_device(w):
+            _lib.launch('camli_gather_wsum_bwd', lib.camli_gather_wsum_bwd, g.data_ptr(), w.data_ptr(), feat.data_ptr(),
+                        idx.data_ptr(), gw.data_ptr() if gw is not None else None, t.data_ptr() if t is not None else None,
+                        b, c, m, n, k, _stream_ptr(w), work=(4.0 * b * c * n * (4 * k + 1) + 8.0 * b * n * k, 'B'))
+            if t is not None:
+                gfeat = _gather_adjoint_sorted(lib, t.view(b, c, n * k), idx.view(b, n * k), m)
+        return gw, gfeat, None
+
+
+def gather_wsum(w, feat, idx):
+    """out[b,c,n] = sum_j w[b,c,n,j] * feat[b,c,idx[b,n,j]] (patch-to-patch aggregation, camlipwc_l_core.py:97-101)."""
+    _require_cuda('gather_wsum', w, feat, idx)
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.shape == (w.shape[0], w.shape[2], w.shape[3])
+    return _GatherWSum.apply(w.float().contiguous(), feat.float().contiguous(), idx)
 
 
 # ------------------------------------------------------------------------------------------------

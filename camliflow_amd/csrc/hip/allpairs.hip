@@ -29,66 +29,133 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GB_T = 128;      // tile edge (M and N)
 constexpr int GB_K = 32;       // K step
 
-// One operand tile [GB_K][GB_T] from global memory into registers (4 float4 per thread) and on to LDS.
+// One operand tile [GB_K][GB_T] goes from global memory into registers (4 float4 per thread, named scalars: an
+// indexed member array here ends up in scratch memory) and on to LDS.
 //   KC = false: element (k, m) at base[k * ld + m]   (m contiguous)
 //   KC = true : element (k, m) at base[m * ld + k]   (k contiguous)
-// Out-of-range elements read as zero.  `vec` = base and ld allow aligned 16-byte loads.
+// CHECK = false: the tile is known to lie inside the operand and 16-byte loads are legal -- unconditional loads (a
+// per-element "in range?" select makes the compiler branch around every load and wait for each one in turn).
+// CHECK = true : out-of-range elements read as zero; `vec` = base and ld allow aligned 16-byte loads.
 template <bool KC>
-struct OperandTile {
+struct TileGeom {
     static constexpr int LD = KC ? 130 : 132;      // LDS row stride in floats
-    float4 r[4];
-
-    __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int m0, int k0, int M, int K,
-                                         bool vec, int tid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * 256;
-            int k, m;
-            if (KC) { k = 4 * (f & 7); m = f >> 3; } else { k = f >> 5; m = 4 * (f & 31); }
-            const int gk = k0 + k, gm = m0 + m;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (KC) {
-                if (gm < M) {
-                    const float* p = base + (int64_t)gm * ld + gk;
-                    if (vec && gk + 3 < K) v = *reinterpret_cast<const float4*>(p);
-                    else {
-                        if (gk < K) v.x = p[0];
-                        if (gk + 1 < K) v.y = p[1];
-                        if (gk + 2 < K) v.z = p[2];
-                        if (gk + 3 < K) v.w = p[3];
-                    }
-                }
-            } else {
-                if (gk < K) {
-                    const float* p = base + (int64_t)gk * ld + gm;
-                    if (vec && gm + 3 < M) v = *reinterpret_cast<const float4*>(p);
-                    else {
-                        if (gm < M) v.x = p[0];
-                        if (gm + 1 < M) v.y = p[1];
-                        if (gm + 2 < M) v.z = p[2];
-                        if (gm + 3 < M) v.w = p[3];
-                    }
-                }
-            }
-            r[i] = v;
-        }
-    }
-
-    __device__ __forceinline__ void store(float* __restrict__ s, int tid) const {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * 256;
-            if (KC) {
-                const int k = 4 * (f & 7), m = f >> 3;
-                float* d = s + k * LD + m;
-                d[0] = r[i].x; d[LD] = r[i].y; d[2 * LD] = r[i].z; d[3 * LD] = r[i].w;
-            } else {
-                const int k = f >> 5, m = 4 * (f & 31);
-                *reinterpret_cast<float4*>(s + k * LD + m) = r[i];
-            }
-        }
-    }
+    static __device__ __forceinline__ int k_of(int f) { return KC ? 4 * (f & 7) : (f >> 5); }
+    static __device__ __forceinline__ int m_of(int f) { return KC ? (f >> 3) : 4 * (f & 31); }
 };
+template <bool KC>
+using OperandTile = TileGeom<KC>;
+
+template <bool KC, bool CHECK>
+__device__ __forceinline__ float4 tile_load_one(const float* __restrict__ base, int64_t ld, int m0, int k0, int M, int K,
+                                                bool vec, int f) {
+    const int gk = k0 + TileGeom<KC>::k_of(f), gm = m0 + TileGeom<KC>::m_of(f);
+    if (!CHECK) {
+        const float* p = KC ? base + (int64_t)gm * ld + gk : base + (int64_t)gk * ld + gm;
+        return *reinterpret_cast<const float4*>(p);
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+        if (gm < M) {
+            const float* p = base + (int64_t)gm * ld + gk;
+            if (vec && gk + 3 < K) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (gk < K) v.x = p[0];
+                if (gk + 1 < K) v.y = p[1];
+                if (gk + 2 < K) v.z = p[2];
+                if (gk + 3 < K) v.w = p[3];
+            }
+        }
+    } else {
+        if (gk < K) {
+            const float* p = base + (int64_t)gk * ld + gm;
+            if (vec && gm + 3 < M) v = *reinterpret_cast<const float4*>(p);
+            else {
+                if (gm < M) v.x = p[0];
+                if (gm + 1 < M) v.y = p[1];
+                if (gm + 2 < M) v.z = p[2];
+                if (gm + 3 < M) v.w = p[3];
+            }
+        }
+    }
+    return v;
+}
+
+template <bool KC>
+__device__ __forceinline__ void tile_store_one(float* __restrict__ s, const float4& v, int f) {
+    constexpr int LD = TileGeom<KC>::LD;
+    float* d = s + TileGeom<KC>::k_of(f) * LD + TileGeom<KC>::m_of(f);
+    if (KC) {
+        d[0] = v.x; d[LD] = v.y; d[2 * LD] = v.z; d[3 * LD] = v.w;
+    } else {
+        *reinterpret_cast<float4*>(d) = v;
+    }
+}
+
+#define GB_LOAD4(KCF, R, base, ld, x0, k0, X, K, vec)                                        \
+    R##0 = tile_load_one<KCF, CHECK>(base, ld, x0, k0, X, K, vec, tid);                     \
+    R##1 = tile_load_one<KCF, CHECK>(base, ld, x0, k0, X, K, vec, tid + 256);               \
+    R##2 = tile_load_one<KCF, CHECK>(base, ld, x0, k0, X, K, vec, tid + 512);               \
+    R##3 = tile_load_one<KCF, CHECK>(base, ld, x0, k0, X, K, vec, tid + 768)
+#define GB_STORE4(KCF, R, s)                                                                 \
+    tile_store_one<KCF>(s, R##0, tid);                                                       \
+    tile_store_one<KCF>(s, R##1, tid + 256);                                                 \
+    tile_store_one<KCF>(s, R##2, tid + 512);                                                 \
+    tile_store_one<KCF>(s, R##3, tid + 768)
+
+// The K loop of one 128x128 tile.  CHECK = false: interior tile, aligned operands, K a multiple of GB_K -- the loop
+// contains no bounds logic at all (a checked load anywhere in the loop makes the compiler wait for the whole
+// prefetch before the matrix-core section, which serialises load latency and MFMA time).
+template <bool A_KC, bool B_KC, bool CHECK>
+__device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, const float* __restrict__ Bb, float* lds,
+                                               f32x16 (&acc)[2][2], int M, int N, int K, int64_t lda, int64_t ldb, int m0,
+                                               int n0, bool vec_a, bool vec_b, int tid, int wm, int wn) {
+    constexpr int LDA = OperandTile<A_KC>::LD, LDB = OperandTile<B_KC>::LD;
+    float* const sA = lds;                          // two buffers of [GB_K][LDA]
+    float* const sB = lds + 2 * GB_K * LDA;         // two buffers of [GB_K][LDB]
+    const int lane = tid & 63;
+    const int fk = lane >> 5, fm = lane & 31;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    GB_LOAD4(A_KC, ra, Ab, lda, m0, 0, M, K, vec_a);
+    GB_LOAD4(B_KC, rb, Bb, ldb, n0, 0, N, K, vec_b);
+    GB_STORE4(A_KC, ra, sA);
+    GB_STORE4(B_KC, rb, sB);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += GB_K) {
+        const bool more = k0 + GB_K < K;
+        if (more) {     // next step's operands: in flight while this step runs on the matrix cores
+            GB_LOAD4(A_KC, ra, Ab, lda, m0, k0 + GB_K, M, K, vec_a);
+            GB_LOAD4(B_KC, rb, Bb, ldb, n0, k0 + GB_K, N, K, vec_b);
+        }
+        const float* a = sA + buf * (GB_K * LDA) + fk * LDA + wm + fm;
+        const float* b = sB + buf * (GB_K * LDB) + fk * LDB + wn + fm;
+        // the fragments of a half step (8 k-pairs x 4 values) are read from LDS in one batch, then 32 MFMAs run
+        // back to back: the matrix pipe never waits on an LDS round trip between its own instructions
+#pragma unroll
+        for (int kh = 0; kh < GB_K; kh += 16) {
+            float fa0[8], fa1[8], fb0[8], fb1[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                fa0[t] = a[(kh + 2 * t) * LDA]; fa1[t] = a[(kh + 2 * t) * LDA + 32];
+                fb0[t] = b[(kh + 2 * t) * LDB]; fb1[t] = b[(kh + 2 * t) * LDB + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb1[t], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb0[t], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            GB_STORE4(A_KC, ra, sA + (buf ^ 1) * (GB_K * LDA));     // the other buffer: its readers finished one barrier ago
+            GB_STORE4(B_KC, rb, sB + (buf ^ 1) * (GB_K * LDB));
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
 
 // C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
 // grid (ceil(N/128), ceil(M/128), batch), block 256
@@ -97,10 +164,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                                                              float* __restrict__ C, int M, int N, int K, int64_t lda,
                                                              int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc,
                                                              float alpha, int vec_a, int vec_b) {
-    constexpr int LDA = OperandTile<A_KC>::LD, LDB = OperandTile<B_KC>::LD;
     extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 * GB_K * (LDA + LDB) floats (> 64 KB: dynamic)
-    float* const sA = lds;                          // two buffers of [GB_K][LDA]
-    float* const sB = lds + 2 * GB_K * LDA;         // two buffers of [GB_K][LDB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int m0 = blockIdx.y * GB_T, n0 = blockIdx.x * GB_T;
@@ -116,41 +180,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    OperandTile<A_KC> ta;
-    OperandTile<B_KC> tb;
-    ta.load(Ab, lda, m0, 0, M, K, vec_a != 0, tid);
-    tb.load(Bb, ldb, n0, 0, N, K, vec_b != 0, tid);
-    ta.store(sA, tid);
-    tb.store(sB, tid);
-    __syncthreads();
+    const bool fast = vec_a && vec_b && (m0 + GB_T <= M) && (n0 + GB_T <= N) && (K % GB_K == 0);    // block-uniform
+    if (fast)
+        gemm_tile_loop<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
+    else
+        gemm_tile_loop<A_KC, B_KC, true>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn);
 
     const int fk = lane >> 5, fm = lane & 31;
-    int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += GB_K) {
-        const bool more = k0 + GB_K < K;
-        if (more) {     // next step's operands: in flight while this step runs on the matrix cores
-            ta.load(Ab, lda, m0, k0 + GB_K, M, K, vec_a != 0, tid);
-            tb.load(Bb, ldb, n0, k0 + GB_K, N, K, vec_b != 0, tid);
-        }
-        const float* a = sA + buf * (GB_K * LDA) + fk * LDA + wm + fm;
-        const float* b = sB + buf * (GB_K * LDB) + fk * LDB + wn + fm;
-#pragma unroll
-        for (int kk = 0; kk < GB_K; kk += 2) {
-            const float a0 = a[kk * LDA], a1 = a[kk * LDA + 32];
-            const float b0 = b[kk * LDB], b1 = b[kk * LDB + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (more) {
-            ta.store(sA + (buf ^ 1) * (GB_K * LDA), tid);     // the other buffer: its readers finished one barrier ago
-            tb.store(sB + (buf ^ 1) * (GB_K * LDB), tid);
-        }
-        __syncthreads();
-        buf ^= 1;
-    }
-
     // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < 2; ++i)

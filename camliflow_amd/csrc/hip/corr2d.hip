@@ -501,7 +501,10 @@ extern "C" int camli_corr2d_fwd(const float* in1_nhwc, const float* in2_nhwc, fl
         case 2: return launch_fwd<2>(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
         case 3: return launch_fwd<3>(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
         case 4:
-            if ((C & 3) == 0 && camli_corr2d_use_tile()) {
+            // the 8 x 64 tile kernel needs enough tiles to fill the chip (one 512-thread workgroup per CU); small
+            // pyramid levels keep the one-row kernel, whose 64-pixel workgroups spread over more CUs
+            if ((C & 3) == 0 && camli_corr2d_use_tile() &&
+                (long long)B * camli_divup(H, 8) * camli_divup(W, 64) >= 192) {
                 return launch_fwd_tile(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);
             }
             return launch_fwd<4>(in1_nhwc, in2_nhwc, out_nchw, B, C, H, W, s);

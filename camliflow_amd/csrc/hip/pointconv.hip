@@ -184,28 +184,53 @@ __global__ __launch_bounds__(256) void pointconv_mix_bwd_point_kernel(const floa
     int m[PCW_K];
 #pragma unroll
     for (int j = 0; j < PCW_K; ++j) m[j] = (int)irow[j];
-    for (int ch = lane; ch < CHP; ch += 64) {
-        const bool ok = ch < CH;
-        float gv[PCW_WN];
+    // channels in blocks of 128 (two per lane): the weights are walked row by row (four 64-byte rows = 64 scalars in
+    // SGPRs at a time, as in the forward kernel) and each one feeds both channel halves
+    for (int c0 = 0; c0 < CHP; c0 += 128) {
+        const int ca = c0 + lane, cb = c0 + 64 + lane;
+        const bool oka = ca < CH, okb = cb < CH;
+        float ga[PCW_WN], gb[PCW_WN];
 #pragma unroll
-        for (int w = 0; w < PCW_WN; ++w) gv[w] = ok ? g[(size_t)w * CH + ch] : 0.0f;
+        for (int w = 0; w < PCW_WN; ++w) {
+            ga[w] = oka ? g[(size_t)w * CH + ca] : 0.0f;
+            gb[w] = okb ? g[(size_t)w * CH + cb] : 0.0f;
+        }
         if (gwgt) {
 #pragma unroll
-            for (int w = 0; w < PCW_WN; ++w) sg[w * CHP + ch] = gv[w];
+            for (int w = 0; w < PCW_WN; ++w) {
+                if (ca < CHP) sg[w * CHP + ca] = ga[w];
+                if (cb < CHP) sg[w * CHP + cb] = gb[w];
+            }
 #pragma unroll
-            for (int j = 0; j < PCW_K; ++j) sf[j * CHP + ch] = ok ? fb[(size_t)m[j] * CH + ch] : 0.0f;
+            for (int j = 0; j < PCW_K; ++j) {
+                const float* __restrict__ row = fb + (size_t)m[j] * CH;
+                if (ca < CHP) sf[j * CHP + ca] = oka ? row[ca] : 0.0f;
+                if (cb < CHP) sf[j * CHP + cb] = okb ? row[cb] : 0.0f;
+            }
         }
         if (trows) {
-            float* __restrict__ t = trows + (size_t)p * PCW_K * CH + ch;
-#pragma unroll 1            // two neighbours' weight columns (16 x 2 scalars) in SGPRs at a time
-            for (int jg = 0; jg < PCW_K; jg += 2) {
+            float ta[PCW_K], tb[PCW_K];
 #pragma unroll
-                for (int j = jg; j < jg + 2; ++j) {
-                    float acc = 0.0f;
+            for (int j = 0; j < PCW_K; ++j) ta[j] = tb[j] = 0.0f;
+#pragma unroll 1
+            for (int wg = 0; wg < PCW_WN; wg += 4) {
 #pragma unroll
-                    for (int w = 0; w < PCW_WN; ++w) acc = __builtin_fmaf(wbase[(size_t)w * N * PCW_K + j], gv[w], acc);
-                    if (ok) t[(size_t)j * CH] = acc;
+                for (int w = wg; w < wg + 4; ++w) {
+                    const float* __restrict__ wr = wbase + (size_t)w * N * PCW_K;
+                    const float gwa = ga[w], gwb = gb[w];
+#pragma unroll
+                    for (int j = 0; j < PCW_K; ++j) {
+                        const float wv = wr[j];
+                        ta[j] = __builtin_fmaf(wv, gwa, ta[j]);
+                        tb[j] = __builtin_fmaf(wv, gwb, tb[j]);
+                    }
                 }
+            }
+            float* __restrict__ t = trows + (size_t)p * PCW_K * CH;
+#pragma unroll
+            for (int j = 0; j < PCW_K; ++j) {
+                if (oka) t[(size_t)j * CH + ca] = ta[j];
+                if (okb) t[(size_t)j * CH + cb] = tb[j];
             }
         }
     }

@@ -166,6 +166,30 @@ int camli_corr3d_gather_bwd(const float *gout, const int64_t *knn, float *gcost,
                             void *stream);
 
 /*
+ * PointPWC learnable cost volume, PWC-style Correlation3D (internal composite op; the reference materialises
+ * [B, 2C+3, N, k] = cat(f1 expanded, gather(f2), dxyz) and runs MLP2d over it: models/camlipwc_l_core.py:53-106).
+ * The first MLP layer is split by input block (see csrc/hip/pwc3d.hip); tensors are [B,C,N,k] with k fastest, k a
+ * power of two <= 64, idx int64 [B,N,k] contiguous.
+ *   pair_fwd : h1 = leaky_relu(a[b,c,n] + bm[b,c,idx[b,n,j]] + e[b,c,n,j], slope)      a [B,C,N], bm [B,C,M]
+ *   pair_bwd : gpre = gh1 * leaky'(h1) (fully written; = the gradient of e, and the source of bm's gradient through
+ *              camli_gather_cf_bwd_sorted), ga[b,c,n] = sum_j gpre (fully written)
+ *   ksum     : out[b,c,n] = sum_j w * h;    bwd: gw = g*h, gh = g*w (either may be NULL)
+ *   gather_wsum : out[b,c,n] = sum_j w[b,c,n,j] * feat[b,c,idx[b,n,j]]   feat [B,C,M];
+ *              bwd: gw = g*feat[idx], t = g*w (-> camli_gather_cf_bwd_sorted gives the gradient of feat)
+ */
+int camli_pwc3d_pair_fwd(const float *a, const float *bm, const float *e, const int64_t *idx, float *h1,
+                         int B, int C, int M, int N, int k, float slope, void *stream);
+int camli_pwc3d_pair_bwd(const float *gh1, const float *h1, float *gpre, float *ga,
+                         int B, int C, int N, int k, float slope, void *stream);
+int camli_ksum_fwd(const float *w, const float *h, float *out, int B, int C, int N, int k, void *stream);
+int camli_ksum_bwd(const float *g, const float *w, const float *h, float *gw, float *gh,
+                   int B, int C, int N, int k, void *stream);
+int camli_gather_wsum_fwd(const float *w, const float *feat, const int64_t *idx, float *out,
+                          int B, int C, int M, int N, int k, void *stream);
+int camli_gather_wsum_bwd(const float *g, const float *w, const float *feat, const int64_t *idx, float *gw, float *t,
+                          int B, int C, int M, int N, int k, void *stream);
+
+/*
  * PointConv neighbourhood mixing and adjoint (internal composite op; the reference composes it from a
  * channel-last gather + matmul, models/point_conv.py:60-66).
  *   feat_cl [B,M,CH] channel-last (CH = in_channels + 3); wgt [B,Wn,N,k] (Wn <= 16, the layout

@@ -204,6 +204,31 @@ def pointconv_mix_fwd(feat_cl, wgt, idx, k):
     return out
 
 
+def pwc3d_pair_fwd(a, bm, e, idx, slope=0.1):
+    a, bm, e, idx = _f32(a), _f32(bm), _f32(e), _i64(idx)
+    B, C, N, k = e.shape
+    out = np.zeros_like(e)
+    _chk(_load().oracle_pwc3d_pair_fwd(_p(a), _p(bm), _p(e), _p(idx), _p(out), B, C, bm.shape[2], N, k,
+                                       ctypes.c_float(slope)), "pwc3d_pair_fwd")
+    return out
+
+
+def ksum_fwd(w, h):
+    w, h = _f32(w), _f32(h)
+    B, C, N, k = w.shape
+    out = np.zeros((B, C, N), dtype=np.float32)
+    _chk(_load().oracle_ksum_fwd(_p(w), _p(h), _p(out), B, C, N, k), "ksum_fwd")
+    return out
+
+
+def gather_wsum_fwd(w, feat, idx):
+    w, feat, idx = _f32(w), _f32(feat), _i64(idx)
+    B, C, N, k = w.shape
+    out = np.zeros((B, C, N), dtype=np.float32)
+    _chk(_load().oracle_gather_wsum_fwd(_p(w), _p(feat), _p(idx), _p(out), B, C, feat.shape[2], N, k), "gather_wsum_fwd")
+    return out
+
+
 def convex_upsample_fwd(flow, mask, scale):
     """flow [B,2,h,w], mask [B,9*S*S,h,w] -> [B,2,h*S,w*S]"""
     flow, mask = _f32(flow), _f32(mask)

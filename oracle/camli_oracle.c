@@ -500,6 +500,57 @@ int oracle_pointconv_mix_fwd(const float *feat_cl, const float *wgt, const int64
 }
 
 /* ------------------------------------------------------------------------------------------
+ * PointPWC cost volume pieces, follow models/camlipwc_l_core.py:66-101 with the first cost-MLP layer split by
+ * input block (W1 . cat[f1, f2_knn, d] = W1a.f1 + W1b.f2_knn + W1c.d; the caller supplies a = W1a.f1,
+ * bm = W1b.f2 and e = W1c.d + b1):
+ *   pair : h1[b,c,n,j] = leaky(a[b,c,n] + bm[b,c,idx[b,n,j]] + e[b,c,n,j])
+ *   ksum : out[b,c,n]  = sum_j w[b,c,n,j] * h[b,c,n,j]                       (:79-81, torch.sum(weights2 * p2p_cost, 3))
+ *   gather_wsum : out[b,c,n] = sum_j w[b,c,n,j] * feat[b,c,idx[b,n,j]]       (:97-101)
+ * ------------------------------------------------------------------------------------------ */
+int oracle_pwc3d_pair_fwd(const float *a, const float *bm, const float *e, const int64_t *idx, float *h1,
+                          int B, int C, int M, int N, int k, float slope)
+{
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int n = 0; n < N; ++n)
+                for (int j = 0; j < k; ++j) {
+                    int64_t m = idx[((size_t)b * N + n) * k + j];
+                    if (m < 0 || m >= M) return -1;
+                    size_t o = (((size_t)b * C + c) * N + n) * k + j;
+                    float v = a[((size_t)b * C + c) * N + n] + bm[((size_t)b * C + c) * M + m] + e[o];
+                    h1[o] = v > 0.0f ? v : slope * v;
+                }
+    return 0;
+}
+
+int oracle_ksum_fwd(const float *w, const float *h, float *out, int B, int C, int N, int k)
+{
+    for (size_t r = 0; r < (size_t)B * C * N; ++r) {
+        double acc = 0.0;
+        for (int j = 0; j < k; ++j) acc += (double)w[r * k + j] * h[r * k + j];
+        out[r] = (float)acc;
+    }
+    return 0;
+}
+
+int oracle_gather_wsum_fwd(const float *w, const float *feat, const int64_t *idx, float *out,
+                           int B, int C, int M, int N, int k)
+{
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int n = 0; n < N; ++n) {
+                double acc = 0.0;
+                for (int j = 0; j < k; ++j) {
+                    int64_t m = idx[((size_t)b * N + n) * k + j];
+                    if (m < 0 || m >= M) return -1;
+                    acc += (double)w[(((size_t)b * C + c) * N + n) * k + j] * feat[((size_t)b * C + c) * M + m];
+                }
+                out[((size_t)b * C + c) * N + n] = (float)acc;
+            }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * convex up-sampling: follows models/utils.py:191-204 (softmax over the 9 taps of the 3x3 unfold)
  *   flow [B,2,h,w], mask [B,9*S*S,h,w] (already scaled), out [B,2,h*S,w*S]
  * ------------------------------------------------------------------------------------------ */
