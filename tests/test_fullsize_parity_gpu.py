@@ -1,0 +1,133 @@
+"""Model-level parity at the FULL sizes of BASELINE.json's configurations (north star: EPE2D / EPE3D of the HIP path
+within 1e-4 of the reference CPU path, fp32).  The reference here is the CPU port -- this repo's cores driven by the
+C oracle operators, itself bit-identical to the reference's models on the CPU (tests/test_models_golden.py) -- on
+SHARED post-IDS core inputs (see tests/test_model_gpu.py for why the IDS transform is shared).  Every HIP run is in
+strict mode: an op with a fused kernel that would drop to the composed formulation fails the test, and the census
+of fused launches is printed.
+
+  configs[2]  CamLiRAFT 960x540 + 8192 pts, 12 iterations                      fp32  vs CPU port   <= 1e-4
+  configs[4]  CamLiRAFT 1242x375 + 16384 pts, 32 iterations (KITTI shape)      fp32  vs CPU port   <= 1e-4
+                                                                               bf16  vs fp32 HIP   <= 0.5 px / 0.05 (stated bound)
+  configs[1]  CamLiPWC 960x540 + 8192 pts, training step                       fp32  hip vs composed on the GPU <= 1e-4,
+                                                                               loss and gradients in norm
+"""
+import pytest
+import torch
+
+from modelutils import camlipwc_cfg, camliraft_cfg, hashed_fill_, oracle_boundary, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _epe(a, b):
+    return torch.linalg.norm(a - b, dim=1).mean().item()
+
+
+def _core_inputs(inputs):
+    from camliflow_amd.cores.camliraft import _camera_pair, _IMAGENET_MEAN, _IMAGENET_STD
+    from camliflow_amd.cores.geometry import InputPadder, persp2paral
+    images = inputs['images'].float()
+    padder = InputPadder(images.shape, x=8)
+    image1, image2 = padder.pad(images[:, :3], images[:, 3:])
+    mean = torch.tensor(_IMAGENET_MEAN).reshape(1, 3, 1, 1)
+    std = torch.tensor(_IMAGENET_STD).reshape(1, 3, 1, 1)
+    persp, paral = _camera_pair(image1.shape[-2], image1.shape[-1], inputs['intrinsics'])
+    pc1 = persp2paral(inputs['pcs'][:, :3], persp, paral)
+    pc2 = persp2paral(inputs['pcs'][:, 3:], persp, paral)
+    return (image1 - mean) / std, (image2 - mean) / std, pc1, pc2, paral, padder
+
+
+def _camliraft_pair(n_iters):
+    from camliflow_amd.cores import CamLiRAFT
+    torch.manual_seed(0)
+    cpu_model = hashed_fill_(CamLiRAFT(camliraft_cfg(n_iters=n_iters)), scale=0.5).eval()
+    gpu_model = CamLiRAFT(camliraft_cfg(n_iters=n_iters))
+    gpu_model.load_state_dict(cpu_model.state_dict())
+    return cpu_model, gpu_model.cuda().eval()
+
+
+def _raft_parity(inputs, n_iters):
+    from camliflow_amd.cores import runtime
+    cpu_model, gpu_model = _camliraft_pair(n_iters)
+    image1, image2, pc1, pc2, paral, padder = _core_inputs(inputs)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))          # the CPU port is fastest at a moderate thread count
+    try:
+        with torch.no_grad(), oracle_boundary():
+            f2d_cpu, f3d_cpu = cpu_model.core(image1, image2, pc1, pc2, paral)
+    finally:
+        torch.set_num_threads(threads)
+    runtime.set_census(True)
+    runtime.reset_census()
+    with torch.no_grad(), runtime.use_backend('hip'):
+        runtime.set_strict(True)
+        try:
+            f2d_gpu, f3d_gpu = gpu_model.core(image1.cuda(), image2.cuda(), pc1.cuda(), pc2.cuda(), paral)
+        finally:
+            runtime.set_strict(False)
+    census = runtime.census()
+    runtime.set_census(False)
+    assert not census['composed'], census['composed']
+    print('fused launches: %d over %d entry points' % (sum(census['fused'].values()), len(census['fused'])))
+    tgt2d = padder.pad(inputs['flow_2d'][:, :2])[0]
+    tgt3d = inputs['flow_3d']
+    worst = (0.0, 0.0)
+    for it in range(len(f2d_cpu)):
+        d2 = abs(_epe(f2d_cpu[it], tgt2d) - _epe(f2d_gpu[it].cpu(), tgt2d))
+        d3 = abs(_epe(f3d_cpu[it], tgt3d) - _epe(f3d_gpu[it].cpu(), tgt3d))
+        worst = (max(worst[0], d2), max(worst[1], d3))
+        assert d2 <= 1e-4 and d3 <= 1e-4, (it, d2, d3)
+    print('%d iterations: worst |dEPE2D| %.2e, |dEPE3D| %.2e; final flow difference 2d %.2e px, 3d %.2e'
+          % (len(f2d_cpu), worst[0], worst[1], _epe(f2d_cpu[-1], f2d_gpu[-1].cpu()), _epe(f3d_cpu[-1], f3d_gpu[-1].cpu())))
+    return gpu_model, (image1, image2, pc1, pc2, paral), (f2d_gpu, f3d_gpu)
+
+
+def test_config3_camliraft_960x540_12_iterations_vs_cpu_port():
+    _raft_parity(synthetic_inputs(1, 540, 960, 8192), 12)
+
+
+def test_config5_kitti_shape_32_iterations_fp32_vs_cpu_port_and_bf16_bound():
+    from camliflow_amd.cores import runtime
+    inputs = synthetic_inputs(1, 375, 1242, 16384, f=721.5, zmax=90.0)
+    gpu_model, (image1, image2, pc1, pc2, paral), (f2d, f3d) = _raft_parity(inputs, 32)
+    # bf16 autocast (convolutions / GEMMs only; KNN, FPS, correlation, CLFM stay fp32 as in the reference): NOT the
+    # fp32 parity bar -- the stated bound is 0.5 px / 0.05 against the fp32 HIP run after all 32 iterations
+    with torch.no_grad(), runtime.use_backend('hip'), torch.autocast('cuda', dtype=torch.bfloat16):
+        l2d, l3d = gpu_model.core(image1.cuda(), image2.cuda(), pc1.cuda(), pc2.cuda(), paral)
+    assert torch.isfinite(l2d[-1]).all() and torch.isfinite(l3d[-1]).all()
+    d2, d3 = _epe(l2d[-1].float(), f2d[-1]), _epe(l3d[-1].float(), f3d[-1])
+    print('bf16 vs fp32 after 32 iterations: 2d %.3f px, 3d %.4f' % (d2, d3))
+    assert d2 < 0.5 and d3 < 0.05
+
+
+def test_config2_camlipwc_960x540_hip_vs_composed_training_step():
+    import camliflow_amd.cores as cores
+    from camliflow_amd.cores import runtime
+    torch.manual_seed(0)
+    model = hashed_fill_(cores.CamLiPWC(camlipwc_cfg()), scale=0.5).cuda().train()
+    inputs = {k: v.cuda() for k, v in synthetic_inputs(1, 540, 960, 8192).items()}
+    res = {}
+    for backend in ('hip', 'composed'):
+        with runtime.use_backend(backend):
+            runtime.set_census(backend == 'hip')
+            runtime.reset_census()
+            model.zero_grad()
+            out = model(inputs)
+            loss = model.get_loss()
+            loss.backward()
+            if backend == 'hip':
+                census = runtime.census()
+                runtime.set_census(False)
+            res[backend] = (out, loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    print('fused launches %d; composed under hip: %s' % (sum(census['fused'].values()), census['composed']))
+    # the only accepted composed op at this size: the SK gate of the 81-channel correlation fusion at C = 627 > 512
+    assert all(k.startswith('sk_gate') for k in census['composed']), census['composed']
+    for name in ('camli_corr2d_fwd', 'camli_pwc3d_pair_fwd', 'camli_gather_wsum_fwd', 'camli_knn_interp_bwd_xyz', 'camli_knn', 'camli_fps'):
+        assert census['fused'].get(name, 0) > 0, name
+    (oh, lh, gh), (oc, lc, gc) = res['hip'], res['composed']
+    for key in oh:
+        assert _epe(oh[key], oc[key]) <= 1e-4, (key, _epe(oh[key], oc[key]))
+    assert abs(lh - lc) <= 1e-4 * max(1.0, abs(lc))
+    num = sum(((gh[n] - gc[n]).double() ** 2).sum().item() for n in gh) ** 0.5
+    den = sum((gc[n].double() ** 2).sum().item() for n in gh) ** 0.5
+    assert gh.keys() == gc.keys() and num / den < 2e-3, num / den

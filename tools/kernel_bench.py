@@ -81,6 +81,10 @@ def cases(batch):
         yield ('knn B%d M%d Nq%d D%d k%d' % (b, m, nq, d, k),
                (lambda inp=inp, qry=qry, k=k: csrc.k_nearest_neighbor(inp, qry, k)), {'camli_knn': 'valu'})
 
+    # the dense-query interpolation of kitti_submission.py:89-93 (every pixel of a 375x1242 map)
+    inp1, qry1 = _rand(g, 1, 8192, 3, scale=10.0), _rand(g, 1, 465750, 3, scale=10.0)
+    yield 'knn B1 M8192 Nq465750 D3 k3', (lambda: csrc.k_nearest_neighbor(inp1, qry1, 3)), {'camli_knn': 'valu'}
+
     # ---- A8 gather / scatter (the cost-volume pooling gathers of Correlation3D.build) ---------------------------
     for (c, m, i) in [(2048, 2048, 3072), (128, 2048, 2048 * 16)]:
         data = _randn(g, b, c, m).requires_grad_(True)
