@@ -91,7 +91,7 @@ class CamLiRAFT_Core(nn.Module):
         with lanes.side():
             h_3d, x_3d = torch.split(b3d.cnet_aligner(featc_3d), [128, 128], dim=1)
             h_3d, x_3d = torch.tanh(h_3d), torch.relu(x_3d)
-            b3d.correlation.build_cost_volume_pyramid(feat1_3d, feat2_3d, xyzs2)
+            b3d.correlation.build_cost_volume_pyramid(feat1_3d, feat2_3d, xyzs2, nested=True)   # build_pc_pyramid: FPS prefixes
             knn_indices = _ops.k_nearest_neighbor(xyz1, xyz1, k=32)
             flow_3d_pred = torch.zeros_like(xyz1)
         h_2d, x_2d = torch.split(b2d.cnet_aligner(featc_2d), [128, 128], dim=1)
@@ -111,7 +111,7 @@ class CamLiRAFT_Core(nn.Module):
             with lanes.side():
                 if it > 0:
                     flow_3d_pred = flow_3d_pred.detach()
-                    xyzs2_warp = backwarp_3d_levels(xyz1, xyzs2, flow_3d_pred)
+                    xyzs2_warp = backwarp_3d_levels(xyz1, xyzs2, flow_3d_pred, nested=True)
                 corr3d = b3d.correlation(xyz1, xyzs2_warp)
             if it > 0:
                 flow_2d_pred = flow_2d_pred.detach()

@@ -130,14 +130,24 @@ def backwarp_3d(xyz1, xyz2, flow12, k=3):
     return xyz2 + flow21
 
 
-def backwarp_3d_levels(xyz1, xyz2_levels, flow12, k=3):
+def backwarp_3d_levels(xyz1, xyz2_levels, flow12, k=3, nested=False):
     """``[backwarp_3d(xyz1, level, flow12) for level in xyz2_levels]`` with the level-independent parts
-    (warped source cloud, negated flow, their layout conversion) evaluated once."""
+    (warped source cloud, negated flow, their layout conversion) evaluated once.
+
+    ``nested``: the caller guarantees that level l+1 is the first n_{l+1} points of level l (the FPS pyramid of
+    build_pc_pyramid, models/utils.py:121-125).  Every warped point depends on its own position only, so the warped
+    coarser levels are prefixes of the warped level 0: one search + one interpolation instead of one per level, and
+    the returned levels are views of one tensor."""
     if not (runtime.fused() and xyz1.is_cuda):
         return [backwarp_3d(xyz1, level, flow12, k) for level in xyz2_levels]
     from ..csrc import fused
     warped, inverse = xyz1 + flow12, -flow12
     warped_cl = warped.detach().transpose(1, 2).contiguous()
+    if nested:
+        level0 = xyz2_levels[0]
+        knn_indices = _ops.k_nearest_neighbor(warped_cl, _channel_last(level0, True), k)
+        warped0 = level0 + fused.knn_interpolate(warped, inverse, level0, knn_indices, k)
+        return [warped0] + [warped0[:, :, :lvl.shape[2]] for lvl in xyz2_levels[1:]]
     out = []
     for level in xyz2_levels:
         knn_indices = _ops.k_nearest_neighbor(warped_cl, _channel_last(level, True), k)

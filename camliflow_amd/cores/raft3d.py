@@ -65,13 +65,19 @@ class Correlation3D(nn.Module):
         self.merge = Conv1dNormRelu(out_channels, out_channels)
         self.cost_volume_pyramid = None
 
-    def build_cost_volume_pyramid(self, feat1, feat2, xyzs2, k=3):
+    def build_cost_volume_pyramid(self, feat1, feat2, xyzs2, k=3, nested=False):
+        """``nested``: the caller guarantees that xyzs2[l+1] is the first n_{l+1} points of xyzs2[l] (the FPS pyramid,
+        models/utils.py:121-125); the lookups of the pass then search and gather all levels in one launch each."""
         dense = torch.bmm(feat1.float().transpose(1, 2), feat2.float()) / feat1.shape[1]
         levels = [dense]
         for coarse, fine in zip(xyzs2[1:], xyzs2[:-1]):
             parents = _ops.k_nearest_neighbor(fine, coarse, k=k)               # [B,M_l,k] into level l-1
             levels.append(batch_indexing(levels[-1], parents).mean(dim=-1))
         self.cost_volume_pyramid = levels
+        self._nested = None
+        if nested and runtime.fused() and dense.is_cuda and len(levels) <= 4 and min(lvl.shape[2] for lvl in levels) >= self.k:
+            from ..csrc import fused
+            self._nested = fused.Corr3DPyramid(levels)
 
     def calc_matching_cost(self, xyz1, xyz2, cost_volume):
         bs, n_src, n_dst = cost_volume.shape
@@ -101,11 +107,22 @@ class Correlation3D(nn.Module):
         launches in both directions, one larger GEMM."""
         from ..csrc import fused
         bs, n_src = xyz1.shape[0], xyz1.shape[2]
-        columns = []
-        for lvl in range(4):
-            cross = knn_channel_first(xyzs2[lvl], xyz1, self.k, invariant_query=True)
-            columns.append(fused.corr3d_lookup_input(self.cost_volume_pyramid[lvl], xyz1, xyzs2[lvl], cross))
-        cost = self.cost_mlp(torch.cat(columns, dim=3))                               # [B,C/4,N,4k]
+        pyr = getattr(self, '_nested', None)
+        if pyr is not None and len(xyzs2) >= len(pyr.levels) and xyzs2[0].shape[2] == pyr.sizes[0]:
+            # nested target levels: one search over the level-0 cloud yields every prefix's neighbours, one gather
+            # writes the concatenated columns, and the adjoint accumulates into per-pass gradient volumes
+            from .geometry import _channel_last
+            level0 = xyzs2[0]
+            crosses = _ops.k_nearest_neighbor_prefixes(level0.detach().transpose(1, 2).contiguous(), _channel_last(xyz1, True),
+                                                       pyr.sizes, self.k)
+            lookup = fused.corr3d_lookup_levels(pyr, xyz1, level0, crosses)
+        else:
+            columns = []
+            for lvl in range(4):
+                cross = knn_channel_first(xyzs2[lvl], xyz1, self.k, invariant_query=True)
+                columns.append(fused.corr3d_lookup_input(self.cost_volume_pyramid[lvl], xyz1, xyzs2[lvl], cross))
+            lookup = torch.cat(columns, dim=3)
+        cost = self.cost_mlp(lookup)                                                  # [B,C/4,N,4k]
         cost = cost.view(bs, -1, n_src, 4, self.k).sum(dim=-1)                        # [B,C/4,N,4]
         cost = cost.permute(0, 3, 1, 2).reshape(bs, -1, n_src)                        # level-major channels
         return self.merge(cost)
@@ -210,7 +227,7 @@ class CamLiRAFT_L_Core(nn.Module):
 
         work1, work2 = pyramid1[top:], pyramid2[top:]               # [2048, 1024, 512, 256]
         xyz1 = work1[0]
-        self.correlation.build_cost_volume_pyramid(feat1, feat2, work2)
+        self.correlation.build_cost_volume_pyramid(feat1, feat2, work2, nested=True)   # build_pc_pyramid: FPS prefixes
         hidden, ctx = torch.split(context, [HIDDEN, HIDDEN], dim=1)
         hidden, ctx = torch.tanh(hidden), torch.relu(ctx)
         neighbours = _ops.k_nearest_neighbor(xyz1, xyz1, k=SELF_KNN)
@@ -222,7 +239,7 @@ class CamLiRAFT_L_Core(nn.Module):
         for step in range(n_iters):
             if step:
                 flow = flow.detach()
-                targets = backwarp_3d_levels(xyz1, work2, flow)
+                targets = backwarp_3d_levels(xyz1, work2, flow, nested=True)
             corr = self.correlation(xyz1, targets)
             motion = self.motion_encoder(xyz1, flow, corr, knn_indices=neighbours)
             hidden = self.gru(xyz1, h=hidden, x=torch.cat([ctx, motion], dim=1), knn_indices=neighbours)

@@ -14,6 +14,7 @@ PROTOTYPES = {
     "camli_version": (_int, []),
     "camli_last_error_string": (ctypes.c_char_p, []),
     "camli_knn": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _int, _int, _int, _int, _stream]),
+    "camli_knn_prefixes": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _int, _int, _int, _int, _int, _int, _stream]),
     "camli_fps": (_int, [_c_float_p, _c_i64_p, _int, _int, _int, _stream]),
     "camli_corr2d_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
     "camli_corr2d_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
@@ -46,6 +47,10 @@ PROTOTYPES = {
                                         _c_float_p, _int, _int, _int, _int, _int, _stream]),
     "camli_corr3d_gather_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _c_float_p,
                                        _int, _int, _int, _int, _stream]),
+    "camli_corr3d_gather_levels_fwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int,
+                                              _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_corr3d_gather_levels_bwd": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int,
+                                              _int, _int, _int, _int, _stream]),
     "camli_corr3d_gather_bwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_pwc3d_pair_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _int,
                                     ctypes.c_float, _stream]),

@@ -879,6 +879,83 @@ def corr3d_lookup_input(cost_volume, xyz1, xyz2, knn_indices):
                                xyz2.float().contiguous(), knn_indices.contiguous())
 
 
+class Corr3DPyramid:
+    """The point cost-volume pyramid of one pass (camliraft_l_core.py:51-60) for the multi-level lookup: `levels` are
+    the [B,N,M_l] volumes (still differentiable functions of the features), `token` ties every lookup to the pass, and
+    the lookups' backward ADD into one persistent gradient volume per level (allocated + zeroed by the first one).
+    The token node's backward then hands those totals to autograd as the gradients of the level tensors.  Without
+    it every lookup of every GRU iteration returns zero-filled volume-sized gradients (250 MB per iteration at batch
+    8) that autograd has to sum."""
+
+    def __init__(self, levels):
+        self.levels = [lvl.float().contiguous() for lvl in levels]
+        self.sizes = [lvl.shape[2] for lvl in self.levels]
+        self.grads = None
+        self.token = _Corr3DToken.apply(self, *self.levels)
+
+
+class _Corr3DToken(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pyr, *levels):
+        ctx.pyr = weakref.ref(pyr)          # pyr.token is this node's output: no strong back-reference (cycle)
+        ctx.meta = [(tuple(lvl.shape), lvl.device) for lvl in levels]
+        return levels[0].new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _gtoken):
+        pyr = ctx.pyr()
+        grads = None
+        if pyr is not None:
+            grads, pyr.grads = pyr.grads, None
+        if grads is None:
+            grads = [torch.zeros(shape, dtype=torch.float32, device=dev) for shape, dev in ctx.meta]
+        return (None, *grads)
+
+
+class _Corr3DLookupLevels(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, token, xyz1, xyz2, pyr, *knn_levels):
+        lib = _lib.load()
+        b, _, n = xyz1.shape
+        m0, k, nl = xyz2.shape[2], knn_levels[0].shape[2], len(knn_levels)
+        out = torch.empty((b, 4, n, nl * k), dtype=torch.float32, device=xyz1.device)
+        sizes = (ctypes.c_int * nl)(*pyr.sizes)
+        with _on_device(xyz1):
+            _lib.launch('camli_corr3d_gather_fwd', lib.camli_corr3d_gather_levels_fwd, xyz1.data_ptr(), xyz2.data_ptr(),
+                        _ptr_array(pyr.levels), _ptr_array(knn_levels), sizes, nl, out.data_ptr(), b, n, m0, k,
+                        _stream_ptr(xyz1), work=(b * n * nl * k * (8.0 + 16.0 + 4.0 + 12.0), 'B'))
+        ctx.save_for_backward(*knn_levels)
+        ctx.pyr, ctx.dims = pyr, (b, n, m0, k, nl)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        lib = _lib.load()
+        knn_levels = ctx.saved_tensors
+        pyr = ctx.pyr
+        b, n, m0, k, nl = ctx.dims
+        gout = gout.contiguous().float()
+        if pyr.grads is None:
+            pyr.grads = [torch.zeros_like(lvl) for lvl in pyr.levels]
+        sizes = (ctypes.c_int * nl)(*pyr.sizes)
+        with _on_device(gout):
+            _lib.launch('camli_corr3d_gather_bwd', lib.camli_corr3d_gather_levels_bwd, gout.data_ptr(), _ptr_array(knn_levels),
+                        _ptr_array(pyr.grads), sizes, nl, b, n, m0, k, _stream_ptr(gout),
+                        work=(b * n * nl * k * (8.0 + 4.0 + 8.0), 'B'))
+        return (_zero_token(gout), None, None, None) + (None,) * nl
+
+
+def corr3d_lookup_levels(pyr, xyz1, xyz2, knn_levels):
+    """Multi-level input of the cost MLP, [B,4,N,L*k], for NESTED target levels (xyz2 [B,3,M0] = the level-0 cloud,
+    level l = its first pyr.sizes[l] points); gradient to the cost volumes only (through pyr.token)."""
+    _require_cuda('corr3d_lookup_levels', xyz1, xyz2, *knn_levels)
+    assert not xyz1.requires_grad and not xyz2.requires_grad and len(knn_levels) == len(pyr.levels) <= 4
+    assert all(kn.is_contiguous() and kn.dtype == torch.int64 for kn in knn_levels) and min(pyr.sizes) >= knn_levels[0].shape[2]
+    return _Corr3DLookupLevels.apply(pyr.token, xyz1.float().contiguous(), xyz2.float().contiguous(), pyr, *knn_levels)
+
+
 # ------------------------------------------------------------------------------------------------
 # PointPWC learnable cost volume (models/camlipwc_l_core.py:53-106), see csrc/hip/pwc3d.hip
 # ------------------------------------------------------------------------------------------------

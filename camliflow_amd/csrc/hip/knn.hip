@@ -242,6 +242,102 @@ __global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_ke
     }
 }
 
+// Nested candidate prefixes in ONE scan.  The point-cloud pyramid is a chain of FPS prefixes (level l+1 = the first
+// n_{l+1} points of level l, models/utils.py:121-125), and the reference searches every level separately
+// (camliraft_l_core.py:62-66 called four times per GRU iteration).  The insertion semantics are sequential in the
+// candidate index, so the k-list after the first M_l candidates IS the answer for level l: the candidate range is cut
+// into NW = M_0 / chunk equal pieces (chunk = the smallest level), one wave each, and wave 0 merges the partial lists
+// in index order, writing a snapshot whenever the merged prefix reaches a level size.  Ties at the k-th distance are
+// detected per snapshot exactly as in knn_kernel and those queries are redone by an in-order scan of that prefix.
+struct KnnPrefixOut {
+    int64_t* out[4];
+    int size[4];        // descending candidate counts, size[0] = M_0; unused entries 0
+    int levels;
+};
+
+template <int D, int K>
+__global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const float* __restrict__ input,
+                                                                          const float* __restrict__ query,
+                                                                          KnnPrefixOut po, int M, int Nq, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nthreads = blockDim.x;
+    const int NW = nthreads >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int q_raw = blockIdx.x * 64 + lane;
+    const int q = q_raw < Nq ? q_raw : Nq - 1;
+    const float* __restrict__ in_b = input + (size_t)b * M * D;
+    const float* qp = query + ((size_t)b * Nq + q) * D;
+    const float ux = qp[0], uy = qp[1], uz = (D == 3) ? qp[2] : 0.0f;
+
+    float dist[K];
+    int idx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        dist[j] = KNN_INIT;
+        idx[j] = 0;
+    }
+    float ev_min = INFINITY;
+    float* qd = smem + threadIdx.x;
+    int* qi = reinterpret_cast<int*>(smem) + QBUF * nthreads + threadIdx.x;
+    scan_range<D, K>(in_b, w * chunk, (w + 1) * chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads);
+
+    __syncthreads();  // queues are dead; the merge region aliases them
+    float* md = smem;                                          // [NW][K][64]
+    int* mi = reinterpret_cast<int*>(smem) + NW * K * 64;      // [NW][K][64]
+    float* mev = smem + 2 * NW * K * 64;                       // [NW][64]
+    if (w > 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            md[(w * K + j) * 64 + lane] = dist[j];
+            mi[(w * K + j) * 64 + lane] = idx[j];
+        }
+        mev[w * 64 + lane] = ev_min;
+    }
+    __syncthreads();
+    if (w > 0) return;
+    float* rqd = smem + 2 * NW * K * 64 + NW * 64 + lane;      // wave 0's private queue for the redo scans
+    int* rqi = reinterpret_cast<int*>(rqd) + QBUF * 64;
+    for (int s = 0; s < NW; ++s) {
+        if (s > 0) {
+            ev_min = fminf(ev_min, mev[s * 64 + lane]);
+            for (int j = 0; j < K; ++j) {
+                float d = md[(s * K + j) * 64 + lane];
+                int c = mi[(s * K + j) * 64 + lane];
+                bool acc = !(d > dist[K - 1]);
+                if (!__ballot(acc)) break;
+                if (acc) list_insert<K>(dist, idx, d, c, ev_min);
+            }
+        }
+        const int covered = (s + 1) * chunk;
+        for (int l = 0; l < po.levels; ++l) {
+            if (po.size[l] != covered) continue;            // wave-uniform
+            int oidx[K];
+#pragma unroll
+            for (int j = 0; j < K; ++j) oidx[j] = idx[j];
+            const bool redo = (s > 0) && (ev_min == dist[K - 1]);
+            if (__ballot(redo)) {
+                if (redo) {
+                    float rd[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        rd[j] = KNN_INIT;
+                        oidx[j] = 0;
+                    }
+                    float ev2 = INFINITY;
+                    scan_range<D, K>(in_b, 0, covered, ux, uy, uz, rd, oidx, ev2, rqd, rqi, 64);
+                }
+            }
+            if (q_raw < Nq) {
+                int64_t* o = po.out[l] + ((size_t)b * Nq + q_raw) * K;
+#pragma unroll
+                for (int j = 0; j < K; ++j) o[j] = (int64_t)oidx[j];
+            }
+        }
+    }
+}
+
 // Literal one-thread-per-query form for any k in 1..64 that has no specialisation above.
 template <int D>
 __global__ __launch_bounds__(64) void knn_generic_kernel(const float* __restrict__ input,
@@ -332,4 +428,53 @@ extern "C" int camli_knn(const float* input, const float* query, int64_t* out_id
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return D == 2 ? dispatch_knn<2>(input, query, out_idx, B, M, Nq, k, s)
                   : dispatch_knn<3>(input, query, out_idx, B, M, Nq, k, s);
+}
+
+// Nested prefixes: out_levels[l] [B,Nq,k] = the k nearest among the FIRST sizes[l] inputs (sizes strictly descending,
+// sizes[0] = M).  One launch when every size is a multiple of the smallest one and M / smallest <= 8 (k = 16; 4 for
+// k = 32); otherwise one camli_knn per level.
+extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_t* const* out_levels, const int* sizes,
+                                  int L, int B, int M, int Nq, int D, int k, void* stream) {
+    if (B == 0 || Nq == 0) return CAMLI_OK;
+    if (!input || !query || !out_levels || !sizes) { camli_set_error("camli_knn_prefixes: null pointer"); return CAMLI_EINVAL; }
+    if (L < 1 || L > 4 || B < 0 || M < 1 || (D != 2 && D != 3) || k < 1 || k > 64 || sizes[0] != M || B > 65535) {
+        camli_set_error("camli_knn_prefixes: bad arguments L=%d B=%d M=%d D=%d k=%d (need 1<=L<=4, sizes[0]=M)", L, B, M, D, k);
+        return CAMLI_EINVAL;
+    }
+    for (int l = 0; l < L; ++l)
+        if (!out_levels[l] || sizes[l] < 1 || (l > 0 && sizes[l] >= sizes[l - 1])) {
+            camli_set_error("camli_knn_prefixes: level sizes must be strictly descending and positive");
+            return CAMLI_EINVAL;
+        }
+    const int chunk = sizes[L - 1];
+    bool one_launch = (D == 3) && (k == 16 || k == 32) && chunk >= 64;
+    for (int l = 0; l < L; ++l) one_launch = one_launch && (sizes[l] % chunk == 0);
+    const int nw = M / chunk;
+    one_launch = one_launch && nw >= 1 && nw <= (k >= 32 ? 4 : 8);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!one_launch) {
+        // general shapes: one plain search per (level, sample) -- a prefix of sample b starts at b * M * D
+        for (int l = 0; l < L; ++l)
+            for (int b = 0; b < B; ++b) {
+                const int rc = camli_knn(input + (size_t)b * M * D, query + (size_t)b * Nq * D,
+                                         out_levels[l] + (size_t)b * Nq * k, 1, sizes[l], Nq, D, k, stream);
+                if (rc != CAMLI_OK) return rc;
+            }
+        return CAMLI_OK;
+    }
+    KnnPrefixOut po;
+    po.levels = L;
+    for (int l = 0; l < 4; ++l) {
+        po.out[l] = l < L ? out_levels[l] : nullptr;
+        po.size[l] = l < L ? sizes[l] : 0;
+    }
+    const size_t q_bytes = (size_t)2 * QBUF * 64 * nw * 4;
+    const size_t m_bytes = ((size_t)2 * nw * k * 64 + (size_t)nw * 64 + (size_t)2 * QBUF * 64) * 4;
+    const size_t lds = q_bytes > m_bytes ? q_bytes : m_bytes;
+    dim3 grid(camli_divup(Nq, 64), B);
+    if (k == 16)
+        hipLaunchKernelGGL((knn_prefix_kernel<3, 16>), grid, dim3(64 * nw), lds, s, input, query, po, M, Nq, chunk);
+    else
+        hipLaunchKernelGGL((knn_prefix_kernel<3, 32>), grid, dim3(64 * nw), lds, s, input, query, po, M, Nq, chunk);
+    return camli_check_launch("camli_knn_prefixes");
 }

@@ -213,6 +213,45 @@ __global__ __launch_bounds__(256) void corr3d_gather_kernel(const float* __restr
     }
 }
 
+// All pyramid levels of the lookup in one launch (nested target prefixes: level l holds the first sizes[l] points of
+// xyz2, so one coordinate tensor serves every level).  out [B,4,N,L*k]: column l*k + j = neighbour j of level l -- the
+// concatenated tensor the shared cost MLP consumes, written directly (the reference runs 4 x (2 gathers + cat)).
+// The adjoint ADDS into persistent per-level gradient volumes: a point's k neighbours are distinct, launches on one
+// stream are ordered, so a plain read-modify-write replaces the atomics AND the per-iteration zero-filled temporaries
+// that autograd would then have to sum over the GRU iterations.
+struct Corr3dLevels {
+    float* cost[4];            // [B,N,size[l]]  (fwd: read; bwd: gradient volume, accumulated)
+    const int64_t* knn[4];     // [B,N,k]
+    int size[4];
+    int levels;
+};
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void corr3d_gather_levels_kernel(const float* __restrict__ xyz1,
+                                                                    const float* __restrict__ xyz2, Corr3dLevels lv,
+                                                                    float* __restrict__ io, int B, int N, int M0, int k) {
+    const int lk = lv.levels * k;
+    const size_t plane = (size_t)N * lk;
+    const size_t total = (size_t)B * plane;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(e % lk);
+        const size_t bn = e / lk;
+        const int b = (int)(bn / N), n = (int)(bn - (size_t)b * N);
+        const int l = col / k, j = col - l * k;
+        const int m = (int)lv.knn[l][bn * k + j];
+        const size_t o = (size_t)b * 4 * plane + (e - (size_t)b * plane);
+        if (!BACKWARD) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                io[o + a * plane] = xyz2[((size_t)b * 3 + a) * M0 + m] - xyz1[((size_t)b * 3 + a) * N + n];
+            io[o + 3 * plane] = lv.cost[l][bn * lv.size[l] + m];
+        } else {
+            float* g = lv.cost[l] + bn * lv.size[l] + m;
+            *g += io[o + 3 * plane];
+        }
+    }
+}
+
 int grid_y_for(int C) { return C < 64 ? C : 64; }
 
 // out[b,c,p] = scale[b,c,p] * data[b,c,idx[b,p]]  -- the nearest-point feature of every pixel times its score
@@ -357,6 +396,60 @@ extern "C" int camli_corr3d_gather_bwd(const float* gout, const int64_t* knn, fl
     hipLaunchKernelGGL((corr3d_gather_kernel<true>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        nullptr, nullptr, gcost, knn, const_cast<float*>(gout), B, N, M, k);
     return camli_check_launch("camli_corr3d_gather_bwd");
+}
+
+static int corr3d_levels_pack(const char* what, Corr3dLevels& lv, float* const* cost, const int64_t* const* knn,
+                              const int* sizes, int L, int B, int N, int M0, int k) {
+    if (!cost || !knn || !sizes) { camli_set_error("%s: null pointer", what); return 0; }
+    if (L < 1 || L > 4 || B < 0 || N < 1 || M0 < 1 || k < 1) {
+        camli_set_error("%s: bad shape L=%d B=%d N=%d M0=%d k=%d", what, L, B, N, M0, k);
+        return 0;
+    }
+    lv.levels = L;
+    for (int l = 0; l < 4; ++l) {
+        lv.cost[l] = l < L ? cost[l] : nullptr;
+        lv.knn[l] = l < L ? knn[l] : nullptr;
+        lv.size[l] = l < L ? sizes[l] : 0;
+        if (l < L && (!cost[l] || !knn[l] || sizes[l] < 1 || sizes[l] > M0)) {
+            camli_set_error("%s: level %d: null pointer or size %d outside [1, %d]", what, l, l < L ? sizes[l] : 0, M0);
+            return 0;
+        }
+    }
+    return 1;
+}
+
+extern "C" int camli_corr3d_gather_levels_fwd(const float* xyz1, const float* xyz2, const float* const* cost_levels,
+                                              const int64_t* const* knn_levels, const int* sizes, int L, float* out, int B,
+                                              int N, int M0, int k, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!xyz1 || !xyz2 || !out) { camli_set_error("camli_corr3d_gather_levels_fwd: null pointer"); return CAMLI_EINVAL; }
+    Corr3dLevels lv;
+    if (!corr3d_levels_pack("camli_corr3d_gather_levels_fwd", lv, const_cast<float* const*>(cost_levels), knn_levels, sizes, L, B, N,
+                            M0, k))
+        return CAMLI_EINVAL;
+    const size_t total = (size_t)B * N * L * k;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL((corr3d_gather_levels_kernel<false>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       xyz1, xyz2, lv, out, B, N, M0, k);
+    return camli_check_launch("camli_corr3d_gather_levels_fwd");
+}
+
+extern "C" int camli_corr3d_gather_levels_bwd(const float* gout, const int64_t* const* knn_levels, float* const* gcost_levels,
+                                              const int* sizes, int L, int B, int N, int M0, int k, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!gout) { camli_set_error("camli_corr3d_gather_levels_bwd: null pointer"); return CAMLI_EINVAL; }
+    Corr3dLevels lv;
+    if (!corr3d_levels_pack("camli_corr3d_gather_levels_bwd", lv, gcost_levels, knn_levels, sizes, L, B, N, M0, k)) return CAMLI_EINVAL;
+    for (int l = 0; l < L; ++l)
+        if (sizes[l] < k) {      // fewer candidates than k: the unfilled slots repeat index 0 and would race
+            camli_set_error("camli_corr3d_gather_levels_bwd: level %d has %d < k = %d points", l, sizes[l], k);
+            return CAMLI_ENOTSUP;
+        }
+    const size_t total = (size_t)B * N * L * k;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL((corr3d_gather_levels_kernel<true>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       nullptr, nullptr, lv, const_cast<float*>(gout), B, N, M0, k);
+    return camli_check_launch("camli_corr3d_gather_levels_bwd");
 }
 
 extern "C" int camli_gather_scale_fwd(const float* data, const float* scale, const int64_t* idx, float* out, int B, int C,

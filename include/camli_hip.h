@@ -49,6 +49,16 @@ int camli_knn(const float *input, const float *query, int64_t *out_idx,
  * No scratch buffer: running distances live in registers (the reference allocates a [B,N] temp,
  * furthest_point_sampling.cpp:12).  Ties -> lowest index.
  */
+/*
+ * The same search over NESTED candidate prefixes in one scan: out_levels[l] [B,Nq,k] = the k nearest among the
+ * first sizes[l] rows of every cloud (sizes strictly descending, sizes[0] = M; L <= 4; HOST arrays).  The FPS pyramid
+ * is a chain of prefixes (models/utils.py:121-125) and the reference searches each level separately
+ * (camliraft_l_core.py:62-66, four calls per GRU iteration); the sequential insertion semantics make the k-list after
+ * the first M_l candidates the level-l answer.  Results are identical to L separate camli_knn calls.
+ */
+int camli_knn_prefixes(const float *input, const float *query, int64_t *const *out_levels, const int *sizes,
+                       int L, int B, int M, int Nq, int D, int k, void *stream);
+
 int camli_fps(const float *xyz, int64_t *out_idx, int B, int N, int n_samples, void *stream);
 
 /*
@@ -162,6 +172,19 @@ int camli_knn_interp_bwd_xyz(const float *in_xyz, const float *feat, const float
  */
 int camli_corr3d_gather_fwd(const float *xyz1, const float *xyz2, const float *cost, const int64_t *knn,
                             float *out, int B, int N, int M, int k, void *stream);
+/*
+ * All levels of that lookup in ONE launch when the target levels are nested prefixes of one cloud (the FPS pyramid):
+ * xyz2 [B,3,M0] is the level-0 cloud, level l uses its first sizes[l] points and cost_levels[l] [B,N,sizes[l]];
+ * out / gout [B,4,N,L*k], column l*k + j = neighbour j of level l (the concatenation the shared cost MLP consumes).
+ * bwd ADDS gout[b,3,n,l*k+j] into gcost_levels[l][b,n,knn] with plain read-modify-writes (a point's neighbours are
+ * distinct when sizes[l] >= k; required): the caller keeps one zero-initialised gradient volume per level for the whole
+ * pass and calls this once per GRU iteration.  HOST arrays of DEVICE pointers; L <= 4.
+ */
+int camli_corr3d_gather_levels_fwd(const float *xyz1, const float *xyz2, const float *const *cost_levels,
+                                   const int64_t *const *knn_levels, const int *sizes, int L, float *out,
+                                   int B, int N, int M0, int k, void *stream);
+int camli_corr3d_gather_levels_bwd(const float *gout, const int64_t *const *knn_levels, float *const *gcost_levels,
+                                   const int *sizes, int L, int B, int N, int M0, int k, void *stream);
 int camli_corr3d_gather_bwd(const float *gout, const int64_t *knn, float *gcost, int B, int N, int M, int k,
                             void *stream);
 

@@ -277,3 +277,59 @@ def test_gather_scale_vs_torch(case):
     gathered = torch.gather(data, 2, idx[:, None, :].expand(-1, c, -1))
     assert torch.equal(out.detach(), score.detach() * gathered)
     assert torch.equal(score.grad, gout * gathered)
+
+
+@pytest.mark.parametrize('case', [(8, 2048, 2048, 16, (2048, 1024, 512, 256)), (2, 1024, 300, 32, (1024, 512, 256)),
+                                  (2, 2048, 500, 16, (2048, 1536, 512)), (3, 900, 200, 16, (900, 450)), (2, 512, 128, 3, (512, 256))],
+                         ids=str)
+def test_knn_prefixes_equal_separate_searches(case, oracle_lib):
+    """camli_knn_prefixes: the neighbours among the first m inputs for every nested prefix size, from one scan --
+    bit-identical to one search per prefix (oracle), on a cloud with 25 % exact duplicates (ties at the k-th distance
+    exercise the per-snapshot redo) and for shapes that take the one-launch kernel as well as the per-level fallback."""
+    from camliflow_amd.csrc import wrapper
+    b, m, nq, k, sizes = case
+    rng = np.random.default_rng(m + k)
+    inp = (rng.random((b, m, 3), dtype=np.float32) * 4).astype(np.float32)
+    dup = rng.integers(0, m, size=m // 4)
+    inp[:, rng.integers(0, m, size=m // 4)] = inp[:, dup]
+    qry = (rng.random((b, nq, 3), dtype=np.float32) * 4).astype(np.float32)
+    qry[:, :8] = inp[:, :8]
+    got = wrapper.k_nearest_neighbor_prefixes(dev(inp), dev(qry), sizes, k)
+    for size, idx in zip(sizes, got):
+        want = oracle_lib.knn(np.ascontiguousarray(inp[:, :size]), qry, k)
+        assert np.array_equal(idx.cpu().numpy(), want), size
+
+
+def test_nested_pyramid_paths_match_per_level_paths():
+    """Correlation3D with nested target levels (one prefix search, one multi-level gather, persistent gradient volumes)
+    and the single back-warp against the per-level forms: identical forward values, gradients to float noise."""
+    from camliflow_amd.cores import geometry, runtime
+    from camliflow_amd.cores.raft3d import Correlation3D
+    from camliflow_amd.cores.setconv import pass_cache
+    from modelutils import hashed_fill_
+    torch.manual_seed(0)
+    mod = hashed_fill_(Correlation3D(out_channels=128, k=16)).cuda()
+    b, n = 2, 1024
+    xyz1 = torch.rand(b, 3, n, device='cuda') * 4
+    base2 = xyz1 + torch.randn(b, 3, n, device='cuda') * 0.2
+    xyzs2 = [base2[:, :, :m].contiguous() for m in (1024, 512, 256, 128)]
+    flow = torch.randn(b, 3, n, device='cuda') * 0.1
+    f1 = torch.randn(b, 128, n, device='cuda', requires_grad=True)
+    f2 = torch.randn(b, 128, n, device='cuda', requires_grad=True)
+    g = torch.randn(b, 128, n, device='cuda')
+    res = {}
+    with runtime.use_backend('hip'):
+        for nested in (True, False):
+            with pass_cache():
+                mod.zero_grad()
+                mod.build_cost_volume_pyramid(f1, f2, xyzs2, nested=nested)
+                warped = geometry.backwarp_3d_levels(xyz1, xyzs2, flow, nested=nested)
+                outs = [mod(xyz1, xyzs2), mod(xyz1, warped)]        # two lookups accumulate into the same volumes
+                grads = torch.autograd.grad(outs, [f1, f2] + list(mod.parameters()), [g, 0.5 * g])
+            res[nested] = ([w.clone() for w in warped], [o.detach() for o in outs], grads)
+    for a, c in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, c)
+    for a, c in zip(res[True][1], res[False][1]):
+        assert torch.allclose(a, c, rtol=1e-6, atol=1e-6)
+    for a, c in zip(res[True][2], res[False][2]):
+        assert (a - c).norm() <= 1e-5 * c.norm() + 1e-7
