@@ -138,9 +138,20 @@ class KernelTimer:
         self.enabled = False
         self.only = None        # optional set of entry-point names to restrict timing to
         self.records = {}
+        self._pool = []         # recycled events: creating one costs as much as recording it
 
     def reset(self):
+        for recs in self.records.values():
+            for r in recs:
+                self._pool.append(r[0])
+                self._pool.append(r[1])
         self.records = {}
+
+    def event(self):
+        if self._pool:
+            return self._pool.pop()
+        import torch
+        return torch.cuda.Event(enable_timing=True)
 
     def summary(self):
         """name -> dict(launches, total_ms, work, unit).  Call after torch.cuda.synchronize()."""
@@ -165,8 +176,7 @@ def launch(name, fn, *args, work=None, flop=0.0):
     if _CENSUS is not None:
         _CENSUS[name] += 1
     if TIMER.enabled and (TIMER.only is None or name in TIMER.only):
-        import torch
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start, end = TIMER.event(), TIMER.event()
         start.record()
         code = fn(*args)
         end.record()
