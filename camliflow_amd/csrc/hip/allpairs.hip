@@ -105,7 +105,11 @@ __device__ __forceinline__ void tile_store_one(float* __restrict__ s, const floa
 // The K loop of one 128x128 tile.  CHECK = false: interior tile, aligned operands, K a multiple of GB_K -- the loop
 // contains no bounds logic at all (a checked load anywhere in the loop makes the compiler wait for the whole
 // prefetch before the matrix-core section, which serialises load latency and MFMA time).
-template <bool A_KC, bool B_KC, bool CHECK>
+// SKIPZ: the B operand is the accumulated lookup gradient of the volume, which is zero outside the windows the GRU
+// iterations visited (a band around the flow field: ~15-20 % of the 128x32 tiles).  The staging pass already holds a
+// tile in registers, so "is any element non-zero" is one OR per thread folded into the step's barrier
+// (__syncthreads_or), and a zero tile skips its 64 MFMAs.  Values are unchanged (adding exact zeros).
+template <bool A_KC, bool B_KC, bool CHECK, bool SKIPZ>
 __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, const float* __restrict__ Bb, float* lds,
                                                f32x16 (&acc)[2][2], int M, int N, int K, int64_t lda, int64_t ldb, int m0,
                                                int n0, bool vec_a, bool vec_b, int tid, int wm, int wn) {
@@ -119,7 +123,12 @@ __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, con
     GB_LOAD4(B_KC, rb, Bb, ldb, n0, 0, N, K, vec_b);
     GB_STORE4(A_KC, ra, sA);
     GB_STORE4(B_KC, rb, sB);
-    __syncthreads();
+#define GB_NONZERO(R) (((R##0).x != 0.f) | ((R##0).y != 0.f) | ((R##0).z != 0.f) | ((R##0).w != 0.f) | ((R##1).x != 0.f) | ((R##1).y != 0.f) | \
+                       ((R##1).z != 0.f) | ((R##1).w != 0.f) | ((R##2).x != 0.f) | ((R##2).y != 0.f) | ((R##2).z != 0.f) | ((R##2).w != 0.f) | \
+                       ((R##3).x != 0.f) | ((R##3).y != 0.f) | ((R##3).z != 0.f) | ((R##3).w != 0.f))
+    int live = 1;
+    if (SKIPZ) live = __syncthreads_or(GB_NONZERO(rb) ? 1 : 0);
+    else __syncthreads();
     int buf = 0;
     for (int k0 = 0; k0 < K; k0 += GB_K) {
         const bool more = k0 + GB_K < K;
@@ -131,6 +140,7 @@ __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, con
         const float* b = sB + buf * (GB_K * LDB) + fk * LDB + wn + fm;
         // the fragments of a half step (8 k-pairs x 4 values) are read from LDS in one batch, then 32 MFMAs run
         // back to back: the matrix pipe never waits on an LDS round trip between its own instructions
+        if (!SKIPZ || live)
 #pragma unroll
         for (int kh = 0; kh < GB_K; kh += 16) {
             float fa0[8], fa1[8], fb0[8], fb1[8];
@@ -152,14 +162,15 @@ __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, con
             GB_STORE4(A_KC, ra, sA + (buf ^ 1) * (GB_K * LDA));     // the other buffer: its readers finished one barrier ago
             GB_STORE4(B_KC, rb, sB + (buf ^ 1) * (GB_K * LDB));
         }
-        __syncthreads();
+        if (SKIPZ) live = __syncthreads_or((more && GB_NONZERO(rb)) ? 1 : 0);
+        else __syncthreads();
         buf ^= 1;
     }
 }
 
 // C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
 // grid (ceil(N/128), ceil(M/128), batch), block 256
-template <bool A_KC, bool B_KC, bool ACC>
+template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                              float* __restrict__ C, int M, int N, int K, int64_t lda,
                                                              int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc,
@@ -182,9 +193,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 
     const bool fast = vec_a && vec_b && (m0 + GB_T <= M) && (n0 + GB_T <= N) && (K % GB_K == 0);    // block-uniform
     if (fast)
-        gemm_tile_loop<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
+        gemm_tile_loop<A_KC, B_KC, false, SKIPZ>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
     else
-        gemm_tile_loop<A_KC, B_KC, true>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn);
+        gemm_tile_loop<A_KC, B_KC, true, SKIPZ>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn);
 
     const int fk = lane >> 5, fm = lane & 31;
     // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool SKIPZ>
 void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                  int64_t sa, int64_t sb, int64_t sc, int batch, float alpha, bool accumulate, hipStream_t stream) {
     const int vec_a = aligned16(A) && (lda % 4 == 0) && (sa % 4 == 0);
@@ -216,18 +227,18 @@ void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K,
     constexpr size_t lds = (size_t)2 * GB_K * (OperandTile<A_KC>::LD + OperandTile<B_KC>::LD) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<A_KC, B_KC, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<A_KC, B_KC, true, SKIPZ>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<A_KC, B_KC, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_mfma_kernel<A_KC, B_KC, false, SKIPZ>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if (accumulate)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, true>), grid, dim3(256), lds, stream, A, Bm, C, M, N, K, lda, ldb,
-                           ldc, sa, sb, sc, alpha, vec_a, vec_b);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, true, SKIPZ>), grid, dim3(256), lds, stream, A, Bm, C, M, N, K, lda,
+                           ldb, ldc, sa, sb, sc, alpha, vec_a, vec_b);
     else
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, false>), grid, dim3(256), lds, stream, A, Bm, C, M, N, K, lda, ldb,
-                           ldc, sa, sb, sc, alpha, vec_a, vec_b);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, false, SKIPZ>), grid, dim3(256), lds, stream, A, Bm, C, M, N, K, lda,
+                           ldb, ldc, sa, sb, sc, alpha, vec_a, vec_b);
 }
 
 int build_args_ok(const char* what, const void* f1, const void* a, const void* b, const int* p_levels, int L, int B, int C,
@@ -254,7 +265,7 @@ extern "C" int camli_allpairs_build_fwd(const float* f1, const float* const* f2_
         if (!f2_levels[l] || !vol_levels[l]) { camli_set_error("camli_allpairs_build_fwd: null level pointer"); return CAMLI_EINVAL; }
         const int Pl = p_levels[l];
         // M = P (source pixel), N = P_l (target pixel), K = C;  A = f1 [K][M], B = f2_l [K][N]
-        launch_gemm<false, false>(f1, f2_levels[l], vol_levels[l], P, Pl, C, P, Pl, Pl, (int64_t)C * P, (int64_t)C * Pl,
+        launch_gemm<false, false, false>(f1, f2_levels[l], vol_levels[l], P, Pl, C, P, Pl, Pl, (int64_t)C * P, (int64_t)C * Pl,
                                   (int64_t)P * Pl, B, scale, false, s);
     }
     return camli_check_launch("camli_allpairs_build_fwd");
@@ -276,10 +287,10 @@ extern "C" int camli_allpairs_build_bwd(const float* f1, const float* const* f2_
         }
         const int Pl = p_levels[l];
         // g_f1: M = C, N = P, K = P_l;  A = f2_l [M][K] (k contiguous), B = gV_l [N][K] (k contiguous); accumulate over levels
-        launch_gemm<true, true>(f2_levels[l], gvol_levels[l], g_f1, C, P, Pl, Pl, Pl, P, (int64_t)C * Pl, (int64_t)P * Pl,
+        launch_gemm<true, true, true>(f2_levels[l], gvol_levels[l], g_f1, C, P, Pl, Pl, Pl, P, (int64_t)C * Pl, (int64_t)P * Pl,
                                 (int64_t)C * P, B, scale, l > 0, s);
         // g_f2_l: M = C, N = P_l, K = P;  A = f1 [M][K] (k contiguous), B = gV_l [K][N] (n contiguous)
-        launch_gemm<true, false>(f1, gvol_levels[l], g_f2_levels[l], C, Pl, P, P, Pl, Pl, (int64_t)C * P, (int64_t)P * Pl,
+        launch_gemm<true, false, true>(f1, gvol_levels[l], g_f2_levels[l], C, Pl, P, P, Pl, Pl, (int64_t)C * P, (int64_t)P * Pl,
                                  (int64_t)C * Pl, B, scale, false, s);
     }
     return camli_check_launch("camli_allpairs_build_bwd");
