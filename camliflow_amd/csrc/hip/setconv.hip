@@ -17,6 +17,8 @@
 // weight-gradient buffer -- k times fewer atomics than the composed path.
 #include "camli_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int SC_CPT = 4;    // channels per thread
@@ -102,7 +104,12 @@ __global__ __launch_bounds__(256) void pointconv_dw_fwd_kernel(const float* __re
 // and every lane then reads back its own k-float row.  The next channel's chunk is already in
 // flight in registers while the current one is multiplied / maxed.  The neighbour index row is
 // converted to int32 once and lives in VGPRs for all channels.
-template <int K>
+// ROWLDS (M <= 4096, M % 4 == 0): the feature row of the wave's current channel is staged in wave-private LDS too
+// (coalesced 16-byte loads, prefetched with the weight chunk) and the K gathers per lane read LDS instead of L1.
+// Measured on the fp32 path: 32 scattered 4-byte global gathers per lane and channel touch ~40 cache lines per wave
+// instruction and keep the CU's texture-address path busier than the HBM stream of the weights (2.3-2.7 TB/s cap);
+// an LDS gather costs a few bank-conflict cycles.
+template <int K, bool ROWLDS>
 __global__ __launch_bounds__(256) void pointconv_dw_fwd_tiled_kernel(const float* __restrict__ feat,
                                                                       const float* __restrict__ weight,
                                                                       const int64_t* __restrict__ idx, int idx_stride,
@@ -119,7 +126,9 @@ __global__ __launch_bounds__(256) void pointconv_dw_fwd_tiled_kernel(const float
     const int n0 = blockIdx.x * 64;
     const int n = n0 + lane;
     const bool valid = n < N;
-    float* tile = lds + w * 64 * LD;
+    constexpr int RV = ROWLDS ? 16 : 1;                     // float4 row loads per lane: M <= 4096
+    float* tile = lds + w * (64 * LD + (ROWLDS ? M : 0));
+    float* rowbuf = tile + 64 * LD;
 
     int m[K];
     {
@@ -147,13 +156,37 @@ __global__ __launch_bounds__(256) void pointconv_dw_fwd_tiled_kernel(const float
         }
     };
 
+    // blockIdx.z splits the channels: 256 (tile, batch) workgroups alone put ONE wave on each SIMD, which leaves the
+    // gather / LDS latency of every channel exposed; CS channel slices per tile give CS waves per SIMD
+    const int cstep = 4 * gridDim.z;
+    float4 rstage[RV];
+    auto issue_row = [&](int c) {
+        if (ROWLDS) {
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(feat + ((size_t)b * C + c) * M);
+#pragma unroll
+            for (int v = 0; v < RV; ++v) {
+                const int e = v * 64 + lane;
+                rstage[v] = e * 4 < M ? src[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto park_row = [&]() {
+        if (ROWLDS) {
+#pragma unroll
+            for (int v = 0; v < RV; ++v) {
+                const int e = v * 64 + lane;
+                if (e * 4 < M) *reinterpret_cast<float4*>(rowbuf + e * 4) = rstage[v];
+            }
+        }
+    };
     float4 stage[V];
-    int c = w;
-    if (c < C) issue(c, stage);
-    for (; c < C; c += 4) {
+    int c = blockIdx.z * 4 + w;
+    if (c < C) { issue(c, stage); issue_row(c); }
+    for (; c < C; c += cstep) {
         park(stage);                                   // wave-private LDS region: no barrier needed
-        if (c + 4 < C) issue(c + 4, stage);            // next channel in flight during the compute below
-        const float* __restrict__ frow = feat + ((size_t)b * C + c) * M;
+        park_row();
+        if (c + cstep < C) { issue(c + cstep, stage); issue_row(c + cstep); }   // next channel in flight during the compute below
+        const float* __restrict__ frow = ROWLDS ? rowbuf : feat + ((size_t)b * C + c) * M;
         float best = -INFINITY;
         int barg = 0;
 #pragma unroll
@@ -282,10 +315,30 @@ extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, co
     if (B == 0) return CAMLI_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define CAMLI_DW_TILED(KK)                                                                                         \
-    hipLaunchKernelGGL((pointconv_dw_fwd_tiled_kernel<KK>), dim3(camli_divup(N, 64), B), dim3(256),                \
-                       (size_t)4 * 64 * (KK + 4) * sizeof(float), s, feat, weight, idx, idx_stride, out, arg, wsel, \
-                       msel, C, M, N);                                                                              \
+    if (rowlds) {                                                                                                   \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointconv_dw_fwd_tiled_kernel<KK, true>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (64 * (KK + 4) + 4096) * 4);  \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL((pointconv_dw_fwd_tiled_kernel<KK, true>), dim3(camli_divup(N, 64), B, cs), dim3(256),   \
+                           (size_t)4 * (64 * (KK + 4) + M) * sizeof(float), s, feat, weight, idx, idx_stride, out,   \
+                           arg, wsel, msel, C, M, N);                                                               \
+    } else {                                                                                                        \
+        hipLaunchKernelGGL((pointconv_dw_fwd_tiled_kernel<KK, false>), dim3(camli_divup(N, 64), B, cs), dim3(256),  \
+                           (size_t)4 * 64 * (KK + 4) * sizeof(float), s, feat, weight, idx, idx_stride, out, arg,    \
+                           wsel, msel, C, M, N);                                                                    \
+    }                                                                                                               \
     return camli_check_launch("camli_pointconv_dw_fwd")
+    // Measured at batch 8, C = 128, 2048 points (tools/kernel_bench.py): staging the feature row in LDS pays from
+    // k = 16 up (k = 32: 116 -> 88 us; k = 4: the row costs more than its four gathers), two channel slices per tile
+    // pay for k <= 16 (k = 16: 64 -> 55 us, k = 4: 37 -> 31 us) and cost at k = 32 (LDS-limited residency).
+    static const int cs_env = [] { const char* e = getenv("CAMLI_DW_CS"); return e ? atoi(e) : 0; }();
+    static const int rowlds_env = [] { const char* e = getenv("CAMLI_DW_ROWLDS"); return e ? atoi(e) : -1; }();
+    const bool row_ok = M <= 4096 && (M % 4) == 0 && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0);
+    const bool rowlds = row_ok && (rowlds_env >= 0 ? rowlds_env != 0 : k >= 16);
+    const int cs = cs_env > 0 ? cs_env : ((k <= 16 && C >= 32) ? 2 : 1);
     switch (k) {
         case 4: CAMLI_DW_TILED(4);
         case 8: CAMLI_DW_TILED(8);
