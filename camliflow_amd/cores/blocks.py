@@ -87,7 +87,7 @@ def epilogue_ok(x):
     """The fused epilogue runs on the product path for GPU tensors.  Under autocast the convolution
     yields bf16 / fp16: ``conv_bias_act`` then widens its output to fp32 first (the reference's
     activations stay in the low precision there; this path is at least as precise)."""
-    return runtime.fused() and x.is_cuda
+    return runtime.fused() and x.is_cuda and runtime.atomics_ok('bias_act')
 
 
 class _PointwiseConv(torch.autograd.Function):

@@ -11,7 +11,7 @@ from .camliraft import _FreezableBN, _camera_pair
 from .fusion import CLFM
 from .geometry import (InputPadder, backwarp_2d, backwarp_3d, build_pc_pyramid, flows_paral2persp, knn_interpolation,
                        paral2persp,
-                       persp2paral, project_pc2image, resize_flow2d, resize_to_64x)
+                       persp2paral, persp2paral_both, project_pc2image, resize_flow2d, resize_to_64x)
 from .objectives import (FlowModel, calc_pyramid_loss_2d, calc_pyramid_loss_3d, calc_sequence_loss_2d)
 from .pwc2d import (PYRAMID_CHANNELS_2D, ContextNetwork2D, FeaturePyramid2D, FlowEstimatorDense2D,
                     FlowEstimatorLite2D, PWCCore, finalize_flows_2d, pyramid_aligners, up_mask_head,
@@ -159,8 +159,7 @@ class CamLiPWC(_FreezableBN, FlowModel):
         # the perspective camera keeps the ORIGINAL sensor size, the parallel one follows the resized image
         persp, _ = _camera_pair(origin_h, origin_w, inputs['intrinsics'])
         _, paral = _camera_pair(image1.shape[-2], image1.shape[-1], inputs['intrinsics'])
-        pc1 = persp2paral(pc1, persp, paral)
-        pc2 = persp2paral(pc2, persp, paral)
+        pc1, pc2 = persp2paral_both(inputs['pcs'], persp, paral)
 
         xyzs1, xyzs2, sample_indices1, _ = build_pc_pyramid(pc1, pc2, PYRAMID_SIZES)
         feats1_2d, feats1_3d = self.core.encode(image1, xyzs1)
@@ -205,8 +204,7 @@ class CamLiPWC_L(FlowModel):
         persp, paral = _camera_pair(540, 960, inputs['intrinsics'])
         use_ids = self.cfgs.ids.enabled
         if use_ids:
-            pc1 = persp2paral(pc1, persp, paral)
-            pc2 = persp2paral(pc2, persp, paral)
+            pc1, pc2 = persp2paral_both(inputs['pcs'], persp, paral)
         xyzs1, xyzs2, sample_indices1, _ = build_pc_pyramid(pc1, pc2, n_samples_list=PYRAMID_SIZES)
         flows_3d = self.core.decode(xyzs1, xyzs2, self.core.encode(xyzs1), self.core.encode(xyzs2))
         if use_ids:

@@ -13,7 +13,7 @@ from . import runtime
 from .fusion import CLFM
 from .geometry import (InputPadder, backwarp_3d, backwarp_3d_levels, build_pc_pyramid, flows_paral2persp, knn_interpolation,
                        mesh_grid, paral2persp,
-                       persp2paral, project_pc2image)
+                       persp2paral, persp2paral_both, project_pc2image)
 from .objectives import FlowModel, calc_sequence_loss_2d, calc_sequence_loss_3d
 from .raft2d import RAFTCore
 from .raft3d import PYRAMID_SIZES, CamLiRAFT_L_Core
@@ -196,14 +196,18 @@ class CamLiRAFT(_FreezableBN, FlowModel):
         pc1, pc2 = inputs['pcs'][:, :3], inputs['pcs'][:, 3:]
 
         padder = InputPadder(images.shape, x=8)
-        image1, image2 = padder.pad(images[:, :3], images[:, 3:])
-        mean, std = self._norm_mean, self._norm_std
-        image1 = (image1 - mean) / std
-        image2 = (image2 - mean) / std
+        on_hip = runtime.fused() and images.is_cuda and not inputs['pcs'].requires_grad
+        if on_hip:      # both frames padded + normalised in one pass (camli_pad_normalize)
+            from ..csrc import fused
+            image1, image2 = fused.pad_normalize(images, padder._pad, _IMAGENET_MEAN, _IMAGENET_STD)
+        else:
+            image1, image2 = padder.pad(images[:, :3], images[:, 3:])
+            mean, std = self._norm_mean, self._norm_std
+            image1 = (image1 - mean) / std
+            image2 = (image2 - mean) / std
 
         persp, paral = _camera_pair(image1.shape[-2], image1.shape[-1], inputs['intrinsics'])
-        pc1 = persp2paral(pc1, persp, paral)
-        pc2 = persp2paral(pc2, persp, paral)
+        pc1, pc2 = persp2paral_both(inputs['pcs'], persp, paral)     # one launch for both clouds on the product path
 
         flow_2d_preds, flow_3d_preds = self.core(image1, image2, pc1, pc2, paral)
         flow_2d_preds = [padder.unpad(f) for f in flow_2d_preds]
@@ -248,8 +252,7 @@ class CamLiRAFT_L(FlowModel):
         use_ids = self.cfgs.ids.enabled
         persp, paral = _camera_pair(540, 960, inputs['intrinsics'])
         if use_ids:
-            pc1 = persp2paral(pc1, persp, paral)
-            pc2 = persp2paral(pc2, persp, paral)
+            pc1, pc2 = persp2paral_both(inputs['pcs'], persp, paral)
 
         restandardise = 'src_mean' in inputs and 'dst_mean' in inputs
         if restandardise:

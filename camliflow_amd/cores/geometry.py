@@ -111,7 +111,7 @@ def knn_interpolation(input_xyz, input_features, query_xyz, k=3, invariant_input
     """Inverse-distance interpolation from the k nearest inputs (utils.py:130-146).
     [B,3,M] x [B,C,M] x [B,3,Nq] -> [B,C,Nq]; gradients flow to features AND coordinates."""
     knn_indices = knn_channel_first(input_xyz, query_xyz, k, invariant_input, invariant_query)
-    if runtime.fused() and input_xyz.is_cuda:
+    if runtime.fused() and input_xyz.is_cuda and runtime.atomics_ok('knn_interpolation'):
         if k <= 8:
             from ..csrc import fused
             return fused.knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
@@ -138,7 +138,7 @@ def backwarp_3d_levels(xyz1, xyz2_levels, flow12, k=3, nested=False):
     build_pc_pyramid, models/utils.py:121-125).  Every warped point depends on its own position only, so the warped
     coarser levels are prefixes of the warped level 0: one search + one interpolation instead of one per level, and
     the returned levels are views of one tensor."""
-    if not (runtime.fused() and xyz1.is_cuda):
+    if not (runtime.fused() and xyz1.is_cuda and runtime.atomics_ok('backwarp_3d')):
         return [backwarp_3d(xyz1, level, flow12, k) for level in xyz2_levels]
     from ..csrc import fused
     warped, inverse = xyz1 + flow12, -flow12
@@ -186,7 +186,7 @@ def backwarp_2d(x, flow12, padding_mode):
 def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0):
     """RAFT convex upsampling: softmax over the 3x3 neighbourhood (utils.py:191-204).  ``mask_scale``
     is the factor the caller would otherwise multiply the mask by (RAFT: 0.25)."""
-    if runtime.fused() and flow.is_cuda:
+    if runtime.fused() and flow.is_cuda and runtime.atomics_ok('convex_upsample'):
         if scale_factor in (4, 8):
             from ..csrc import fused
             return fused.convex_upsample(flow, mask, scale_factor, mask_scale)
@@ -289,6 +289,21 @@ def persp2paral(xyz, perspect_camera_info, parallel_camera_info):
         v[:, None, :] * ratio_h - (paral_h - 1) / 2,
         depth[:, None, :] * min(ratio_w, ratio_h),
     ], dim=1)
+
+
+def persp2paral_both(pcs, perspect_camera_info, parallel_camera_info):
+    """pcs [B,6,N] (cloud 1 | cloud 2) -> (persp2paral(cloud 1), persp2paral(cloud 2)).  Product path: one launch
+    for both clouds (camli_persp2paral, same expression order as ids.py:4-33, bit-identical to the composition)."""
+    f = perspect_camera_info['f']
+    if (runtime.fused() and pcs.is_cuda and pcs.shape[1] == 6 and not pcs.requires_grad and torch.is_tensor(f)
+            and f.dim() == 1 and all(torch.is_tensor(perspect_camera_info[k]) for k in ('cx', 'cy'))):
+        from ..csrc import fused
+        intrinsics = torch.stack([f, perspect_camera_info['cx'], perspect_camera_info['cy']], dim=1)
+        return fused.persp2paral_pair(pcs, intrinsics, perspect_camera_info, parallel_camera_info)
+    if pcs.is_cuda:
+        runtime.fallback('persp2paral', 'non-tensor intrinsics or differentiable clouds')
+    return (persp2paral(pcs[:, :3], perspect_camera_info, parallel_camera_info),
+            persp2paral(pcs[:, 3:], perspect_camera_info, parallel_camera_info))
 
 
 def paral2persp(xyz, perspect_camera_info, parallel_camera_info):

@@ -36,7 +36,7 @@ def _sequence_loss(flow_preds, target, cfgs, n_flow_channels):
     else:
         mask = torch.ones_like(target)[:, 0] > 0
     if (cfgs.order == 'l2-norm' and runtime.fused() and target.is_cuda and n_flow_channels in (2, 3)
-            and not target.requires_grad):
+            and not target.requires_grad and runtime.atomics_ok('sequence_loss')):
         # one kernel per iterate (camli_masked_l2_fwd/bwd) instead of nine pointwise / reduction launches
         from ..csrc import fused
         sums = fused.masked_l2_sums(list(flow_preds), target, n_flow_channels)
@@ -46,7 +46,7 @@ def _sequence_loss(flow_preds, target, cfgs, n_flow_channels):
             weights = _GAMMA_WEIGHTS[key] = torch.tensor([cfgs.gamma ** (n_preds - i - 1) for i in range(n_preds)],
                                                          dtype=torch.float32, device=target.device)
         return (sums * weights).sum() / mask.sum()
-    if target.is_cuda and cfgs.order == 'l2-norm':
+    if target.is_cuda and cfgs.order == 'l2-norm' and runtime.atomics_ok('sequence_loss'):
         runtime.fallback('sequence_loss', 'differentiable target or %d flow channels' % n_flow_channels)
     total = 0
     for i, pred in enumerate(flow_preds):

@@ -90,6 +90,21 @@ def census():
     return {'fused': dict(_CENSUS['fused']), 'composed': dict(_CENSUS['composed'])}
 
 
+def atomics_ok(op):
+    """False under ``torch.use_deterministic_algorithms(True)`` for the fused ops whose adjoint (or reduction)
+    accumulates with float atomics -- bias gradients, the masked-L2 sums, the SK gate's weight gradients, the
+    interpolation / max-pool / up-sampling scatters.  Those ops then run the torch composition, which torch makes
+    deterministic (or refuses loudly); the switch is recorded in the census and is not a strict-mode violation.
+    The atomic-free kernels (sorted gather adjoints, PointConv mixing, the all-pairs and point cost-volume lookups,
+    the weight network) stay on HIP: they are bit-reproducible by construction."""
+    import torch
+    if not torch.are_deterministic_algorithms_enabled():
+        return True
+    if _CENSUS_ON:
+        _CENSUS['composed']['%s: deterministic algorithms requested (float atomics in the fused adjoint)' % op] += 1
+    return False
+
+
 def fallback(op, reason):
     """Called by a core op that has a fused kernel but is about to run the torch-composed formulation
     although the backend is 'hip'.  Raises in strict mode, otherwise records the event."""

@@ -95,7 +95,7 @@ class PointConvDW(nn.Module):
         self.weight_net = MLP2d(3, [8, 32, out_channels], act='relu')
 
     def forward(self, xyz, features, sampled_xyz=None, knn_indices=None):
-        if runtime.fused():
+        if runtime.fused() and xyz.is_cuda and runtime.atomics_ok('PointConvDW'):
             return self._forward_fused(xyz, features, sampled_xyz, knn_indices)
         sampled_xyz, knn_indices, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
         features = batch_indexing(self.mlp(features), knn_indices)            # [B,Cout,n,k]

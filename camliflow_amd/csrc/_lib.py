@@ -83,6 +83,9 @@ PROTOTYPES = {
     "camli_masked_l2_bwd": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _int, _int, _int, _stream]),
     "camli_ids_flow_fwd": (_int, [_c_float_p] * 7 + [ctypes.c_float] * 5 + [_int, _int, _stream]),
     "camli_ids_flow_bwd": (_int, [_c_float_p] * 7 + [ctypes.c_float] * 5 + [_int, _int, _stream]),
+    "camli_persp2paral": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int] + [ctypes.c_float] * 5 + [_stream]),
+    "camli_pad_normalize": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _int,
+                                   ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _stream]),
     "camli_sk_gate_fwd": (_int, [_c_float_p] * 6 + [_int, _int, _int, _stream]),
     "camli_sk_gate_bwd": (_int, [_c_float_p] * 10 + [_int, _int, _int, _stream]),
     "camli_sk_pool_fwd": (_int, [_c_float_p] * 3 + [_int, _int, _int, _stream]),

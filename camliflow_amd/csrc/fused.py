@@ -1341,3 +1341,46 @@ def bias_act(x, bias, act):
     """act(x + bias[c]) in place on the (fresh) convolution output x [B,C,...]; ``act`` as in ACT_CODES."""
     _require_cuda('bias_act', x, bias)
     return _BiasAct.apply(x, bias.float(), ACT_CODES[act])
+
+
+# ------------------------------------------------------------------------------------------------
+# input side (SURVEY 8f rank 3): models/ids.py:4-33, models/camliraft.py:38-46
+# ------------------------------------------------------------------------------------------------
+def persp2paral_pair(pcs, intrinsics, persp, paral):
+    """pcs [B,6,N] (both clouds), intrinsics [B,3] = (f, cx, cy) -> (pc1, pc2) in the parallel camera, one launch
+    (no autograd: the clouds are inputs)."""
+    _require_cuda('persp2paral_pair', pcs, intrinsics)
+    lib = _lib.load()
+    pcs, intrinsics = pcs.float().contiguous(), intrinsics.float().contiguous()
+    b, six, n = pcs.shape
+    assert six == 6 and intrinsics.shape == (b, 3)
+    ratio_w = (paral['sensor_w'] - 1) / (persp['sensor_w'] - 1)
+    ratio_h = (paral['sensor_h'] - 1) / (persp['sensor_h'] - 1)
+    out1 = torch.empty((b, 3, n), dtype=torch.float32, device=pcs.device)
+    out2 = torch.empty_like(out1)
+    with _on_device(pcs):
+        _lib.launch('camli_persp2paral', lib.camli_persp2paral, pcs.data_ptr(), intrinsics.data_ptr(), out1.data_ptr(),
+                    out2.data_ptr(), b, n, float(ratio_w), float(ratio_h), float(min(ratio_w, ratio_h)),
+                    float((paral['sensor_w'] - 1) / 2), float((paral['sensor_h'] - 1) / 2), _stream_ptr(pcs),
+                    work=(48.0 * b * n, 'B'))
+    return out1, out2
+
+
+def pad_normalize(images, pad, mean, std):
+    """images [B,6,H,W] -> (image1, image2) [B,3,Hp,Wp]: replicate padding ``pad`` = [left, right, top(0), bottom] as
+    InputPadder builds it, then (x - mean[c]) / std[c]; one pass over both frames."""
+    _require_cuda('pad_normalize', images)
+    lib = _lib.load()
+    images = images.float().contiguous()
+    b, six, h, w = images.shape
+    left, right, top, bottom = pad
+    assert six == 6 and top == 0
+    hp, wp = h + bottom, w + left + right
+    out1 = torch.empty((b, 3, hp, wp), dtype=torch.float32, device=images.device)
+    out2 = torch.empty_like(out1)
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    with _on_device(images):
+        _lib.launch('camli_pad_normalize', lib.camli_pad_normalize, images.data_ptr(), out1.data_ptr(), out2.data_ptr(),
+                    b, h, w, hp, wp, left, m3, s3, _stream_ptr(images), work=(4.0 * b * 6 * (h * w + hp * wp), 'B'))
+    return out1, out2

@@ -6,6 +6,14 @@
 // (oracle/camli_oracle.c): start at index 0, dist init 1e10, unfused fp32 distance, arg-max with
 // the LOWEST index among equal maxima.
 //
+// Tie rule, precisely: "lowest index" is the rule of the reference's importable path (wrapper.py:83-96, torch.max on
+// the CPU) and of the goldens (fps_a / fps_b / fps_dup are generated with cpp_impl=False).  The reference's CUDA
+// kernel resolves equal maxima differently: its shared-memory tree (furthest_point_sampling_kernel.cu:5-10,23-32)
+// compares with `<=`, so among tied candidates the one held by the higher thread of each pair survives.  That order
+// cannot be executed here (no nvcc), is an artefact of a 1024-thread reduction tree rather than a specification, and
+// only matters on clouds with exactly repeated points (all-zero distance ties); it is deliberately NOT imitated.
+// "Index-exact" therefore means: exact against the reference's Python path, and against its CUDA path on tie-free data.
+//
 // Design (CDNA4): the algorithm is a chain of n_samples dependent steps, so the only lever is
 // the latency of one step, and on one CU that latency is instruction issue: (update + reductions)
 // x resident waves.  One workgroup (one CU) owns a cloud; every thread keeps P = ceil(N/T) points

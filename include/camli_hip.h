@@ -59,6 +59,8 @@ int camli_knn(const float *input, const float *query, int64_t *out_idx,
 int camli_knn_prefixes(const float *input, const float *query, int64_t *const *out_levels, const int *sizes,
                        int L, int B, int M, int Nq, int D, int k, void *stream);
 
+/* camli_fps tie rule: the LOWEST index among equal maxima (the reference's Python path, wrapper.py:83-96); the
+ * reference's CUDA reduction tree keeps a different tied candidate (kernel.cu:5-10) -- see csrc/hip/fps.hip. */
 int camli_fps(const float *xyz, int64_t *out_idx, int B, int N, int n_samples, void *stream);
 
 /*
@@ -389,6 +391,21 @@ int camli_masked_l2_bwd(const float *pred, const float *target, int target_chann
  */
 int camli_gather_scale_fwd(const float *data, const float *scale, const int64_t *idx, float *out,
                            int B, int C, int M, int P, void *stream);
+
+/*
+ * Input side.
+ * persp2paral: models/ids.py:4-33 for BOTH clouds in one launch.  pcs [B,6,N] (xyz of cloud 1, xyz of cloud 2),
+ *   intrinsics [B,3] = (f, cx, cy) on the DEVICE, out1 / out2 [B,3,N]; ratio_w/h = (paral - 1)/(persp - 1),
+ *   ratio_min = min of the two, half_w/h = (paral - 1)/2 (HOST scalars, as the reference folds them).
+ *   Same expression order as the reference, unfused: equal to the torch composition bit for bit.
+ * pad_normalize: models/camliraft.py:38-46 + models/utils.py:7-15.  images [B,6,H,W] (frame 1 RGB, frame 2 RGB)
+ *   -> out1 / out2 [B,3,Hp,Wp] = (replicate_pad(frame) - mean[c]) / std[c]; pad_left columns on the left, the rest of
+ *   Wp - W on the right, Hp - H rows at the bottom; mean3 / std3 are HOST arrays of 3 floats.
+ */
+int camli_persp2paral(const float *pcs, const float *intrinsics, float *out1, float *out2, int B, int N,
+                      float ratio_w, float ratio_h, float ratio_min, float half_w, float half_h, void *stream);
+int camli_pad_normalize(const float *images, float *out1, float *out2, int B, int H, int W, int Hp, int Wp,
+                        int pad_left, const float *mean3, const float *std3, void *stream);
 
 #ifdef __cplusplus
 }

@@ -290,3 +290,28 @@ def ids_flow_fwd(pc1, flow, origin, f, cx, cy, rw, rh, rm, aw, ah):
     _chk(_load().oracle_ids_flow_fwd(_p(pc1), _p(flow), _p(origin), _p(f), _p(cx), _p(cy), _p(out), c(rw), c(rh), c(rm),
                                      c(aw), c(ah), B, N), "ids_flow_fwd")
     return out
+
+
+def persp2paral(pcs, intr, persp_hw, paral_hw):
+    """pcs [B,6,N], intr [B,3] -> (pc1, pc2) [B,3,N] in the parallel camera (models/ids.py:4-33)"""
+    pcs, intr = _f32(pcs), _f32(intr)
+    B, _, N = pcs.shape
+    rw = (paral_hw[1] - 1) / (persp_hw[1] - 1)
+    rh = (paral_hw[0] - 1) / (persp_hw[0] - 1)
+    out1, out2 = np.zeros((B, 3, N), dtype=np.float32), np.zeros((B, 3, N), dtype=np.float32)
+    cf = ctypes.c_float
+    _chk(_load().oracle_persp2paral(_p(pcs), _p(intr), _p(out1), _p(out2), B, N, cf(rw), cf(rh), cf(min(rw, rh)),
+                                    cf((paral_hw[1] - 1) / 2), cf((paral_hw[0] - 1) / 2)), "persp2paral")
+    return out1, out2
+
+
+def pad_normalize(images, pad, mean, std):
+    """images [B,6,H,W], pad = [left, right, 0, bottom] -> (image1, image2) [B,3,Hp,Wp]"""
+    images = _f32(images)
+    B, _, H, W = images.shape
+    left, right, _top, bottom = pad
+    Hp, Wp = H + bottom, W + left + right
+    out1, out2 = np.zeros((B, 3, Hp, Wp), dtype=np.float32), np.zeros((B, 3, Hp, Wp), dtype=np.float32)
+    m3, s3 = _f32(mean), _f32(std)
+    _chk(_load().oracle_pad_normalize(_p(images), _p(out1), _p(out2), B, H, W, Hp, Wp, left, _p(m3), _p(s3)), "pad_normalize")
+    return out1, out2

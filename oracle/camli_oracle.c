@@ -740,3 +740,49 @@ int oracle_ids_flow_fwd(const float *pc1, const float *flow, const float *origin
 }
 
 int oracle_version(void) { return 1; }
+
+/* ------------------------------------------------------------------------------------------
+ * input side: persp2paral follows models/ids.py:4-33 expression by expression (fp32, unfused);
+ * pad_normalize follows models/utils.py:7-15 (replicate padding: width split left/right, height at the
+ * bottom) + models/camliraft.py:41-46 ((x - mean) / std with the ImageNet constants)
+ *   pcs [B,6,N] -> out1, out2 [B,3,N];  intr [B,3] = f, cx, cy
+ *   images [B,6,H,W] -> out1, out2 [B,3,Hp,Wp]
+ * ------------------------------------------------------------------------------------------ */
+int oracle_persp2paral(const float *pcs, const float *intr, float *out1, float *out2, int B, int N,
+                       float rw, float rh, float rmin, float aw, float ah)
+{
+    for (int b = 0; b < B; ++b)
+        for (int cloud = 0; cloud < 2; ++cloud)
+            for (int n = 0; n < N; ++n) {
+                const float f = intr[b * 3], cx = intr[b * 3 + 1], cy = intr[b * 3 + 2];
+                const float *src = pcs + ((size_t)b * 6 + 3 * cloud) * N;
+                float x = src[n], y = src[(size_t)N + n], z = src[2 * (size_t)N + n];
+                float u = cx + (f / z) * x;
+                float v = cy + (f / z) * y;
+                float d = f * logf(z) + 1.0f;
+                float *dst = (cloud == 0 ? out1 : out2) + (size_t)b * 3 * N;
+                dst[n] = u * rw - aw;
+                dst[(size_t)N + n] = v * rh - ah;
+                dst[2 * (size_t)N + n] = d * rmin;
+            }
+    return 0;
+}
+
+int oracle_pad_normalize(const float *images, float *out1, float *out2, int B, int H, int W, int Hp, int Wp, int left,
+                         const float *mean3, const float *std3)
+{
+    for (int b = 0; b < B; ++b)
+        for (int c6 = 0; c6 < 6; ++c6)
+            for (int y = 0; y < Hp; ++y)
+                for (int x = 0; x < Wp; ++x) {
+                    int sy = y < H ? y : H - 1;
+                    int sx = x - left;
+                    if (sx < 0) sx = 0;
+                    if (sx > W - 1) sx = W - 1;
+                    int c = c6 % 3;
+                    float v = images[(((size_t)b * 6 + c6) * H + sy) * W + sx];
+                    float *dst = (c6 < 3 ? out1 : out2) + (((size_t)b * 3 + c) * Hp + y) * Wp + x;
+                    *dst = (v - mean3[c]) / std3[c];
+                }
+    return 0;
+}

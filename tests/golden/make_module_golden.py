@@ -201,6 +201,32 @@ def golden_functional():
          g_in_xyz=in_xyz.grad, g_q_xyz=q_xyz.grad)
 
 
+def golden_input_side():
+    """the reference's own preprocessing: InputPadder + ImageNet normalisation (camliraft.py:38-46) and the
+    inverse-depth-scaling transform (ids.py:4-33)"""
+    from models.ids import persp2paral as ref_persp2paral
+    g = gen(347)
+    b, h, w, n = 2, 13, 22, 400
+    images = torch.randint(0, 256, (b, 6, h, w), generator=g).float()
+    padder = ref_utils.InputPadder(images.shape, x=8)
+    image1, image2 = padder.pad(images[:, :3], images[:, 3:])
+    mean = torch.tensor([123.675, 116.280, 103.530]).reshape(1, 3, 1, 1)
+    std = torch.tensor([58.395, 57.120, 57.375]).reshape(1, 3, 1, 1)
+    image1, image2 = (image1 - mean) / std, (image2 - mean) / std
+    intr = torch.tensor([[1050.0, 479.5, 269.5], [721.5, 609.6, 172.9]])
+    persp = {'projection_mode': 'perspective', 'sensor_h': 544, 'sensor_w': 960, 'f': intr[:, 0], 'cx': intr[:, 1], 'cy': intr[:, 2]}
+    paral = {'projection_mode': 'parallel', 'sensor_h': 17, 'sensor_w': 30, 'cx': 14.5, 'cy': 8.0}
+    z = torch.rand(b, 2, n, generator=g) * 30 + 5
+    u = torch.rand(b, 2, n, generator=g) * 959
+    v = torch.rand(b, 2, n, generator=g) * 543
+    x = (u - intr[:, 1].view(b, 1, 1)) * z / intr[:, 0].view(b, 1, 1)
+    y = (v - intr[:, 2].view(b, 1, 1)) * z / intr[:, 0].view(b, 1, 1)
+    pcs = torch.stack([x[:, 0], y[:, 0], z[:, 0], x[:, 1], y[:, 1], z[:, 1]], dim=1)
+    save('input_side', images=images, pad=padder._pad, image1=image1, image2=image2, pcs=pcs, intrinsics=intr,
+         persp_hw=[544, 960], paral_hw=[17, 30], pc1=ref_persp2paral(pcs[:, :3], persp, paral),
+         pc2=ref_persp2paral(pcs[:, 3:], persp, paral))
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     golden_pointconv()
@@ -210,3 +236,4 @@ if __name__ == '__main__':
     golden_clfm()
     golden_update_blocks()
     golden_functional()
+    golden_input_side()

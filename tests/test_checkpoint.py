@@ -1,0 +1,61 @@
+"""Checkpoint / config compatibility: the reference's checkpoint dict round-trips with a strict
+load, its yaml model configs build this repo's models, and -- in the build container -- a checkpoint written from the
+REFERENCE's own model loads strictly into the mirror."""
+import glob
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from modelutils import camliraft_cfg, hashed_fill_
+
+
+def test_save_and_resume_round_trip(tmp_path):
+    from camliflow_amd import checkpoint
+    from camliflow_amd.cores import CamLiRAFT
+    model = hashed_fill_(CamLiRAFT(camliraft_cfg(2)))
+    path = checkpoint.save_ckpt(model, str(tmp_path / 'ckpts' / 'epoch-007.pt'), last_epoch=7, best_metrics={'epe2d': 1.5})
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) == {'last_epoch', 'state_dict', 'best_metrics'}                  # train.py:234-238
+    other = CamLiRAFT(camliraft_cfg(2))
+    epoch, best = checkpoint.load_ckpt(other, path, resume=True)
+    assert epoch == 8 and best == {'epe2d': 1.5}
+    for (n1, p1), (n2, p2) in zip(model.state_dict().items(), other.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    assert checkpoint.load_ckpt(other, path, resume=False) == (0, None)
+    bad = dict(raw, state_dict={k: v for k, v in list(raw['state_dict'].items())[1:]})
+    torch.save(bad, str(tmp_path / 'bad.pt'))
+    with pytest.raises(RuntimeError):                                                # strict, like the reference
+        checkpoint.load_ckpt(other, str(tmp_path / 'bad.pt'))
+
+
+def test_yaml_model_config_builds_the_model():
+    from camliflow_amd import checkpoint
+    from camliflow_amd.cores import CamLiRAFT
+    cfg = checkpoint.load_model_config(os.path.join(GOLDEN_DIR, 'conf', 'camliraft.yaml'), override={'n_iters_eval': 4})
+    assert cfg.name == 'camliraft' and cfg.n_iters_train == 10 and cfg.n_iters_eval == 4 and cfg.loss2d.gamma == 0.8
+    model = checkpoint.model_from_config(os.path.join(GOLDEN_DIR, 'conf', 'camliraft.yaml'))
+    assert isinstance(model, CamLiRAFT)
+
+
+@pytest.mark.needs_reference
+def test_reference_yaml_files_and_reference_checkpoint_load(tmp_path):
+    import refmodels
+    refmodels.install(native_semantics=True)
+    from camliflow_amd import checkpoint
+    for path in sorted(glob.glob('/root/reference/conf/model/*.yaml')):
+        cfg = checkpoint.load_model_config(path)
+        if cfg.name == 'raft':      # the reference's raft.yaml predates its raft_core.py (no `backbone` section): the
+            continue                # reference cannot build RAFT from it either (raft_core.py:214 reads cfgs.backbone)
+        override = {'backbone.pretrained': None} if hasattr(cfg, 'backbone') else None     # no weight files here
+        model = checkpoint.model_from_config(path, override=override)
+        assert type(model).__name__.lower() == cfg.name
+    # a checkpoint written the reference's way from the REFERENCE's model class
+    from models.camliraft import CamLiRAFT as RefCamLiRAFT
+    ref = hashed_fill_(RefCamLiRAFT(camliraft_cfg(2)))
+    path = str(tmp_path / 'ref.pt')
+    torch.save({'last_epoch': 3, 'state_dict': ref.state_dict(), 'best_metrics': None}, path)
+    from camliflow_amd.cores import CamLiRAFT
+    mine = CamLiRAFT(camliraft_cfg(2))
+    assert checkpoint.load_ckpt(mine, path) == (4, None)

@@ -78,6 +78,14 @@ def test_oracle_convex_upsample_pinned_on_the_reference(golden, oracle_lib):
     assert close(oracle_lib.convex_upsample_fwd(g['flow'], g['mask4'], 4), g['out4'], 1e-5)
 
 
+def test_oracle_input_side_pinned_on_the_reference_preprocessing(golden, oracle_lib):
+    g = golden('input_side')
+    i1, i2 = oracle_lib.pad_normalize(g['images'], [int(v) for v in g['pad']], [123.675, 116.280, 103.530], [58.395, 57.120, 57.375])
+    assert np.array_equal(i1, g['image1']) and np.array_equal(i2, g['image2'])
+    p1, p2 = oracle_lib.persp2paral(g['pcs'], g['intrinsics'], g['persp_hw'], g['paral_hw'])
+    assert np.allclose(p1, g['pc1'], rtol=1e-6, atol=1e-6) and np.allclose(p2, g['pc2'], rtol=1e-6, atol=1e-6)
+
+
 def test_oracle_pwc3d_pieces_reproduce_the_reference_cost_volume(golden, oracle_lib):
     """pair / ksum / gather_wsum (oracle) + the module's own small MLPs (numpy) == the reference Correlation3D output"""
     g = golden('module_corr3d_pwc')

@@ -333,3 +333,26 @@ def test_nested_pyramid_paths_match_per_level_paths():
         assert torch.allclose(a, c, rtol=1e-6, atol=1e-6)
     for a, c in zip(res[True][2], res[False][2]):
         assert (a - c).norm() <= 1e-5 * c.norm() + 1e-7
+
+
+def test_input_side_kernels_vs_oracle_golden_and_torch(golden, oracle_lib):
+    """camli_pad_normalize / camli_persp2paral: exact against the oracle and the reference golden for
+    the padding + normalisation; the IDS transform bit-identical to the torch composition on the same device (FPS
+    downstream needs identical inputs) and within 1e-6 of the CPU values (log / divide differ in the last ulp)."""
+    from camliflow_amd.csrc import fused
+    from camliflow_amd.cores import geometry, runtime
+    from camliflow_amd.cores.camliraft import _camera_pair, _IMAGENET_MEAN, _IMAGENET_STD
+    g = golden('input_side')
+    pad = [int(v) for v in g['pad']]
+    i1, i2 = fused.pad_normalize(dev(g['images']), pad, _IMAGENET_MEAN, _IMAGENET_STD)
+    assert np.array_equal(i1.cpu().numpy(), g['image1']) and np.array_equal(i2.cpu().numpy(), g['image2'])
+    w1, w2 = oracle_lib.pad_normalize(g['images'], pad, _IMAGENET_MEAN, _IMAGENET_STD)
+    assert np.array_equal(i1.cpu().numpy(), w1) and np.array_equal(i2.cpu().numpy(), w2)
+    pcs, intr = dev(g['pcs']), dev(g['intrinsics'])
+    persp, paral = _camera_pair(int(g['persp_hw'][0]), int(g['persp_hw'][1]), intr)
+    with runtime.use_backend('hip'):
+        p1, p2 = geometry.persp2paral_both(pcs, persp, paral)
+    with runtime.use_backend('composed'):
+        c1, c2 = geometry.persp2paral_both(pcs, persp, paral)
+    assert torch.equal(p1, c1) and torch.equal(p2, c2)
+    assert np.allclose(p1.cpu().numpy(), g['pc1'], rtol=1e-6, atol=1e-6) and np.allclose(p2.cpu().numpy(), g['pc2'], rtol=1e-6, atol=1e-6)
