@@ -103,3 +103,40 @@ def test_kitti_shape_bf16_autocast_config5():
     for key, tol in (('flow_2d', 0.5), ('flow_3d', 0.05)):
         assert torch.isfinite(low[key]).all()
         assert torch.linalg.norm(low[key].float() - ref[key], dim=1).mean().item() < tol, key
+
+
+def test_deterministic_algorithms_route_atomic_adjoints_to_torch():
+    """torch.use_deterministic_algorithms is honoured -- the fused ops whose adjoints use float atomics
+    (bias gradient, masked-L2 sums, SK gate, interpolation / max-pool / up-sampling scatters) switch to the torch
+    composition (recorded in the census), the atomic-free kernels stay on HIP, and the step still matches."""
+    from camliflow_amd.cores import CamLiRAFT, runtime
+    from modelutils import camliraft_cfg, hashed_fill_, synthetic_inputs
+    torch.manual_seed(0)
+    model = hashed_fill_(CamLiRAFT(camliraft_cfg(n_iters=2)), scale=0.5).cuda().train()
+    inputs = {k: v.cuda() for k, v in synthetic_inputs(1, 128, 160, 4608).items()}
+
+    def run():
+        model.zero_grad()
+        out = model(inputs)
+        loss = model.get_loss()
+        loss.backward()
+        return out, loss.item()
+
+    with runtime.use_backend('hip'):
+        base_out, base_loss = run()
+        runtime.set_census(True)
+        runtime.reset_census()
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        try:
+            det_out, det_loss = run()
+        finally:
+            torch.use_deterministic_algorithms(False)
+            census = runtime.census()
+            runtime.set_census(False)
+    switched = [k for k in census['composed'] if 'deterministic' in k]
+    assert any(k.startswith('bias_act') for k in switched) and any(k.startswith('PointConvDW') for k in switched), switched
+    assert 'camli_bias_act_bwd' not in census['fused'] and 'camli_pointconv_dw_bwd' not in census['fused']
+    assert census['fused'].get('camli_knn', 0) > 0 and census['fused'].get('camli_allpairs_lookup_bwd', 0) > 0
+    assert abs(det_loss - base_loss) <= 1e-4 * max(1.0, abs(base_loss))
+    for key in base_out:
+        assert torch.linalg.norm(det_out[key] - base_out[key], dim=1).mean().item() <= 1e-4
