@@ -109,11 +109,17 @@ class _PointwiseConv(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
+        if gy.dtype != w.dtype or x.dtype != gy.dtype:
+            # the forward ran under autocast (fp32 operands, reduced-precision output): the adjoints run in the
+            # forward's compute type, as the library's own autocast backward does
+            x, w = x.to(gy.dtype), w.to(gy.dtype)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = torch.ops.aten.convolution_backward(gy, x, w, None, *ctx.conv_args, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             gy3, xt3 = gy.flatten(2), x.flatten(2).transpose(1, 2)
+            if gy3.dtype != torch.float32:       # fp32 accumulation of the weight gradient
+                gy3, xt3 = gy3.float(), xt3.float()
             if ctx.param is not None and runtime.deferred_param_grads():
                 # one [B,Co,Ci] accumulator per parameter and pass, GEMM with beta = 1; summed over the batch and
                 # moved into .grad once, at the end of backward()
@@ -121,7 +127,7 @@ class _PointwiseConv(torch.autograd.Function):
                                                                             dtype=torch.float32, device=gy.device), True)
                 acc.baddbmm_(gy3, xt3)
             else:
-                gw = torch.bmm(gy3, xt3).sum(0).view_as(w)
+                gw = torch.bmm(gy3, xt3).sum(0).view_as(w).to(ctx.saved_tensors[1].dtype)
         return gx, gw
 
 

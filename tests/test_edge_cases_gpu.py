@@ -105,6 +105,35 @@ def test_kitti_shape_bf16_autocast_config5():
         assert torch.linalg.norm(low[key].float() - ref[key], dim=1).mean().item() < tol, key
 
 
+def test_bf16_autocast_training_step():
+    """configs[4] trains under autocast: forward + backward through every custom adjoint with reduced-precision
+    convolution outputs (the 1x1-convolution function sees bf16 gradients for fp32 operands); gradients are fp32,
+    finite, and close in norm to the fp32 step."""
+    from camliflow_amd.cores import CamLiRAFT, runtime
+    from modelutils import camliraft_cfg, hashed_fill_, synthetic_inputs
+    torch.manual_seed(0)
+    model = hashed_fill_(CamLiRAFT(camliraft_cfg(n_iters=2)), scale=0.5).cuda().train()
+    inputs = {k: v.cuda() for k, v in synthetic_inputs(1, 128, 160, 4608).items()}
+
+    def grads(autocast):
+        model.zero_grad()
+        with runtime.use_backend('hip'), torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+            model(inputs)
+            loss = model.get_loss()
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    loss32, g32 = grads(False)
+    loss16, g16 = grads(True)
+    assert abs(loss16 - loss32) < 0.05 * abs(loss32) + 1e-3
+    assert set(g16) == set(g32)
+    n32 = torch.sqrt(sum((g.double() ** 2).sum() for g in g32.values())).item()
+    diff = torch.sqrt(sum(((g16[n].double() - g32[n].double()) ** 2).sum() for n in g32)).item()
+    for n, g in g16.items():
+        assert g.dtype == torch.float32 and torch.isfinite(g).all(), n
+    assert diff < 0.25 * n32, (diff, n32)
+
+
 def test_deterministic_algorithms_route_atomic_adjoints_to_torch():
     """torch.use_deterministic_algorithms is honoured -- the fused ops whose adjoints use float atomics
     (bias gradient, masked-L2 sums, SK gate, interpolation / max-pool / up-sampling scatters) switch to the torch

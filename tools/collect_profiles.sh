@@ -1,53 +1,83 @@
 #!/bin/bash
 # Evidence run on the GPU box (gpurun): bench lines, rocprofv3 kernel stats and PMC passes for the north-star kernels.
-# Usage (from the repo root on the box):  bash tools/collect_profiles.sh <tag>     -> gpurun_out/<tag>/
+# Usage (from the repo root on the box):  bash tools/collect_profiles.sh <tag> <stage>...     -> gpurun_out/<tag>/
+#   bench    headline bench line (parity, roofline rows, cpu baseline) + the other configurations
+#   trace    rocprofv3 --kernel-trace --stats of the bench step and of tools/kernel_bench.py
+#   pmc      HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and MFMA busy of the isolated north-star kernels
+#   pmcb     HBM traffic of the roofline kernel over the bench command itself
 # PMC counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never together with a
-# sys / hip / hsa trace), as MI355X_MICROARCH.md prescribes.
+# sys / hip / hsa trace), as MI355X_MICROARCH.md prescribes.  Every rocprofv3 command runs under its own `timeout`; a
+# canary (a two-kernel trace) guards each stage so a box whose profiler hangs costs one minute, not the whole call
+# (-k: rocprofv3 catches SIGTERM and can then sit in its finalisation for good).
 set -u
 TAG=${1:-r02}
+shift
+STAGES="${*:-bench trace pmc pmcb}"
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 
-# 1. headline bench line (parity, roofline rows, cpu baseline) + the other configurations
-( cd $ROOT && timeout 900 python bench.py --steps 10 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench_line.err )
-for cfg in camlipwc kitti eval; do
-  ( cd $ROOT && timeout 400 python bench.py --config $cfg --steps 5 --warmup 2 > $OUT/bench_$cfg.json 2> /dev/null )
-done
+canary() {
+  timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/canary -o c -- \
+      python $ROOT/tools/kernel_bench.py --reps 1 --only corr3d > $OUT/canary.log 2>&1
+  local rc=$?
+  rm -rf /tmp/canary
+  [ $rc -eq 0 ] || echo "rocprofv3 canary failed (rc=$rc): profiler stages skipped" | tee -a $OUT/canary.log
+  return $rc
+}
 
-# 2. steady-state kernel statistics of the bench step (trace reduced on the box, the raw trace is not kept)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench -o b -- \
-    python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated > $OUT/trace_bench.log 2>&1
-python $ROOT/tools/trace_stats.py $OUT/trace_bench/b_kernel_trace.csv --steps 5 --top 90 > $OUT/bench_steady_kernel_stats.csv 2>> $OUT/trace_bench.log
-rm -rf $OUT/trace_bench
-
-# 3. isolated kernels: rocprofv3 --kernel-trace --stats of tools/kernel_bench.py (the roofline_rows command)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_kb -o kb -- \
-    python $ROOT/tools/kernel_bench.py --reps 5 --json $OUT/kernel_bench_rows.json > $OUT/kernel_bench.log 2>&1
-cp $OUT/trace_kb/kb_kernel_stats.csv $OUT/kernel_bench_kernel_stats.csv 2>/dev/null
-rm -rf $OUT/trace_kb
-
-# 4. PMC: HBM traffic of the isolated north-star kernels (separate passes), MFMA busy of the GEMM / weight-net kernels
-RX='pointconv_dw_fwd|pointconv_mix|corr2d_fwd|corr2d_bwd|allpairs_lookup|gather_cf|gemm_f32_mfma|segment_row_sum|knn_interp|corr3d_gather|weightnet|pointconv_dw_bwd|pointconv_dw_expand'
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $OUT/pmc_$c -o p -- \
-      python $ROOT/tools/kernel_bench.py --reps 2 > /dev/null 2>&1
-  python $ROOT/tools/pmc_summary.py $OUT/pmc_$c/p_counter_collection.csv > $OUT/pmc_kernel_bench_$c.txt 2>&1
-  rm -rf $OUT/pmc_$c
-done
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace \
-    --kernel-include-regex 'gemm_f32_mfma|weightnet' --output-format csv -d $OUT/pmc_mfma -o p -- \
-    python $ROOT/tools/kernel_bench.py --reps 2 --only 'a' > /dev/null 2>&1
-python $ROOT/tools/pmc_summary.py $OUT/pmc_mfma/p_counter_collection.csv > $OUT/pmc_kernel_bench_mfma.txt 2>&1
-rm -rf $OUT/pmc_mfma
-
-# 5. PMC in situ: traffic of the roofline kernel over the bench command itself
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'pointconv_dw_fwd|pointconv_mix|allpairs_lookup' --output-format csv \
-      -d $OUT/pmcb_$c -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated > /dev/null 2>&1
-  python $ROOT/tools/pmc_summary.py $OUT/pmcb_$c/p_counter_collection.csv > $OUT/pmc_bench_$c.txt 2>&1
-  rm -rf $OUT/pmcb_$c
+for stage in $STAGES; do
+case $stage in
+bench)
+  ( cd $ROOT && timeout 600 python bench.py --steps 10 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench_line.err )
+  for cfg in camlipwc kitti eval; do
+    ( cd $ROOT && timeout 300 python bench.py --config $cfg --steps 5 --warmup 2 > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err )
+  done
+  ;;
+trace)
+  canary || continue
+  # steady-state kernel statistics of the bench step (trace reduced on the box, the raw trace is not kept)
+  # single-lane (CAMLI_OVERLAP=0): with the point branch on its second HIP stream the process stalls under
+  # rocprofv3's queue interception on this image (host blocked in a library launch, r02 evidence runs); the bench
+  # line printed by this very run (events, same single-lane setting) is kept next to the trace for comparison
+  CAMLI_OVERLAP=0 CAMLI_FAULT_DUMP=380 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench -o b -- \
+      python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated > $OUT/trace_bench.log 2>&1
+  python $ROOT/tools/trace_stats.py $OUT/trace_bench/b_kernel_trace.csv --steps 5 --top 90 > $OUT/bench_steady_kernel_stats.csv 2>> $OUT/trace_bench.log
+  grep '^{"metric"' $OUT/trace_bench.log > $OUT/bench_line_single_lane_traced.json
+  cp $OUT/trace_bench/b_kernel_stats.csv $OUT/bench_whole_process_kernel_stats.csv 2>/dev/null
+  rm -rf $OUT/trace_bench
+  # isolated kernels: rocprofv3 --kernel-trace --stats of tools/kernel_bench.py (the roofline_rows command)
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_kb -o kb -- \
+      python $ROOT/tools/kernel_bench.py --reps 5 --json $OUT/kernel_bench_rows.json > $OUT/kernel_bench.log 2>&1
+  cp $OUT/trace_kb/kb_kernel_stats.csv $OUT/kernel_bench_kernel_stats.csv 2>/dev/null
+  rm -rf $OUT/trace_kb
+  ;;
+pmc)
+  canary || continue
+  RX='pointconv_dw_fwd|pointconv_mix|corr2d_fwd|corr2d_bwd|allpairs_lookup|gather_cf|gemm_f32_mfma|segment_row_sum|knn_interp|corr3d_gather|weightnet|pointconv_dw_bwd|pointconv_dw_expand'
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $OUT/pmc_$c -o p -- \
+        python $ROOT/tools/kernel_bench.py --reps 2 > /dev/null 2>&1
+    python $ROOT/tools/pmc_summary.py $OUT/pmc_$c/p_counter_collection.csv > $OUT/pmc_kernel_bench_$c.txt 2>&1
+    rm -rf $OUT/pmc_$c
+  done
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace \
+      --kernel-include-regex 'gemm_f32_mfma|weightnet' --output-format csv -d $OUT/pmc_mfma -o p -- \
+      python $ROOT/tools/kernel_bench.py --reps 2 --only 'a' > /dev/null 2>&1
+  python $ROOT/tools/pmc_summary.py $OUT/pmc_mfma/p_counter_collection.csv > $OUT/pmc_kernel_bench_mfma.txt 2>&1
+  rm -rf $OUT/pmc_mfma
+  ;;
+pmcb)
+  canary || continue
+  for c in FETCH_SIZE WRITE_SIZE; do
+    CAMLI_OVERLAP=0 CAMLI_FAULT_DUMP=380 timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'pointconv_dw_fwd|pointconv_dw_bwd|allpairs_lookup' --output-format csv \
+        -d $OUT/pmcb_$c -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated > /dev/null 2>&1
+    python $ROOT/tools/pmc_summary.py $OUT/pmcb_$c/p_counter_collection.csv > $OUT/pmc_bench_$c.txt 2>&1
+    rm -rf $OUT/pmcb_$c
+  done
+  ;;
+esac
 done
 ls -la $OUT
