@@ -11,6 +11,9 @@
 // are written in full 256-byte wave rows and the index row of a point is read once per thread.
 #include "camli_common.h"
 
+#include <stdint.h>
+#include <stdlib.h>
+
 namespace {
 
 // ---- gather along the point axis, channel-first --------------------------------------------------
@@ -56,6 +59,62 @@ __global__ __launch_bounds__(256) void gather_cf_bwd_sorted_kernel(const float* 
         for (int e = beg; e < end; ++e) acc += row[order[e]];
         gdata[((size_t)b * C + c) * M + m] = acc;
     }
+}
+
+// Same adjoint with the gout rows staged in LDS.  The reads above are 4-byte gathers inside an I*4-byte row: every one
+// of them occupies a texture-path slot for a whole cache line, and that rate -- not HBM -- bounds the kernel (0.05-0.09
+// of the roofline).  Here a workgroup copies TC consecutive (b, c) rows -- one contiguous span of gout -- into LDS with
+// 16-byte loads, then each thread walks the inverse list of its points m against LDS: gout is read from memory exactly
+// once, fully coalesced; `order` is read once per TC channels; summation order is unchanged (e ascending).
+// grid (channel groups, B); dynamic LDS TC * I floats.
+template <int TC>
+__global__ __launch_bounds__(1024) void gather_cf_bwd_lds_kernel(const float* __restrict__ gout,
+                                                                  const int32_t* __restrict__ order,
+                                                                  const int32_t* __restrict__ offsets,
+                                                                  float* __restrict__ gdata, int C, int M, int I, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];      // [TC][I]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int b = blockIdx.y;
+    const int base = b * I;
+    for (int c0 = blockIdx.x * TC; c0 < C; c0 += gridDim.x * TC) {
+        const int nc = min(TC, C - c0);
+        const float* __restrict__ src = gout + ((size_t)b * C + c0) * I;
+        const int total = nc * I;
+        if (vec) {
+            for (int t = tid * 4; t < total; t += nt * 4)
+                *reinterpret_cast<float4*>(rows + t) = *reinterpret_cast<const float4*>(src + t);
+        } else {
+            for (int t = tid; t < total; t += nt) rows[t] = src[t];
+        }
+        __syncthreads();
+        for (int m = tid; m < M; m += nt) {
+            const int beg = offsets[(size_t)b * M + m], end = offsets[(size_t)b * M + m + 1];
+            float acc[TC];
+#pragma unroll
+            for (int j = 0; j < TC; ++j) acc[j] = 0.0f;
+            for (int e = beg; e < end; ++e) {
+                const int i = order[e] - base;
+#pragma unroll
+                for (int j = 0; j < TC; ++j) acc[j] += rows[(j < nc ? j : 0) * I + i];
+            }
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                if (j < nc) gdata[((size_t)b * C + c0 + j) * M + m] = acc[j];
+        }
+        __syncthreads();
+    }
+}
+
+template <int TC>
+void launch_gather_cf_bwd_lds(const float* gout, const int32_t* order, const int32_t* offsets, float* gdata, int B, int C,
+                              int M, int I, hipStream_t stream) {
+    const size_t lds = (size_t)TC * I * sizeof(float);
+    const int threads = lds <= 48 * 1024 ? 512 : 1024;
+    const int vec = (I % 4 == 0) && ((reinterpret_cast<uintptr_t>(gout) & 15) == 0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_cf_bwd_lds_kernel<TC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gather_cf_bwd_lds_kernel<TC>), dim3(camli_divup(C, TC), B), dim3(threads), lds, stream, gout,
+                       order, offsets, gdata, C, M, I, vec);
 }
 
 // ---- inverse-distance interpolation from precomputed k nearest neighbours -------------------------
@@ -314,8 +373,20 @@ extern "C" int camli_gather_cf_bwd_sorted(const float* gout, const int32_t* inv_
         camli_set_error("camli_gather_cf_bwd_sorted: bad shape B=%d C=%d M=%d I=%d", B, C, M, I);
         return CAMLI_EINVAL;
     }
-    hipLaunchKernelGGL(gather_cf_bwd_sorted_kernel, dim3(camli_divup(M, 256), grid_y_for(C), B), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), gout, inv_order, inv_offsets, gdata, C, M, I);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // rows in LDS when they fit: as many channels per pass as stay within 48 KiB (3 workgroups per CU), at least one
+    // within 128 KiB; longer rows (I > 32768) keep the direct-gather form
+    static const int use_lds = [] { const char* e = getenv("CAMLI_GATHER_BWD_LDS"); return e ? atoi(e) : 1; }();
+    const size_t row = (size_t)I * sizeof(float);
+    if (use_lds && I > 0 && row <= 128 * 1024) {
+        if (8 * row <= 48 * 1024 && C >= 8) launch_gather_cf_bwd_lds<8>(gout, inv_order, inv_offsets, gdata, B, C, M, I, s);
+        else if (4 * row <= 48 * 1024 && C >= 4) launch_gather_cf_bwd_lds<4>(gout, inv_order, inv_offsets, gdata, B, C, M, I, s);
+        else if (2 * row <= 48 * 1024 && C >= 2) launch_gather_cf_bwd_lds<2>(gout, inv_order, inv_offsets, gdata, B, C, M, I, s);
+        else launch_gather_cf_bwd_lds<1>(gout, inv_order, inv_offsets, gdata, B, C, M, I, s);
+    } else {
+        hipLaunchKernelGGL(gather_cf_bwd_sorted_kernel, dim3(camli_divup(M, 256), grid_y_for(C), B), dim3(256), 0, s, gout,
+                           inv_order, inv_offsets, gdata, C, M, I);
+    }
     return camli_check_launch("camli_gather_cf_bwd_sorted");
 }
 

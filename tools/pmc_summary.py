@@ -9,7 +9,7 @@ with open(sys.argv[1], newline='') as f:
         name = r['Kernel_Name']
         if len(sys.argv) > 2 and sys.argv[2] not in name:
             continue
-        short = name.replace('void (anonymous namespace)::', '').split('(')[0]
+        short = name.replace('(anonymous namespace)::', '').replace('void ', '', 1).split('(')[0]
         grid = r.get('Grid_Size', '')
         acc[(short, grid, r['Counter_Name'])].append(float(r['Counter_Value']))
 for (short, grid, counter), vals in sorted(acc.items()):
