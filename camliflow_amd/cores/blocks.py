@@ -3,6 +3,8 @@
 Parameter names (``conv_fn``, ``norm_fn``, ``convs.N``) are those of the reference so that its
 checkpoints load; the classes are generated from one dimension-generic implementation.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -90,9 +92,12 @@ def epilogue_ok(x):
     return runtime.fused() and x.is_cuda and runtime.atomics_ok('bias_act')
 
 
+_PW_DX_GEMM = os.environ.get('CAMLI_PW_DX', 'gemm') != 'lib'
+
+
 class _PointwiseConv(torch.autograd.Function):
-    """1x1, stride-1 convolution without bias.  Forward and data gradient stay on the library (a GEMM,
-    no layout change); the WEIGHT gradient is taken as a batched GEMM over the positions
+    """1x1, stride-1 convolution without bias.  The forward stays on the library (a GEMM, no layout
+    change); the data gradient is a batched GEMM (see backward); the WEIGHT gradient is taken as a batched GEMM over the positions
     (dW = sum_b gy_b x_b^T), because the library's weight-gradient path for these shapes is an NHWC
     implicit-GEMM kernel wrapped in three layout transposes and a zero-fill (measured, B8 128->128 at
     68x120: 137 us for dx+dW against 55 + 39 us)."""
@@ -115,7 +120,15 @@ class _PointwiseConv(torch.autograd.Function):
             x, w = x.to(gy.dtype), w.to(gy.dtype)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy, x, w, None, *ctx.conv_args, [True, False, False])[0]
+            if _PW_DX_GEMM:
+                # dx_b = W^T gy_b: one strided-batched GEMM.  The library's data-gradient entry costs ~340 us of HOST
+                # time per call here (solution lookup on every call + a zero-fill launch, 304 calls per step =
+                # 100 ms of the step's enqueue time) for the same GEMM on the device.
+                gy3 = gy.flatten(2)
+                wt = w.flatten(1).t().unsqueeze(0).expand(gy3.shape[0], -1, -1)      # batch stride 0: no copy
+                gx = torch.bmm(wt, gy3).view(x.shape)
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, w, None, *ctx.conv_args, [True, False, False])[0]
         if ctx.needs_input_grad[1]:
             gy3, xt3 = gy.flatten(2), x.flatten(2).transpose(1, 2)
             if gy3.dtype != torch.float32:       # fp32 accumulation of the weight gradient

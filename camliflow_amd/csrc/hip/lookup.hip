@@ -18,6 +18,8 @@
 // and launches on one stream are ordered, so NO atomics and NO per-call volume-sized temporaries.
 #include "camli_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int LK_MAX_LEVELS = 8;
@@ -29,7 +31,7 @@ struct LookupLevels {
 };
 
 // grid (ceil(P/64), B, L), block 64
-template <int R, bool BACKWARD>
+template <int R, bool BACKWARD, int U>
 __global__ __launch_bounds__(64) void allpairs_lookup_kernel(LookupLevels lv, const float* __restrict__ coords,
                                                               float* __restrict__ io /* out (fwd) | gout (bwd) */,
                                                               int P, int L) {
@@ -66,7 +68,6 @@ __global__ __launch_bounds__(64) void allpairs_lookup_kernel(LookupLevels lv, co
     if (!BACKWARD) {
         // ---- stage the 64 windows: lanes run along the window elements; U windows (2U loads) are
         // put in flight before any is written to LDS -- the kernel is latency-bound otherwise ----
-        constexpr int U = 16;
         for (int pp0 = 0; pp0 < npix; pp0 += U) {
             float v[U][2];
 #pragma unroll
@@ -137,7 +138,6 @@ __global__ __launch_bounds__(64) void allpairs_lookup_kernel(LookupLevels lv, co
         __syncthreads();
         // ---- add each window into the gradient volume (disjoint per source pixel: plain RMW);
         // U windows' loads are issued before the first add/store ----
-        constexpr int U = 8;
         for (int pp0 = 0; pp0 < npix; pp0 += U) {
             float v[U][2];
             int off[U][2];
@@ -163,6 +163,158 @@ __global__ __launch_bounds__(64) void allpairs_lookup_kernel(LookupLevels lv, co
                 for (int h = 0; h < 2; ++h)
                     if (off[u][h] >= 0) vol[off[u][h]] = v[u][h] + win[ppc * LD + h * 64 + lane];
             }
+        }
+    }
+}
+
+// Four waves per 64 source pixels.  Measured on the bench shape (tools/ab_lookup.py): one level costs 18-21 us whether its
+// slices are 32 KB or 480 B, and deeper load batches change nothing -- the time is the SERIAL chain of the single wave
+// that owns a pixel group (128 staging loads with their address arithmetic, 100 LDS reads, ~350 FMAs, 81 stores) times
+// the number of rounds the LDS footprint allows (6 one-wave workgroups per CU).  Here the same 25.8 KB window tile is
+// shared by four waves: each stages 16 of the 64 windows and produces a quarter of the tap rows (forward) / window rows
+// (adjoint), so the chain is ~4x shorter and a CU holds 24 waves.  Arithmetic per output element is unchanged
+// (same products, same summation order).
+// PB = source pixels per workgroup (64 or 32), block 4 * PB threads.  With PB = 32 the two waves of a workgroup each
+// stage 16 windows and every wave interpolates all 32 pixels twice over -- lanes 0-31 and 32-63 take different row
+// groups -- so a CU holds twice as many independent (stage -> barrier -> interpolate/store) chains in the same LDS.
+// grid (ceil(P/PB), B, L)
+template <int R, bool BACKWARD, int PB>
+__global__ __launch_bounds__(4 * PB) void allpairs_lookup4_kernel(LookupLevels lv, const float* __restrict__ coords,
+                                                                  float* __restrict__ io /* out (fwd) | gout (bwd) */,
+                                                                  int P, int L) {
+    constexpr int DD = 2 * R + 1;      // taps per axis
+    constexpr int WN = 2 * R + 2;      // window extent
+    constexpr int WE = WN * WN;        // window elements
+    constexpr int LD = WE + 1;         // LDS row stride (odd -> conflict-free per-lane rows)
+    constexpr int PW = 16;             // windows staged per wave
+    static_assert(R == 4 && (PB == 64 || PB == 32), "row split below is written for radius 4");
+    __shared__ float win[PB * LD];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pl = lane & (PB - 1);                                   // pixel of this lane within the group
+    const int grp = PB == 64 ? wv : 2 * wv + (lane >> 5);              // row group 0..3 this lane works on
+    const int b = blockIdx.y, l = blockIdx.z;
+    const int p0 = blockIdx.x * PB;
+    const int p = p0 + pl;
+    const bool valid = p < P;
+    const int pc = valid ? p : P - 1;
+    const int hl = lv.h[l], wl = lv.w[l];
+    float* __restrict__ vol = lv.vol[l] + ((size_t)b * P + p0) * (size_t)hl * wl;
+
+    const float scale = 1.0f / (float)(1 << l);
+    const float bx = coords[((size_t)b * 2 + 0) * P + pc] * scale;
+    const float by = coords[((size_t)b * 2 + 1) * P + pc] * scale;
+    const float fx = floorf(bx), fy = floorf(by);
+    const float wx0 = bx - fx, wy0 = by - fy;           // weight of the +1 neighbour
+    const float wx1 = (fx + 1.0f) - bx, wy1 = (fy + 1.0f) - by;
+    const float lim = 1.0e6f;
+    const int x0 = (int)fminf(fmaxf(fx, -lim), lim) - R;
+    const int y0 = (int)fminf(fmaxf(fy, -lim), lim) - R;
+
+    const int npix = min(PB, P - p0);
+    const size_t plane = (size_t)P;
+    float* __restrict__ chan = io + ((size_t)b * L + l) * DD * DD * plane + p;   // + t*plane per tap
+    // element of the window this lane carries during staging / scatter (two per lane: e and e + 64)
+    const int e0r = lane / WN, e0c = lane - e0r * WN;
+    const int e1 = lane + 64;
+    const int e1r = e1 / WN, e1c = e1 - e1r * WN;
+    const bool e1_in = e1 < WE;
+
+    if (!BACKWARD) {
+        // ---- stage: wave wv pulls windows [16 wv, 16 wv + 16), all 32 loads in flight before the first LDS write ----
+        float v[PW][2];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+            const int pp = min(wv * PW + u, npix - 1);
+            const int sx = __shfl(x0, pp, 64), sy = __shfl(y0, pp, 64);
+            const float* __restrict__ src = vol + (size_t)pp * hl * wl;
+            const int gy0 = sy + e0r, gx0 = sx + e0c, gy1 = sy + e1r, gx1 = sx + e1c;
+            const bool in0 = (gx0 >= 0) & (gx0 < wl) & (gy0 >= 0) & (gy0 < hl);
+            const bool in1 = e1_in & (gx1 >= 0) & (gx1 < wl) & (gy1 >= 0) & (gy1 < hl);
+            v[u][0] = in0 ? src[gy0 * wl + gx0] : 0.0f;
+            v[u][1] = in1 ? src[gy1 * wl + gx1] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+            const int pp = wv * PW + u;
+            if (pp < npix) {
+                win[pp * LD + lane] = v[u][0];
+                if (e1_in) win[pp * LD + e1] = v[u][1];
+            }
+        }
+        __syncthreads();
+        if (!valid) return;
+        // ---- interpolate: tap rows {0,1,2} {3,4} {5,6} {7,8} per group; tap row j blends window rows j and j+1 ----
+        const int j0 = grp == 0 ? 0 : 2 * grp + 1;
+        const int j1 = grp == 0 ? 2 : 2 * grp + 2;         // inclusive
+        float hrow[2][DD];
+#pragma unroll
+        for (int r = 0; r < WN; ++r) {
+            if (r >= j0 && r <= j1 + 1) {                   // wave-uniform for PB = 64, per half-wave for PB = 32
+                float wrow[WN];
+#pragma unroll
+                for (int c = 0; c < WN; ++c) wrow[c] = win[pl * LD + r * WN + c];
+#pragma unroll
+                for (int i = 0; i < DD; ++i) hrow[r & 1][i] = wrow[i] * wx1 + wrow[i + 1] * wx0;
+                if (r > j0) {
+                    const int j = r - 1;
+#pragma unroll
+                    for (int i = 0; i < DD; ++i)
+                        chan[(size_t)(i * DD + j) * plane] = hrow[(r - 1) & 1][i] * wy1 + hrow[r & 1][i] * wy0;
+                }
+            }
+        }
+    } else {
+        // ---- window rows {0,1,2} {3,4,5} {6,7} {8,9} per group; row r collects tap rows r-1 (weight wy0) and r (wy1),
+        // added in the order of the one-wave kernel: (r-1,c-1) (r-1,c) (r,c-1) (r,c) ----
+        const int r0 = grp < 2 ? 3 * grp : 2 * grp + 2;
+        const int r1 = grp < 2 ? 3 * grp + 2 : 2 * grp + 3;   // inclusive
+        float gprev[DD], gcur[DD];                          // gout tap rows r-1 and r of this lane's pixel
+#pragma unroll
+        for (int i = 0; i < DD; ++i) gprev[i] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < WN; ++r) {
+            if (r >= r0 - 1 && r <= r1) {                   // r0 - 1 only loads the tap row
+#pragma unroll
+                for (int i = 0; i < DD; ++i) gcur[i] = (valid && r < DD) ? chan[(size_t)(i * DD + r) * plane] : 0.0f;
+                if (r >= r0) {
+#pragma unroll
+                    for (int c = 0; c < WN; ++c) {
+                        float acc = 0.0f;
+                        if (r >= 1 && c >= 1) acc += (gprev[c - 1] * wy0) * wx0;
+                        if (r >= 1 && c < DD) acc += (gprev[c] * wy0) * wx1;
+                        if (r < DD && c >= 1) acc += (gcur[c - 1] * wy1) * wx0;
+                        if (r < DD && c < DD) acc += (gcur[c] * wy1) * wx1;
+                        win[pl * LD + r * WN + c] = acc;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < DD; ++i) gprev[i] = gcur[i];
+            }
+        }
+        __syncthreads();
+        // ---- add windows [16 wv, 16 wv + 16) into the gradient volume (disjoint per source pixel: plain RMW) ----
+        float v[PW][2];
+        int off[PW][2];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+            const int pp = wv * PW + u;
+            const int ppc = min(pp, npix - 1);
+            const int sx = __shfl(x0, ppc, 64), sy = __shfl(y0, ppc, 64);
+            const int gy0 = sy + e0r, gx0 = sx + e0c, gy1 = sy + e1r, gx1 = sx + e1c;
+            const bool in0 = (pp < npix) & (gx0 >= 0) & (gx0 < wl) & (gy0 >= 0) & (gy0 < hl);
+            const bool in1 = (pp < npix) & e1_in & (gx1 >= 0) & (gx1 < wl) & (gy1 >= 0) & (gy1 < hl);
+            off[u][0] = in0 ? (ppc * hl + gy0) * wl + gx0 : -1;
+            off[u][1] = in1 ? (ppc * hl + gy1) * wl + gx1 : -1;
+            v[u][0] = in0 ? vol[off[u][0]] : 0.0f;
+            v[u][1] = in1 ? vol[off[u][1]] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+            const int ppc = min(wv * PW + u, npix - 1);
+            if (off[u][0] >= 0) vol[off[u][0]] = v[u][0] + win[ppc * LD + lane];
+            if (off[u][1] >= 0) vol[off[u][1]] = v[u][1] + win[ppc * LD + e1];
         }
     }
 }
@@ -194,8 +346,18 @@ int launch_lookup(float* const* vols, const int* hs, const int* ws, int L, const
         lv.w[l] = ws[l];
     }
     const int P = h * w;
-    dim3 grid(camli_divup(P, 64), B, L);
-    hipLaunchKernelGGL((allpairs_lookup_kernel<4, BACKWARD>), grid, dim3(64), 0, stream, lv, coords, io, P, L);
+    // CAMLI_LOOKUP_WAVES=1 keeps the one-wave-per-pixel-group form; CAMLI_LOOKUP_PB picks the pixel-group size (A/B runs)
+    static const int waves = [] { const char* e = getenv("CAMLI_LOOKUP_WAVES"); return e ? atoi(e) : 4; }();
+    static const int pb = [] { const char* e = getenv("CAMLI_LOOKUP_PB"); return e ? atoi(e) : 64; }();
+    if (waves == 1)
+        hipLaunchKernelGGL((allpairs_lookup_kernel<4, BACKWARD, BACKWARD ? 8 : 16>), dim3(camli_divup(P, 64), B, L), dim3(64), 0,
+                           stream, lv, coords, io, P, L);
+    else if (pb == 32)
+        hipLaunchKernelGGL((allpairs_lookup4_kernel<4, BACKWARD, 32>), dim3(camli_divup(P, 32), B, L), dim3(128), 0, stream,
+                           lv, coords, io, P, L);
+    else
+        hipLaunchKernelGGL((allpairs_lookup4_kernel<4, BACKWARD, 64>), dim3(camli_divup(P, 64), B, L), dim3(256), 0, stream,
+                           lv, coords, io, P, L);
     return camli_check_launch(what);
 }
 
