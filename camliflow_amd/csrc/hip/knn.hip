@@ -20,6 +20,15 @@
 //     ties the final k-th distance was dropped anywhere; that is detected from the minimum
 //     evicted distance and those (rare: exact duplicates only) queries are recomputed by a
 //     single-wave in-order scan.
+//   * splitting multiplies the insertions: a wave that sees M/NW candidates accepts ~k(1 + ln(M/(NW k))) of them, so 8
+//     waves insert 8 x 82 candidates per query where one in-order scan inserts 116 (k = 16, M = 8192) -- the insertion
+//     network, not the distance arithmetic, then dominates.  Cure: every wave publishes (per lane, in LDS, at each
+//     drain) the distance at position k/G - 1 of its list, G = the number of waves whose union the result is taken
+//     over.  G waves x k/G entries are k distinct candidates, so the MAXIMUM of the published values bounds the final
+//     k-th distance of the union from above -- and it is ~G x tighter than the wave's own k-th distance.  A candidate
+//     is queued only if it passes min(own k-th, that bound).  Published values only decrease, so a stale read is still
+//     a valid bound: no barrier is needed, and exactness is untouched (only candidates strictly farther than the final
+//     k-th distance are skipped; evictions are still tracked for the tie test).
 #include "camli_common.h"
 
 #include <stdlib.h>
@@ -68,10 +77,60 @@ __device__ __forceinline__ void list_insert(float (&dist)[K], int (&idx)[K], flo
 // In-order scan of candidates [lo, hi) for the lane's query.  lo/hi are wave-uniform, so the
 // candidate coordinates come in through scalar loads; four candidates are fetched per trip to
 // keep a batch of s_loads in flight.
+// Walk candidates [lo, hi) in trips of U: the U*D coordinates of a trip are consecutive floats fetched as ONE run of
+// scalar loads from a single base address (per-candidate address arithmetic keeps the compiler from merging them),
+// and the next trip's run is requested before the current one is consumed, so the scalar-cache latency overlaps the
+// distance arithmetic.  visit(d, c) per candidate in index order, after_trip() once per trip.
+template <int D, typename Visit, typename AfterTrip>
+__device__ __forceinline__ void for_each_candidate(const float* __restrict__ in_b, int lo, int hi, float ux, float uy,
+                                                   float uz, Visit&& visit, AfterTrip&& after_trip) {
+    constexpr int U = KNN_UNROLL;
+    int c = lo;
+    const int trips = (hi - lo) / U;
+    float cur[U * D], nxt[U * D];
+    if (trips > 0) {
+        const float* __restrict__ p = in_b + (size_t)lo * D;
+#pragma unroll
+        for (int i = 0; i < U * D; ++i) cur[i] = p[i];
+    }
+    for (int t = 0; t < trips; ++t, c += U) {
+        if (t + 1 < trips) {
+            const float* __restrict__ p = in_b + (size_t)(c + U) * D;
+#pragma unroll
+            for (int i = 0; i < U * D; ++i) nxt[i] = p[i];
+        }
+        float dd[U];       // plain fp32 ops: pairing candidates on v_pk_add/mul_f32 measured 8-11 % SLOWER (dependent
+                           // packed ops need extra wait states) although it issues 5 instead of 8 instructions
+#pragma unroll
+        for (int u = 0; u < U; ++u) dd[u] = sqdist<D>(ux, uy, uz, cur + u * D);
+#pragma unroll
+        for (int u = 0; u < U; ++u) visit(dd[u], c + u);
+        after_trip();
+#pragma unroll
+        for (int i = 0; i < U * D; ++i) cur[i] = nxt[i];
+    }
+    for (; c < hi; ++c) {
+        visit(sqdist<D>(ux, uy, uz, in_b + (size_t)c * D), c);
+        after_trip();
+    }
+}
+
+// `slots` (may be null): the published bounds, [4][nw][64] floats, row g holds position (K >> (g+1)) - 1 of every wave's
+// list; `group` = G above (1: this wave takes no bound from the others, it still publishes).
+constexpr int KNN_SLOT_ROWS = 4;
+template <int K>
+__device__ __forceinline__ float list_entry_for_group(const float (&dist)[K], int g) {
+    // position K/2 - 1, K/4 - 1, K/8 - 1, K/16 - 1 (clamped to 0 when K is smaller than the divisor)
+    constexpr int P0 = K / 2 >= 1 ? K / 2 - 1 : 0, P1 = K / 4 >= 1 ? K / 4 - 1 : 0, P2 = K / 8 >= 1 ? K / 8 - 1 : 0,
+                  P3 = K / 16 >= 1 ? K / 16 - 1 : 0;
+    return g == 0 ? dist[P0] : (g == 1 ? dist[P1] : (g == 2 ? dist[P2] : dist[P3]));
+}
+
 template <int D, int K>
 __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int lo, int hi, float ux, float uy,
                                            float uz, float (&dist)[K], int (&idx)[K], float& ev_min,
-                                           float* __restrict__ qd, int* __restrict__ qi, int qstride) {
+                                           float* __restrict__ qd, int* __restrict__ qi, int qstride,
+                                           volatile float* slots = nullptr, int nw = 1, int w = 0, int group = 1) {
     constexpr int U = KNN_UNROLL;
     if (K == 1) {
         float best = dist[0];
@@ -81,31 +140,12 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int l
             best = take ? d : best;
             bi = take ? c : bi;
         };
-        int c = lo;
-        for (; c + U <= hi; c += U) {
-            float dd[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) dd[u] = sqdist<D>(ux, uy, uz, in_b + (size_t)(c + u) * D);
-#pragma unroll
-            for (int u = 0; u < U; ++u) visit(dd[u], c + u);
-        }
-        for (; c < hi; ++c) visit(sqdist<D>(ux, uy, uz, in_b + (size_t)c * D), c);
+        for_each_candidate<D>(in_b, lo, hi, ux, uy, uz, visit, [] {});
         dist[0] = best;
         idx[0] = bi;
     } else if (K <= 4) {
-        int c = lo;
-        for (; c + U <= hi; c += U) {
-            float dd[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) dd[u] = sqdist<D>(ux, uy, uz, in_b + (size_t)(c + u) * D);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (!(dd[u] > dist[K - 1])) list_insert<K>(dist, idx, dd[u], c + u, ev_min);
-        }
-        for (; c < hi; ++c) {
-            float d = sqdist<D>(ux, uy, uz, in_b + (size_t)c * D);
-            if (!(d > dist[K - 1])) list_insert<K>(dist, idx, d, c, ev_min);
-        }
+        for_each_candidate<D>(in_b, lo, hi, ux, uy, uz,
+                              [&](float d, int c) { if (!(d > dist[K - 1])) list_insert<K>(dist, idx, d, c, ev_min); }, [] {});
     } else {
         int cnt = 0;
         float thr = dist[K - 1];
@@ -122,6 +162,18 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int l
             }
             cnt = 0;
             thr = dist[K - 1];
+            if (slots) {
+                const int lane = threadIdx.x & 63;
+#pragma unroll
+                for (int g = 0; g < KNN_SLOT_ROWS; ++g)
+                    if ((K >> (g + 1)) >= 1 && (2 << g) <= nw) slots[(g * nw + w) * 64 + lane] = list_entry_for_group<K>(dist, g);
+                if (group > 1) {
+                    const int g = group == 2 ? 0 : (group == 4 ? 1 : (group == 8 ? 2 : 3));
+                    float bnd = slots[(g * nw) * 64 + lane];
+                    for (int o = 1; o < group; ++o) bnd = fmaxf(bnd, slots[(g * nw + o) * 64 + lane]);
+                    thr = fminf(thr, bnd);
+                }
+            }
         };
         auto enqueue = [&](float d, int c) {
             if (!(d > thr)) {
@@ -130,19 +182,7 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int l
                 ++cnt;
             }
         };
-        int c = lo;
-        for (; c + U <= hi; c += U) {
-            float dd[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) dd[u] = sqdist<D>(ux, uy, uz, in_b + (size_t)(c + u) * D);
-#pragma unroll
-            for (int u = 0; u < U; ++u) enqueue(dd[u], c + u);
-            if (__ballot(cnt > QBUF - U)) drain();  // room for the next U candidates in every lane
-        }
-        for (; c < hi; ++c) {
-            enqueue(sqdist<D>(ux, uy, uz, in_b + (size_t)c * D), c);
-            if (__ballot(cnt > QBUF - U)) drain();
-        }
+        for_each_candidate<D>(in_b, lo, hi, ux, uy, uz, enqueue, [&] { if (__ballot(cnt > QBUF - U)) drain(); });
         drain();
     }
 }
@@ -152,7 +192,7 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int l
 //   merge region : NW * K * 64 * 2 dwords + NW*64     (NW > 1 only)   -- the two regions alias
 template <int D, int K>
 __global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_kernel(const float* __restrict__ input, const float* __restrict__ query,
-                                                    int64_t* __restrict__ out, int M, int Nq) {
+                                                    int64_t* __restrict__ out, int M, int Nq, int share) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nthreads = blockDim.x;
     const int NW = nthreads >> 6;
@@ -180,7 +220,15 @@ __global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_ke
 
     const int lo = (int)(((long long)w * M) / NW);
     const int hi = (int)(((long long)(w + 1) * M) / NW);
-    scan_range<D, K>(in_b, lo, hi, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads);
+    // published bounds (K >= 8, NW > 1, at least one list entry per wave of the group): after the queue region
+    volatile float* slots = nullptr;
+    if (K >= 8 && NW > 1 && K / NW >= 1 && share) {
+        slots = smem + 2 * QBUF * nthreads;
+#pragma unroll
+        for (int g = 0; g < KNN_SLOT_ROWS; ++g) slots[(g * NW + w) * 64 + lane] = KNN_INIT;
+        __syncthreads();
+    }
+    scan_range<D, K>(in_b, lo, hi, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, NW);
 
     if (NW > 1) {
         __syncthreads();  // queues are dead; the merge region aliases them
@@ -258,7 +306,8 @@ struct KnnPrefixOut {
 template <int D, int K>
 __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const float* __restrict__ input,
                                                                           const float* __restrict__ query,
-                                                                          KnnPrefixOut po, int M, int Nq, int chunk) {
+                                                                          KnnPrefixOut po, int M, int Nq, int chunk,
+                                                                          int share) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nthreads = blockDim.x;
     const int NW = nthreads >> 6;
@@ -281,7 +330,22 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
     float ev_min = INFINITY;
     float* qd = smem + threadIdx.x;
     int* qi = reinterpret_cast<int*>(smem) + QBUF * nthreads + threadIdx.x;
-    scan_range<D, K>(in_b, w * chunk, (w + 1) * chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads);
+    // bound group of this wave: the chunks of the SMALLEST level that contains chunk w (the wave's list only ever
+    // contributes to levels at least that large, and k candidates among the group's chunks bound every one of them)
+    int group = NW;
+    for (int l = 0; l < po.levels; ++l) {
+        const int sl = po.size[l] / chunk;
+        if (sl > w && sl < group) group = sl;
+    }
+    if (!(group == 2 || group == 4 || group == 8 || group == 16) || K / group < 1) group = 1;
+    volatile float* slots = nullptr;
+    if (NW > 1 && share) {
+        slots = smem + 2 * QBUF * nthreads;
+#pragma unroll
+        for (int g = 0; g < KNN_SLOT_ROWS; ++g) slots[(g * NW + w) * 64 + lane] = KNN_INIT;
+        __syncthreads();
+    }
+    scan_range<D, K>(in_b, w * chunk, (w + 1) * chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
 
     __syncthreads();  // queues are dead; the merge region aliases them
     float* md = smem;                                          // [NW][K][64]
@@ -371,6 +435,12 @@ __global__ __launch_bounds__(64) void knn_generic_kernel(const float* __restrict
     for (int i = 0; i < k; ++i) o[i] = (int64_t)ni[i];
 }
 
+// CAMLI_KNN_SHARE=0 switches the published bounds off (A/B runs)
+static int knn_share() {
+    static const int v = [] { const char* e = getenv("CAMLI_KNN_SHARE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 template <int D, int K>
 int launch_knn(const float* input, const float* query, int64_t* out, int B, int M, int Nq, hipStream_t stream) {
     const int qblocks = camli_divup(Nq, 64);
@@ -381,10 +451,11 @@ int launch_knn(const float* input, const float* query, int64_t* out, int B, int 
     static const long long target_waves = [] { const char* e = getenv("CAMLI_KNN_TARGET_WAVES"); return e ? atoll(e) : 4096LL; }();
     while (nw < lds_cap_nw && base_waves * nw < target_waves && M / (nw * 2) >= 128) nw *= 2;
     size_t q_bytes = (K >= 8) ? (size_t)2 * QBUF * 64 * nw * 4 : 0;
+    if (K >= 8 && nw > 1) q_bytes += (size_t)KNN_SLOT_ROWS * nw * 64 * 4;      // published bounds
     size_t m_bytes = (nw > 1) ? ((size_t)2 * nw * K * 64 + (size_t)nw * 64 + (size_t)2 * QBUF * 64) * 4 : 0;
     size_t lds = q_bytes > m_bytes ? q_bytes : m_bytes;
     dim3 grid(qblocks, B);
-    hipLaunchKernelGGL((knn_kernel<D, K>), grid, dim3(64 * nw), lds, stream, input, query, out, M, Nq);
+    hipLaunchKernelGGL((knn_kernel<D, K>), grid, dim3(64 * nw), lds, stream, input, query, out, M, Nq, knn_share());
     return camli_check_launch("camli_knn");
 }
 
@@ -468,13 +539,13 @@ extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_
         po.out[l] = l < L ? out_levels[l] : nullptr;
         po.size[l] = l < L ? sizes[l] : 0;
     }
-    const size_t q_bytes = (size_t)2 * QBUF * 64 * nw * 4;
+    const size_t q_bytes = (size_t)2 * QBUF * 64 * nw * 4 + (size_t)KNN_SLOT_ROWS * nw * 64 * 4;
     const size_t m_bytes = ((size_t)2 * nw * k * 64 + (size_t)nw * 64 + (size_t)2 * QBUF * 64) * 4;
     const size_t lds = q_bytes > m_bytes ? q_bytes : m_bytes;
     dim3 grid(camli_divup(Nq, 64), B);
     if (k == 16)
-        hipLaunchKernelGGL((knn_prefix_kernel<3, 16>), grid, dim3(64 * nw), lds, s, input, query, po, M, Nq, chunk);
+        hipLaunchKernelGGL((knn_prefix_kernel<3, 16>), grid, dim3(64 * nw), lds, s, input, query, po, M, Nq, chunk, knn_share());
     else
-        hipLaunchKernelGGL((knn_prefix_kernel<3, 32>), grid, dim3(64 * nw), lds, s, input, query, po, M, Nq, chunk);
+        hipLaunchKernelGGL((knn_prefix_kernel<3, 32>), grid, dim3(64 * nw), lds, s, input, query, po, M, Nq, chunk, knn_share());
     return camli_check_launch("camli_knn_prefixes");
 }
