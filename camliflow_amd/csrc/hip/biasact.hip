@@ -50,8 +50,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x
     if ((P & 3) == 0 && (chunk & 3) == 0) {
         float4* __restrict__ p4 = reinterpret_cast<float4*>(plane);
         unsigned long long* __restrict__ mrow = MASK ? mask + ((size_t)b * C + c) * mask_words(P) * 4 : nullptr;
-        for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
-            float4 v = p4[e];
+        auto apply = [&](float4 v, int e) {
             v.x = act_fwd<ACT>(v.x + bv); v.y = act_fwd<ACT>(v.y + bv); v.z = act_fwd<ACT>(v.z + bv); v.w = act_fwd<ACT>(v.w + bv);
             p4[e] = v;
             if (MASK) {
@@ -62,7 +61,17 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x
                     w[0] = mx; w[1] = my; w[2] = mz; w[3] = mw;
                 }
             }
+        };
+        // four 16-byte loads in flight per lane before the first store (the plane is updated in place, so the compiler
+        // will not hoist a later load above an earlier store itself); the test is wave-uniform so that a mask word is
+        // always produced by one full-wave ballot
+        int e = beg / 4 + threadIdx.x;
+        const int e4 = end / 4;
+        for (; e - (int)(threadIdx.x & 63) + 63 + 768 < e4; e += 1024) {
+            const float4 v0 = p4[e], v1 = p4[e + 256], v2 = p4[e + 512], v3 = p4[e + 768];
+            apply(v0, e); apply(v1, e + 256); apply(v2, e + 512); apply(v3, e + 768);
         }
+        for (; e < e4; e += 256) apply(p4[e], e);
     } else {
         for (int e = beg + threadIdx.x; e < end; e += 256) plane[e] = act_fwd<ACT>(plane[e] + bv);
     }
@@ -86,25 +95,37 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
             const unsigned long long* __restrict__ mrow = mask + ((size_t)b * C + c) * mask_words(P) * 4;
             const int lane = threadIdx.x & 63;
             constexpr float neg = ACT == 1 ? 0.0f : 0.1f;
-            for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
-                const float4 g = g4[e];
+            auto apply = [&](const float4 g, int e) {
                 const unsigned long long* w = mrow + (size_t)(e >> 6) * 4;
                 float4 o;
                 o.x = g.x * (((w[0] >> lane) & 1ull) ? 1.0f : neg); o.y = g.y * (((w[1] >> lane) & 1ull) ? 1.0f : neg);
                 o.z = g.z * (((w[2] >> lane) & 1ull) ? 1.0f : neg); o.w = g.w * (((w[3] >> lane) & 1ull) ? 1.0f : neg);
                 o4[e] = o;
                 acc += (o.x + o.y) + (o.z + o.w);
+            };
+            int e = beg / 4 + threadIdx.x;
+            const int e4 = end / 4;
+            for (; e + 768 < e4; e += 1024) {      // four loads in flight per lane
+                const float4 g0 = g4[e], g1 = g4[e + 256], g2 = g4[e + 512], g3 = g4[e + 768];
+                apply(g0, e); apply(g1, e + 256); apply(g2, e + 512); apply(g3, e + 768);
             }
+            for (; e < e4; e += 256) apply(g4[e], e);
         } else {
             const float4* __restrict__ y4 = reinterpret_cast<const float4*>(y + base);
-            for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
-                const float4 g = g4[e], yy = y4[e];
+            auto apply = [&](const float4 g, const float4 yy, int e) {
                 float4 o;
                 o.x = g.x * act_grad<ACT>(yy.x); o.y = g.y * act_grad<ACT>(yy.y);
                 o.z = g.z * act_grad<ACT>(yy.z); o.w = g.w * act_grad<ACT>(yy.w);
                 o4[e] = o;
                 acc += (o.x + o.y) + (o.z + o.w);
+            };
+            int e = beg / 4 + threadIdx.x;
+            const int e4 = end / 4;
+            for (; e + 256 < e4; e += 512) {       // two (gy, y) pairs = four loads in flight per lane
+                const float4 g0 = g4[e], y0 = y4[e], g1 = g4[e + 256], y1 = y4[e + 256];
+                apply(g0, y0, e); apply(g1, y1, e + 256);
             }
+            for (; e < e4; e += 256) apply(g4[e], y4[e], e);
         }
     } else {
         for (int e = beg + threadIdx.x; e < end; e += 256) {
@@ -131,7 +152,16 @@ __global__ __launch_bounds__(256) void bias_sum_kernel(const float* __restrict__
     float acc = 0.0f;
     if ((P & 3) == 0 && (chunk & 3) == 0) {
         const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gy + base);
-        for (int e = beg / 4 + threadIdx.x; e < end / 4; e += 256) {
+        int e = beg / 4 + threadIdx.x;
+        const int e4 = end / 4;
+        for (; e + 768 < e4; e += 1024) {
+            const float4 a = g4[e], b4 = g4[e + 256], c4 = g4[e + 512], d4 = g4[e + 768];
+            acc += (a.x + a.y) + (a.z + a.w);
+            acc += (b4.x + b4.y) + (b4.z + b4.w);
+            acc += (c4.x + c4.y) + (c4.z + c4.w);
+            acc += (d4.x + d4.y) + (d4.z + d4.w);
+        }
+        for (; e < e4; e += 256) {
             const float4 g = g4[e];
             acc += (g.x + g.y) + (g.z + g.w);
         }
