@@ -12,7 +12,10 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize('case', [(2, 5, 40, (17, 3)), (8, 130, 2048, (8160, 1)), (2, 2048, 2048, (1024, 3)), (1, 3, 8192, (4096,))],
+# the adjoint stages 8 / 4 / 2 / 1 rows of gout in LDS depending on the row length (I*4 bytes), falls back to direct
+# gathers above 128 KiB rows, and takes the scalar staging path when I % 4 != 0: one case per branch
+@pytest.mark.parametrize('case', [(2, 5, 40, (17, 3)), (8, 130, 2048, (8160, 1)), (2, 2048, 2048, (1024, 3)), (1, 3, 8192, (4096,)),
+                                  (2, 19, 300, (1500,)), (1, 4, 50, (33000,))],
                          ids=str)
 def test_gather_points(case, oracle_lib):
     from camliflow_amd.csrc import fused
