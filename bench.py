@@ -325,6 +325,8 @@ def roofline_report(summary, steps, args, step_ms):
         elif kind == 'mfma' and rec.get('flop', 0) > 0:
             entry['tflops'] = round(rec['flop'] / secs / 1e12, 2)
             entry['frac'] = round(entry['tflops'] / MFMA_F32_PEAK_TFLOPS, 4)
+            if name == 'camli_allpairs_build_bwd':     # dense product counted, unvisited gradient blocks skipped
+                entry['dense_equivalent'] = True
         elif kind == 'valu':
             entry['frac'] = round(rate / 1e9 / VALU_PAIR_PEAK_G, 4)
         if 'frac' in entry and kind in ('hbm', 'mfma'):

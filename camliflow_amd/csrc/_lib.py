@@ -23,6 +23,10 @@ PROTOTYPES = {
                                         ctypes.c_float, _stream]),
     "camli_allpairs_build_bwd": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                         ctypes.c_void_p, _int, _int, _int, ctypes.c_float, _stream]),
+    "camli_allpairs_build_bwd_marked": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
+                                               ctypes.c_void_p, _int, _int, _int, ctypes.c_float, ctypes.c_void_p, _stream]),
+    "camli_allpairs_lookup_bwd_marked": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
+                                                _c_float_p, _int, _int, _int, _int, ctypes.c_void_p, _stream]),
     "camli_allpairs_lookup_fwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                          _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_allpairs_lookup_bwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,

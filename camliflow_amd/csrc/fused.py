@@ -7,6 +7,7 @@ torch.float32)``): the kernels take raw fp32 device pointers, and the reference 
 fp32 under AMP as well (``.float()`` at raft_core.py:53-54, clfm.py:31-32, camliraft_l_core.py:52).
 """
 import ctypes
+import os
 import math
 import weakref
 
@@ -21,6 +22,10 @@ from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_slice, _zero_
 # ------------------------------------------------------------------------------------------------
 # all-pairs cost-volume pyramid (models/raft_core.py:52-107)
 # ------------------------------------------------------------------------------------------------
+# CAMLI_ALLPAIRS_MARKS=0: the pyramid adjoint examines every gradient tile instead of following the lookups' visit marks
+_USE_MARKS = os.environ.get('CAMLI_ALLPAIRS_MARKS', '1') != '0'
+
+
 class AllPairsPyramid:
     """The 4-level all-pairs volume of one forward pass plus the state its backward needs.
 
@@ -35,6 +40,7 @@ class AllPairsPyramid:
     def __init__(self):
         self.levels = None      # list of [B*P, h_l, w_l] fp32
         self.grads = None       # same shapes, lazily allocated by the first lookup backward
+        self.marks = None       # per level [B, ceil(P/32), ceil(P_l/32)] uint8: blocks of the gradient the lookups wrote
         self.token = None
         self.shape = None       # (B, h, w)
 
@@ -93,9 +99,10 @@ class _BuildPyramid(torch.autograd.Function):
         fmap1, *f2_levels = ctx.saved_tensors
         bs, dim, h, w = ctx.dims
         p = h * w
-        grads = None
+        grads = marks = None
         if pyr is not None:
             grads, pyr.grads = pyr.grads, None
+            marks, pyr.marks = pyr.marks, None
         if grads is None:
             return torch.zeros_like(fmap1), torch.zeros_like(fmap1), None, None
         sizes = ctx.sizes
@@ -103,11 +110,17 @@ class _BuildPyramid(torch.autograd.Function):
         total = sum(a * b for a, b in sizes)
         g1 = torch.empty_like(fmap1)
         g2_levels = [torch.empty_like(t) for t in f2_levels]
+        work = dict(work=(4.0 * bs * p * total + 4.0 * bs * dim * 2 * (p + total), 'B'), flop=4.0 * bs * p * total * dim)
         with _on_device(fmap1):
-            _lib.launch('camli_allpairs_build_bwd', lib.camli_allpairs_build_bwd, fmap1.data_ptr(), _ptr_array(f2_levels),
-                        _ptr_array(grads), p_levels, len(sizes), g1.data_ptr(), _ptr_array(g2_levels), bs, dim, p,
-                        1.0 / math.sqrt(dim), _stream_ptr(fmap1),
-                        work=(4.0 * bs * p * total + 4.0 * bs * dim * 2 * (p + total), 'B'), flop=4.0 * bs * p * total * dim)
+            if marks is not None:
+                # the lookups marked the 32x32 blocks they wrote: the GEMMs never load the rest of the volume
+                _lib.launch('camli_allpairs_build_bwd', lib.camli_allpairs_build_bwd_marked, fmap1.data_ptr(), _ptr_array(f2_levels),
+                            _ptr_array(grads), p_levels, len(sizes), g1.data_ptr(), _ptr_array(g2_levels), bs, dim, p,
+                            1.0 / math.sqrt(dim), _ptr_array(marks), _stream_ptr(fmap1), **work)
+            else:       # a gradient pyramid that did not come from the lookups (tests): every tile is examined
+                _lib.launch('camli_allpairs_build_bwd', lib.camli_allpairs_build_bwd, fmap1.data_ptr(), _ptr_array(f2_levels),
+                            _ptr_array(grads), p_levels, len(sizes), g1.data_ptr(), _ptr_array(g2_levels), bs, dim, p,
+                            1.0 / math.sqrt(dim), _stream_ptr(fmap1), **work)
         # adjoint of the avg_pool2d chain on the SMALL maps ([B,C,h_l,w_l]): fold the coarse levels into level 0
         g2 = g2_levels[-1]
         for lvl in range(len(g2_levels) - 2, -1, -1):
@@ -146,12 +159,20 @@ class _Lookup(torch.autograd.Function):
         bs, h, w = pyr.shape
         if pyr.grads is None:
             pyr.grads = [torch.zeros_like(lvl) for lvl in pyr.levels]
+            sb = (h * w + 31) // 32
+            if _USE_MARKS:
+                pyr.marks = [torch.zeros((bs, sb, (lvl.shape[-2] * lvl.shape[-1] + 31) // 32), dtype=torch.uint8, device=lvl.device)
+                             for lvl in pyr.levels]
         gout = gout.contiguous().float()
         n, ptrs, hs, ws = pyr._level_args(pyr.grads)
+        work = (4.0 * bs * h * w * (n * (2 * ctx.radius + 1) ** 2 + 2 * n * (2 * ctx.radius + 2) ** 2 + 2), 'B')
         with _on_device(coords):
-            _lib.launch('camli_allpairs_lookup_bwd', lib.camli_allpairs_lookup_bwd, ptrs, hs, ws, n, coords.data_ptr(), gout.data_ptr(),
-                                                     bs, h, w, ctx.radius, _stream_ptr(coords),
-                        work=(4.0 * bs * h * w * (n * (2 * ctx.radius + 1) ** 2 + 2 * n * (2 * ctx.radius + 2) ** 2 + 2), 'B'))
+            if pyr.marks is not None:
+                _lib.launch('camli_allpairs_lookup_bwd', lib.camli_allpairs_lookup_bwd_marked, ptrs, hs, ws, n, coords.data_ptr(),
+                            gout.data_ptr(), bs, h, w, ctx.radius, _ptr_array(pyr.marks), _stream_ptr(coords), work=work)
+            else:       # gradient pyramid supplied from outside: no marks to maintain
+                _lib.launch('camli_allpairs_lookup_bwd', lib.camli_allpairs_lookup_bwd, ptrs, hs, ws, n, coords.data_ptr(),
+                            gout.data_ptr(), bs, h, w, ctx.radius, _stream_ptr(coords), work=work)
         return _zero_token(gout), None, None, None
 
 

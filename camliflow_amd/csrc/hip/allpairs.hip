@@ -168,13 +168,108 @@ __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, con
     }
 }
 
+// The same K loop driven by visit marks instead of tests on loaded data.  The lookup adjoint records which 32x32
+// blocks (32 source pixels x 32 target pixels) of a gradient level it ever wrote (camli_allpairs_lookup_bwd_marked);
+// a K step whose B tile holds no marked block is never loaded, staged or multiplied.  ~80 % of the level-0 tiles are
+// untouched, and with the data-driven skip each of them still cost one exposed load latency (only one step is
+// prefetched ahead) plus its 16 KB of HBM traffic.  mode 1: B = gV [N = source][K = target] (tile rows n0.. are 4
+// source blocks, step s is target block s); mode 2: B = gV [K = source][N = target] (step s is source block s, the
+// tile's columns n0.. are 4 target blocks).  marks: this sample's [src_blocks][tb] bytes.  K <= 8192 (256 steps).
+template <bool A_KC, bool B_KC, bool CHECK>
+__device__ __forceinline__ void gemm_tile_loop_marked(const float* __restrict__ Ab, const float* __restrict__ Bb, float* lds,
+                                                      f32x16 (&acc)[2][2], int M, int N, int K, int64_t lda, int64_t ldb,
+                                                      int m0, int n0, bool vec_a, bool vec_b, int tid, int wm, int wn,
+                                                      const unsigned char* __restrict__ marks, int mode, int tb, int src_blocks) {
+    constexpr int LDA = OperandTile<A_KC>::LD, LDB = OperandTile<B_KC>::LD;
+    __shared__ unsigned long long s_live[4];        // step s has a marked block (bit s & 63 of word s >> 6)
+    float* const sA = lds;
+    float* const sB = lds + 2 * GB_K * LDA;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int fk = lane >> 5, fm = lane & 31;
+    {
+        const int steps = (K + GB_K - 1) / GB_K;
+        const int nb = n0 >> 5;
+        bool live = false;
+        if (tid < steps) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (mode == 1) { if (nb + i < src_blocks) live |= marks[(size_t)(nb + i) * tb + tid] != 0; }
+                else           { if (nb + i < tb) live |= marks[(size_t)tid * tb + nb + i] != 0; }
+            }
+        }
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_live[wave] = m;
+        __syncthreads();
+    }
+    // smallest live step > after, or -1 (block-uniform)
+    auto next_live = [&](int after) -> int {
+        const int from = after + 1;
+        int found = -1;
+#pragma unroll
+        for (int w = 3; w >= 0; --w) {
+            unsigned long long m = s_live[w];
+            if (w == (from >> 6)) m &= ~0ull << (from & 63);
+            if (w < (from >> 6)) m = 0;
+            if (m) found = w * 64 + __builtin_ctzll(m);
+        }
+        return __builtin_amdgcn_readfirstlane(found);
+    };
+    int cur = next_live(-1);
+    if (cur < 0) return;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    GB_LOAD4(A_KC, ra, Ab, lda, m0, cur * GB_K, M, K, vec_a);
+    GB_LOAD4(B_KC, rb, Bb, ldb, n0, cur * GB_K, N, K, vec_b);
+    GB_STORE4(A_KC, ra, sA);
+    GB_STORE4(B_KC, rb, sB);
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        const int nxt = next_live(cur);
+        if (nxt >= 0) {
+            GB_LOAD4(A_KC, ra, Ab, lda, m0, nxt * GB_K, M, K, vec_a);
+            GB_LOAD4(B_KC, rb, Bb, ldb, n0, nxt * GB_K, N, K, vec_b);
+        }
+        const float* a = sA + buf * (GB_K * LDA) + fk * LDA + wm + fm;
+        const float* b = sB + buf * (GB_K * LDB) + fk * LDB + wn + fm;
+        // (leaving out the MFMAs of a 32-column block whose gradient block is unmarked was measured: no gain -- a live
+        // step is bound by its loads, LDS stores and barrier, not by the matrix pipe)
+#pragma unroll
+        for (int kh = 0; kh < GB_K; kh += 16) {
+            float fa0[8], fa1[8], fb0[8], fb1[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                fa0[t] = a[(kh + 2 * t) * LDA]; fa1[t] = a[(kh + 2 * t) * LDA + 32];
+                fb0[t] = b[(kh + 2 * t) * LDB]; fb1[t] = b[(kh + 2 * t) * LDB + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb1[t], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb0[t], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (nxt >= 0) {
+            GB_STORE4(A_KC, ra, sA + (buf ^ 1) * (GB_K * LDA));
+            GB_STORE4(B_KC, rb, sB + (buf ^ 1) * (GB_K * LDB));
+        }
+        __syncthreads();
+        if (nxt < 0) break;
+        buf ^= 1;
+        cur = nxt;
+    }
+}
+
 // C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
 // grid (ceil(N/128), ceil(M/128), batch), block 256
 template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                              float* __restrict__ C, int M, int N, int K, int64_t lda,
                                                              int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc,
-                                                             float alpha, int vec_a, int vec_b) {
+                                                             float alpha, int vec_a, int vec_b,
+                                                             const unsigned char* __restrict__ marks, int mark_mode,
+                                                             int mark_tb, int mark_src_blocks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 * GB_K * (LDA + LDB) floats (> 64 KB: dynamic)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -192,7 +287,15 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const bool fast = vec_a && vec_b && (m0 + GB_T <= M) && (n0 + GB_T <= N) && (K % GB_K == 0);    // block-uniform
-    if (fast)
+    if (SKIPZ && marks) {
+        const unsigned char* mk = marks + (size_t)blockIdx.z * mark_src_blocks * mark_tb;
+        if (fast)
+            gemm_tile_loop_marked<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn, mk,
+                                                     mark_mode, mark_tb, mark_src_blocks);
+        else
+            gemm_tile_loop_marked<A_KC, B_KC, true>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm,
+                                                    wn, mk, mark_mode, mark_tb, mark_src_blocks);
+    } else if (fast)
         gemm_tile_loop<A_KC, B_KC, false, SKIPZ>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
     else
         gemm_tile_loop<A_KC, B_KC, true, SKIPZ>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn);
@@ -220,7 +323,9 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 template <bool A_KC, bool B_KC, bool SKIPZ>
 void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                 int64_t sa, int64_t sb, int64_t sc, int batch, float alpha, bool accumulate, hipStream_t stream) {
+                 int64_t sa, int64_t sb, int64_t sc, int batch, float alpha, bool accumulate, hipStream_t stream,
+                 const unsigned char* marks = nullptr, int mark_mode = 0, int mark_tb = 0, int mark_src_blocks = 0) {
+    if (K > 256 * GB_K) marks = nullptr;      // the live-step masks hold 256 steps; longer loops test the data instead
     const int vec_a = aligned16(A) && (lda % 4 == 0) && (sa % 4 == 0);
     const int vec_b = aligned16(Bm) && (ldb % 4 == 0) && (sb % 4 == 0);
     dim3 grid(camli_divup(N, GB_T), camli_divup(M, GB_T), batch);
@@ -235,10 +340,10 @@ void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K,
     }
     if (accumulate)
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, true, SKIPZ>), grid, dim3(256), lds, stream, A, Bm, C, M, N, K, lda,
-                           ldb, ldc, sa, sb, sc, alpha, vec_a, vec_b);
+                           ldb, ldc, sa, sb, sc, alpha, vec_a, vec_b, marks, mark_mode, mark_tb, mark_src_blocks);
     else
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, false, SKIPZ>), grid, dim3(256), lds, stream, A, Bm, C, M, N, K, lda,
-                           ldb, ldc, sa, sb, sc, alpha, vec_a, vec_b);
+                           ldb, ldc, sa, sb, sc, alpha, vec_a, vec_b, marks, mark_mode, mark_tb, mark_src_blocks);
 }
 
 int build_args_ok(const char* what, const void* f1, const void* a, const void* b, const int* p_levels, int L, int B, int C,
@@ -273,25 +378,47 @@ extern "C" int camli_allpairs_build_fwd(const float* f1, const float* const* f2_
 
 // g_f1[b, c, p]   = scale * sum_l sum_q gV_l[b, p, q] * f2_l[b, c, q]         (fully written)
 // g_f2_l[b, c, q] = scale * sum_p f1[b, c, p] * gV_l[b, p, q]                 (fully written, per level)
-extern "C" int camli_allpairs_build_bwd(const float* f1, const float* const* f2_levels, const float* const* gvol_levels,
-                                        const int* p_levels, int L, float* g_f1, float* const* g_f2_levels, int B, int C,
-                                        int P, float scale, void* stream) {
+static int allpairs_build_bwd_impl(const float* f1, const float* const* f2_levels, const float* const* gvol_levels,
+                                   const int* p_levels, int L, float* g_f1, float* const* g_f2_levels, int B, int C, int P,
+                                   float scale, const unsigned char* const* marks, void* stream, const char* what) {
     if (B == 0) return CAMLI_OK;
-    if (!build_args_ok("camli_allpairs_build_bwd", f1, f2_levels, gvol_levels, p_levels, L, B, C, P)) return CAMLI_EINVAL;
-    if (!g_f1 || !g_f2_levels) { camli_set_error("camli_allpairs_build_bwd: null pointer"); return CAMLI_EINVAL; }
+    if (!build_args_ok(what, f1, f2_levels, gvol_levels, p_levels, L, B, C, P)) return CAMLI_EINVAL;
+    if (!g_f1 || !g_f2_levels) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int sb = camli_divup(P, 32);
     for (int l = 0; l < L; ++l) {
-        if (!f2_levels[l] || !gvol_levels[l] || !g_f2_levels[l]) {
-            camli_set_error("camli_allpairs_build_bwd: null level pointer");
+        if (!f2_levels[l] || !gvol_levels[l] || !g_f2_levels[l] || (marks && !marks[l])) {
+            camli_set_error("%s: null level pointer", what);
             return CAMLI_EINVAL;
         }
         const int Pl = p_levels[l];
+        const unsigned char* mk = marks ? marks[l] : nullptr;
+        const int tb = camli_divup(Pl, 32);
         // g_f1: M = C, N = P, K = P_l;  A = f2_l [M][K] (k contiguous), B = gV_l [N][K] (k contiguous); accumulate over levels
         launch_gemm<true, true, true>(f2_levels[l], gvol_levels[l], g_f1, C, P, Pl, Pl, Pl, P, (int64_t)C * Pl, (int64_t)P * Pl,
-                                (int64_t)C * P, B, scale, l > 0, s);
+                                (int64_t)C * P, B, scale, l > 0, s, mk, 1, tb, sb);
         // g_f2_l: M = C, N = P_l, K = P;  A = f1 [M][K] (k contiguous), B = gV_l [K][N] (n contiguous)
         launch_gemm<true, false, true>(f1, gvol_levels[l], g_f2_levels[l], C, Pl, P, P, Pl, Pl, (int64_t)C * P, (int64_t)P * Pl,
-                                 (int64_t)C * Pl, B, scale, false, s);
+                                 (int64_t)C * Pl, B, scale, false, s, mk, 2, tb, sb);
     }
-    return camli_check_launch("camli_allpairs_build_bwd");
+    return camli_check_launch(what);
+}
+
+extern "C" int camli_allpairs_build_bwd(const float* f1, const float* const* f2_levels, const float* const* gvol_levels,
+                                        const int* p_levels, int L, float* g_f1, float* const* g_f2_levels, int B, int C,
+                                        int P, float scale, void* stream) {
+    return allpairs_build_bwd_impl(f1, f2_levels, gvol_levels, p_levels, L, g_f1, g_f2_levels, B, C, P, scale, nullptr, stream,
+                                   "camli_allpairs_build_bwd");
+}
+
+// Same adjoint, skipping every K step whose gradient tile was never written: marks[l] = [B][ceil(P/32)][ceil(P_l/32)]
+// bytes, non-zero where camli_allpairs_lookup_bwd_marked added a window into that 32x32 block of level l (a superset of
+// the non-zero blocks is enough; an all-zero gradient volume with all-zero marks yields zero gradients).
+extern "C" int camli_allpairs_build_bwd_marked(const float* f1, const float* const* f2_levels,
+                                               const float* const* gvol_levels, const int* p_levels, int L, float* g_f1,
+                                               float* const* g_f2_levels, int B, int C, int P, float scale,
+                                               const unsigned char* const* marks, void* stream) {
+    if (!marks && B > 0) { camli_set_error("camli_allpairs_build_bwd_marked: null marks"); return CAMLI_EINVAL; }
+    return allpairs_build_bwd_impl(f1, f2_levels, gvol_levels, p_levels, L, g_f1, g_f2_levels, B, C, P, scale, marks, stream,
+                                   "camli_allpairs_build_bwd_marked");
 }

@@ -28,6 +28,11 @@ struct LookupLevels {
     float* vol[LK_MAX_LEVELS];
     int h[LK_MAX_LEVELS];
     int w[LK_MAX_LEVELS];
+    // adjoint only, optional: visit marks per level, [B][sb][tb[l]] bytes -- one per block of 32 source pixels x 32
+    // target pixels of the gradient volume (camli_allpairs_build_bwd_marked skips the blocks never marked)
+    unsigned char* mark[LK_MAX_LEVELS];
+    int tb[LK_MAX_LEVELS];
+    int sb;
 };
 
 // grid (ceil(P/64), B, L), block 64
@@ -266,6 +271,21 @@ __global__ __launch_bounds__(4 * PB) void allpairs_lookup4_kernel(LookupLevels l
             }
         }
     } else {
+        // ---- visit marks: every window row is a run of <= 10 target pixels, i.e. at most two 32-pixel blocks ----
+        if (lv.mark[l] && wv == 0 && valid && (PB == 64 || lane < 32)) {
+            unsigned char* __restrict__ mk = lv.mark[l] + ((size_t)b * lv.sb + (p >> 5)) * lv.tb[l];
+            const int xa = max(x0, 0), xb = min(x0 + WN - 1, wl - 1);
+            if (xa <= xb) {
+#pragma unroll
+                for (int r = 0; r < WN; ++r) {
+                    const int gy = y0 + r;
+                    if (gy >= 0 && gy < hl) {
+                        mk[(gy * wl + xa) >> 5] = 1;
+                        mk[(gy * wl + xb) >> 5] = 1;
+                    }
+                }
+            }
+        }
         // ---- window rows {0,1,2} {3,4,5} {6,7} {8,9} per group; row r collects tap rows r-1 (weight wy0) and r (wy1),
         // added in the order of the one-wave kernel: (r-1,c-1) (r-1,c) (r,c-1) (r,c) ----
         const int r0 = grp < 2 ? 3 * grp : 2 * grp + 2;
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(4 * PB) void allpairs_lookup4_kernel(LookupLevels l
 
 template <bool BACKWARD>
 int launch_lookup(float* const* vols, const int* hs, const int* ws, int L, const float* coords, float* io, int B,
-                  int h, int w, int r, hipStream_t stream, const char* what) {
+                  int h, int w, int r, hipStream_t stream, const char* what, unsigned char* const* marks = nullptr) {
     if (!vols || !hs || !ws || !coords || !io) {
         camli_set_error("%s: null pointer", what);
         return CAMLI_EINVAL;
@@ -344,12 +364,20 @@ int launch_lookup(float* const* vols, const int* hs, const int* ws, int L, const
         lv.vol[l] = vols[l];
         lv.h[l] = hs[l];
         lv.w[l] = ws[l];
+        if (marks && !marks[l]) {
+            camli_set_error("%s: level %d has no mark array", what, l);
+            return CAMLI_EINVAL;
+        }
+        lv.mark[l] = marks ? marks[l] : nullptr;
+        lv.tb[l] = camli_divup(hs[l] * ws[l], 32);
     }
+    for (int l = L; l < LK_MAX_LEVELS; ++l) { lv.mark[l] = nullptr; lv.tb[l] = 0; }
+    lv.sb = camli_divup(h * w, 32);
     const int P = h * w;
     // CAMLI_LOOKUP_WAVES=1 keeps the one-wave-per-pixel-group form; CAMLI_LOOKUP_PB picks the pixel-group size (A/B runs)
     static const int waves = [] { const char* e = getenv("CAMLI_LOOKUP_WAVES"); return e ? atoi(e) : 4; }();
     static const int pb = [] { const char* e = getenv("CAMLI_LOOKUP_PB"); return e ? atoi(e) : 64; }();
-    if (waves == 1)
+    if (waves == 1 && !marks)      // the one-wave form does not write marks
         hipLaunchKernelGGL((allpairs_lookup_kernel<4, BACKWARD, BACKWARD ? 8 : 16>), dim3(camli_divup(P, 64), B, L), dim3(64), 0,
                            stream, lv, coords, io, P, L);
     else if (pb == 32)
@@ -376,4 +404,16 @@ extern "C" int camli_allpairs_lookup_bwd(float* const* gvols, const int* hs, con
     if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     return launch_lookup<true>(gvols, hs, ws, L, coords, const_cast<float*>(gout), B, h, w, r,
                                reinterpret_cast<hipStream_t>(stream), "camli_allpairs_lookup_bwd");
+}
+
+// The adjoint plus visit marks: marks[l] ([B][ceil(h*w/32)][ceil(hs[l]*ws[l]/32)] bytes, zeroed by the caller once per
+// backward pass) receives a non-zero byte for every 32 x 32 block (source pixels x target pixels) of gvols[l] a window
+// was added into.  camli_allpairs_build_bwd_marked reads them.
+extern "C" int camli_allpairs_lookup_bwd_marked(float* const* gvols, const int* hs, const int* ws, int L,
+                                                const float* coords, const float* gout, int B, int h, int w, int r,
+                                                unsigned char* const* marks, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!marks) { camli_set_error("camli_allpairs_lookup_bwd_marked: null marks"); return CAMLI_EINVAL; }
+    return launch_lookup<true>(gvols, hs, ws, L, coords, const_cast<float*>(gout), B, h, w, r,
+                               reinterpret_cast<hipStream_t>(stream), "camli_allpairs_lookup_bwd_marked", marks);
 }

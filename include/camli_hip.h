@@ -104,10 +104,25 @@ int camli_allpairs_build_bwd(const float *f1, const float *const *f2_levels, con
  *   bwd ACCUMULATES into gvols (caller zero-fills once, then may call once per GRU iteration);
  *   coords carry no gradient (they are built from detached flow, raft_core.py:248).
  */
+/* Adjoint of the pyramid build that skips the never-visited part of the gradient volume.  marks[l] is
+ * [B][ceil(P/32)][ceil(p_levels[l]/32)] bytes: non-zero where camli_allpairs_lookup_bwd_marked added a window into that
+ * block of 32 source pixels x 32 target pixels of gvol_levels[l] (any superset of the non-zero blocks is valid).  A K step
+ * of the two adjoint GEMMs whose gradient tile holds no marked block is neither loaded nor multiplied; results equal
+ * camli_allpairs_build_bwd bit for bit (only exact zeros are skipped).  Replaces the same reference lines. */
+int camli_allpairs_build_bwd_marked(const float *f1, const float *const *f2_levels, const float *const *gvol_levels,
+                                    const int *p_levels, int L, float *g_f1, float *const *g_f2_levels, int B, int C,
+                                    int P, float scale, const unsigned char *const *marks, void *stream);
+
 int camli_allpairs_lookup_fwd(const float *const *vols, const int *hs, const int *ws, int L,
                               const float *coords, float *out, int B, int h, int w, int r, void *stream);
 int camli_allpairs_lookup_bwd(float *const *gvols, const int *hs, const int *ws, int L,
                               const float *coords, const float *gout, int B, int h, int w, int r, void *stream);
+
+/* camli_allpairs_lookup_bwd plus visit marks (see camli_allpairs_build_bwd_marked); the caller zeroes marks[l] once per
+ * backward pass, together with the gradient pyramid. */
+int camli_allpairs_lookup_bwd_marked(float *const *gvols, const int *hs, const int *ws, int L, const float *coords,
+                                     const float *gout, int B, int h, int w, int r, unsigned char *const *marks,
+                                     void *stream);
 
 /*
  * Depth-wise set-conv core and adjoint (internal composite op; the reference composes it from

@@ -134,3 +134,50 @@ def test_allpairs_build_on_the_matrix_cores_vs_torch(shape):
     g1, g2 = torch.autograd.grad(pyr.token, [f1, f2], torch.zeros(1, device='cuda'))
     for got, ref in ((g1, want_g1), (g2, want_g2)):
         assert (got - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 20, 24), (1, 256, 36, 60), (1, 32, 9, 13)], ids=str)
+def test_pyramid_adjoint_following_visit_marks_equals_full_scan(shape):
+    """camli_allpairs_lookup_bwd_marked + camli_allpairs_build_bwd_marked: the adjoint GEMMs skip every gradient tile no
+    lookup ever wrote.  Only exact zeros are skipped, so the feature gradients must equal the unmarked path BIT FOR BIT;
+    the marks themselves must cover every non-zero 32x32 block of the gradient pyramid."""
+    from camliflow_amd.csrc import fused
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    f1 = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+    f2 = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    base = torch.stack([xs, ys])[None].repeat(b, 1, 1, 1)
+    coords = [(base + torch.randn(b, 2, h, w, generator=g) * s).cuda() for s in (0.5, 2.0, 6.0)]
+    gouts = [torch.randn(b, 4 * 81, h, w, generator=g).cuda() for _ in coords]
+
+    def run(use_marks, keep=None):
+        saved = fused._USE_MARKS
+        fused._USE_MARKS = use_marks
+        try:
+            pyr = fused.allpairs_pyramid(f1, f2, 4)
+            outs = [fused.allpairs_lookup(pyr, cc, 4) for cc in coords]
+            if keep is not None:       # snapshot gradient pyramid + marks right before the build node consumes them
+                hook = pyr.token.register_hook(lambda _g: keep.update(grads=[x.clone() for x in pyr.grads],
+                                                                       marks=[m.clone() for m in pyr.marks]))
+            res = torch.autograd.grad(outs, [f1, f2], gouts)
+            if keep is not None:
+                hook.remove()
+            return res
+        finally:
+            fused._USE_MARKS = saved
+
+    keep = {}
+    got = run(True, keep)
+    want = run(False)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    p = h * w
+    for grad, mark in zip(keep['grads'], keep['marks']):
+        pl = grad.shape[-2] * grad.shape[-1]
+        nz = (grad.reshape(b, p, pl) != 0)
+        sb, tb = mark.shape[1], mark.shape[2]
+        pad = torch.zeros(b, sb * 32, tb * 32, dtype=torch.bool, device=nz.device)
+        pad[:, :p, :pl] = nz
+        blocks = pad.reshape(b, sb, 32, tb, 32).any(dim=4).any(dim=2)
+        assert not (blocks & (mark == 0)).any(), 'a non-zero gradient block is not marked'
+        assert (mark != 0).float().mean() < 1.0 or pl <= 128
