@@ -263,20 +263,14 @@ __device__ __forceinline__ void gemm_tile_loop_marked(const float* __restrict__ 
 
 // C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
 // grid (ceil(N/128), ceil(M/128), batch), block 256
+// One 128x128 output tile (m0, n0) of one batch entry: Ab / Bb / Cb / mk already point at that entry.
 template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                             float* __restrict__ C, int M, int N, int K, int64_t lda,
-                                                             int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc,
-                                                             float alpha, int vec_a, int vec_b,
-                                                             const unsigned char* __restrict__ marks, int mark_mode,
-                                                             int mark_tb, int mark_src_blocks) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 * GB_K * (LDA + LDB) floats (> 64 KB: dynamic)
+__device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const float* __restrict__ Bb, float* __restrict__ Cb,
+                                           int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, int vec_a,
+                                           int vec_b, const unsigned char* __restrict__ mk, int mark_mode, int mark_tb,
+                                           int mark_src_blocks, int m0, int n0, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.y * GB_T, n0 = blockIdx.x * GB_T;
-    const float* __restrict__ Ab = A + (int64_t)blockIdx.z * sa;
-    const float* __restrict__ Bb = Bm + (int64_t)blockIdx.z * sb;
-    float* __restrict__ Cb = C + (int64_t)blockIdx.z * sc;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -287,8 +281,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const bool fast = vec_a && vec_b && (m0 + GB_T <= M) && (n0 + GB_T <= N) && (K % GB_K == 0);    // block-uniform
-    if (SKIPZ && marks) {
-        const unsigned char* mk = marks + (size_t)blockIdx.z * mark_src_blocks * mark_tb;
+    if (SKIPZ && mk) {
         if (fast)
             gemm_tile_loop_marked<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn, mk,
                                                      mark_mode, mark_tb, mark_src_blocks);
@@ -317,6 +310,49 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                 }
             }
         }
+}
+
+template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                             float* __restrict__ C, int M, int N, int K, int64_t lda,
+                                                             int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc,
+                                                             float alpha, int vec_a, int vec_b,
+                                                             const unsigned char* __restrict__ marks, int mark_mode,
+                                                             int mark_tb, int mark_src_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 * GB_K * (LDA + LDB) floats (> 64 KB: dynamic)
+    const unsigned char* mk = marks ? marks + (size_t)blockIdx.z * mark_src_blocks * mark_tb : nullptr;
+    gemm_block<A_KC, B_KC, ACC, SKIPZ>(A + (int64_t)blockIdx.z * sa, Bm + (int64_t)blockIdx.z * sb, C + (int64_t)blockIdx.z * sc,
+                                       M, N, K, lda, ldb, ldc, alpha, vec_a, vec_b, mk, mark_mode, mark_tb, mark_src_blocks,
+                                       blockIdx.y * GB_T, blockIdx.x * GB_T, lds);
+}
+
+// The g_f2_l GEMMs of ALL pyramid levels in one launch.  Per level they are M = C (2 row tiles), N = P_l, K = P: the
+// coarse levels have 16 / 4 / 1 column tiles, i.e. 256 / 64 / 16 workgroups walking a 255-step K loop -- launched one
+// after the other they leave the chip mostly idle for ~1.5 ms.  grid.x enumerates the column tiles of the levels, coarse
+// levels FIRST (their long loops start at once, the level-0 tiles fill the remaining CUs).  A = f1 is shared.
+constexpr int GG_MAX = 8;
+struct GemmGroup {
+    const float* B[GG_MAX];
+    float* C[GG_MAX];
+    const unsigned char* marks[GG_MAX];
+    int N[GG_MAX];
+    int tile_begin[GG_MAX + 1];        // in launch order
+    int groups;
+};
+__global__ __launch_bounds__(256) void gemm_gf2_grouped_kernel(const float* __restrict__ A, GemmGroup g, int M, int K,
+                                                                int64_t lda, int64_t sa, float alpha, int vec_a, int vec_ok,
+                                                                int mark_src_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int l = 0;
+    while (l + 1 < g.groups && (int)blockIdx.x >= g.tile_begin[l + 1]) ++l;
+    const int N = g.N[l];
+    const int tb = (N + 31) / 32;
+    const int n0 = ((int)blockIdx.x - g.tile_begin[l]) * GB_T;
+    const unsigned char* mk = g.marks[l] ? g.marks[l] + (size_t)blockIdx.z * mark_src_blocks * tb : nullptr;
+    const int vec_b = vec_ok && (N % 4 == 0);
+    gemm_block<true, false, false, true>(A + (int64_t)blockIdx.z * sa, g.B[l] + (int64_t)blockIdx.z * K * N,
+                                         g.C[l] + (int64_t)blockIdx.z * M * N, M, N, K, lda, N, N, alpha, vec_a, vec_b, mk, 2, tb,
+                                         mark_src_blocks, blockIdx.y * GB_T, n0, lds);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -386,20 +422,45 @@ static int allpairs_build_bwd_impl(const float* f1, const float* const* f2_level
     if (!g_f1 || !g_f2_levels) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int sb = camli_divup(P, 32);
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < L; ++l)
         if (!f2_levels[l] || !gvol_levels[l] || !g_f2_levels[l] || (marks && !marks[l])) {
             camli_set_error("%s: null level pointer", what);
             return CAMLI_EINVAL;
         }
+    // g_f2_l for every level in one launch: M = C, N = P_l, K = P;  A = f1 [M][K] (k contiguous), B = gV_l [K][N] (n contiguous)
+    {
+        GemmGroup g;
+        g.groups = L;
+        int tiles = 0, vec_ok = aligned16(f1) ? 1 : 0;
+        for (int i = 0; i < L; ++i) {
+            const int l = L - 1 - i;            // coarse levels first
+            g.B[i] = gvol_levels[l];
+            g.C[i] = g_f2_levels[l];
+            g.marks[i] = (marks && P <= 256 * GB_K) ? marks[l] : nullptr;
+            g.N[i] = p_levels[l];
+            g.tile_begin[i] = tiles;
+            tiles += camli_divup(p_levels[l], GB_T);
+            vec_ok = vec_ok && aligned16(gvol_levels[l]);
+        }
+        g.tile_begin[L] = tiles;
+        const int vec_a = aligned16(f1) && (P % 4 == 0) && (((int64_t)C * P) % 4 == 0);
+        constexpr size_t lds = (size_t)2 * GB_K * (OperandTile<true>::LD + OperandTile<false>::LD) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_gf2_grouped_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_gf2_grouped_kernel, dim3(tiles, camli_divup(C, GB_T), B), dim3(256), lds, s, f1, g, C, P,
+                           (int64_t)P, (int64_t)C * P, scale, vec_a, vec_ok, sb);
+    }
+    for (int l = 0; l < L; ++l) {
         const int Pl = p_levels[l];
         const unsigned char* mk = marks ? marks[l] : nullptr;
         const int tb = camli_divup(Pl, 32);
         // g_f1: M = C, N = P, K = P_l;  A = f2_l [M][K] (k contiguous), B = gV_l [N][K] (k contiguous); accumulate over levels
         launch_gemm<true, true, true>(f2_levels[l], gvol_levels[l], g_f1, C, P, Pl, Pl, Pl, P, (int64_t)C * Pl, (int64_t)P * Pl,
                                 (int64_t)C * P, B, scale, l > 0, s, mk, 1, tb, sb);
-        // g_f2_l: M = C, N = P_l, K = P;  A = f1 [M][K] (k contiguous), B = gV_l [K][N] (n contiguous)
-        launch_gemm<true, false, true>(f1, gvol_levels[l], g_f2_levels[l], C, Pl, P, P, Pl, Pl, (int64_t)C * P, (int64_t)P * Pl,
-                                 (int64_t)C * Pl, B, scale, false, s, mk, 2, tb, sb);
     }
     return camli_check_launch(what);
 }
