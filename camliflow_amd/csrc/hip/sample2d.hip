@@ -17,7 +17,9 @@
 
 namespace {
 
-// grid (ceil(N/64), B), block 256: wave w handles channels w, w+4, ...
+// grid (ceil(N/64), B, CS), block 256: wave w of channel slice z handles channels 4z + w, 4z + w + 4 CS, ...
+// (CS slices so that the launch carries ~4 waves per SIMD: at [8,128,68,120] x 2048 points one slice is 1,024 waves,
+// each a serial chain of 32 x 4 dependent gathers)
 __global__ __launch_bounds__(256) void bilinear_sample_kernel(const float* __restrict__ feat,
                                                               const float* __restrict__ uv, float* __restrict__ out,
                                                               int C, int H, int W, int N) {
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void bilinear_sample_kernel(const float* __res
     const float* __restrict__ src = feat + (size_t)b * C * plane;
     float* __restrict__ dst = out + (size_t)b * C * N + n;
 #pragma unroll 4
-    for (int c = wave; c < C; c += 4) {
+    for (int c = wave + 4 * (int)blockIdx.z; c < C; c += 4 * (int)gridDim.z) {
         const float* __restrict__ p = src + (size_t)c * plane;
         float acc = p[o_nw] * w_nw;
         acc += p[o_ne] * w_ne;
@@ -71,7 +73,9 @@ extern "C" int camli_bilinear_sample_fwd(const float* feat, const float* uv, flo
         camli_set_error("camli_bilinear_sample_fwd: bad shape B=%d C=%d H=%d W=%d N=%d", B, C, H, W, N);
         return CAMLI_EINVAL;
     }
-    hipLaunchKernelGGL(bilinear_sample_kernel, dim3(camli_divup(N, 64), B), dim3(256), 0,
+    int cs = 1;
+    while (cs * 2 * 4 <= C && (long long)camli_divup(N, 64) * B * 4 * cs < 4096) cs *= 2;
+    hipLaunchKernelGGL(bilinear_sample_kernel, dim3(camli_divup(N, 64), B, cs), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), feat, uv, out, C, H, W, N);
     return camli_check_launch("camli_bilinear_sample_fwd");
 }

@@ -18,16 +18,19 @@
 
 namespace {
 
-// grid (ceil(w/64), h, B), block 64
+// grid (ceil(w/64), h, B * IG), block 64: the S fine rows of a coarse row are independent, so IG workgroups share them
+// (S/IG rows each).  One wave walking all S*S sub-pixel positions is a chain of 64 dependent (9 loads -> softmax) groups
+// on a launch of ~1,000 waves -- one per SIMD, nothing to overlap the load latency with: 160 us for 183 MB.
 template <int S, bool BACKWARD>
 __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __restrict__ flow,
                                                               const float* __restrict__ mask,
                                                               float* __restrict__ out_or_gout,
                                                               float* __restrict__ gflow, float* __restrict__ gmask,
-                                                              int h, int w, float mask_scale) {
+                                                              int h, int w, float mask_scale, int IG) {
     __shared__ float tile[2][S][64 + 1];    // [channel][j][x_local]
     const int lane = threadIdx.x;
-    const int x0 = blockIdx.x * 64, x = x0 + lane, y = blockIdx.y, b = blockIdx.z;
+    const int x0 = blockIdx.x * 64, x = x0 + lane, y = blockIdx.y, b = blockIdx.z / IG;
+    const int i_beg = (blockIdx.z % IG) * (S / IG), i_end = i_beg + S / IG;
     const bool valid = x < w;
     const int xc = valid ? x : w - 1;
     const size_t plane = (size_t)h * w;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __rest
         for (int k = 0; k < 9; ++k) gf[k][0] = gf[k][1] = 0.0f;
     }
 
-    for (int i = 0; i < S; ++i) {
+    for (int i = i_beg; i < i_end; ++i) {
         float* __restrict__ orow0 = out_or_gout + (((size_t)b * 2 + 0) * h * S + (size_t)y * S + i) * W + (size_t)x0 * S;
         float* __restrict__ orow1 = out_or_gout + (((size_t)b * 2 + 1) * h * S + (size_t)y * S + i) * W + (size_t)x0 * S;
         if (BACKWARD) {
@@ -138,13 +141,16 @@ int launch_upsample(const float* flow, const float* mask, float* io, float* gflo
         camli_set_error("%s: bad shape B=%d h=%d w=%d scale=%d (scale must be 4 or 8)", what, B, h, w, S);
         return CAMLI_EINVAL;
     }
-    dim3 grid(camli_divup(w, 64), h, B);
+    // split the fine rows until the launch carries ~4 waves per SIMD (4096 waves)
+    int ig = 1;
+    while (ig < S && (long long)camli_divup(w, 64) * h * B * ig < 4096 && (long long)B * ig * 2 <= 65535) ig *= 2;
+    dim3 grid(camli_divup(w, 64), h, B * ig);
     if (S == 8)
         hipLaunchKernelGGL((convex_upsample_kernel<8, BACKWARD>), grid, dim3(64), 0, s, flow, mask, io, gflow, gmask, h, w,
-                           mask_scale);
+                           mask_scale, ig);
     else
         hipLaunchKernelGGL((convex_upsample_kernel<4, BACKWARD>), grid, dim3(64), 0, s, flow, mask, io, gflow, gmask, h, w,
-                           mask_scale);
+                           mask_scale, ig);
     return camli_check_launch(what);
 }
 
