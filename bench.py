@@ -121,6 +121,14 @@ class GraphedStep:
         return self.loss
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def make_optimizer(model, capturable=False):
     """AdamW with the reference's split learning rates (conf/training/flyingthings3d_subset/camliraft.yaml,
     factory.py:50-58: parameters under core.branch_3d get lr_3d)."""
@@ -142,8 +150,7 @@ def allreduce_gradients(model, world, force=False):
     flat = torch._utils._flatten_dense_tensors(grads)
     dist.all_reduce(flat)
     flat.div_(world)
-    for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-        g.copy_(f)
+    torch._foreach_copy_(grads, list(torch._utils._unflatten_dense_tensors(flat, grads)))     # one multi-tensor launch
 
 
 def train_step(model, optimizer, batch, world=1, force_dist=False, autocast=None):
@@ -393,7 +400,10 @@ def main():
     dist_on = world > 1 or (os.environ.get('CAMLI_FORCE_DIST') == '1' and 'RANK' in os.environ)
     if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)  # RCCL over xGMI
+        # no device_id: binding the group to the device at construction (eager communicator) was measured to cost 8 % of
+        # EVERY step in this process (293 vs 270 ms with identical work, idle communicator included); the communicator
+        # is created by the first collective instead
+        dist.init_process_group('nccl', rank=rank, world_size=world)  # RCCL over xGMI
 
     from camliflow_amd.cores import runtime
     from camliflow_amd.csrc import _lib
@@ -475,6 +485,9 @@ def main():
         runtime.set_census(False)
         roofline_steps, roofline_how = 2, 'two eager steps after the graph-replayed timed region (HIP events on the launch stream)'
 
+    _flush_c_stdio()          # every rank: nothing of theirs may follow rank 0's line
+    if dist_on:
+        dist.barrier()
     failed = False
     if rank == 0:
         global_batch = args.batch * world
@@ -536,6 +549,9 @@ def main():
             if autocast is None:
                 line['parity'] = parity_check(args, state_dict, sample, ref, device)
                 failed = not line['parity']['ok']
+        # RCCL writes its version banner through C stdio when the communicator is created; flush it so that the JSON
+        # line is the LAST line on stdout
+        _flush_c_stdio()
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

@@ -45,8 +45,8 @@ def test_forced_dist_step_matches_plain_step():
         with runtime.use_backend('hip'):
             plain = base.cuda().train()
             loss0, g0 = grads_of(plain, 1, False)
-            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1,
-                                    device_id=torch.device('cuda', 0))
+            # as bench.py: no device_id (an eagerly bound communicator slows every later step of the process by 8 %)
+            dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % _free_port(), rank=0, world_size=1)
             try:
                 model = CamLiRAFT(camliraft_cfg(n_iters=3))
                 model.load_state_dict(state)
