@@ -129,6 +129,27 @@ def _flush_c_stdio():
         pass
 
 
+def _start_watchdog(progress, world, limit_s=90.0):
+    """Last line of defence for the single-process run: if no step completes for `limit_s` seconds during warm-up or the
+    timed region (the two-lane dead-lock described in main()), replace the process by a single-stream run of the same
+    command -- a slower line (~10 %) instead of no line.  Multi-rank jobs cannot restart one rank; they rely on the priming
+    step alone.  CAMLI_NO_WATCHDOG=1 switches it off."""
+    import threading
+    if world != 1 or os.environ.get('CAMLI_NO_WATCHDOG') == '1' or os.environ.get('CAMLI_OVERLAP', '1') != '1':
+        return
+
+    def watch():
+        while progress['phase'] != 'done':
+            time.sleep(2.0)
+            if progress['phase'] != 'done' and time.monotonic() - progress['t'] > limit_s:
+                sys.stderr.write('bench.py: no step completed for %.0f s during %s with two lanes; restarting single-stream '
+                                 '(CAMLI_OVERLAP=0)\n' % (limit_s, progress['phase']))
+                sys.stderr.flush()
+                env = dict(os.environ, CAMLI_OVERLAP='0', CAMLI_NO_WATCHDOG='1')
+                os.execve(sys.executable, [sys.executable] + sys.argv, env)
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def make_optimizer(model, capturable=False):
     """AdamW with the reference's split learning rates (conf/training/flyingthings3d_subset/camliraft.yaml,
     factory.py:50-58: parameters under core.branch_3d get lr_3d)."""
@@ -442,10 +463,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Priming step on ONE stream, before anything runs two-lane.  With the point branch on its own HIP stream the very first
+    # steps of a process can dead-lock on this ROCm image (host blocked inside the first backward; always under rocprofv3,
+    # on some boxes in half of the plain runs; never once a step has completed): every first-use event of the process --
+    # code-object loads, MIOpen solver set-up, allocator growth -- then happens with cross-stream waits in flight.  One
+    # untimed single-stream step takes those out of the way; the W warm-up steps and the timed steps run two-lane.
+    progress = {'t': time.monotonic(), 'phase': 'priming'}
+    _start_watchdog(progress, world)
+    if runtime.overlap():
+        runtime.set_overlap(False)
+        step()
+        torch.cuda.synchronize()
+        runtime.set_overlap(True)
+    progress.update(t=time.monotonic(), phase='warm-up')
     graphed = GraphedStep(step) if use_graph else None
     for _ in range(args.warmup):
         graphed() if graphed else step()
+        progress['t'] = time.monotonic()
     barrier()
+    progress.update(t=time.monotonic(), phase='timed')
     runtime.set_census(True)
     runtime.reset_census()
     _lib.TIMER.reset()
@@ -459,8 +495,10 @@ def main():
         h0 = time.perf_counter()
         loss = graphed() if graphed else step()
         host_s += time.perf_counter() - h0
+        progress['t'] = time.monotonic()
     barrier()
     elapsed = time.perf_counter() - t0
+    progress['phase'] = 'done'
     _lib.TIMER.enabled = False
     census = runtime.census()
     runtime.set_census(False)
