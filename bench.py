@@ -104,11 +104,20 @@ class GraphedStep:
     and replayed.  Both HIP streams of the two-lane execution are captured (the side stream forks from and joins
     the capture stream).  Single GPU only (collectives stay outside graphs here)."""
 
-    def __init__(self, step_fn, warmup=3):
+    def __init__(self, step_fn, warmup=3, prime=False):
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            if prime:
+                # the single-stream priming step of main(), but on this side stream: the parameters' AccumulateGrad nodes
+                # remember the stream of their first use, and a first use on the legacy stream makes the later capture
+                # fail ("legacy stream would depend on a capturing stream")
+                from camliflow_amd.cores import runtime
+                runtime.set_overlap(False)
+                step_fn()
+                side.synchronize()
+                runtime.set_overlap(True)
             for _ in range(warmup):
                 step_fn()
         torch.cuda.current_stream().wait_stream(side)
@@ -470,13 +479,13 @@ def main():
     # untimed single-stream step takes those out of the way; the W warm-up steps and the timed steps run two-lane.
     progress = {'t': time.monotonic(), 'phase': 'priming'}
     _start_watchdog(progress, world)
-    if runtime.overlap():
+    if runtime.overlap() and not use_graph:
         runtime.set_overlap(False)
         step()
         torch.cuda.synchronize()
         runtime.set_overlap(True)
     progress.update(t=time.monotonic(), phase='warm-up')
-    graphed = GraphedStep(step) if use_graph else None
+    graphed = GraphedStep(step, prime=runtime.overlap()) if use_graph else None       # primes on its own side stream
     for _ in range(args.warmup):
         graphed() if graphed else step()
         progress['t'] = time.monotonic()

@@ -34,14 +34,20 @@ def _run(graphed, n_steps, warmup):
         return loss
 
     with runtime.use_backend('hip'):
-        runtime.set_overlap(True)
         runtime.set_deferred_param_grads(True)
+        runtime.set_overlap(True)
         try:
+            # both runs start with ONE single-stream priming step, as bench.py does (two-lane start-up dead-lock, DESIGN
+            # section 8); the graphed run takes it inside GraphedStep, on the side stream the capture will use
             if graphed:
-                g = bench.GraphedStep(step, warmup=warmup)      # `warmup` eager steps, then the capture (not executed)
+                g = bench.GraphedStep(step, warmup=warmup, prime=True)      # prime + `warmup` eager steps, then the capture
                 for _ in range(n_steps - warmup):
                     loss = g()
             else:
+                runtime.set_overlap(False)
+                step()
+                torch.cuda.synchronize()
+                runtime.set_overlap(True)
                 for _ in range(n_steps):
                     loss = step()
             torch.cuda.synchronize()
