@@ -9,15 +9,20 @@ One process per GPU, batch-dimension data parallel (SyncBatchNorm + one flat-buc
 RCCL/xGMI per step); per-GPU batch is fixed, so the scaling is weak.  Rank 0 prints ONE JSON line.  `value` =
 global frame-pairs per second with the inputs resident in HBM before the timed region.
 
-Besides the driver contract the line carries (N = 1, default config only):
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks (one process per
+GPU, the role of train.py:307's mp.spawn) and refuses cleanly when the box has fewer than N GPUs.
+
+The ONE line on stdout is compact (< 4 KB, tests/test_bench_line.py): the driver contract + `config` + (N = 1, default
+config only):
+  roofline      the dominant north-star kernel (most device time in the timed region): in situ figure (HIP events on
+                the launch stream over the timed region), `single_lane` (same kernel with the chip to itself), `traffic`
+  cpu_baseline  the CPU port timed on the host cores: 1 warm-up + 2 timed steps at 8 threads (~25 s)
   parity        EPE2D / EPE3D of the HIP path against the CPU port (this repo's cores driven by the C oracle
                 operators) on one sample of the SAME workload with shared post-IDS core inputs, plus bit-equality
                 of the FPS / KNN indices; the run FAILS when |dEPE| > 1e-4 or an index differs
-  roofline      the dominant north-star kernel (most device time in the timed region), in situ (HIP events on the
-                launch stream over the timed region)
-  roofline_rows one row per north-star kernel measured alone on the idle GPU (tools/kernel_bench.py)
-  cpu_baseline  the CPU port timed on the host cores: 1 warm-up + 2 repetitions at 8 threads, 1 each at 32 and all
-  census        fused launches vs composed fall-backs under the 'hip' backend (cores/runtime.py)
+Everything bulky goes to `gpurun_out/bench_detail.json` (path in the line's `detail`): `hip_kernels` (every timed entry
+point in situ), `roofline_rows` (one row per north-star kernel alone on the idle GPU, tools/kernel_bench.py), `census`
+(fused launches vs composed fall-backs under the 'hip' backend, cores/runtime.py) and the long forms of the above.
 
 Other configurations (own bench lines, not the headline; the batch-1 ones replay a HIP graph by default): --config camlipwc (configs[1]), kitti (configs[4],
 bf16 autocast, 32 iterations), eval (batch 8, 20 iterations, inference).
@@ -104,22 +109,17 @@ class GraphedStep:
     and replayed.  Both HIP streams of the two-lane execution are captured (the side stream forks from and joins
     the capture stream).  Single GPU only (collectives stay outside graphs here)."""
 
-    def __init__(self, step_fn, warmup=3, prime=False):
+    def __init__(self, step_fn, warmup=3):
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            if prime:
-                # the single-stream priming step of main(), but on this side stream: the parameters' AccumulateGrad nodes
-                # remember the stream of their first use, and a first use on the legacy stream makes the later capture
-                # fail ("legacy stream would depend on a capturing stream")
-                from camliflow_amd.cores import runtime
-                runtime.set_overlap(False)
+            # the first of these steps is the one-lane priming pass of runtime.Lanes, and it runs on THIS side stream: the
+            # parameters' AccumulateGrad nodes remember the stream of their first use, and a first use on the legacy
+            # stream makes the later capture fail ("legacy stream would depend on a capturing stream")
+            for _ in range(warmup + 1):
                 step_fn()
                 side.synchronize()
-                runtime.set_overlap(True)
-            for _ in range(warmup):
-                step_fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.cuda.graph(self.graph):
@@ -139,24 +139,69 @@ def _flush_c_stdio():
 
 
 def _start_watchdog(progress, world, limit_s=90.0):
-    """Last line of defence for the single-process run: if no step completes for `limit_s` seconds during warm-up or the
-    timed region (the two-lane dead-lock described in main()), replace the process by a single-stream run of the same
-    command -- a slower line (~10 %) instead of no line.  Multi-rank jobs cannot restart one rank; they rely on the priming
-    step alone.  CAMLI_NO_WATCHDOG=1 switches it off."""
+    """Safety net of the single-process two-lane run: if no step completes for `limit_s` seconds (the start-up stall
+    described in DESIGN.md section 8), the process is replaced by a ONE-lane run of the same command.  Nothing about it is
+    silent: the restarted run's line says `config.lanes: 1` and `config.lanes_note: restarted ...`.  Multi-rank runs never
+    need it: they default to one lane.  CAMLI_NO_WATCHDOG=1 switches it off."""
     import threading
-    if world != 1 or os.environ.get('CAMLI_NO_WATCHDOG') == '1' or os.environ.get('CAMLI_OVERLAP', '1') != '1':
+    if world != 1 or os.environ.get('CAMLI_NO_WATCHDOG') == '1' or not progress.get('two_lane'):
         return
 
     def watch():
         while progress['phase'] != 'done':
             time.sleep(2.0)
             if progress['phase'] != 'done' and time.monotonic() - progress['t'] > limit_s:
-                sys.stderr.write('bench.py: no step completed for %.0f s during %s with two lanes; restarting single-stream '
+                sys.stderr.write('bench.py: no step completed for %.0f s during %s with two lanes; restarting with one lane '
                                  '(CAMLI_OVERLAP=0)\n' % (limit_s, progress['phase']))
                 sys.stderr.flush()
-                env = dict(os.environ, CAMLI_OVERLAP='0', CAMLI_NO_WATCHDOG='1')
+                env = dict(os.environ, CAMLI_OVERLAP='0', CAMLI_NO_WATCHDOG='1',
+                           CAMLI_LANES_NOTE='restarted with one lane after a two-lane stall during %s' % progress['phase'])
                 os.execve(sys.executable, [sys.executable] + sys.argv, env)
     threading.Thread(target=watch, daemon=True).start()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` (the reference: train.py:307 mp.spawn, one process per GPU)
+# ------------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n, argv, device_count=None, backend_env=None):
+    """Start `n` ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), wait for them,
+    pass rank 0's stdout through.  Refuses (exit code 2, nothing started) when the box has fewer than `n` GPUs: two
+    ranks on one device is not a measurement.  A rank that fails takes the others down (exact PIDs, no patterns)."""
+    if device_count is None:
+        device_count = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if device_count < n:
+        sys.stderr.write('bench.py: --gpus %d needs %d GPUs, this box has %d; refusing to oversubscribe\n'
+                         % (n, n, device_count))
+        return 2
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.update(backend_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    code = 0
+    pending = list(procs)
+    while pending:
+        for proc in list(pending):
+            rc = proc.poll()
+            if rc is None:
+                continue
+            pending.remove(proc)
+            if rc != 0 and code == 0:
+                code = rc
+                for other in pending:       # one rank failed: the collective of the others would never complete
+                    other.terminate()
+        time.sleep(0.2)
+    return code
 
 
 def make_optimizer(model, capturable=False):
@@ -230,11 +275,11 @@ def _cpu_model_name():
 
 def cpu_baseline_and_reference(args, state_dict):
     """The CPU restatement path (this repo's cores driven by the C oracle operators) on the host cores: one
-    sample (batch 1) of the same workload.  1 warm-up + 2 timed training steps at 8 threads (the thread count of the
-    in-container reference timing), then one step each at 32 threads and at all cores -- the port,
-    like the reference's Python path, is fastest at a moderate thread count; `value` is the best of them and `cores`
-    the thread count that produced it.  The warm-up step's forward is also the parity reference: it returns the final
-    flows of that sample.  Reported, not the target."""
+    sample (batch 1) of the same workload.  1 warm-up + 2 timed training steps at 8 threads -- the thread count of the
+    in-container reference timing and the port's best: measured on the 128-core GPU box in round 2,
+    8 threads 6.9 s, 32 threads 8.6 s, 128 threads 50 s per step (CAMLI_CPU_THREAD_SWEEP=1 repeats that sweep).  The
+    warm-up step's forward is also the parity reference: it returns the final flows of that sample.  Reported, not
+    the target."""
     from modelutils import oracle_boundary
     all_threads = torch.get_num_threads()
     model = build_model(args).train()
@@ -245,7 +290,7 @@ def cpu_baseline_and_reference(args, state_dict):
     ref = None
     if args.config == 'camliraft':
         plan = [('warmup', min(8, all_threads), 1), ('t8', min(8, all_threads), 2)]
-        if all_threads > 8:
+        if all_threads > 8 and os.environ.get('CAMLI_CPU_THREAD_SWEEP') == '1':
             plan += [('t32', min(32, all_threads), 1), ('all', all_threads, 1)]
     else:       # the other configurations are side lines: parity reference + one timed step
         plan = [('warmup', min(8, all_threads), 1), ('t8', min(8, all_threads), 1)]
@@ -270,11 +315,10 @@ def cpu_baseline_and_reference(args, state_dict):
     timed = [(t, n) for label, runs in times.items() if label != 'warmup' for t, n in runs]
     best_t, best_n = min(timed)
     base = {'value': round(1.0 / best_t, 5), 'unit': 'frame-pairs/s', 'cores': best_n, 'kind': 'port',
-            'sample': '1 sample (batch 1) of the same training step (fwd+bwd+clip+AdamW), %dx%d + %d pts, %d iters: '
-                      '1 warm-up (%.1f s) + timed steps %s; best taken'
+            'sample': 'batch-1 training step (fwd+bwd+clip+AdamW) of the same workload, %dx%d + %d pts, %d iters: '
+                      '1 warm-up (%.1f s) + %s; best taken'
                       % (args.width, args.height, args.points, args.iters, times['warmup'][0][0],
-                         ', '.join('%.1f s @ %d threads' % (t, n) for t, n in timed)),
-            'seconds_by_threads': {str(n): round(min(t for t, m in timed if m == n), 2) for n in sorted({m for _, m in timed})},
+                         ', '.join('%.1f s @ %d thr' % (t, n) for t, n in timed)),
             'cpu_model': _cpu_model_name(), 'os_cpu_count': os.cpu_count()}
     return base, batch, ref
 
@@ -360,10 +404,14 @@ def roofline_report(summary, steps, args, step_ms):
         if kind == 'hbm':
             entry['frac'] = round(rate / 1e9 / HBM_PEAK_GBS, 4)
         elif kind == 'mfma' and rec.get('flop', 0) > 0:
-            entry['tflops'] = round(rec['flop'] / secs / 1e12, 2)
-            entry['frac'] = round(entry['tflops'] / MFMA_F32_PEAK_TFLOPS, 4)
-            if name == 'camli_allpairs_build_bwd':     # dense product counted, unvisited gradient blocks skipped
-                entry['dense_equivalent'] = True
+            if name == 'camli_allpairs_build_bwd':
+                # the adjoint skips the gradient blocks no lookup visited: the flop it EXECUTES is only known from the
+                # visit marks on the device (tools/kernel_bench.py reads them back -> roofline_rows); in situ only the
+                # dense-product equivalent is known, and that is not a roofline fraction
+                entry['dense_equivalent_tflops'] = round(rec['flop'] / secs / 1e12, 2)
+            else:
+                entry['tflops'] = round(rec['flop'] / secs / 1e12, 2)
+                entry['frac'] = round(entry['tflops'] / MFMA_F32_PEAK_TFLOPS, 4)
         elif kind == 'valu':
             entry['frac'] = round(rate / 1e9 / VALU_PAIR_PEAK_G, 4)
         if 'frac' in entry and kind in ('hbm', 'mfma'):
@@ -381,9 +429,61 @@ def roofline_report(summary, steps, args, step_ms):
     roofline = {'kernel': name, 'bound': NORTH_STAR[name], 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
                 'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(name, args), 'launches': rec['launches'],
                 'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
-                'algorithmic_work_per_launch': round(per_launch), 'measured': 'in situ, HIP events on the launch stream over the timed region',
-                'selection': 'the north-star kernel with the most device time in the timed region'}
+                'algorithmic_work_per_launch': round(per_launch), 'measured': 'in situ: HIP events on the launch stream, timed region'}
     return roofline, table
+
+
+def write_detail(full):
+    """The bulky parts of the report (per-kernel tables, isolated rows, census, long-form parity / baseline) go to a file;
+    `gpurun_out/` is the directory that travels back from a GPU box."""
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, os.environ.get('CAMLI_BENCH_DETAIL', 'bench_detail.json'))
+        with open(path, 'w') as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as err:
+        sys.stderr.write('bench.py: could not write the detail file: %s\n' % err)
+        return None
+
+
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                 'vs_baseline', 'dtype', 'data', 'config')
+LINE_LIMIT_BYTES = 4096
+
+
+def compact_line(full, detail_path=None):
+    """The ONE stdout line: contract fields + config + roofline (one kernel) + cpu_baseline + parity, < 4 KB by
+    construction (the round-2 line was 20 KB and the driver's tail cut it).  No fraction above 1 is ever printed."""
+    line = {k: full[k] for k in CONTRACT_KEYS if k in full}
+    roof = full.get('roofline')
+    if roof is not None:
+        keep = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us', 'launches',
+                'algorithmic_work_per_launch', 'measured')
+        line['roofline'] = {k: roof[k] for k in keep if k in roof}
+        if 'single_lane' in roof:
+            line['roofline']['single_lane'] = {k: roof['single_lane'][k] for k in ('avg_launch_us', 'achieved', 'frac')}
+        assert line['roofline']['frac'] <= 1.0, 'a roofline fraction above 1 is a mis-stated work figure'
+    base = full.get('cpu_baseline')
+    if base is not None:
+        line['cpu_baseline'] = {k: base[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model') if k in base}
+    par = full.get('parity')
+    if par is not None:
+        line['parity'] = {k: par[k] for k in ('epe2d_abs_diff', 'epe3d_abs_diff', 'fps_equal', 'knn_equal', 'tolerance', 'ok')}
+        line['parity']['vs'] = 'CPU port (cores + C oracle), batch-1 sample of the workload, shared post-IDS inputs'
+    if detail_path:
+        line['detail'] = detail_path
+    size = len(json.dumps(line))
+    if size >= LINE_LIMIT_BYTES:      # never let free-text fields push the contract fields out of the driver's tail
+        for key in ('parity', 'cpu_baseline'):
+            if key in line and 'sample' in line[key]:
+                line[key]['sample'] = line[key]['sample'][:120]
+            if key in line and 'vs' in line[key]:
+                line[key].pop('vs')
+        line['config'].pop('lanes_note', None)
+    assert len(json.dumps(line)) < LINE_LIMIT_BYTES
+    return line
 
 
 def main():
@@ -404,6 +504,9 @@ def main():
                     help='capture the whole training step in one HIP graph and replay it (single GPU); default for the '
                          'batch-1 configurations camlipwc / kitti, whose steps are bound by host enqueue time')
     ap.add_argument('--no-graph', dest='graph', action='store_false')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='rendezvous only (gloo, no GPU): every rank joins, one all-reduce, rank 0 prints a line; '
+                         'tests/test_bench_line.py uses it to cover the self-launcher on CPU')
     args = ap.parse_args()
     if os.environ.get('CAMLI_FAULT_DUMP'):      # debugging aid: dump every thread's Python stack after N seconds
         import faulthandler
@@ -415,14 +518,28 @@ def main():
     args.iters = iters if args.iters is None else args.iters
     args.batch = args.batch or batch
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: this process becomes the launcher of N ranks (train.py:307)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], device_count=args.gpus if args.launch_check else None))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.launch_check:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({'launch_check': True, 'n_gpus': world, 'rank_sum': t.item()}), flush=True)
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path is the product, there is no CPU fallback')
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit('rank %d: LOCAL_RANK %d but only %d GPUs visible; refusing to oversubscribe'
+                         % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     # CAMLI_FORCE_DIST=1 under a 1-rank torch.distributed.run exercises the whole multi-GPU path
@@ -434,12 +551,16 @@ def main():
         # EVERY step in this process (293 vs 270 ms with identical work, idle communicator included); the communicator
         # is created by the first collective instead
         dist.init_process_group('nccl', rank=rank, world_size=world)  # RCCL over xGMI
+    # lanes: the single process defaults to two (point branch on a side HIP stream, its first pass primed one-lane by
+    # runtime.Lanes, watchdog as a visible safety net); multi-rank jobs default to ONE lane -- a rank that stalls cannot be
+    # restarted alone, and a collective the others wait in would hang the job.  CAMLI_OVERLAP=0/1 overrides either.
+    two_lane = os.environ.get('CAMLI_OVERLAP', '0' if world > 1 else '1') == '1'
 
     from camliflow_amd.cores import runtime
     from camliflow_amd.csrc import _lib
     _lib.load()
     runtime.set_backend('hip')
-    runtime.set_overlap(os.environ.get('CAMLI_OVERLAP', '1') == '1')
+    runtime.set_overlap(two_lane)
     # parameter gradients of the iteration-shared 1x1 convolutions / biases accumulate inside their kernels and
     # reach .grad once per backward() (cores/runtime.py)
     runtime.set_deferred_param_grads(os.environ.get('CAMLI_DEFER_GRADS', '1') == '1')
@@ -472,20 +593,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Priming step on ONE stream, before anything runs two-lane.  With the point branch on its own HIP stream the very first
-    # steps of a process can dead-lock on this ROCm image (host blocked inside the first backward; always under rocprofv3,
-    # on some boxes in half of the plain runs; never once a step has completed): every first-use event of the process --
-    # code-object loads, MIOpen solver set-up, allocator growth -- then happens with cross-stream waits in flight.  One
-    # untimed single-stream step takes those out of the way; the W warm-up steps and the timed steps run two-lane.
-    progress = {'t': time.monotonic(), 'phase': 'priming'}
+    # The first pass of this input signature runs on ONE stream whatever `lanes` says (runtime.set_overlap: first-use work
+    # of the process must not happen with cross-stream waits in flight); it is untimed and comes before the W warm-up steps.
+    progress = {'t': time.monotonic(), 'phase': 'priming', 'two_lane': two_lane}
     _start_watchdog(progress, world)
-    if runtime.overlap() and not use_graph:
-        runtime.set_overlap(False)
+    if two_lane and not use_graph:
         step()
         torch.cuda.synchronize()
-        runtime.set_overlap(True)
     progress.update(t=time.monotonic(), phase='warm-up')
-    graphed = GraphedStep(step, prime=runtime.overlap()) if use_graph else None       # primes on its own side stream
+    graphed = GraphedStep(step) if use_graph else None       # primes on its own side stream
     for _ in range(args.warmup):
         graphed() if graphed else step()
         progress['t'] = time.monotonic()
@@ -576,7 +692,8 @@ def main():
                                    % (args.model, what, args.width, args.height, args.points,
                                       ('%d GRU iters' % args.iters) if args.iters else 'coarse-to-fine pyramid',
                                       args.batch, stands_for),
-                       'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hip_graph': bool(graphed),
+                       'global_batch': global_batch, 'parallelism': 'dp%d' % world,
+                       'lanes': 2 if two_lane else 1, 'hip_graph': bool(graphed),
                        'loss': round(float(loss.detach()), 4),
                        'host_enqueue_ms_per_step': round(host_s / args.steps * 1e3, 1),
                        'hip_launches_per_step': round(sum(census['fused'].values()) / roofline_steps, 1)},
@@ -585,6 +702,8 @@ def main():
             'census': {'fused_launches_per_step': {k: round(v / roofline_steps, 1) for k, v in sorted(census['fused'].items())},
                        'composed_calls_per_step': {k: round(v / roofline_steps, 1) for k, v in sorted(census['composed'].items())}},
         }
+        if os.environ.get('CAMLI_LANES_NOTE'):
+            line['config']['lanes_note'] = os.environ['CAMLI_LANES_NOTE']
         if world == 1 and not args.no_isolated and args.config == 'camliraft':
             import kernel_bench
             line['roofline_rows'] = kernel_bench.run(batch=args.batch, reps=5)
@@ -596,10 +715,11 @@ def main():
             if autocast is None:
                 line['parity'] = parity_check(args, state_dict, sample, ref, device)
                 failed = not line['parity']['ok']
+        detail_path = write_detail(line)
         # RCCL writes its version banner through C stdio when the communicator is created; flush it so that the JSON
         # line is the LAST line on stdout
         _flush_c_stdio()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(compact_line(line, detail_path)), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

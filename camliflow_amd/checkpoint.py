@@ -22,14 +22,19 @@ def save_ckpt(model, filepath, last_epoch, best_metrics=None):
     return filepath
 
 
-def load_ckpt(model, filepath, resume=True, map_location='cpu'):
-    """train.py:240-247: strict load; returns (epoch to continue from, best_metrics) -- (0, None) when not resuming."""
-    checkpoint = torch.load(filepath, map_location=map_location, weights_only=False)
+def load_ckpt(model, filepath, resume=True, map_location='cpu', trust_pickle=False):
+    """train.py:240-247: strict load; returns (epoch to continue from, best_metrics).  Not resuming leaves the trainer's
+    initial state untouched, i.e. (1, None): ``curr_epoch`` starts at 1 (train.py:39) and only a resume overwrites it.
+
+    The file is a plain dict of tensors, ints and a metrics dict, so it is read with ``weights_only=True`` -- published
+    checkpoints are untrusted input and a full unpickle executes whatever they contain.  ``trust_pickle=True`` opts into
+    the full unpickler for a file whose ``best_metrics`` holds objects outside that allow-list."""
+    checkpoint = torch.load(filepath, map_location=map_location, weights_only=not trust_pickle)
     module = getattr(model, 'module', model)
     module.load_state_dict(checkpoint['state_dict'], strict=True)
     if resume:
         return checkpoint['last_epoch'] + 1, checkpoint.get('best_metrics')
-    return 0, None
+    return 1, None
 
 
 def _to_namespace(node):

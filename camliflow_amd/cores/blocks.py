@@ -105,7 +105,7 @@ class _PointwiseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        ctx.param = w if (w.is_leaf and w.requires_grad) else None      # identity of the Parameter, for deferral
+        ctx.param = runtime.deferral_target(w)      # identity of the Parameter, for deferral
         nd = x.dim() - 2
         ctx.conv_args = ([1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1)
         return torch.ops.aten.convolution(x, w, None, *ctx.conv_args)
@@ -133,7 +133,7 @@ class _PointwiseConv(torch.autograd.Function):
             gy3, xt3 = gy.flatten(2), x.flatten(2).transpose(1, 2)
             if gy3.dtype != torch.float32:       # fp32 accumulation of the weight gradient
                 gy3, xt3 = gy3.float(), xt3.float()
-            if ctx.param is not None and runtime.deferred_param_grads():
+            if ctx.param is not None:
                 # one [B,Co,Ci] accumulator per parameter and pass, GEMM with beta = 1; summed over the batch and
                 # moved into .grad once, at the end of backward()
                 acc = runtime.PARAM_GRADS.slot(ctx.param, lambda: torch.zeros(gy3.shape[0], gy3.shape[1], xt3.shape[2],

@@ -58,7 +58,7 @@ class CamLiRAFT_Core(nn.Module):
         (a second HIP stream when ``runtime.overlap()`` is on, otherwise a no-op context); the two
         only meet at the CLFM fusion points, where ``to_main`` / ``to_side`` order the streams."""
         b2d, b3d, cfgs = self.branch_2d, self.branch_3d, self.cfgs
-        lanes = runtime.Lanes(image1.device)
+        lanes = runtime.Lanes(image1.device, key=(tuple(image1.shape), tuple(pc1.shape), self.training))
         feat_hw = (image1.shape[-2] // 8, image1.shape[-1] // 8)
 
         lanes.to_side(pc1, pc2)
@@ -196,7 +196,11 @@ class CamLiRAFT(_FreezableBN, FlowModel):
         pc1, pc2 = inputs['pcs'][:, :3], inputs['pcs'][:, 3:]
 
         padder = InputPadder(images.shape, x=8)
-        on_hip = runtime.fused() and images.is_cuda and not inputs['pcs'].requires_grad
+        on_hip = runtime.fused() and images.is_cuda
+        if on_hip and torch.is_grad_enabled() and images.requires_grad:
+            # the kernel has no autograd node: input-gradient uses (saliency, adversarial images) keep the composition
+            runtime.fallback('pad_normalize', 'differentiable input images')
+            on_hip = False
         if on_hip:      # both frames padded + normalised in one pass (camli_pad_normalize)
             from ..csrc import fused
             image1, image2 = fused.pad_normalize(images, padder._pad, _IMAGENET_MEAN, _IMAGENET_STD)

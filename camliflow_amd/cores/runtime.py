@@ -124,7 +124,8 @@ def fallback(op, reason):
 # one buffer per parameter inside their own kernels (GEMM with beta = 1, float atomics) and a
 # callback at the end of backward() moves the totals into .grad.  Opt-in because it bypasses the
 # functional API: torch.autograd.grad(...) would not see these gradients (training loops call
-# .backward()).
+# .backward()).  Parameters that have hooks, and every parameter of a model wrapped in
+# DistributedDataParallel, are excluded automatically (deferral_target).
 # ------------------------------------------------------------------------------------------------
 _DEFER_PARAM_GRADS = False
 
@@ -138,43 +139,70 @@ def deferred_param_grads():
     return _DEFER_PARAM_GRADS
 
 
+def deferral_target(tensor):
+    """The Parameter a fused node may accumulate into, or None.  Called in the node's FORWARD.
+
+    Deferral bypasses the parameter's AccumulateGrad node, so everything hooked onto that node or onto the parameter
+    would be skipped.  DistributedDataParallel is the case that matters: its reducer registers C++ post-hooks on the
+    grad accumulators -- invisible from Python (``param._backward_hooks`` stays None) -- so DDP is recognised by the
+    forward running inside ``DistributedDataParallel.forward`` (``_active_ddp_module``), and Python-level hooks by their
+    dicts.  In all these cases the node returns its gradient to autograd in the ordinary way (correct, just not deferred)."""
+    if not (_DEFER_PARAM_GRADS and tensor.is_leaf and tensor.requires_grad):
+        return None
+    if getattr(tensor, '_backward_hooks', None) or getattr(tensor, '_post_accumulate_grad_hooks', None):
+        return None
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        if getattr(DDP, '_active_ddp_module', None) is not None:
+            return None
+    except ImportError:
+        pass
+    return tensor
+
+
 class _ParamGradSink:
-    """Per-parameter accumulators of one backward pass (see set_deferred_param_grads)."""
+    """Per-parameter accumulators, one table per running backward (graph task): a re-entrant backward (activation
+    checkpointing) has its own table and flush, and does not disturb the outer one."""
+    MAX_TABLES = 4      # tables of backwards that raised are never flushed: the oldest are dropped beyond this
 
     def __init__(self):
-        self.entries = {}
-        self.armed = False
-        self.task = None
+        self.tables = {}        # graph-task id -> {id(param): [param, accumulator, reduce_batch, stream]}
+
+    @property
+    def entries(self):
+        return {k: v for table in self.tables.values() for k, v in table.items()}
+
+    @property
+    def armed(self):
+        return bool(self.tables)
 
     def slot(self, param, make, reduce_batch):
         import torch
-        # tie the sink to the running backward: accumulators that survived a failed backward (its queued
-        # callbacks are skipped when the engine raises) must not leak into the next one
         task = torch._C._current_graph_task_id()
-        if task != self.task:
-            self.entries, self.armed, self.task = {}, False, task
-        if getattr(param, '_backward_hooks', None):
-            raise RuntimeError('deferred parameter gradients bypass AccumulateGrad: a parameter with backward hooks '
-                               '(e.g. under DistributedDataParallel) cannot use them; call '
-                               'runtime.set_deferred_param_grads(False)')
-        entry = self.entries.get(id(param))
+        table = self.tables.get(task)
+        if table is None:
+            table = self.tables[task] = {}
+            torch.autograd.variable.Variable._execution_engine.queue_callback(lambda task=task: self.flush(task))
+            while len(self.tables) > self.MAX_TABLES:       # leftovers of failed backwards (their callbacks never ran)
+                del self.tables[min(self.tables)]
+        entry = table.get(id(param))
         if entry is None:
-            if not self.armed:
-                torch.autograd.variable.Variable._execution_engine.queue_callback(self.flush)
-                self.armed = True
-            entry = self.entries[id(param)] = [param, make(), reduce_batch, None]
-        entry[3] = torch.cuda.current_stream(param.device)
+            entry = table[id(param)] = [param, make(), reduce_batch, None]
+        entry[3] = torch.cuda.current_stream(param.device) if param.is_cuda else None
         return entry[1]
 
-    def flush(self):
+    def flush(self, task):
         import torch
-        entries, self.entries, self.armed, self.task = self.entries, {}, False, None
+        table = self.tables.pop(task, {})
+        for stale in [t for t in self.tables if t > task]:     # nested backwards end before their parent: leftovers
+            del self.tables[stale]
         with torch.no_grad():
-            for param, acc, reduce_batch, stream in entries.values():
-                current = torch.cuda.current_stream(param.device)
-                if stream is not None and stream != current:
-                    current.wait_stream(stream)          # the accumulator was last written on another lane
-                    acc.record_stream(current)
+            for param, acc, reduce_batch, stream in table.values():
+                if stream is not None:
+                    current = torch.cuda.current_stream(param.device)
+                    if stream != current:
+                        current.wait_stream(stream)          # the accumulator was last written on another lane
+                        acc.record_stream(current)
                 grad = (acc.sum(0) if reduce_batch else acc).view_as(param)
                 param.grad = grad if param.grad is None else param.grad + grad
 
@@ -186,19 +214,34 @@ PARAM_GRADS = _ParamGradSink()
 # two-lane execution: point branch on a side HIP stream next to the image branch
 # ------------------------------------------------------------------------------------------------
 _OVERLAP = False
+_PRIME_FIRST_PASS = True
+_PRIMED = set()
 _side_streams = {}
 
 
-def set_overlap(enabled):
+def set_overlap(enabled, prime_first_pass=True):
     """Run the 3-D (point) branch of the fused model on a second HIP stream.  The point kernels are
     small (B*2048 points) and leave most CUs idle; the image branch's convolutions do not depend
-    on them between fusion points, so the two lanes overlap.  Results are unchanged."""
-    global _OVERLAP
+    on them between fusion points, so the two lanes overlap.  Results are unchanged.
+
+    ``prime_first_pass`` (default): the FIRST pass of a process for a given (device, input signature) still runs on
+    one stream -- forward and, because autograd replays a node on the stream of its forward, its backward.  On this
+    ROCm image the first two-lane steps of a process can stall for good (host blocked inside the first backward;
+    always under rocprofv3, on some boxes in half of the plain runs, never once a step of that shape has completed):
+    every first-use event -- code-object loads, MIOpen solver set-up, allocator growth -- then happens while
+    cross-stream waits are in flight.  Priming belongs here, not in a benchmark script, so that EVERY caller of
+    ``set_overlap(True)`` gets it (training loops, tests, bench.py)."""
+    global _OVERLAP, _PRIME_FIRST_PASS
     _OVERLAP = bool(enabled)
+    _PRIME_FIRST_PASS = bool(prime_first_pass)
 
 
 def overlap():
     return _OVERLAP
+
+
+def reset_lane_priming():
+    _PRIMED.clear()
 
 
 def _flatten(items):
@@ -214,9 +257,14 @@ class Lanes:
     ``to_side(...)`` / ``to_main(...)`` order the two streams at a hand-over and tell the caching
     allocator that the handed-over tensors are in use on the other stream."""
 
-    def __init__(self, device):
+    def __init__(self, device, key=None):
         import torch
         self.enabled = _OVERLAP and _BACKEND == 'hip' and device.type == 'cuda'
+        if self.enabled and _PRIME_FIRST_PASS:
+            signature = (device.index, torch.is_grad_enabled(), key)
+            if signature not in _PRIMED:        # first pass of this shape: one lane (see set_overlap)
+                _PRIMED.add(signature)
+                self.enabled = False
         if self.enabled:
             self._torch = torch
             self.main = torch.cuda.current_stream(device)

@@ -417,7 +417,7 @@ class _SkGate(torch.autograd.Function):
                         m.data_ptr(), z.data_ptr(), w.data_ptr(), bs, c, r, _stream_ptr(s),
                         work=(4.0 * (bs * (4 * c + r) + 3 * c * r), 'B'))
         ctx.save_for_backward(s, m, z, w, wmid, wout)
-        ctx.params = [t if (t.is_leaf and t.requires_grad) else None for t in (wmid, wout)]
+        ctx.params = [_runtime.deferral_target(t) for t in (wmid, wout)]
         return w
 
     @staticmethod
@@ -432,7 +432,7 @@ class _SkGate(torch.autograd.Function):
         grads = []
         deferred = []
         for param, like in zip(ctx.params, (wmid, wout)):
-            if param is not None and _runtime.deferred_param_grads():
+            if param is not None:
                 grads.append(_runtime.PARAM_GRADS.slot(param, lambda like=like: torch.zeros_like(like), False))
                 deferred.append(True)
             else:
@@ -1331,7 +1331,7 @@ class _BiasAct(torch.autograd.Function):
         elif act != 0:
             ctx.save_for_backward(x)
         ctx.act, ctx.masked, ctx.dims = act, mask is not None, (b, c, p)
-        ctx.bias_param = bias if (bias.is_leaf and bias.requires_grad) else None
+        ctx.bias_param = _runtime.deferral_target(bias)
         return x
 
     @staticmethod
@@ -1343,7 +1343,7 @@ class _BiasAct(torch.autograd.Function):
         gy = gy.contiguous().float()
         identity = ctx.act == 0
         gx = gy if identity else torch.empty_like(gy)       # identity: the input gradient IS gy, only the bias sums are reduced
-        deferred = ctx.bias_param is not None and _runtime.deferred_param_grads()
+        deferred = ctx.bias_param is not None
         if identity and not (deferred or ctx.needs_input_grad[1]):
             return gx, None, None
         if deferred:      # the kernel's atomics accumulate straight into the parameter's per-pass buffer

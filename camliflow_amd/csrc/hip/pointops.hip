@@ -267,7 +267,19 @@ __global__ __launch_bounds__(256) void corr3d_gather_kernel(const float* __restr
                 io[o + a * plane] = xyz2[((size_t)b * 3 + a) * M + m] - xyz1[((size_t)b * 3 + a) * N + n];
             io[o + 3 * plane] = cost[bn * M + m];
         } else {
-            unsafeAtomicAdd(cost + bn * M + m, io[o + 3 * plane]);
+            // gcost is zero-filled and (b, n) rows belong to one thread group of k: a neighbour index that occurs once
+            // (every row when M >= k) is a plain store.  Duplicates only exist when M < k (the search pads with index
+            // 0): the FIRST occurrence in the row sums all of them in j order -- no atomics, bit-reproducible.
+            const int j = (int)(e - bn * k);
+            const int64_t* __restrict__ row = knn + bn * k;
+            bool first = true;
+            for (int jj = 0; jj < j; ++jj) first = first && ((int)row[jj] != m);
+            if (first) {
+                float acc = io[o + 3 * plane];
+                for (int jj = j + 1; jj < k; ++jj)
+                    if ((int)row[jj] == m) acc += io[o + 3 * plane + (jj - j)];
+                cost[bn * M + m] += acc;
+            }
         }
     }
 }

@@ -298,29 +298,36 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
         }
     }
 
-    // ---- combine the four waves in LDS; the workgroup's partial sums go to its slice of the workspace
-    // (a second kernel adds the slices in a fixed order: no global atomics, deterministic) ----
+    // ---- combine the four waves in LDS in a FIXED order (wave 0, 1, 2, 3 take turns; within a turn every lane owns
+    // its addresses; the two half-wave partials of the bias sums are merged in registers first), then the workgroup's
+    // partial sums go to its slice of the workspace and a second kernel adds the slices in a fixed order: no atomics
+    // anywhere, bit-reproducible (round 2 merged the waves with LDS float atomics, whose order is not) ----
     __syncthreads();
     constexpr int RED_W3 = 32 * MT * WN_LD;      // gw3 rows padded to 33: column 32 = gb3
     constexpr int RED_W2 = RED_W3 + 32 * 9;      // [gw2 | gb2] as [32][9]
     constexpr int RED_ALL = RED_W2 + 8 * 4;      // [gw1 | gb1] as [8][4]
     float* red = &s_t[0][0][0];                  // 4*2*32*33 floats >= RED_ALL
     for (int e = tid; e < RED_ALL; e += 256) red[e] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) gb[t] += __shfl_xor(gb[t], 32, 64);
     __syncthreads();
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+            for (int t = 0; t < MT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(&red[(32 * t + wn_row(r, half)) * WN_LD + cl], gw[t][r]);
-        atomicAdd(&red[(32 * t + cl) * WN_LD + 32], gb[t]);
+                for (int r = 0; r < 16; ++r) red[(32 * t + wn_row(r, half)) * WN_LD + cl] += gw[t][r];
+                if (half == 0) red[(32 * t + cl) * WN_LD + 32] += gb[t];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = wn_row(r, half);
+                if (cl < 9) red[RED_W3 + q * 9 + cl] += gsm[r];
+                if (r < 4 && cl >= 16 && cl < 20) red[RED_W2 + q * 4 + cl - 16] += gsm[r];   // rows 0..7: r in 0..3
+            }
+        }
+        __syncthreads();
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = wn_row(r, half);
-        if (cl < 9) atomicAdd(&red[RED_W3 + q * 9 + cl], gsm[r]);
-        if (r < 4 && cl >= 16 && cl < 20) atomicAdd(&red[RED_W2 + q * 4 + cl - 16], gsm[r]);   // rows 0..7: r in 0..3
-
-    }
-    __syncthreads();
     float* __restrict__ mine = partials + (size_t)blockIdx.x * RED_ALL;
     for (int e = tid; e < RED_ALL; e += 256) mine[e] = red[e];
 }

@@ -1,0 +1,82 @@
+"""bench.py's reporting contract, on CPU: the ONE stdout line stays below the driver's tail (round 2 lost its headline
+because the line had grown to 20 KB), never carries a roofline fraction above 1, and `python bench.py --gpus N`
+launches its own ranks (train.py:307 mp.spawn in the reference) or refuses cleanly."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+
+
+def _full_line():
+    """The full round-2 report (everything bench.py gathered, 20 KB) as the worst-case input."""
+    with open(os.path.join(ROOT, 'profiles', 'r02_bench_line.json')) as f:
+        text = f.read()
+    return json.loads(text[text.index('{'):])
+
+
+def test_compact_line_fits_the_driver_tail():
+    import bench
+    full = _full_line()
+    assert len(json.dumps(full)) > 15000
+    full['config']['lanes'] = 2
+    line = bench.compact_line(full, 'gpurun_out/bench_detail.json')
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT_BYTES
+    for key in bench.CONTRACT_KEYS:
+        assert key in line, key
+    assert line['roofline']['frac'] <= 1.0 and line['roofline']['single_lane']['frac'] <= 1.0
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(line['roofline'])
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(line['cpu_baseline'])
+    assert line['parity']['ok'] is True and line['detail'] == 'gpurun_out/bench_detail.json'
+    assert 'hip_kernels' not in line and 'roofline_rows' not in line and 'census' not in line
+
+
+def test_compact_line_survives_long_free_text():
+    import bench
+    full = _full_line()
+    full['cpu_baseline']['sample'] = 'x' * 5000
+    full['config']['lanes_note'] = 'y' * 3000
+    assert len(json.dumps(bench.compact_line(full, None))) < bench.LINE_LIMIT_BYTES
+
+
+def test_compact_line_rejects_fraction_above_one():
+    import bench
+    full = _full_line()
+    full['roofline']['frac'] = 1.65
+    with pytest.raises(AssertionError):
+        bench.compact_line(full, None)
+
+
+def test_self_launch_refuses_oversubscription(capfd):
+    import bench
+    assert bench.launch_ranks(2, [], device_count=1) == 2
+    assert 'refusing to oversubscribe' in capfd.readouterr().err
+
+
+@pytest.mark.timeout(300)
+def test_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the process launches two ranks, they rendezvous on 127.0.0.1,
+    and exactly one line comes out of rank 0 (the rendezvous-only mode needs no GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--launch-check'],
+                         capture_output=True, text=True, env=env, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec == {'launch_check': True, 'n_gpus': 2, 'rank_sum': 3.0}
+
+
+@pytest.mark.timeout(300)
+def test_cli_refuses_more_ranks_than_gpus():
+    """The command-line path of the refusal: exit code 2, nothing started."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64'], capture_output=True, text=True,
+                         env=env, timeout=280)
+    assert out.returncode == 2 and 'refusing to oversubscribe' in out.stderr

@@ -23,7 +23,7 @@ def test_save_and_resume_round_trip(tmp_path):
     assert epoch == 8 and best == {'epe2d': 1.5}
     for (n1, p1), (n2, p2) in zip(model.state_dict().items(), other.state_dict().items()):
         assert n1 == n2 and torch.equal(p1, p2)
-    assert checkpoint.load_ckpt(other, path, resume=False) == (0, None)
+    assert checkpoint.load_ckpt(other, path, resume=False) == (1, None)      # train.py:39: curr_epoch starts at 1
     bad = dict(raw, state_dict={k: v for k, v in list(raw['state_dict'].items())[1:]})
     torch.save(bad, str(tmp_path / 'bad.pt'))
     with pytest.raises(RuntimeError):                                                # strict, like the reference

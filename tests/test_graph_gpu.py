@@ -37,18 +37,15 @@ def _run(graphed, n_steps, warmup):
         runtime.set_deferred_param_grads(True)
         runtime.set_overlap(True)
         try:
-            # both runs start with ONE single-stream priming step, as bench.py does (two-lane start-up dead-lock, DESIGN
-            # section 8); the graphed run takes it inside GraphedStep, on the side stream the capture will use
+            # both runs start with ONE one-lane priming step: runtime.Lanes runs the first pass of a process on one stream
+            # (two-lane start-up stall); GraphedStep takes it on the side stream its capture will use
+            runtime.reset_lane_priming()
             if graphed:
-                g = bench.GraphedStep(step, warmup=warmup, prime=True)      # prime + `warmup` eager steps, then the capture
+                g = bench.GraphedStep(step, warmup=warmup)      # priming + `warmup` eager steps, then the capture
                 for _ in range(n_steps - warmup):
                     loss = g()
             else:
-                runtime.set_overlap(False)
-                step()
-                torch.cuda.synchronize()
-                runtime.set_overlap(True)
-                for _ in range(n_steps):
+                for _ in range(n_steps + 1):
                     loss = step()
             torch.cuda.synchronize()
         finally:
