@@ -111,6 +111,31 @@ def test_fps_all_points_identical(ops, oracle_lib):
     assert np.array_equal(got, oracle_lib.fps(xyz, 10))
 
 
+PRUNED_CASES = [(2, 8192, 8191), (1, 16384, 2048), (3, 4100, 4096), (2, 1024, 1023), (1, 65, 64), (1, 64, 63), (1, 7, 6), (1, 2, 1),
+                (4, 777, 300)]
+
+
+@pytest.mark.parametrize('variant', ['p16', 'p32', 'p8t1024', 'p16t1024'])
+@pytest.mark.parametrize('kind', ['uniform', 'dup', 'lattice', 'plane'])
+def test_fps_bucket_pruned_variants_bit_exact(variant, kind, ops, oracle_lib, monkeypatch):
+    """The bucket-pruned kernel (round 3: Morton-sorted buckets, exact box test) in every register / thread shape, forced
+    through CAMLI_FPS on clouds its default dispatch would not see: tiny, ragged, all but one point picked (the wrapper requires n_samples < N like wrapper.py:98), many exact
+    ties (lattice: lowest ORIGINAL index must win although the points are permuted) and a degenerate planar cloud."""
+    monkeypatch.setenv('CAMLI_FPS', variant)
+    cap = {'p16': 16 * 512, 'p32': 32 * 512, 'p8t1024': 8 * 1024, 'p16t1024': 16 * 1024}[variant]
+    for case in PRUNED_CASES:
+        b, n, ns = case
+        if n > cap or (kind == 'lattice' and n > 4100):
+            continue
+        rng = np.random.default_rng(hash((case, kind)) % (2 ** 32))
+        xyz = _cloud(rng, b, n, 3, 'uniform' if kind == 'plane' else kind)
+        if kind == 'plane':
+            xyz[:, :, 2] = 3.0
+        got = ops.furthest_point_sampling(dev(xyz), ns).cpu().numpy()
+        want = oracle_lib.fps(xyz, ns)
+        assert np.array_equal(got, want), (case, 'first mismatch at %s' % (np.argwhere(got != want)[:1],))
+
+
 CORR_CASES = [(2, 32, 24, 40, 4), (1, 64, 18, 30, 4), (1, 96, 36, 60, 4), (1, 128, 18, 30, 4), (1, 192, 9, 15, 4),
               (2, 20, 7, 70, 3), (1, 300, 5, 9, 2), (1, 8, 5, 6, 1), (1, 16, 6, 6, 5)]
 
