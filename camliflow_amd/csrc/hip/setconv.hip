@@ -18,6 +18,7 @@
 #include "camli_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -216,6 +217,120 @@ __global__ __launch_bounds__(256) void pointconv_dw_fwd_tiled_kernel(const float
     }
 }
 
+// Forward, shared-row form (round 3).  The tiled kernel above gives every 64-point tile its own workgroup, so the
+// feature row of a channel ([M] floats) is staged once per TILE: at N = M = 2048 that is 32 L2 reads of every row,
+// 268 MB of L2 -> LDS traffic next to the 134 MB weight stream the kernel exists for (k = 16; PMC: 1.37x the
+// algorithmic HBM bytes, and the L2 path busier than HBM).  Here a workgroup is NWV waves = NWV consecutive tiles of
+// the SAME batch element walking the SAME channel slice in step: the row of the current channel is staged ONCE per
+// workgroup into a double-buffered LDS row (one barrier per channel), every wave gathers from it, and each wave still
+// streams its own [64 x K] weight chunk through a wave-private LDS transposition with the next channel's chunk and
+// row already in flight in registers.  Row traffic drops by NWV (8x), the index rows are read once per channel slice.
+// grid (ceil(N / (64*NWV)), B, CS), block 64*NWV.  dynamic LDS: NWV * 64 * (K+4) floats + 2 * M floats.
+template <int K, int NWV, int RVT>
+__global__ __launch_bounds__(64 * NWV) void pointconv_dw_fwd_shared_kernel(const float* __restrict__ feat,
+                                                                           const float* __restrict__ weight,
+                                                                           const int64_t* __restrict__ idx, int idx_stride,
+                                                                           float* __restrict__ out,
+                                                                           unsigned char* __restrict__ arg,
+                                                                           float* __restrict__ wsel, int* __restrict__ msel,
+                                                                           int C, int M, int N) {
+    constexpr int T = 64 * NWV;
+    constexpr int LD = K + 4;
+    constexpr int V = K / 4;                  // float4 per weight row; RVT = float4 row loads per thread: M <= 4 * RVT * T
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int b = blockIdx.y;
+    const int n0 = (blockIdx.x * NWV + w) * 64;
+    const int n = n0 + lane;
+    const bool valid = n < N;
+    float* tile = lds + w * (64 * LD);
+    float* rows = lds + NWV * (64 * LD);      // [2][M]
+    const int m4 = M >> 2;
+
+    int m[K];
+    {
+        const int64_t* __restrict__ irow = idx + ((size_t)b * N + (valid ? n : N - 1)) * idx_stride;
+#pragma unroll
+        for (int j = 0; j < K; ++j) m[j] = (int)irow[j];
+    }
+    const int rows_here = n0 < N ? min(64, N - n0) : 0;
+    const int chunk = rows_here * K;
+
+    float4 stage[V];
+    float4 rstage[RVT];
+    auto issue = [&](int c, float4 (&stage)[V], float4 (&rstage)[RVT]) {
+        const float* __restrict__ src = weight + (((size_t)b * C + c) * N + n0) * K;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int e = (v * 64 + lane) * 4;
+            stage[v] = e < chunk ? *reinterpret_cast<const float4*>(src + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4* __restrict__ rsrc = reinterpret_cast<const float4*>(feat + ((size_t)b * C + c) * M);
+#pragma unroll
+        for (int v = 0; v < RVT; ++v) {
+            const int e = v * T + tid;
+            rstage[v] = e < m4 ? rsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto park = [&](float* rowbuf, const float4 (&stage)[V], const float4 (&rstage)[RVT]) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int e = (v * 64 + lane) * 4;
+            const int r = e / K, col = e - r * K;
+            *reinterpret_cast<float4*>(tile + r * LD + col) = stage[v];
+        }
+#pragma unroll
+        for (int v = 0; v < RVT; ++v) {
+            const int e = v * T + tid;
+            if (e < m4) *reinterpret_cast<float4*>(rowbuf + e * 4) = rstage[v];
+        }
+    };
+
+    // One register stage.  Measured (tools/kernel_bench.py, C128 k16): a second stage (two chunks in flight per wave) was
+    // SLOWER, 54 vs 48 us -- its VGPRs halve the resident workgroups, the bytes in flight per CU stay the same; and with
+    // the gathers and all stores compiled out the pipeline still takes 43 us, i.e. what bounds the kernel is the
+    // load -> LDS transposition -> compute chain of the <= 16 waves a CU holds, not the gathers or the stores.
+    const int cstep = gridDim.z;
+    int cur = 0;
+    int c = blockIdx.z;
+    if (c < C) issue(c, stage, rstage);
+    for (; c < C; c += cstep) {
+        float* rowbuf = rows + cur * M;
+        park(rowbuf, stage, rstage);
+        if (c + cstep < C) issue(c + cstep, stage, rstage);
+        __syncthreads();      // the row of channel c is complete; the other buffer is free again after this barrier
+        float best = -INFINITY;
+        int barg = 0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float4 w4 = *reinterpret_cast<const float4*>(tile + lane * LD + v * 4);
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float p = rowbuf[m[v * 4 + t]] * wv[t];
+                const bool gt = p > best;
+                best = gt ? p : best;
+                barg = gt ? v * 4 + t : barg;
+            }
+        }
+        if (valid) {
+            const size_t o = ((size_t)b * C + c) * N + n;
+            out[o] = best;
+            arg[o] = (unsigned char)barg;
+            if (wsel) {
+                wsel[o] = tile[lane * LD + barg];
+                int ms = m[0];
+#pragma unroll
+                for (int j = 1; j < K; ++j) ms = (barg == j) ? m[j] : ms;
+                msel[o] = ms;
+            }
+        }
+        cur ^= 1;
+    }
+}
+
 // Adjoint, row form.  One workgroup owns one (b, c) row: the feature row and the row of its
 // gradient live in LDS (2*M floats), the scatter is an LDS float atomic, and the finished gradient
 // row is written once -- no global atomics, no zero-fill of gfeat.
@@ -339,6 +454,42 @@ extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, co
     const bool row_ok = M <= 4096 && (M % 4) == 0 && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0);
     const bool rowlds = row_ok && (rowlds_env >= 0 ? rowlds_env != 0 : k >= 16);
     const int cs = cs_env > 0 ? cs_env : ((k <= 16 && C >= 32) ? 2 : 1);
+    // shared-row form: 8 tiles per workgroup share the staged feature row (see the kernel).  Channel slices so that the
+    // launch has >= 512 workgroups; CAMLI_DW_FWD=tiled keeps the per-tile kernel (A/B runs).
+    static const bool shared_off = [] { const char* e = getenv("CAMLI_DW_FWD"); return e && !strcmp(e, "tiled"); }();
+    if (!shared_off && (M % 4) == 0 && M <= 16 * 512 && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) &&
+        (k == 4 || k == 8 || k == 16 || k == 32)) {
+        constexpr int NWV = 8;
+        const int tiles = camli_divup(N, 64 * NWV);
+        int slices = cs_env > 0 ? cs_env : camli_divup(512, tiles * B);
+        slices = slices < 1 ? 1 : (slices > C ? C : slices);
+        if (slices > 65535) slices = 65535;
+        const size_t bytes = ((size_t)NWV * 64 * (k + 4) + 2 * (size_t)M) * sizeof(float);
+#define CAMLI_DW_SHARED(KK, RV)                                                                                       \
+    {                                                                                                                 \
+        static size_t attr_bytes = 0;                                                                                 \
+        if (bytes > attr_bytes) {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pointconv_dw_fwd_shared_kernel<KK, NWV, RV>),    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                        \
+            attr_bytes = bytes;                                                                                       \
+        }                                                                                                             \
+        hipLaunchKernelGGL((pointconv_dw_fwd_shared_kernel<KK, NWV, RV>), dim3(tiles, B, slices), dim3(64 * NWV),     \
+                           bytes, s, feat, weight, idx, idx_stride, out, arg, wsel, msel, C, M, N);                   \
+        return camli_check_launch("camli_pointconv_dw_fwd");                                                          \
+    }
+#define CAMLI_DW_SHARED_K(KK)                   \
+    if (M <= 2048) CAMLI_DW_SHARED(KK, 1)       \
+    if (M <= 4096) CAMLI_DW_SHARED(KK, 2)       \
+    CAMLI_DW_SHARED(KK, 4)
+        switch (k) {
+            case 4: CAMLI_DW_SHARED_K(4);
+            case 8: CAMLI_DW_SHARED_K(8);
+            case 16: CAMLI_DW_SHARED_K(16);
+            default: CAMLI_DW_SHARED_K(32);
+        }
+#undef CAMLI_DW_SHARED_K
+#undef CAMLI_DW_SHARED
+    }
     switch (k) {
         case 4: CAMLI_DW_TILED(4);
         case 8: CAMLI_DW_TILED(8);

@@ -8,7 +8,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize('case', [(2, 128, 2048, 2048, 16, 32), (1, 125, 2048, 2048, 16, 32), (3, 32, 500, 300, 32, 32),
-                                  (2, 128, 2048, 2048, 4, 32), (1, 7, 100, 77, 5, 9), (1, 16, 64, 64, 16, 16)],
+                                  (2, 128, 2048, 2048, 4, 32), (1, 7, 100, 77, 5, 9), (1, 16, 64, 64, 16, 16),
+                                  # shared-row kernel: partial last workgroup / tile, M > 2048 and > 4096 row loads, odd M falls back
+                                  (2, 20, 4100, 1100, 8, 8), (1, 9, 8192, 700, 16, 16), (1, 12, 2047, 513, 32, 32), (2, 5, 4096, 65, 4, 4)],
                          ids=lambda c: 'B%d_C%d_M%d_N%d_k%d_kk%d' % c)
 def test_core_fwd_bwd_vs_oracle(case, oracle_lib):
     from camliflow_amd.csrc import fused
