@@ -187,6 +187,43 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int l
     }
 }
 
+// Merge of two ascending k-lists into the k smallest of their union, as a bitonic network (round 3; the serial form
+// inserted the other list's entries one by one: 16 x 80 dependent VALU ops per merged list, on ONE wave while the
+// others had already retired -- the tail was ~1/3 of a split search).  `dist/idx` = the list of the EARLIER candidate
+// range, `od/oi` the later one.  Half-cleaner against the reversed second list keeps the k smaller of each pair (a tie
+// keeps the earlier range's entry), then log2(k) compare-exchange stages order them by (distance, index) -- the order
+// sequential insertion produces for entries that stay inside the list.  Every dropped distance goes into ev_min: a
+// dropped candidate that ties the final k-th distance is the one case where the in-order result can differ, and it is
+// detected from ev_min == dist[K-1] exactly as before.  K must be a power of two.
+template <int K>
+__device__ __forceinline__ void merge_topk(float (&dist)[K], int (&idx)[K], const float (&od)[K], const int (&oi)[K],
+                                           float& ev_min) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        const float bd = od[K - 1 - i];
+        const int bi = oi[K - 1 - i];
+        const bool take = bd < dist[i];
+        ev_min = fminf(ev_min, take ? dist[i] : bd);
+        dist[i] = take ? bd : dist[i];
+        idx[i] = take ? bi : idx[i];
+    }
+#pragma unroll
+    for (int s = K / 2; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            if ((i & s) == 0) {
+                const float a = dist[i], b = dist[i + s];
+                const int ai = idx[i], bi = idx[i + s];
+                const bool sw = (b < a) || (b == a && bi < ai);
+                dist[i] = sw ? b : a;
+                dist[i + s] = sw ? a : b;
+                idx[i] = sw ? bi : ai;
+                idx[i + s] = sw ? ai : bi;
+            }
+        }
+    }
+}
+
 // grid (ceil(Nq/64), B); block 64*NW threads.  LDS (dynamic):
 //   queue region : 2 * QBUF * 64*NW dwords            (K >= 8 only)
 //   merge region : NW * K * 64 * 2 dwords + NW*64     (NW > 1 only)   -- the two regions alias
@@ -235,6 +272,34 @@ __global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_ke
         float* md = smem;                                          // [NW][K][64]
         int* mi = reinterpret_cast<int*>(smem) + NW * K * 64;      // [NW][K][64]
         float* mev = smem + 2 * NW * K * 64;                       // [NW][64]
+        if (K >= 4 && (K & (K - 1)) == 0) {
+            // binary tree over the waves (NW is a power of two): round `step` merges list w + step into list w for
+            // every w that is a multiple of 2*step -- log2(NW) bitonic merges on the critical path instead of NW - 1
+            // serial ones.  The ranges stay in candidate order (w's range precedes w + step's).
+            for (int step = 1; step < NW; step <<= 1) {
+                if ((w & (2 * step - 1)) == step) {        // this wave's list is consumed in this round
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        md[(w * K + j) * 64 + lane] = dist[j];
+                        mi[(w * K + j) * 64 + lane] = idx[j];
+                    }
+                    mev[w * 64 + lane] = ev_min;
+                }
+                __syncthreads();
+                if ((w & (2 * step - 1)) == 0 && w + step < NW) {
+                    float od[K];
+                    int oi[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        od[j] = md[((w + step) * K + j) * 64 + lane];
+                        oi[j] = mi[((w + step) * K + j) * 64 + lane];
+                    }
+                    ev_min = fminf(ev_min, mev[(w + step) * 64 + lane]);
+                    merge_topk<K>(dist, idx, od, oi, ev_min);
+                }
+            }
+            if (w > 0) return;
+        } else {
         if (w > 0) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -261,6 +326,7 @@ __global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_ke
                     }
                 }
             }
+        }
         }
         if (K > 1) {
             // a candidate tying the final k-th distance was dropped somewhere: the merged list
@@ -351,36 +417,16 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
     float* md = smem;                                          // [NW][K][64]
     int* mi = reinterpret_cast<int*>(smem) + NW * K * 64;      // [NW][K][64]
     float* mev = smem + 2 * NW * K * 64;                       // [NW][64]
-    if (w > 0) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            md[(w * K + j) * 64 + lane] = dist[j];
-            mi[(w * K + j) * 64 + lane] = idx[j];
-        }
-        mev[w * 64 + lane] = ev_min;
-    }
-    __syncthreads();
-    if (w > 0) return;
     float* rqd = smem + 2 * NW * K * 64 + NW * 64 + lane;      // wave 0's private queue for the redo scans
     int* rqi = reinterpret_cast<int*>(rqd) + QBUF * 64;
-    for (int s = 0; s < NW; ++s) {
-        if (s > 0) {
-            ev_min = fminf(ev_min, mev[s * 64 + lane]);
-            for (int j = 0; j < K; ++j) {
-                float d = md[(s * K + j) * 64 + lane];
-                int c = mi[(s * K + j) * 64 + lane];
-                bool acc = !(d > dist[K - 1]);
-                if (!__ballot(acc)) break;
-                if (acc) list_insert<K>(dist, idx, d, c, ev_min);
-            }
-        }
-        const int covered = (s + 1) * chunk;
+    // snapshot of the merged prefix of `covered` candidates into every level of that size (wave 0 only)
+    auto emit = [&](int covered, bool merged) {
         for (int l = 0; l < po.levels; ++l) {
             if (po.size[l] != covered) continue;            // wave-uniform
             int oidx[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) oidx[j] = idx[j];
-            const bool redo = (s > 0) && (ev_min == dist[K - 1]);
+            const bool redo = merged && (ev_min == dist[K - 1]);
             if (__ballot(redo)) {
                 if (redo) {
                     float rd[K];
@@ -399,6 +445,63 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
                 for (int j = 0; j < K; ++j) o[j] = (int64_t)oidx[j];
             }
         }
+    };
+    // binary tree when the wave count and every level size (in chunks) are powers of two -- the FPS pyramids are
+    // (2048, 1024, 512, 256): the merged prefix after round r covers 2^(r+1) chunks, which is where the snapshots fall
+    bool tree = (NW & (NW - 1)) == 0;
+    for (int l = 0; l < po.levels; ++l) {
+        const int sl = po.size[l] / chunk;
+        tree = tree && (sl & (sl - 1)) == 0;
+    }
+    if (tree) {
+        if (w == 0) emit(chunk, false);
+        for (int step = 1; step < NW; step <<= 1) {
+            if ((w & (2 * step - 1)) == step) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    md[(w * K + j) * 64 + lane] = dist[j];
+                    mi[(w * K + j) * 64 + lane] = idx[j];
+                }
+                mev[w * 64 + lane] = ev_min;
+            }
+            __syncthreads();
+            if ((w & (2 * step - 1)) == 0 && w + step < NW) {
+                float od[K];
+                int oi[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    od[j] = md[((w + step) * K + j) * 64 + lane];
+                    oi[j] = mi[((w + step) * K + j) * 64 + lane];
+                }
+                ev_min = fminf(ev_min, mev[(w + step) * 64 + lane]);
+                merge_topk<K>(dist, idx, od, oi, ev_min);
+            }
+            if (w == 0) emit(2 * step * chunk, true);
+        }
+        return;
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            md[(w * K + j) * 64 + lane] = dist[j];
+            mi[(w * K + j) * 64 + lane] = idx[j];
+        }
+        mev[w * 64 + lane] = ev_min;
+    }
+    __syncthreads();
+    if (w > 0) return;
+    for (int s = 0; s < NW; ++s) {
+        if (s > 0) {
+            ev_min = fminf(ev_min, mev[s * 64 + lane]);
+            for (int j = 0; j < K; ++j) {
+                float d = md[(s * K + j) * 64 + lane];
+                int c = mi[(s * K + j) * 64 + lane];
+                bool acc = !(d > dist[K - 1]);
+                if (!__ballot(acc)) break;
+                if (acc) list_insert<K>(dist, idx, d, c, ev_min);
+            }
+        }
+        emit((s + 1) * chunk, s > 0);
     }
 }
 
