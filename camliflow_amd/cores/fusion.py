@@ -143,10 +143,10 @@ class SKFusion(nn.Module):
             w_mid, w_out = self.fc_mid[0].weight, self.fc_out[0].weight
             if not runtime.atomics_ok('sk_gate'):
                 weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
-            elif w_mid.shape[1] <= 512 and w_mid.shape[0] <= 256:
+            elif w_mid.shape[1] <= 1024 and w_mid.shape[0] <= 512:
                 weight = fused.sk_gate(squeezed, w_mid, w_out)           # the whole gate in one launch each way
             else:
-                runtime.fallback('sk_gate', 'C=%d R=%d outside the gate kernel (C<=512, R<=256)' % (w_mid.shape[1], w_mid.shape[0]))
+                runtime.fallback('sk_gate', 'C=%d R=%d outside the gate kernel (C<=1024, R<=512)' % (w_mid.shape[1], w_mid.shape[0]))
                 weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
             return fused.sk_mix(feat_2d, feat_3d, weight, state)
         squeezed = self.avg_pool(feat_2d + feat_3d).reshape(bs, -1)

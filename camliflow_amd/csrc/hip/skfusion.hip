@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void sk_mix_bwd_x_kernel(const float* __restri
 // ---- the gate: w = softmax_pairs(sigmoid(relu(s Wmid^T) Wout^T)) on [B,C] vectors (clfm.py:183-184,
 // 199-203: two bias-free Linear layers, ReLU, Sigmoid, reshape [B,C,2], softmax over the pair).  In torch
 // this is ~5 launches forward and ~9 backward per SKFusion call, all on kilobyte-sized tensors. ----
-constexpr int SKG_MAXC = 512, SKG_MAXR = 256;
+constexpr int SKG_MAXC = 1024, SKG_MAXR = 512;   // CamLiPWC fuses a 627-channel correlation feature (clfm.py:171-214 at configs[1])
 
 // grid B, block 256
 __global__ __launch_bounds__(256) void sk_gate_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wmid,

@@ -125,3 +125,29 @@ def grad_fingerprint(model, every=7):
     import numpy as np
     named = [(n, p) for n, p in model.named_parameters() if p.grad is not None][::every]
     return [n for n, _ in named], np.array([p.grad.double().norm().item() for _, p in named])
+
+
+def share_clouds(monkeypatch, pc1=None, pc2=None, rel_tol=1e-4):
+    """Make ``build_pc_pyramid`` of every core module receive given post-IDS clouds on the GPU instead of the ones the
+    GPU transform produced: FPS is only reproducible on bit-identical inputs, the IDS transform's log / divide differ
+    in the last ulp between CPU and GPU.  The clouds are either passed in (reference-recorded) or RECORDED from the
+    first CPU call that passes through (the CPU port's run).  The GPU's own clouds must agree with them to rounding."""
+    import importlib
+    state = {'pc1': pc1, 'pc2': pc2}
+    for name in ('camlipwc', 'camliraft', 'raft3d', 'pwc3d'):
+        mod = importlib.import_module('camliflow_amd.cores.' + name)
+        if not hasattr(mod, 'build_pc_pyramid'):
+            continue
+        original = mod.build_pc_pyramid
+
+        def shared(_pc1, _pc2, *args, _orig=original, **kwargs):
+            if not _pc1.is_cuda:          # the CPU port's own call: untouched, remembered
+                if state['pc1'] is None:
+                    state['pc1'], state['pc2'] = _pc1.detach().clone(), _pc2.detach().clone()
+                return _orig(_pc1, _pc2, *args, **kwargs)
+            assert state['pc1'] is not None and _pc1.shape == state['pc1'].shape
+            ref1, ref2 = state['pc1'].cuda(), state['pc2'].cuda()
+            assert (_pc1 - ref1).abs().max().item() <= rel_tol * max(1.0, ref1.abs().max().item())
+            return _orig(ref1, ref2, *args, **kwargs)
+        monkeypatch.setattr(mod, 'build_pc_pyramid', shared)
+    return state

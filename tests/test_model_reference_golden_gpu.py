@@ -1,0 +1,69 @@
+"""GPU <-> reference in ONE hop (parity chain): every model family on the MI355X under the 'hip' backend
+against the flows, losses and gradient fingerprints RECORDED FROM THE REFERENCE'S OWN MODEL CODE
+(tests/golden/model_*.npz, tests/golden/make_model_golden.py).  The clouds the reference handed to build_pc_pyramid --
+after its IDS transform, recorded in model_*_core_inputs.npz -- are fed to the HIP cores bit-for-bit: FPS is a chain of
+thousands of arg-max decisions and only reproducible on identical inputs, while the IDS transform's log / divide differ
+in the last ulp between CPU and GPU.  Tolerances: EPE <= 1e-4 (north star), loss 1e-4 relative, gradient norms 5e-3
+relative (float atomics in a few adjoints)."""
+import numpy as np
+import pytest
+import torch
+
+from modelutils import MODEL_CASES, grad_fingerprint, hashed_fill_, synthetic_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _share_reference_clouds(monkeypatch, core_inputs):
+    """build_pc_pyramid of every core module receives the reference's recorded clouds instead of the GPU's own."""
+    if core_inputs is None or 'pyr_pc1' not in core_inputs.files:
+        return
+    from modelutils import share_clouds
+    share_clouds(monkeypatch, torch.from_numpy(core_inputs['pyr_pc1']), torch.from_numpy(core_inputs['pyr_pc2']))
+
+
+@pytest.mark.parametrize('name', sorted(MODEL_CASES))
+def test_hip_model_matches_reference_recording(name, golden, monkeypatch):
+    import os
+    import camliflow_amd.cores as cores
+    from camliflow_amd.cores import runtime
+    from conftest import GOLDEN_DIR
+    g = golden('model_' + name)
+    path = os.path.join(GOLDEN_DIR, 'model_%s_core_inputs.npz' % name)
+    core_inputs = np.load(path) if os.path.exists(path) else None
+    _, cls, cfg_fn, shape = MODEL_CASES[name]
+    torch.manual_seed(0)
+    model = hashed_fill_(getattr(cores, cls)(cfg_fn()), scale=0.5).cuda()
+    inputs = {k: v.cuda() for k, v in synthetic_inputs(*shape).items()}
+    _share_reference_clouds(monkeypatch, core_inputs)
+    if core_inputs is not None and 'arg0' in core_inputs.files and hasattr(model, 'core'):
+        recorded = {int(k[3:]): torch.from_numpy(core_inputs[k]).cuda() for k in core_inputs.files if k.startswith('arg')}
+
+        def substitute(_mod, args):      # the reference's own padded + normalised images (and clouds) into the core
+            return tuple(recorded.get(i, a) for i, a in enumerate(args))
+        model.core.register_forward_pre_hook(substitute)
+    with runtime.use_backend('hip'):
+        runtime.set_census(True)
+        runtime.reset_census()
+        try:
+            for mode in ('eval', 'train'):
+                getattr(model, mode)()
+                model.zero_grad()
+                res = model(inputs)
+                loss = model.get_loss()
+                for k, v in res.items():
+                    want = g['%s_%s' % (mode, k)]
+                    epe = np.linalg.norm(v.detach().cpu().numpy() - want, axis=1).mean()
+                    assert epe <= 1e-4, (mode, k, epe)
+                ref_loss = float(g['%s_loss' % mode])
+                assert abs(loss.item() - ref_loss) <= 1e-4 * max(1.0, abs(ref_loss)), (mode, loss.item(), ref_loss)
+                if mode == 'train':
+                    loss.backward()
+                    names, norms = grad_fingerprint(model)
+                    assert names == list(g['grad_names'])
+                    assert np.allclose(norms, g['grad_norms'], rtol=5e-3, atol=1e-6), np.abs(norms / g['grad_norms'] - 1).max()
+        finally:
+            census = runtime.census()
+            runtime.set_census(False)
+    assert sum(census['fused'].values()) > 0, 'nothing ran on HIP'
+    print(name, 'fused launches', sum(census['fused'].values()), 'composed', census['composed'])

@@ -65,7 +65,7 @@ def test_skfusion_module_hip_vs_composed(fmt):
         assert (u - v).norm() <= 2e-4 * v.norm() + 1e-6, ((u - v).norm() / v.norm()).item()
 
 
-@pytest.mark.parametrize('dims', [(8, 128, 64), (3, 20, 7), (1, 256, 128), (8, 324, 162), (2, 512, 256)],
+@pytest.mark.parametrize('dims', [(8, 128, 64), (3, 20, 7), (1, 256, 128), (8, 324, 162), (2, 512, 256), (1, 627, 313), (2, 1024, 512)],
                          ids=lambda d: 'B%d_C%d_R%d' % d)
 def test_gate_vs_torch(dims):
     from camliflow_amd.csrc import fused
