@@ -154,6 +154,9 @@ def conv_bias_act(conv, x, act):
     """``act(conv(x))`` with the bias add, the activation and (backward) the bias-gradient reduction
     fused into one pass over the convolution output (camli_bias_act_fwd/bwd)."""
     from ..csrc import fused
+    if act is None and fused.conv3x3_co2_supported(conv, x):
+        # a flow head's last convolution (wide map -> 2 channels): own HBM-bound kernels, bias included
+        return fused.conv3x3_co2(x, conv.weight, conv.bias)
     if _is_pointwise(conv) and x.dtype == torch.float32 and x.is_contiguous():
         y = _PointwiseConv.apply(x, conv.weight)
     else:
@@ -163,6 +166,16 @@ def conv_bias_act(conv, x, act):
     if conv.bias is None:
         return y if act is None else fused.bias_act(y, torch.zeros(y.shape[1], device=y.device), act)
     return fused.bias_act(y, conv.bias, act)
+
+
+def flow_conv(conv, x):
+    """A bare ``nn.Conv2d`` that ends a flow head (wide map -> 2 channels, pwc_core.py / raft_core.py:169-181): on the
+    product path the two-channel 3x3 kernels of csrc/hip/smallconv.hip, otherwise the module itself."""
+    if runtime.fused() and x.is_cuda:
+        from ..csrc import fused
+        if fused.conv3x3_co2_supported(conv, x):
+            return fused.conv3x3_co2(x, conv.weight, conv.bias)
+    return conv(x)
 
 
 class Conv1dNormRelu(_ConvNormAct):

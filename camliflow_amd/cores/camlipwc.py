@@ -6,7 +6,7 @@ import torch.nn as nn
 from torch.nn.functional import interpolate, leaky_relu
 
 from ..csrc import wrapper as _ops
-from .blocks import Conv1dNormRelu, Conv2dNormRelu
+from .blocks import Conv1dNormRelu, Conv2dNormRelu, flow_conv
 from .camliraft import _FreezableBN, _camera_pair
 from .fusion import CLFM
 from .geometry import (InputPadder, backwarp_2d, backwarp_3d, build_pc_pyramid, flows_paral2persp, knn_interpolation,
@@ -69,10 +69,7 @@ class CamLiPWC_Core(nn.Module):
 
     @staticmethod
     def _project(xyz, camera_info, image_h, image_w):
-        uv = project_pc2image(xyz, camera_info)
-        uv[:, 0] *= (image_w - 1) / (camera_info['sensor_w'] - 1)
-        uv[:, 1] *= (image_h - 1) / (camera_info['sensor_h'] - 1)
-        return uv
+        return project_pc2image(xyz, camera_info, grid_hw=(image_h, image_w))
 
     def decode(self, xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, camera_info):
         assert len(xyzs1) == len(xyzs2) == len(feats1_2d) == len(feats2_2d) == len(feats1_3d) == len(feats2_3d)
@@ -121,7 +118,7 @@ class CamLiPWC_Core(nn.Module):
                 flow_feat_2d = self.branch_2d_flow_estimator(x_2d)
                 flow_feat_3d = self.branch_3d_flow_estimator(xyz1, x_3d, knn_xyz1)
                 flow_feat_2d, flow_feat_3d = self.estimator_clfm(uv1, flow_feat_2d, flow_feat_3d)
-                flow_delta_2d = self.branch_2d_conv_last(flow_feat_2d)
+                flow_delta_2d = flow_conv(self.branch_2d_conv_last, flow_feat_2d)
                 flow_delta_3d = self.branch_3d_conv_last(flow_feat_3d)
             else:
                 flow_feat_2d, flow_delta_2d = self.branch_2d_flow_estimator(x_2d)

@@ -43,10 +43,7 @@ class CamLiRAFT_Core(nn.Module):
             self.clfm_hidden = CLFM(128, 128)
 
     def _project_to_feature_grid(self, xyz, camera_info, feat_hw):
-        uv = project_pc2image(xyz, camera_info)
-        uv[:, 0] *= (feat_hw[1] - 1) / (camera_info['sensor_w'] - 1)
-        uv[:, 1] *= (feat_hw[0] - 1) / (camera_info['sensor_h'] - 1)
-        return uv
+        return project_pc2image(xyz, camera_info, grid_hw=feat_hw)
 
     def forward(self, image1, image2, pc1, pc2, camera_info):
         with pass_cache():   # iteration-invariant set-conv weights live for exactly one pass

@@ -224,15 +224,29 @@ def resize_to_64x(inputs, target, x=64):
     return inputs, target
 
 
-def project_pc2image(pc, camera_info):
-    """[B,3,N] -> pixel coordinates [B,2,N] under a perspective or parallel camera (utils.py:234-259)."""
+def project_pc2image(pc, camera_info, grid_hw=None):
+    """[B,3,N] -> pixel coordinates [B,2,N] under a perspective or parallel camera (utils.py:234-259).
+    ``grid_hw`` = (h, w): additionally rescale to a feature grid of that size, uv * (grid - 1) / (sensor - 1), as every
+    caller in the cores does right after the projection (camliraft_core.py:51-56, camlipwc_core.py:112-114); on the
+    product path both steps are one launch (camli_project_pc2image)."""
     assert pc.shape[1] == 3
+    scale = (1.0, 1.0)
+    if grid_hw is not None:
+        scale = ((grid_hw[1] - 1) / (camera_info['sensor_w'] - 1), (grid_hw[0] - 1) / (camera_info['sensor_h'] - 1))
+    mode = camera_info['projection_mode']
+    if runtime.fused() and pc.is_cuda and mode in ('perspective', 'parallel'):
+        scalar_camera = not any(isinstance(camera_info[k], torch.Tensor) for k in ('cx', 'cy'))
+        tensor_camera = all(isinstance(camera_info.get(k), torch.Tensor) and camera_info[k].dim() == 1 for k in ('f', 'cx', 'cy'))
+        if (torch.is_grad_enabled() and pc.requires_grad) or not (scalar_camera if mode == 'parallel' else tensor_camera):
+            runtime.fallback('project_pc2image', 'differentiable cloud or mixed scalar / tensor camera constants')
+        else:
+            from ..csrc import fused
+            return fused.project_pc2image(pc, camera_info, scale)
     batch_size, n_points = pc.shape[0], pc.shape[-1]
     cx, cy = camera_info['cx'], camera_info['cy']
     if isinstance(cx, torch.Tensor):
         cx = cx[:, None].expand(batch_size, n_points)
         cy = cy[:, None].expand(batch_size, n_points)
-    mode = camera_info['projection_mode']
     if mode == 'perspective':
         f = camera_info['f'][:, None].expand(batch_size, n_points)
         image_x = cx + (f / pc[:, 2, :]) * pc[:, 0, :]
@@ -242,7 +256,11 @@ def project_pc2image(pc, camera_info):
         image_y = pc[:, 1, :] + cy
     else:
         raise NotImplementedError(mode)
-    return torch.cat([image_x[:, None, :], image_y[:, None, :]], dim=1)
+    uv = torch.cat([image_x[:, None, :], image_y[:, None, :]], dim=1)
+    if grid_hw is not None:
+        uv[:, 0] *= scale[0]
+        uv[:, 1] *= scale[1]
+    return uv
 
 
 def grid_sample_wrapper(feat_2d, uv):

@@ -7,7 +7,7 @@ import torch.nn as nn
 from torch.nn.functional import interpolate, leaky_relu
 
 from ..csrc import wrapper as _ops
-from .blocks import Conv2dNormRelu
+from .blocks import Conv2dNormRelu, flow_conv
 from .geometry import backwarp_2d, convex_upsample
 
 PYRAMID_CHANNELS_2D = [3, 16, 32, 64, 96, 128, 192]
@@ -50,7 +50,7 @@ class _FlowEstimator2D(nn.Module):
     def _finish(self, flow_feat):
         if self.conv_last is None:
             return flow_feat
-        return flow_feat, self.conv_last(flow_feat)
+        return flow_feat, flow_conv(self.conv_last, flow_feat)
 
     def _make_last(self, conv_last):
         self.conv_last = nn.Conv2d(self.flow_feat_dim, 2, kernel_size=3, stride=1, padding=1) if conv_last else None
@@ -108,7 +108,7 @@ class ContextNetwork2D(nn.Module):
     def forward(self, x):
         for conv in self.convs:
             x = conv(x)
-        return x, self.conv_last(x)
+        return x, flow_conv(self.conv_last, x)
 
 
 def pyramid_aligners(conv_cls):

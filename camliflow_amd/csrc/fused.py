@@ -1365,6 +1365,73 @@ def bias_act(x, bias, act):
 
 
 # ------------------------------------------------------------------------------------------------
+# two-channel 3x3 convolution heads (models/raft_core.py:169-181 FlowHead2D.conv2, PWC's conv_last)
+# ------------------------------------------------------------------------------------------------
+class _Conv3x3Co2(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        b, cin, h, w = x.shape
+        y = torch.empty((b, 2, h, w), dtype=torch.float32, device=x.device)
+        with _on_device(x):
+            _lib.launch('camli_conv3x3_co2_fwd', lib.camli_conv3x3_co2_fwd, x.data_ptr(), weight.data_ptr(),
+                        bias.data_ptr() if bias is not None else None, y.data_ptr(), b, cin, h, w, _stream_ptr(x),
+                        work=(4.0 * b * h * w * (cin + 2), 'B'))
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.w_param = _runtime.deferral_target(weight)
+        ctx.b_param = _runtime.deferral_target(bias) if bias is not None else None
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        b, cin, h, w = x.shape
+        gy = gy.contiguous().float()
+        gx = gw = gb = None
+        with _on_device(x):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                _lib.launch('camli_conv3x3_co2_bwd_data', lib.camli_conv3x3_co2_bwd_data, gy.data_ptr(), weight.data_ptr(),
+                            gx.data_ptr(), b, cin, h, w, _stream_ptr(x), work=(4.0 * b * h * w * (cin + 2), 'B'))
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1] or want_b:
+                ws = torch.empty(lib.camli_conv3x3_co2_bwd_weight_workspace_bytes(b, cin, w) // 4, dtype=torch.float32, device=x.device)
+                deferred = ctx.w_param is not None and (not want_b or ctx.b_param is not None)
+                if deferred:      # iteration-shared parameters: the kernel adds into the per-pass accumulators
+                    gw_buf = _runtime.PARAM_GRADS.slot(ctx.w_param, lambda: torch.zeros_like(weight), False)
+                    gb_buf = _runtime.PARAM_GRADS.slot(ctx.b_param, lambda: _zero_slice(2, gy), False) if want_b else None
+                else:
+                    gw_buf = torch.empty_like(weight)
+                    gb_buf = torch.empty(2, dtype=torch.float32, device=x.device) if want_b else None
+                _lib.launch('camli_conv3x3_co2_bwd_weight', lib.camli_conv3x3_co2_bwd_weight, gy.data_ptr(), x.data_ptr(),
+                            ws.data_ptr(), gw_buf.data_ptr(), gb_buf.data_ptr() if gb_buf is not None else None,
+                            1 if deferred else 0, b, cin, h, w, _stream_ptr(x), work=(4.0 * b * h * w * (cin + 2), 'B'))
+                if not deferred:
+                    gw, gb = gw_buf, gb_buf
+        return gx, gw, gb
+
+
+def conv3x3_co2_supported(conv, x):
+    """A plain 3x3 / stride 1 / padding 1 convolution to exactly two channels on a contiguous fp32 NCHW map."""
+    return (isinstance(conv, torch.nn.Conv2d) and conv.out_channels == 2 and tuple(conv.kernel_size) == (3, 3)
+            and tuple(conv.stride) == (1, 1) and conv.padding == (1, 1) and tuple(conv.dilation) == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == 'zeros' and conv.in_channels <= 640 and x.dim() == 4 and x.is_cuda
+            and x.shape[2] <= 65535 and x.shape[0] <= 65535 and x.shape[1] * x.shape[2] * x.shape[3] < 2 ** 31)
+
+
+def conv3x3_co2(x, weight, bias):
+    """y = conv2d(x, weight, bias, padding=1) for weight [2,Cin,3,3]: three HBM-bound kernels instead of an implicit
+    GEMM with N = 2 (csrc/hip/smallconv.hip)."""
+    _require_cuda('conv3x3_co2', x, weight)
+    assert weight.shape[0] == 2 and weight.shape[2:] == (3, 3) and weight.shape[1] == x.shape[1]
+    return _Conv3x3Co2.apply(x.float().contiguous(), weight.float().contiguous(), bias.float() if bias is not None else None)
+
+
+# ------------------------------------------------------------------------------------------------
 # input side (SURVEY 8f rank 3): models/ids.py:4-33, models/camliraft.py:38-46
 # ------------------------------------------------------------------------------------------------
 def persp2paral_pair(pcs, intrinsics, persp, paral):
@@ -1385,6 +1452,29 @@ def persp2paral_pair(pcs, intrinsics, persp, paral):
                     float((paral['sensor_w'] - 1) / 2), float((paral['sensor_h'] - 1) / 2), _stream_ptr(pcs),
                     work=(48.0 * b * n, 'B'))
     return out1, out2
+
+
+def project_pc2image(pc, camera_info, scale=(1.0, 1.0)):
+    """pc [B,3,N] -> uv [B,2,N]: models/utils.py:234-259 times ``scale`` = (grid - 1) / (sensor - 1) per axis, one
+    launch (no autograd: the clouds are inputs / detached)."""
+    _require_cuda('project_pc2image', pc)
+    lib = _lib.load()
+    pc = pc.float().contiguous()
+    b, three, n = pc.shape
+    assert three == 3
+    uv = torch.empty((b, 2, n), dtype=torch.float32, device=pc.device)
+    mode = camera_info['projection_mode']
+    if mode == 'perspective':
+        intr = torch.stack([camera_info['f'], camera_info['cx'], camera_info['cy']], dim=1).float().contiguous()
+        args = (intr.data_ptr(), uv.data_ptr(), b, n, 1, 0.0, 0.0)
+    elif mode == 'parallel':
+        args = (None, uv.data_ptr(), b, n, 0, float(camera_info['cx']), float(camera_info['cy']))
+    else:
+        raise NotImplementedError(mode)
+    with _on_device(pc):
+        _lib.launch('camli_project_pc2image', lib.camli_project_pc2image, pc.data_ptr(), *args, float(scale[0]), float(scale[1]),
+                    _stream_ptr(pc), work=((12.0 if mode == 'perspective' else 8.0) * b * n + 8.0 * b * n, 'B'))
+    return uv
 
 
 def pad_normalize(images, pad, mean, std):

@@ -8,6 +8,9 @@
 //                 (width split left/right, height at the bottom) and apply the ImageNet mean / std: two pads and four
 //                 elementwise passes over [B,3,H,W] in torch; here one pass that reads [B,6,H,W] once and writes both
 //                 padded, normalised frames.
+//   project_pc2image models/utils.py:234-259 followed by the feature-grid rescale every caller applies
+//                 (camliraft_core.py:51-56, camlipwc_core.py:112-114): [B,3,N] -> pixel coordinates [B,2,N] of a
+//                 parallel or perspective camera, times (grid - 1) / (sensor - 1): ~8 launches in torch, here one.
 // Operation ORDER follows the reference expression by expression (this file is built with -ffp-contract=off), so
 // the results equal the torch composition on the same device bit for bit: FPS is a chain of 4096 arg-max decisions
 // on these coordinates and must see identical inputs.
@@ -54,7 +57,48 @@ __global__ __launch_bounds__(256) void pad_normalize_kernel(const float* __restr
     *dst = (v - mean) / std;                                        // camliraft.py:45-46
 }
 
+// grid (ceil(N/256), B)
+template <bool PERSPECTIVE>
+__global__ __launch_bounds__(256) void project_pc2image_kernel(const float* __restrict__ pc /*[B,3,N]*/,
+                                                                const float* __restrict__ intr /*[B,3] = f, cx, cy*/,
+                                                                float* __restrict__ uv /*[B,2,N]*/, int N, float cx,
+                                                                float cy, float sx, float sy) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= N) return;
+    const float* __restrict__ src = pc + (size_t)b * 3 * N;
+    const float x = src[n], y = src[(size_t)N + n];
+    float u, v;
+    if (PERSPECTIVE) {
+        const float f = intr[b * 3 + 0], cxb = intr[b * 3 + 1], cyb = intr[b * 3 + 2];
+        const float z = src[2 * (size_t)N + n];
+        u = cxb + (f / z) * x;                        // utils.py:247
+        v = cyb + (f / z) * y;                        // utils.py:248
+    } else {
+        u = x + cx;                                   // utils.py:250-251
+        v = y + cy;
+    }
+    float* __restrict__ dst = uv + (size_t)b * 2 * N;
+    dst[n] = u * sx;                                  // camliraft_core.py:54-55
+    dst[(size_t)N + n] = v * sy;
+}
+
 }  // namespace
+
+extern "C" int camli_project_pc2image(const float* pc, const float* intrinsics, float* uv, int B, int N, int perspective,
+                                      float cx, float cy, float scale_x, float scale_y, void* stream) {
+    if (B == 0 || N == 0) return CAMLI_OK;
+    if (!pc || !uv || (perspective && !intrinsics)) { camli_set_error("camli_project_pc2image: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || N < 0 || B > 65535) { camli_set_error("camli_project_pc2image: bad shape B=%d N=%d", B, N); return CAMLI_EINVAL; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (perspective)
+        hipLaunchKernelGGL(project_pc2image_kernel<true>, dim3(camli_divup(N, 256), B), dim3(256), 0, s, pc, intrinsics, uv, N,
+                           cx, cy, scale_x, scale_y);
+    else
+        hipLaunchKernelGGL(project_pc2image_kernel<false>, dim3(camli_divup(N, 256), B), dim3(256), 0, s, pc, intrinsics, uv, N,
+                           cx, cy, scale_x, scale_y);
+    return camli_check_launch("camli_project_pc2image");
+}
 
 extern "C" int camli_persp2paral(const float* pcs, const float* intrinsics, float* out1, float* out2, int B, int N,
                                  float ratio_w, float ratio_h, float ratio_min, float half_w, float half_h, void* stream) {

@@ -421,6 +421,30 @@ int camli_persp2paral(const float *pcs, const float *intrinsics, float *out1, fl
                       float ratio_w, float ratio_h, float ratio_min, float half_w, float half_h, void *stream);
 int camli_pad_normalize(const float *images, float *out1, float *out2, int B, int H, int W, int Hp, int Wp,
                         int pad_left, const float *mean3, const float *std3, void *stream);
+/*
+ * project_pc2image (models/utils.py:234-259) + the feature-grid rescale of its callers (camliraft_core.py:51-56,
+ * camlipwc_core.py:112-114): pc [B,3,N] -> uv [B,2,N].
+ *   perspective = 0: u = (x + cx) * scale_x, v = (y + cy) * scale_y with HOST scalars cx, cy (the parallel camera);
+ *   perspective = 1: u = (cx_b + (f_b / z) * x) * scale_x, ... with intrinsics [B,3] = (f, cx, cy) on the DEVICE
+ *   (cx, cy arguments ignored).  Same expression order as the reference, unfused.  No autograd (clouds are inputs).
+ */
+int camli_project_pc2image(const float *pc, const float *intrinsics, float *uv, int B, int N, int perspective,
+                           float cx, float cy, float scale_x, float scale_y, void *stream);
+
+/*
+ * Two-channel 3x3 convolution heads (FlowHead2D.conv2 of models/raft_core.py:169-181 and PWC's
+ * conv_last): fp32 NCHW, stride 1, zero padding 1, Cout = 2.  x [B,Cin,H,W], w [2,Cin,3,3], bias [2] or NULL,
+ * y [B,2,H,W] fully written.  bwd_data: gx [B,Cin,H,W] fully written.  bwd_weight: gw [2,Cin,3,3] and gb [2] (NULL to
+ * skip) are WRITTEN (accumulate = 0) or ADDED TO (accumulate = 1: iteration-shared parameters sum over the GRU
+ * iterations); workspace = camli_conv3x3_co2_bwd_weight_workspace_bytes(B, Cin, W) bytes of per-wave partial sums,
+ * reduced in a fixed order (no atomics).
+ */
+int camli_conv3x3_co2_fwd(const float *x, const float *w, const float *bias, float *y, int B, int Cin, int H, int W,
+                          void *stream);
+int camli_conv3x3_co2_bwd_data(const float *gy, const float *w, float *gx, int B, int Cin, int H, int W, void *stream);
+long long camli_conv3x3_co2_bwd_weight_workspace_bytes(int B, int Cin, int W);
+int camli_conv3x3_co2_bwd_weight(const float *gy, const float *x, float *workspace, float *gw, float *gb, int accumulate,
+                                 int B, int Cin, int H, int W, void *stream);
 
 #ifdef __cplusplus
 }

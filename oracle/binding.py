@@ -305,6 +305,18 @@ def persp2paral(pcs, intr, persp_hw, paral_hw):
     return out1, out2
 
 
+def project_pc2image(pc, intr, perspective, cx, cy, sx, sy):
+    """pc [B,3,N] (+ intr [B,3] for the perspective camera) -> uv [B,2,N] (models/utils.py:234-259 + grid rescale)"""
+    pc = _f32(pc)
+    B, _, N = pc.shape
+    intr = _f32(intr) if intr is not None else np.zeros((B, 3), dtype=np.float32)
+    uv = np.zeros((B, 2, N), dtype=np.float32)
+    cf = ctypes.c_float
+    _chk(_load().oracle_project_pc2image(_p(pc), _p(intr), _p(uv), B, N, int(bool(perspective)), cf(cx), cf(cy), cf(sx), cf(sy)),
+         "project_pc2image")
+    return uv
+
+
 def pad_normalize(images, pad, mean, std):
     """images [B,6,H,W], pad = [left, right, 0, bottom] -> (image1, image2) [B,3,Hp,Wp]"""
     images = _f32(images)

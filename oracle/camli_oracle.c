@@ -768,6 +768,31 @@ int oracle_persp2paral(const float *pcs, const float *intr, float *out1, float *
     return 0;
 }
 
+/* project_pc2image follows models/utils.py:234-259, then the callers' feature-grid rescale
+ * (camliraft_core.py:51-56, camlipwc_core.py:112-114):  pc [B,3,N] -> uv [B,2,N]
+ *   perspective: u = (cx_b + (f_b / z) * x) * sx   (intr [B,3] = f, cx, cy);   parallel: u = (x + cx) * sx */
+int oracle_project_pc2image(const float *pc, const float *intr, float *uv, int B, int N, int perspective,
+                            float cx, float cy, float sx, float sy)
+{
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const float *src = pc + (size_t)b * 3 * N;
+            float x = src[n], y = src[(size_t)N + n], z = src[2 * (size_t)N + n];
+            float u, v;
+            if (perspective) {
+                float f = intr[b * 3], cxb = intr[b * 3 + 1], cyb = intr[b * 3 + 2];
+                u = cxb + (f / z) * x;
+                v = cyb + (f / z) * y;
+            } else {
+                u = x + cx;
+                v = y + cy;
+            }
+            uv[(size_t)b * 2 * N + n] = u * sx;
+            uv[(size_t)b * 2 * N + N + n] = v * sy;
+        }
+    return 0;
+}
+
 int oracle_pad_normalize(const float *images, float *out1, float *out2, int B, int H, int W, int Hp, int Wp, int left,
                          const float *mean3, const float *std3)
 {

@@ -227,8 +227,36 @@ def golden_input_side():
          pc2=ref_persp2paral(pcs[:, 3:], persp, paral))
 
 
+def golden_projection():
+    """the reference's project_pc2image (utils.py:234-259) under both cameras, followed by the feature-grid rescale its
+    callers apply in place (camliraft_core.py:51-56)"""
+    g = gen(911)
+    b, n = 2, 500
+    intr = torch.tensor([[1050.0, 479.5, 269.5], [721.5, 609.6, 172.9]])
+    persp = {'projection_mode': 'perspective', 'sensor_h': 544, 'sensor_w': 960, 'f': intr[:, 0], 'cx': intr[:, 1], 'cy': intr[:, 2]}
+    paral = {'projection_mode': 'parallel', 'sensor_h': 17, 'sensor_w': 30, 'cx': 14.5, 'cy': 8.0}
+    z = torch.rand(b, n, generator=g) * 30 + 5
+    pc_persp = torch.stack([(torch.rand(b, n, generator=g) - 0.5) * z, (torch.rand(b, n, generator=g) - 0.5) * z * 0.6, z], dim=1)
+    pc_paral = torch.stack([torch.rand(b, n, generator=g) * 29 - 14.5, torch.rand(b, n, generator=g) * 16 - 8.0,
+                            torch.rand(b, n, generator=g) * 60 + 40], dim=1)
+    out = {}
+    for name, pc, cam in (('persp', pc_persp, persp), ('paral', pc_paral, paral)):
+        uv = ref_utils.project_pc2image(pc, cam)
+        out['uv_' + name] = uv.clone()
+        grid_h, grid_w = 68, 120
+        uv[:, 0] *= (grid_w - 1) / (cam['sensor_w'] - 1)
+        uv[:, 1] *= (grid_h - 1) / (cam['sensor_h'] - 1)
+        out['uv_grid_' + name] = uv
+        out['pc_' + name] = pc
+    save('project_pc2image', intrinsics=intr, persp_hw=[544, 960], paral_hw=[17, 30], paral_c=[14.5, 8.0], grid_hw=[68, 120], **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:       # regenerate single fixtures:  python make_module_golden.py golden_projection ...
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     golden_pointconv()
     golden_pointconv_dw_bwd()
     golden_corr3d_raft()

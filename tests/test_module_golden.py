@@ -86,6 +86,18 @@ def test_oracle_input_side_pinned_on_the_reference_preprocessing(golden, oracle_
     assert np.allclose(p1, g['pc1'], rtol=1e-6, atol=1e-6) and np.allclose(p2, g['pc2'], rtol=1e-6, atol=1e-6)
 
 
+def test_oracle_projection_pinned_on_the_reference(golden, oracle_lib):
+    """oracle_project_pc2image == the reference's project_pc2image (both cameras) + the in-place grid rescale"""
+    g = golden('project_pc2image')
+    gh, gw = [int(v) for v in g['grid_hw']]
+    for name, persp, (sh, sw) in (('persp', 1, g['persp_hw']), ('paral', 0, g['paral_hw'])):
+        cx, cy = [float(v) for v in g['paral_c']]
+        plain = oracle_lib.project_pc2image(g['pc_' + name], g['intrinsics'], persp, cx, cy, 1.0, 1.0)
+        assert np.array_equal(plain, g['uv_' + name])
+        grid = oracle_lib.project_pc2image(g['pc_' + name], g['intrinsics'], persp, cx, cy, (gw - 1) / (int(sw) - 1), (gh - 1) / (int(sh) - 1))
+        assert np.array_equal(grid, g['uv_grid_' + name])
+
+
 def test_oracle_pwc3d_pieces_reproduce_the_reference_cost_volume(golden, oracle_lib):
     """pair / ksum / gather_wsum (oracle) + the module's own small MLPs (numpy) == the reference Correlation3D output"""
     g = golden('module_corr3d_pwc')

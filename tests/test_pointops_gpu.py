@@ -359,3 +359,41 @@ def test_input_side_kernels_vs_oracle_golden_and_torch(golden, oracle_lib):
         c1, c2 = geometry.persp2paral_both(pcs, persp, paral)
     assert torch.equal(p1, c1) and torch.equal(p2, c2)
     assert np.allclose(p1.cpu().numpy(), g['pc1'], rtol=1e-6, atol=1e-6) and np.allclose(p2.cpu().numpy(), g['pc2'], rtol=1e-6, atol=1e-6)
+
+
+def test_projection_kernel_vs_oracle_golden_and_composition(golden, oracle_lib):
+    """camli_project_pc2image (round 3; utils.py:234-259 + grid rescale): bit-exact against the oracle and the
+    reference golden for the parallel camera (add, multiply), within 1 ulp-level tolerance of the CPU golden for the
+    perspective camera (its divide is the one op that may differ CPU <-> GPU) and bit-identical to the torch
+    composition on the same device; the cores' call sites go through the kernel under strict mode."""
+    from camliflow_amd.cores import geometry, runtime
+    g = golden('project_pc2image')
+    gh, gw = [int(v) for v in g['grid_hw']]
+    intr = dev(g['intrinsics'])
+    cams = {
+        'persp': {'projection_mode': 'perspective', 'sensor_h': int(g['persp_hw'][0]), 'sensor_w': int(g['persp_hw'][1]),
+                  'f': intr[:, 0].contiguous(), 'cx': intr[:, 1].contiguous(), 'cy': intr[:, 2].contiguous()},
+        'paral': {'projection_mode': 'parallel', 'sensor_h': int(g['paral_hw'][0]), 'sensor_w': int(g['paral_hw'][1]),
+                  'cx': float(g['paral_c'][0]), 'cy': float(g['paral_c'][1])}}
+    for name, cam in cams.items():
+        pc = dev(g['pc_' + name])
+        for grid_hw, key in ((None, 'uv_'), ((gh, gw), 'uv_grid_')):
+            with runtime.use_backend('hip'):
+                runtime.set_strict(True)
+                try:
+                    got = geometry.project_pc2image(pc, cam, grid_hw=grid_hw)
+                finally:
+                    runtime.set_strict(False)
+            with runtime.use_backend('composed'):
+                same_device = geometry.project_pc2image(pc, cam, grid_hw=grid_hw)
+            assert torch.equal(got, same_device), (name, key)
+            want = g[key + name]
+            if name == 'paral':
+                assert np.array_equal(got.cpu().numpy(), want)
+            else:
+                assert np.allclose(got.cpu().numpy(), want, rtol=1e-6, atol=1e-5)
+    # a cloud that requires grad keeps the composition (and says so)
+    pc = dev(g['pc_paral']).requires_grad_(True)
+    with runtime.use_backend('hip'):
+        uv = geometry.project_pc2image(pc, cams['paral'], grid_hw=(gh, gw))
+    assert uv.requires_grad

@@ -1,0 +1,64 @@
+"""Two-channel 3x3 convolution heads (csrc/hip/smallconv.hip: FlowHead2D.conv2 of raft_core.py:169-181, PWC's
+conv_last) against torch's fp32 convolution on the same device -- forward, data gradient, weight and bias gradients;
+tolerances are those of a 2304-term fp32 dot product in a different summation order.  Weight gradients are
+bit-reproducible (no atomics)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [(8, 256, 68, 120), (1, 256, 47, 156), (2, 529, 9, 15), (1, 7, 1, 1), (3, 5, 2, 65), (1, 64, 130, 64), (2, 33, 17, 129)]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'B%d_C%d_%dx%d' % c)
+@pytest.mark.parametrize('with_bias', [True, False])
+def test_conv3x3_co2_vs_torch(case, with_bias):
+    from camliflow_amd.csrc import fused
+    b, c, h, w = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+    wt = (torch.randn(2, c, 3, 3, generator=g) * (9 * c) ** -0.5).cuda().requires_grad_(True)
+    bias = torch.randn(2, generator=g).cuda().requires_grad_(True) if with_bias else None
+    gy = torch.randn(b, 2, h, w, generator=g).cuda()
+
+    y = fused.conv3x3_co2(x, wt, bias)
+    grads = torch.autograd.grad(y, [x, wt] + ([bias] if with_bias else []), gy)
+    y_ref = F.conv2d(x, wt, bias, padding=1)
+    refs = torch.autograd.grad(y_ref, [x, wt] + ([bias] if with_bias else []), gy)
+    assert torch.allclose(y, y_ref, rtol=1e-4, atol=1e-5), (y - y_ref).abs().max().item()
+    for name, got, ref in zip(('gx', 'gw', 'gb'), grads, refs):
+        err = (got - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        assert err < 2e-5, (name, err)
+    again = torch.autograd.grad(fused.conv3x3_co2(x, wt, bias), [wt], gy)[0]
+    assert torch.equal(again, grads[1])            # fixed summation order
+
+
+def test_flow_head_module_uses_the_kernels_and_defers_parameter_gradients():
+    """FlowHead2D through the product path: the last convolution runs on camli_conv3x3_co2_*, with deferred parameter
+    gradients the weight / bias totals of three 'iterations' land in .grad once and equal the plain sums."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.raft2d import FlowHead2D
+    torch.manual_seed(0)
+    head = FlowHead2D(128, 256).cuda()
+    xs = [torch.randn(2, 128, 20, 28, device='cuda') for _ in range(3)]
+
+    def run(backend, deferred):
+        head.zero_grad()
+        runtime.set_deferred_param_grads(deferred)
+        try:
+            with runtime.use_backend(backend):
+                runtime.set_census(True)
+                runtime.reset_census()
+                sum(head(x).square().sum() for x in xs).backward()
+                census = runtime.census()
+                runtime.set_census(False)
+        finally:
+            runtime.set_deferred_param_grads(False)
+        return {n: p.grad.clone() for n, p in head.named_parameters()}, census
+    want, _ = run('composed', False)
+    for deferred in (False, True):
+        got, census = run('hip', deferred)
+        assert census['fused'].get('camli_conv3x3_co2_fwd', 0) == 3 and census['fused'].get('camli_conv3x3_co2_bwd_weight', 0) == 3
+        for n in want:
+            assert (got[n] - want[n]).norm() <= 2e-4 * want[n].norm() + 1e-6, (deferred, n)
