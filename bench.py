@@ -138,26 +138,10 @@ def _flush_c_stdio():
         pass
 
 
-def _start_watchdog(progress, world, limit_s=90.0):
-    """Safety net of the single-process two-lane run: if no step completes for `limit_s` seconds (the start-up stall
-    described in DESIGN.md section 8), the process is replaced by a ONE-lane run of the same command.  Nothing about it is
-    silent: the restarted run's line says `config.lanes: 1` and `config.lanes_note: restarted ...`.  Multi-rank runs never
-    need it: they default to one lane.  CAMLI_NO_WATCHDOG=1 switches it off."""
-    import threading
-    if world != 1 or os.environ.get('CAMLI_NO_WATCHDOG') == '1' or not progress.get('two_lane'):
-        return
-
-    def watch():
-        while progress['phase'] != 'done':
-            time.sleep(2.0)
-            if progress['phase'] != 'done' and time.monotonic() - progress['t'] > limit_s:
-                sys.stderr.write('bench.py: no step completed for %.0f s during %s with two lanes; restarting with one lane '
-                                 '(CAMLI_OVERLAP=0)\n' % (limit_s, progress['phase']))
-                sys.stderr.flush()
-                env = dict(os.environ, CAMLI_OVERLAP='0', CAMLI_NO_WATCHDOG='1',
-                           CAMLI_LANES_NOTE='restarted with one lane after a two-lane stall during %s' % progress['phase'])
-                os.execve(sys.executable, [sys.executable] + sys.argv, env)
-    threading.Thread(target=watch, daemon=True).start()
+def _log(msg):
+    """Progress notes on stderr (never stdout: the one JSON line is the only thing there)."""
+    sys.stderr.write('bench.py: %s\n' % msg)
+    sys.stderr.flush()
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -551,10 +535,9 @@ def main():
         # EVERY step in this process (293 vs 270 ms with identical work, idle communicator included); the communicator
         # is created by the first collective instead
         dist.init_process_group('nccl', rank=rank, world_size=world)  # RCCL over xGMI
-    # lanes: the single process defaults to two (point branch on a side HIP stream, its first pass primed one-lane by
-    # runtime.Lanes, watchdog as a visible safety net); multi-rank jobs default to ONE lane -- a rank that stalls cannot be
-    # restarted alone, and a collective the others wait in would hang the job.  CAMLI_OVERLAP=0/1 overrides either.
-    two_lane = os.environ.get('CAMLI_OVERLAP', '0' if world > 1 else '1') == '1'
+    # lanes: two by default at every N (point branch on a side HIP stream; the first pass of a process is primed one-lane
+    # by runtime.Lanes), so that the 1/2/4/8-GPU points of a scaling run are the same configuration.  CAMLI_OVERLAP=0 -> one.
+    two_lane = os.environ.get('CAMLI_OVERLAP', '1') == '1'
 
     from camliflow_amd.cores import runtime
     from camliflow_amd.csrc import _lib
@@ -593,20 +576,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The first pass of this input signature runs on ONE stream whatever `lanes` says (runtime.set_overlap: first-use work
-    # of the process must not happen with cross-stream waits in flight); it is untimed and comes before the W warm-up steps.
-    progress = {'t': time.monotonic(), 'phase': 'priming', 'two_lane': two_lane}
-    _start_watchdog(progress, world)
-    if two_lane and not use_graph:
+    # The first pass of this input signature runs on ONE stream whatever `lanes` says (runtime.set_overlap); it is untimed
+    # and comes before the W warm-up steps.  It is also where a process pays the libraries' first-use work -- MIOpen /
+    # hipBLASLt solution look-ups and code-object loads: 20-60 s on most boxes, 231 s measured on a slow one
+    # (profiles/r03_first_step_probe.txt).  Round 2 mistook that stall for a two-stream dead-lock and restarted the run
+    # from a watchdog; there is no watchdog any more, only this log line.
+    t_first = time.perf_counter()
+    if not use_graph:
         step()
         torch.cuda.synchronize()
-    progress.update(t=time.monotonic(), phase='warm-up')
+        _log('first step of the process (one lane, first-use work of the libraries included): %.1f s' % (time.perf_counter() - t_first))
     graphed = GraphedStep(step) if use_graph else None       # primes on its own side stream
     for _ in range(args.warmup):
         graphed() if graphed else step()
-        progress['t'] = time.monotonic()
     barrier()
-    progress.update(t=time.monotonic(), phase='timed')
     runtime.set_census(True)
     runtime.reset_census()
     _lib.TIMER.reset()
@@ -620,10 +603,8 @@ def main():
         h0 = time.perf_counter()
         loss = graphed() if graphed else step()
         host_s += time.perf_counter() - h0
-        progress['t'] = time.monotonic()
     barrier()
     elapsed = time.perf_counter() - t0
-    progress['phase'] = 'done'
     _lib.TIMER.enabled = False
     census = runtime.census()
     runtime.set_census(False)
@@ -702,8 +683,6 @@ def main():
             'census': {'fused_launches_per_step': {k: round(v / roofline_steps, 1) for k, v in sorted(census['fused'].items())},
                        'composed_calls_per_step': {k: round(v / roofline_steps, 1) for k, v in sorted(census['composed'].items())}},
         }
-        if os.environ.get('CAMLI_LANES_NOTE'):
-            line['config']['lanes_note'] = os.environ['CAMLI_LANES_NOTE']
         if world == 1 and not args.no_isolated and args.config == 'camliraft':
             import kernel_bench
             line['roofline_rows'] = kernel_bench.run(batch=args.batch, reps=5)

@@ -225,12 +225,13 @@ def set_overlap(enabled, prime_first_pass=True):
     on them between fusion points, so the two lanes overlap.  Results are unchanged.
 
     ``prime_first_pass`` (default): the FIRST pass of a process for a given (device, input signature) still runs on
-    one stream -- forward and, because autograd replays a node on the stream of its forward, its backward.  On this
-    ROCm image the first two-lane steps of a process can stall for good (host blocked inside the first backward;
-    always under rocprofv3, on some boxes in half of the plain runs, never once a step of that shape has completed):
-    every first-use event -- code-object loads, MIOpen solver set-up, allocator growth -- then happens while
-    cross-stream waits are in flight.  Priming belongs here, not in a benchmark script, so that EVERY caller of
-    ``set_overlap(True)`` gets it (training loops, tests, bench.py)."""
+    one stream -- forward and, because autograd replays a node on the stream of its forward, its backward.  The first
+    step of a process is where the libraries do their first-use work (MIOpen / hipBLASLt solution look-ups, code-object
+    loads): 20-60 s on most boxes of this pool, 231 s measured on a slow one, on ONE stream
+    (profiles/r03_first_step_probe.txt).  Round 2 read that stall as a two-stream dead-lock; round 3 found no evidence
+    of one.  Keeping that step on one stream costs nothing (it is never a timed step) and keeps a first-use problem
+    from being confused with a stream-ordering problem again.  It lives here, not in a benchmark script, so that EVERY
+    caller of ``set_overlap(True)`` gets it (training loops, tests, bench.py)."""
     global _OVERLAP, _PRIME_FIRST_PASS
     _OVERLAP = bool(enabled)
     _PRIME_FIRST_PASS = bool(prime_first_pass)
