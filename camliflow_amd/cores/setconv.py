@@ -124,12 +124,16 @@ class PointConvDW(nn.Module):
         if entry is None:
             if self._weightnet_on_matrix_cores() and not (xyz.requires_grad or centres.requires_grad):
                 # offsets + 3 -> 8 -> 32 -> C in one launch, the wide layer on MFMA (camli_weightnet_fwd/bwd)
-                weight = fused.weightnet(xyz, centres, knn_indices, self.k, self.weight_net)
+                # k-major weights [B,C,k,N] where the forward kernel covers the shape: k coalesced rows per lane and
+                # channel instead of an LDS transposition of every weight chunk
+                k_major = fused.dw_k_major_ok(self.k, xyz.shape[2])
+                weight = fused.weightnet(xyz, centres, knn_indices, self.k, self.weight_net, k_major=k_major)
             else:
+                k_major = False
                 runtime.fallback('weightnet', 'weight_net is not MLP2d(3,[8,32,C<=128],relu) or the coordinates are differentiable')
                 _, _, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
                 weight = self.weight_net(knn_offset)
-            shared = fused.SharedSetConvWeights(weight)
+            shared = fused.SharedSetConvWeights(weight, k_major=k_major)
             if _pass_cache is not None:
                 # the key holds raw addresses: keep the keyed tensors alive so an address is never recycled
                 _pass_cache[key] = (shared, (xyz, centres, knn_indices))

@@ -33,10 +33,12 @@ PROTOTYPES = {
                                          _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_pointconv_dw_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p, ctypes.c_void_p,
                                       _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _int, _stream]),
+    "camli_pointconv_dw_fwd_kmajor": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, ctypes.c_void_p,
+                                             _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _int, _stream]),
     "camli_pointconv_dw_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p,
                                       _int, _int, _int, _int, _stream]),
     "camli_pointconv_dw_expand": (_int, [ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
-                                         _int, _int, _int, _int, _stream]),
+                                         _int, _int, _int, _int, _int, _stream]),
     "camli_gather_cf_fwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_gather_cf_bwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_gather_cf_bwd_sorted": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _int, _int, _int, _int, _stream]),
@@ -80,7 +82,7 @@ PROTOTYPES = {
     "camli_bias_act_fwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _stream]),
     "camli_bias_act_bwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_weightnet_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int] + [_c_float_p] * 7
-                            + [_int, _int, _int, _int, _int, _stream]),
+                            + [_int, _int, _int, _int, _int, _int, _stream]),
     "camli_bilinear_sample_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
     "camli_gather_scale_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_masked_l2_fwd": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _int, _int, _int, _stream]),
@@ -103,7 +105,7 @@ PROTOTYPES = {
     "camli_sk_mix_bwd_x": (_int, [_c_float_p] * 5 + [_int, _int, _int, _stream]),
     "camli_weightnet_bwd_workspace_bytes": (ctypes.c_int64, [_int]),
     "camli_weightnet_bwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int] + [_c_float_p] * 14
-                            + [ctypes.c_int64, _int, _int, _int, _int, _int, _stream]),
+                            + [ctypes.c_int64, _int, _int, _int, _int, _int, _int, _stream]),
 }
 
 _lib = None

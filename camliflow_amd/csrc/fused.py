@@ -210,10 +210,28 @@ class SharedSetConvWeights:
     ``weight_net`` is differentiated once per pass instead of once per iteration.
     """
 
-    def __init__(self, weight):
+    def __init__(self, weight, k_major=False):
         self.weight = weight.detach().float().contiguous()     # fp32 even when weight_net ran under autocast
+        self.k_major = bool(k_major)   # [B,C,k,N] instead of [B,C,N,k]: what weightnet(..., k_major=True) produces
         self.records = []          # [(gwsel [B,C,N] fp32, arg [B,C,N] uint8)] appended by the backward calls
         self.token = _ShareWeights.apply(weight, self)
+        self._idx_kn = None        # (knn_indices kept alive, k, int32 [B,k,N]) for the k-major forward
+
+    def idx_kn(self, knn_indices, k):
+        """The neighbour table as int32 [B,k,N] (k coalesced rows per lane), built once per pass and table."""
+        hit = self._idx_kn
+        if hit is None or hit[0] is not knn_indices or hit[1] != k:
+            table = knn_indices[:, :, :k].to(torch.int32).permute(0, 2, 1).contiguous()
+            hit = self._idx_kn = (knn_indices, k, table)
+        return hit[2]
+
+    @property
+    def n_points(self):
+        return self.weight.shape[3 if self.k_major else 2]
+
+    @property
+    def k(self):
+        return self.weight.shape[2 if self.k_major else 3]
 
 
 class _ShareWeights(torch.autograd.Function):
@@ -235,7 +253,8 @@ class _ShareWeights(torch.autograd.Function):
             return torch.zeros(ctx.wshape, dtype=torch.float32, device=ctx.wdevice), None
         records, shared.records = shared.records, []
         weight = shared.weight
-        b, c, n, k = weight.shape
+        b, c = weight.shape[:2]
+        n, k = shared.n_points, shared.k
         grad = torch.empty_like(weight)
         with _on_device(weight):
             for start in range(0, len(records), 64):       # the kernel takes <= 64 calls at a time
@@ -244,7 +263,7 @@ class _ShareWeights(torch.autograd.Function):
                 gptrs = (ctypes.c_void_p * len(chunk))(*[g.data_ptr() for g, _ in chunk])
                 aptrs = (ctypes.c_void_p * len(chunk))(*[a.data_ptr() for _, a in chunk])
                 _lib.launch('camli_pointconv_dw_expand', lib.camli_pointconv_dw_expand, gptrs, aptrs, len(chunk),
-                            part.data_ptr(), b, c, n, k, _stream_ptr(weight),
+                            part.data_ptr(), b, c, n, k, int(shared.k_major), _stream_ptr(weight),
                         work=(4.0 * b * c * n * k + 5.0 * len(chunk) * b * c * n, 'B'))
                 if start:
                     grad += part
@@ -258,18 +277,26 @@ class _PointConvDW(torch.autograd.Function):
         lib = _lib.load()
         weight = shared.weight
         b, c, m = feat.shape
-        n = weight.shape[2]
+        if shared.k_major and feat.data_ptr() % 16:
+            feat = feat.clone()          # the k-major kernel stages feature rows with 16-byte loads
+        n = shared.n_points
         out = torch.empty((b, c, n), dtype=torch.float32, device=feat.device)
         arg = torch.empty((b, c, n), dtype=torch.uint8, device=feat.device)
         need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]   # grad mode is off inside forward()
         wsel = torch.empty((b, c, n), dtype=torch.float32, device=feat.device) if need_grad else None
         msel = torch.empty((b, c, n), dtype=torch.int32, device=feat.device) if need_grad else None
+        work = (4.0 * b * c * n * k + 4.0 * b * c * m + (4.0 if shared.k_major else 8.0) * b * n * k + 13.0 * b * c * n, 'B')
         with _on_device(feat):
-            _lib.launch('camli_pointconv_dw_fwd', lib.camli_pointconv_dw_fwd, feat.data_ptr(), weight.data_ptr(),
-                        knn_indices.data_ptr(), knn_indices.stride(1), out.data_ptr(), arg.data_ptr(),
-                        wsel.data_ptr() if need_grad else None, msel.data_ptr() if need_grad else None,
-                        b, c, m, n, k, _stream_ptr(feat),
-                        work=(4.0 * b * c * n * k + 4.0 * b * c * m + 8.0 * b * n * k + 13.0 * b * c * n, 'B'))
+            if shared.k_major:
+                _lib.launch('camli_pointconv_dw_fwd', lib.camli_pointconv_dw_fwd_kmajor, feat.data_ptr(), weight.data_ptr(),
+                            shared.idx_kn(knn_indices, k).data_ptr(), out.data_ptr(), arg.data_ptr(),
+                            wsel.data_ptr() if need_grad else None, msel.data_ptr() if need_grad else None,
+                            b, c, m, n, k, _stream_ptr(feat), work=work)
+            else:
+                _lib.launch('camli_pointconv_dw_fwd', lib.camli_pointconv_dw_fwd, feat.data_ptr(), weight.data_ptr(),
+                            knn_indices.data_ptr(), knn_indices.stride(1), out.data_ptr(), arg.data_ptr(),
+                            wsel.data_ptr() if need_grad else None, msel.data_ptr() if need_grad else None,
+                            b, c, m, n, k, _stream_ptr(feat), work=work)
         if need_grad:
             ctx.save_for_backward(feat, wsel, msel, arg)
         ctx.shared = shared
@@ -302,7 +329,7 @@ def pointconv_dw(feat, shared, knn_indices, k):
     assert knn_indices.dtype == torch.int64 and knn_indices.stride(2) == 1 and knn_indices.shape[2] >= k
     assert knn_indices.stride(0) == knn_indices.shape[1] * knn_indices.stride(1)
     assert shared.weight.shape[0] == feat.shape[0] and shared.weight.shape[1] == feat.shape[1]
-    assert shared.weight.shape[3] == k
+    assert shared.k == k
     return _PointConvDW.apply(feat.float().contiguous(), shared.token, knn_indices, k, shared)
 
 
@@ -635,16 +662,17 @@ class _WeightNet(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, xyz, centres, knn_indices, k, w1, b1, w2, b2, w3, b3):
+    def forward(ctx, xyz, centres, knn_indices, k, w1, b1, w2, b2, w3, b3, k_major=False):
         lib = _lib.load()
         bs, _, m = xyz.shape
         n, c = centres.shape[2], w3.shape[0]
         params = [t.reshape(t.shape[0], -1).contiguous() for t in (w1, b1, w2, b2, w3, b3)]
-        out = torch.empty((bs, c, n, k), dtype=torch.float32, device=xyz.device)
+        out = torch.empty((bs, c, k, n) if k_major else (bs, c, n, k), dtype=torch.float32, device=xyz.device)
+        ctx.k_major = bool(k_major)
         with _on_device(xyz):
             _lib.launch('camli_weightnet_fwd', lib.camli_weightnet_fwd, xyz.data_ptr(), centres.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), *[t.data_ptr() for t in params],
-                        out.data_ptr(), bs, c, m, n, k, _stream_ptr(xyz),
+                        out.data_ptr(), bs, c, m, n, k, int(ctx.k_major), _stream_ptr(xyz),
                         work=(4.0 * bs * c * n * k + 8.0 * bs * n * k + 12.0 * bs * (m + n), 'B'),
                         flop=2.0 * bs * n * k * (24 + 256 + 32 * c))
         ctx.save_for_backward(xyz, centres, knn_indices, *params)
@@ -669,11 +697,11 @@ class _WeightNet(torch.autograd.Function):
             _lib.launch('camli_weightnet_bwd', lib.camli_weightnet_bwd, xyz.data_ptr(), centres.data_ptr(),
                         knn_indices.data_ptr(), knn_indices.stride(1), *[t.data_ptr() for t in params],
                         gout.data_ptr(), *[g.data_ptr() for g in grads], workspace.data_ptr(), ws_bytes,
-                        bs, c, m, n, k, _stream_ptr(xyz),
+                        bs, c, m, n, k, int(ctx.k_major), _stream_ptr(xyz),
                         work=(4.0 * bs * c * n * k + 8.0 * bs * n * k + 12.0 * bs * (m + n), 'B'),
                         flop=2.0 * bs * n * k * (3 * 32 * c + 2 * 32 * 32))
         grads = [g.view(shape) for g, shape in zip(grads, ctx.shapes)]
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, *grads, None)
 
 
 def weightnet_supported(mlp, c_out):
@@ -705,10 +733,10 @@ def weightnet_hidden8(xyz, centres, knn_indices, k, mlp):
     args = (xyz.float().contiguous(), centres.float().contiguous(), knn_indices, k)
     c = w3.shape[0]
     if c <= 128:
-        return _WeightNet.apply(*args, w1, b1, w2p, b2p, w3p, b3)
+        return _WeightNet.apply(*args, w1, b1, w2p, b2p, w3p, b3, False)
     half = c // 2
-    return torch.cat([_WeightNet.apply(*args, w1, b1, w2p, b2p, w3p[:half], b3[:half]),
-                      _WeightNet.apply(*args, w1, b1, w2p, b2p, w3p[half:], b3[half:])], dim=1)
+    return torch.cat([_WeightNet.apply(*args, w1, b1, w2p, b2p, w3p[:half], b3[:half], False),
+                      _WeightNet.apply(*args, w1, b1, w2p, b2p, w3p[half:], b3[half:], False)], dim=1)
 
 
 def weightnet_hidden8_supported(mlp):
@@ -721,8 +749,14 @@ def weightnet_hidden8_supported(mlp):
     return plain and dims[0] == (3, 8) and dims[1] == (8, 8) and dims[2][0] == 8 and dims[2][1] <= 256
 
 
-def weightnet(xyz, centres, knn_indices, k, mlp):
-    """xyz [B,3,M], centres [B,3,N], knn_indices int64 [B,N,>=k] -> weight_net(xyz[knn] - centre) [B,C,N,k]."""
+def dw_k_major_ok(k, m, feat_like=None):
+    """Shapes the k-major set-conv forward covers (camli_pointconv_dw_fwd, k_major = 1)."""
+    return k in (4, 8, 16, 32) and m % 4 == 0 and m <= 8192
+
+
+def weightnet(xyz, centres, knn_indices, k, mlp, k_major=False):
+    """xyz [B,3,M], centres [B,3,N], knn_indices int64 [B,N,>=k] -> weight_net(xyz[knn] - centre) [B,C,N,k], or
+    [B,C,k,N] with ``k_major`` (the layout the set-conv forward streams without an LDS transposition)."""
     _require_cuda('weightnet', xyz, centres, knn_indices)
     assert knn_indices.dtype == torch.int64 and knn_indices.stride(2) == 1 and knn_indices.shape[2] >= k
     assert knn_indices.stride(0) == knn_indices.shape[1] * knn_indices.stride(1)
@@ -730,7 +764,7 @@ def weightnet(xyz, centres, knn_indices, k, mlp):
     convs = mlp.convs
     return _WeightNet.apply(xyz.float().contiguous(), centres.float().contiguous(), knn_indices, k,
                             convs[0].conv_fn.weight, convs[0].conv_fn.bias, convs[1].conv_fn.weight,
-                            convs[1].conv_fn.bias, convs[2].conv_fn.weight, convs[2].conv_fn.bias)
+                            convs[1].conv_fn.bias, convs[2].conv_fn.weight, convs[2].conv_fn.bias, k_major)
 
 
 

@@ -331,6 +331,100 @@ __global__ __launch_bounds__(64 * NWV) void pointconv_dw_fwd_shared_kernel(const
     }
 }
 
+// Forward, k-major weights [B,C,k,N] (round 3).  With the neighbour slot j as the slow axis a lane's K weights of a
+// channel are K perfectly coalesced dword rows: they go from HBM straight into the registers that multiply them -- no
+// LDS transposition, no staging registers, and all K loads of the NEXT channel are in flight while the current one is
+// reduced (the [B,C,N,k] kernels push every weight through global -> VGPR -> LDS -> VGPR; with gathers and stores
+// compiled out that chain alone took 43 of their 48 us).  The weight network writes this layout directly (column
+// enumeration with the point index fastest, weightnet.hip), the dense weight gradient is expanded into it.
+// Workgroup = NWV waves = NWV consecutive 64-point tiles of one batch element walking one channel slice in step; the
+// feature row of the current channel is staged once per workgroup in a double-buffered LDS row (one barrier per
+// channel).  grid (ceil(N / (64*NWV)), B, CS), block 64*NWV.  dynamic LDS: 2 * M floats.
+template <int K, int NWV, int RVT>
+__global__ __launch_bounds__(64 * NWV) void pointconv_dw_fwd_kmajor_kernel(const float* __restrict__ feat,
+                                                                           const float* __restrict__ weight,
+                                                                           const int* __restrict__ idx_kn,
+                                                                           float* __restrict__ out,
+                                                                           unsigned char* __restrict__ arg,
+                                                                           float* __restrict__ wsel, int* __restrict__ msel,
+                                                                           int C, int M, int N) {
+    constexpr int T = 64 * NWV;
+    extern __shared__ __attribute__((aligned(16))) float rows[];     // [2][M]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int b = blockIdx.y;
+    const int n = (blockIdx.x * NWV + w) * 64 + lane;
+    const bool valid = n < N;
+    const int nc = valid ? n : N - 1;
+    const int m4 = M >> 2;
+
+    // neighbour table k-major too, int32 [B,K,N]: K coalesced rows.  (Read as int64 rows [B,N,stride] every workgroup
+    // pulled 64 cache lines per load instruction -- with the channels split over 16-32 workgroups per tile that was
+    // more line traffic than the weights, and it made every variant of this kernel stall at the same 3.5 TB/s.)
+    int m[K];
+    {
+        const int* __restrict__ icol = idx_kn + (size_t)b * K * N + nc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) m[j] = icol[(size_t)j * N];
+    }
+    float cur_w[K], nxt_w[K];
+    float4 rstage[RVT];
+    auto issue = [&](int c, float (&wv)[K], float4 (&rst)[RVT]) {
+        const float* __restrict__ src = weight + ((size_t)b * C + c) * K * (size_t)N + nc;
+#pragma unroll
+        for (int j = 0; j < K; ++j) wv[j] = src[(size_t)j * N];
+        const float4* __restrict__ rsrc = reinterpret_cast<const float4*>(feat + ((size_t)b * C + c) * M);
+#pragma unroll
+        for (int v = 0; v < RVT; ++v) {
+            const int e = v * T + tid;
+            rst[v] = e < m4 ? rsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int cstep = gridDim.z;
+    int buf = 0;
+    int c = blockIdx.z;
+    if (c < C) issue(c, cur_w, rstage);
+    for (; c < C; c += cstep) {
+        float* rowbuf = rows + buf * M;
+#pragma unroll
+        for (int v = 0; v < RVT; ++v) {
+            const int e = v * T + tid;
+            if (e < m4) *reinterpret_cast<float4*>(rowbuf + e * 4) = rstage[v];
+        }
+        if (c + cstep < C) issue(c + cstep, nxt_w, rstage);     // next channel's K weight rows + feature row in flight
+        __syncthreads();      // the row of channel c is complete; the other buffer is free again after this barrier
+        float best = -INFINITY;
+        int barg = 0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float p = rowbuf[m[j]] * cur_w[j];
+            const bool gt = p > best;
+            best = gt ? p : best;
+            barg = gt ? j : barg;
+        }
+        if (valid) {
+            const size_t o = ((size_t)b * C + c) * N + n;
+            out[o] = best;
+            arg[o] = (unsigned char)barg;
+            if (wsel) {
+                float ws = cur_w[0];
+                int ms = m[0];
+#pragma unroll
+                for (int j = 1; j < K; ++j) {
+                    ws = (barg == j) ? cur_w[j] : ws;
+                    ms = (barg == j) ? m[j] : ms;
+                }
+                wsel[o] = ws;
+                msel[o] = ms;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) cur_w[j] = nxt_w[j];
+        buf ^= 1;
+    }
+}
+
 // Adjoint, row form.  One workgroup owns one (b, c) row: the feature row and the row of its
 // gradient live in LDS (2*M floats), the scatter is an LDS float atomic, and the finished gradient
 // row is written once -- no global atomics, no zero-fill of gfeat.
@@ -410,6 +504,28 @@ __global__ __launch_bounds__(256) void pointconv_dw_expand_kernel(ExpandCalls ca
         const int r = (int)(e / k), j = (int)(e - (size_t)r * k);
         dst[e] = tile[r * ld + j];
     }
+}
+
+// k-major form of the expansion: gweight [B,C,k,N].  thread = one (b, c, n): it sums its records into k registers and
+// writes k coalesced rows (lanes along n); no LDS.
+template <int K>
+__global__ __launch_bounds__(256) void pointconv_dw_expand_kmajor_kernel(ExpandCalls calls, int n_calls,
+                                                                          float* __restrict__ gweight, size_t rows, int N) {
+    const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = 0.0f;
+    for (int i = 0; i < n_calls; ++i) {
+        const int a = calls.arg[i][row];
+        const float g = calls.gwsel[i][row];
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] += (a == j) ? g : 0.0f;
+    }
+    const size_t bc = row / N, n = row - bc * N;
+    float* __restrict__ dst = gweight + bc * K * (size_t)N + n;
+#pragma unroll
+    for (int j = 0; j < K; ++j) dst[(size_t)j * N] = acc[j];
 }
 
 }  // namespace
@@ -513,6 +629,52 @@ extern "C" int camli_pointconv_dw_fwd(const float* feat, const float* weight, co
     return camli_check_launch("camli_pointconv_dw_fwd");
 }
 
+extern "C" int camli_pointconv_dw_fwd_kmajor(const float* feat, const float* weight_kn, const int* idx_kn, float* out,
+                                             unsigned char* arg, float* wsel, int* msel, int B, int C, int M, int N, int k,
+                                             void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!feat || !weight_kn || !idx_kn || !out || !arg || ((wsel == nullptr) != (msel == nullptr))) {
+        camli_set_error("camli_pointconv_dw_fwd_kmajor: null pointer");
+        return CAMLI_EINVAL;
+    }
+    if (B < 0 || C < 1 || M < 1 || N < 1 || B > 65535) {
+        camli_set_error("camli_pointconv_dw_fwd_kmajor: bad shape B=%d C=%d M=%d N=%d k=%d", B, C, M, N, k);
+        return CAMLI_EINVAL;
+    }
+    if (!((M % 4) == 0 && M <= 16 * 512 && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) && (k == 4 || k == 8 || k == 16 || k == 32))) {
+        camli_set_error("camli_pointconv_dw_fwd_kmajor: needs k in {4,8,16,32}, M %% 4 == 0, M <= 8192, 16-byte aligned feat (M=%d k=%d)", M, k);
+        return CAMLI_ENOTSUP;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    {
+        constexpr int NWV = 8;
+        const int tiles = camli_divup(N, 64 * NWV);
+        static const int cs_kmajor = [] { const char* e = getenv("CAMLI_DW_CS"); return e ? atoi(e) : 0; }();
+        int slices = cs_kmajor > 0 ? cs_kmajor : camli_divup(1024, tiles * B);
+        slices = slices < 1 ? 1 : (slices > C ? C : slices);
+        if (slices > 65535) slices = 65535;
+        const size_t bytes = 2 * (size_t)M * sizeof(float);
+#define CAMLI_DW_KMAJOR(KK, RV)                                                                                          \
+    {                                                                                                                    \
+        hipLaunchKernelGGL((pointconv_dw_fwd_kmajor_kernel<KK, NWV, RV>), dim3(tiles, B, slices), dim3(64 * NWV), bytes, s, \
+                           feat, weight_kn, idx_kn, out, arg, wsel, msel, C, M, N);                                      \
+        return camli_check_launch("camli_pointconv_dw_fwd_kmajor");                                                      \
+    }
+#define CAMLI_DW_KMAJOR_K(KK)                   \
+    if (M <= 2048) CAMLI_DW_KMAJOR(KK, 1)       \
+    if (M <= 4096) CAMLI_DW_KMAJOR(KK, 2)       \
+    CAMLI_DW_KMAJOR(KK, 4)
+        switch (k) {
+            case 4: CAMLI_DW_KMAJOR_K(4);
+            case 8: CAMLI_DW_KMAJOR_K(8);
+            case 16: CAMLI_DW_KMAJOR_K(16);
+            default: CAMLI_DW_KMAJOR_K(32);
+        }
+#undef CAMLI_DW_KMAJOR_K
+#undef CAMLI_DW_KMAJOR
+    }
+}
+
 extern "C" int camli_pointconv_dw_bwd(const float* gout, const float* feat, const float* wsel, const int* msel,
                                       float* gfeat, float* gwsel, int B, int C, int M, int N, void* stream) {
     if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
@@ -545,7 +707,8 @@ extern "C" int camli_pointconv_dw_bwd(const float* gout, const float* feat, cons
 }
 
 extern "C" int camli_pointconv_dw_expand(const float* const* gwsel_list, const unsigned char* const* arg_list,
-                                         int n_calls, float* gweight, int B, int C, int N, int k, void* stream) {
+                                         int n_calls, float* gweight, int B, int C, int N, int k, int k_major,
+                                         void* stream) {
     if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!gwsel_list || !arg_list || !gweight) {
         camli_set_error("camli_pointconv_dw_expand: null pointer");
@@ -567,6 +730,18 @@ extern "C" int camli_pointconv_dw_expand(const float* const* gwsel_list, const u
         calls.arg[i] = arg_list[i];
     }
     const size_t rows = (size_t)B * C * N;
+    if (k_major) {
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        const unsigned blocks = (unsigned)((rows + 255) / 256);
+        switch (k) {
+            case 4: hipLaunchKernelGGL(pointconv_dw_expand_kmajor_kernel<4>, dim3(blocks), dim3(256), 0, st, calls, n_calls, gweight, rows, N); break;
+            case 8: hipLaunchKernelGGL(pointconv_dw_expand_kmajor_kernel<8>, dim3(blocks), dim3(256), 0, st, calls, n_calls, gweight, rows, N); break;
+            case 16: hipLaunchKernelGGL(pointconv_dw_expand_kmajor_kernel<16>, dim3(blocks), dim3(256), 0, st, calls, n_calls, gweight, rows, N); break;
+            case 32: hipLaunchKernelGGL(pointconv_dw_expand_kmajor_kernel<32>, dim3(blocks), dim3(256), 0, st, calls, n_calls, gweight, rows, N); break;
+            default: camli_set_error("camli_pointconv_dw_expand: k-major needs k in {4,8,16,32}, got %d", k); return CAMLI_ENOTSUP;
+        }
+        return camli_check_launch("camli_pointconv_dw_expand");
+    }
     const size_t lds = (size_t)256 * (k + 1) * sizeof(float);
     hipLaunchKernelGGL(pointconv_dw_expand_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), lds,
                        reinterpret_cast<hipStream_t>(stream), calls, n_calls, gweight, rows, k);

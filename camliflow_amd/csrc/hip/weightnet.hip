@@ -35,8 +35,12 @@ __device__ __forceinline__ int wn_row(int r, int half) { return (r & 3) + 8 * (r
 __device__ __forceinline__ void wn_hidden1(const float* __restrict__ xyz, const float* __restrict__ centres,
                                            const int64_t* __restrict__ idx, int idx_stride,
                                            const float* __restrict__ w1, const float* __restrict__ b1, int b, int M,
-                                           int N, int k, int col, float (&h1)[8], float (&off)[3]) {
-    const int n = col / k, j = col - n * k;
+                                           int N, int k, int col, float (&h1)[8], float (&off)[3], int kmajor = 0) {
+    // column enumeration of the [.., N*k] output: (n, j) with j fastest ([B,C,N,k]), or -- k-major, [B,C,k,N] -- with n
+    // fastest: 32 consecutive columns are then 32 consecutive points of ONE neighbour slot, which is the order the
+    // set-conv forward streams them in (setconv.hip, k-major kernel)
+    const int n = kmajor ? col % N : col / k;
+    const int j = kmajor ? col / N : col - n * k;
     const int id = (int)idx[((size_t)b * N + n) * idx_stride + j];
 #pragma unroll
     for (int d = 0; d < 3; ++d) off[d] = xyz[((size_t)b * 3 + d) * M + id] - centres[((size_t)b * 3 + d) * N + n];
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void weightnet_fwd_kernel(
     const float* __restrict__ xyz, const float* __restrict__ centres, const int64_t* __restrict__ idx, int idx_stride,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
-    float* __restrict__ out, int B, int C, int M, int N, int k) {
+    float* __restrict__ out, int B, int C, int M, int N, int k, int kmajor) {
     __shared__ __attribute__((aligned(16))) float s_w2[32 * 8];
     __shared__ float s_b2[32];
     __shared__ __attribute__((aligned(16))) float s_b3[WN_MAXC];
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void weightnet_fwd_kernel(
         const int col = (tile - b * tiles_per_batch) * 32 + cl;
         const bool valid = col < NK;
         float h1[8], off[3];
-        wn_hidden1(xyz, centres, idx, idx_stride, w1, b1, b, M, N, k, valid ? col : NK - 1, h1, off);
+        wn_hidden1(xyz, centres, idx, idx_stride, w1, b1, b, M, N, k, valid ? col : NK - 1, h1, off, kmajor);
         float h2[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
     const float* __restrict__ xyz, const float* __restrict__ centres, const int64_t* __restrict__ idx, int idx_stride,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
-    const float* __restrict__ gout, float* __restrict__ partials, int B, int C, int M, int N, int k) {
+    const float* __restrict__ gout, float* __restrict__ partials, int B, int C, int M, int N, int k, int kmajor) {
     __shared__ __attribute__((aligned(16))) float s_w2[32 * 8];
     __shared__ float s_b2[32];
     __shared__ __attribute__((aligned(16))) float s_b3[WN_MAXC];
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
         const int col = (tile - b * tiles_per_batch) * 32 + cl;
         const bool valid = col < NK;
         float h1[8], off[3];
-        wn_hidden1(xyz, centres, idx, idx_stride, w1, b1, b, M, N, k, valid ? col : NK - 1, h1, off);
+        wn_hidden1(xyz, centres, idx, idx_stride, w1, b1, b, M, N, k, valid ? col : NK - 1, h1, off, kmajor);
 
         // ---- hidden layer 2 in C/D row order: transpose tile for gw3, ReLU mask for g2 ----
         unsigned h2_mask = 0;
@@ -370,7 +374,8 @@ inline int wn_red_all(int C) { return 32 * ((C + 31) / 32) * WN_LD + 32 * 9 + 8 
 
 extern "C" int camli_weightnet_fwd(const float* xyz, const float* centres, const int64_t* idx, int idx_stride,
                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
-                                   const float* b3, float* out, int B, int C, int M, int N, int k, void* stream) {
+                                   const float* b3, float* out, int B, int C, int M, int N, int k, int k_major,
+                                   void* stream) {
     if (B == 0 || N == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!xyz || !centres || !idx || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out) {
         camli_set_error("camli_weightnet_fwd: null pointer");
@@ -392,7 +397,7 @@ extern "C" int camli_weightnet_fwd(const float* xyz, const float* centres, const
     const int blocks = (int)(tiles / 4 + 1 < 512 ? tiles / 4 + 1 : 512);
 #define CAMLI_WN_LAUNCH(MT)                                                                                       \
     hipLaunchKernelGGL((weightnet_fwd_kernel<MT>), dim3(blocks), dim3(256), 0, s, xyz, centres, idx, idx_stride, \
-                       w1, b1, w2, b2, w3, b3, out, B, C, M, N, k)
+                       w1, b1, w2, b2, w3, b3, out, B, C, M, N, k, k_major)
     if (C <= 32) CAMLI_WN_LAUNCH(1);
     else if (C <= 64) CAMLI_WN_LAUNCH(2);
     else if (C <= 96) CAMLI_WN_LAUNCH(3);
@@ -410,7 +415,7 @@ extern "C" int camli_weightnet_bwd(const float* xyz, const float* centres, const
                                    const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                                    const float* b3, const float* gout, float* gw1, float* gb1, float* gw2, float* gb2,
                                    float* gw3, float* gb3, float* workspace, int64_t workspace_bytes, int B, int C,
-                                   int M, int N, int k, void* stream) {
+                                   int M, int N, int k, int k_major, void* stream) {
     if (!xyz || !centres || !idx || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !gw1 || !gb1 || !gw2 || !gb2 || !gw3 ||
         !gb3 || !workspace || (!gout && B > 0 && N > 0)) {
         camli_set_error("camli_weightnet_bwd: null pointer");
@@ -435,7 +440,7 @@ extern "C" int camli_weightnet_bwd(const float* xyz, const float* centres, const
     const int blocks = (int)(tiles / 4 + 1 < WN_BWD_BLOCKS ? tiles / 4 + 1 : WN_BWD_BLOCKS);
 #define CAMLI_WN_LAUNCH(MT)                                                                                       \
     hipLaunchKernelGGL((weightnet_bwd_kernel<MT>), dim3(blocks), dim3(256), 0, s, xyz, centres, idx, idx_stride, \
-                       w1, b1, w2, b2, w3, b3, gout, workspace, B, C, M, N, k)
+                       w1, b1, w2, b2, w3, b3, gout, workspace, B, C, M, N, k, k_major)
     if (C <= 32) CAMLI_WN_LAUNCH(1);
     else if (C <= 64) CAMLI_WN_LAUNCH(2);
     else if (C <= 96) CAMLI_WN_LAUNCH(3);

@@ -136,14 +136,21 @@ int camli_allpairs_lookup_bwd_marked(float *const *gvols, const int *hs, const i
  *   needed; may be NULL), gwsel [B,C,N] = gout*feat[msel] (fully written; may be NULL).
  *   expand: dense gweight [B,C,N,k] (fully written) = sum over the n_calls <= 64 calls of one pass of
  *   one-hot(arg_i) * gwsel_i; gwsel_list / arg_list are HOST arrays of device pointers.
+ *   k-major forms (round 3; camli_pointconv_dw_fwd_kmajor, expand with k_major = 1): weight_kn / gweight are laid out
+ *   [B,C,k,N] and the neighbour table is idx_kn int32 [B,k,N] -- the neighbour slot is the slow axis, so a lane's k
+ *   weights (and its k neighbour indices) are k coalesced rows that go straight from HBM into registers, no LDS
+ *   transposition.  Needs k in {4,8,16,32}, M % 4 == 0, M <= 8192, feat 16-byte aligned; results identical.
  */
 int camli_pointconv_dw_fwd(const float *feat, const float *weight, const int64_t *idx, int idx_stride,
                            float *out, unsigned char *arg, float *wsel, int *msel,
                            int B, int C, int M, int N, int k, void *stream);
+int camli_pointconv_dw_fwd_kmajor(const float *feat, const float *weight_kn, const int *idx_kn, float *out,
+                                  unsigned char *arg, float *wsel, int *msel, int B, int C, int M, int N, int k,
+                                  void *stream);
 int camli_pointconv_dw_bwd(const float *gout, const float *feat, const float *wsel, const int *msel,
                            float *gfeat, float *gwsel, int B, int C, int M, int N, void *stream);
 int camli_pointconv_dw_expand(const float *const *gwsel_list, const unsigned char *const *arg_list, int n_calls,
-                              float *gweight, int B, int C, int N, int k, void *stream);
+                              float *gweight, int B, int C, int N, int k, int k_major, void *stream);
 
 /*
  * batch_indexing, channel-first (models/utils.py:61-83): out[b,c,i] = data[b,c,idx[b,i]].
@@ -318,16 +325,18 @@ int camli_bias_act_bwd(const float *gy, const float *y, const void *sign_mask, f
  *   `workspace` (camli_weightnet_bwd_workspace_bytes(C) bytes, contents undefined afterwards) and are
  *   added in a fixed order by a second kernel: no atomics, bit-reproducible.  The coordinates receive no
  *   gradient (they are constants on this path: models/camliraft_core.py:105-106).
+ * k_major = 1: out / gout are [B,C,k,N] (the columns of the [C x N*k] product are enumerated with the point index
+ *   fastest) -- the layout camli_pointconv_dw_fwd streams without an LDS transposition.  Same values.
  */
 int camli_weightnet_fwd(const float *xyz, const float *centres, const int64_t *idx, int idx_stride,
                         const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
-                        const float *b3, float *out, int B, int C, int M, int N, int k, void *stream);
+                        const float *b3, float *out, int B, int C, int M, int N, int k, int k_major, void *stream);
 int64_t camli_weightnet_bwd_workspace_bytes(int C);
 int camli_weightnet_bwd(const float *xyz, const float *centres, const int64_t *idx, int idx_stride,
                         const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                         const float *b3, const float *gout, float *gw1, float *gb1, float *gw2, float *gb2,
                         float *gw3, float *gb3, float *workspace, int64_t workspace_bytes,
-                        int B, int C, int M, int N, int k, void *stream);
+                        int B, int C, int M, int N, int k, int k_major, void *stream);
 
 /*
  * Bilinear sampling of a feature map at pixel positions (2-D -> 3-D half of the CLFM fusion).

@@ -92,3 +92,35 @@ def test_pointconv_mix_vs_oracle_and_composed(case, oracle_lib):
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
     assert torch.allclose(gf, tf.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(gw, tw.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('case', [(2, 128, 2048, 2048, 16, 32), (1, 125, 2048, 2048, 32, 32), (3, 32, 500, 300, 8, 32),
+                                  (2, 20, 4100, 1100, 4, 8), (1, 9, 8192, 700, 16, 16), (1, 5, 64, 1, 4, 4)],
+                         ids=lambda c: 'B%d_C%d_M%d_N%d_k%d_kk%d' % c)
+def test_k_major_layout_is_the_same_operator(case, oracle_lib):
+    """Round 3: the product path keeps the neighbour weights k-major, [B,C,k,N].  Forward (values AND arg-max: same
+    products, same first-maximum rule), feature gradient and the expanded dense weight gradient must equal the
+    [B,C,N,k] kernels' results after the permutation, and the oracle's."""
+    from camliflow_amd.csrc import fused
+    b, c, m, n, k, kk = case
+    rng = np.random.default_rng(sum(case) + 1)
+    feat = rng.standard_normal((b, c, m)).astype(np.float32)
+    weight = np.maximum(rng.standard_normal((b, c, n, k)), 0).astype(np.float32)
+    idx = rng.integers(0, m, size=(b, n, kk)).astype(np.int64)
+    gout = rng.standard_normal((b, c, n)).astype(np.float32)
+    res = {}
+    for k_major in (False, True):
+        tf = torch.from_numpy(feat).cuda().requires_grad_(True)
+        w_np = np.ascontiguousarray(weight.transpose(0, 1, 3, 2)) if k_major else weight
+        tw = torch.from_numpy(w_np).cuda().requires_grad_(True)
+        shared = fused.SharedSetConvWeights(tw, k_major=k_major)
+        out = fused.pointconv_dw(tf, shared, torch.from_numpy(idx).cuda(), k)
+        out.backward(torch.from_numpy(gout).cuda())
+        gw = tw.grad.permute(0, 1, 3, 2) if k_major else tw.grad
+        res[k_major] = (out.detach().cpu().numpy(), tf.grad.cpu().numpy(), gw.cpu().numpy())
+    want, arg = oracle_lib.pointconv_dw_fwd(feat, weight, idx, k)
+    gfeat, gweight = oracle_lib.pointconv_dw_bwd(gout, feat, weight, idx, arg, k)
+    for k_major in (False, True):
+        assert np.array_equal(res[k_major][0], want)
+        assert np.allclose(res[k_major][1], gfeat, rtol=1e-5, atol=1e-5)
+        assert np.array_equal(res[k_major][2], gweight)

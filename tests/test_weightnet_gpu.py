@@ -116,3 +116,27 @@ def test_unsupported_width_is_reported():
     idx = torch.zeros(1, 64, 4, dtype=torch.int64, device='cuda')
     with pytest.raises(CamliHipError):
         fused.weightnet(xyz, xyz, idx, 4, mlp)
+
+
+@pytest.mark.parametrize('case', [(2, 128, 2048, 2048, 16, 32), (1, 125, 1024, 1000, 16, 16), (1, 64, 300, 77, 4, 9), (2, 16, 512, 512, 32, 32)],
+                         ids=lambda c: 'B%d_C%d_M%d_N%d_k%d_kk%d' % c)
+def test_k_major_output_layout(case, oracle_lib):
+    """weightnet(..., k_major=True) is the same network written [B,C,k,N]: bit-identical to the [B,C,N,k] output after
+    the permutation (same fmaf chains per column), parameter gradients equal in norm to the oracle's float64 sums."""
+    from camliflow_amd.csrc import fused
+    b, c, m, n, k, kk = case
+    xyz, centres, idx, params = _problem(case)
+    mlp = _mlp(params, c)
+    t_idx = torch.from_numpy(idx).cuda()
+    plain = fused.weightnet(torch.from_numpy(xyz).cuda(), torch.from_numpy(centres).cuda(), t_idx, k, mlp)
+    kmaj = fused.weightnet(torch.from_numpy(xyz).cuda(), torch.from_numpy(centres).cuda(), t_idx, k, mlp, k_major=True)
+    assert kmaj.shape == (b, c, k, n)
+    assert torch.equal(kmaj.permute(0, 1, 3, 2), plain)
+    gout = np.random.default_rng(2).standard_normal(plain.shape).astype(np.float32)
+    kmaj.backward(torch.from_numpy(np.ascontiguousarray(gout.transpose(0, 1, 3, 2))).cuda())
+    refs = oracle_lib.weightnet_bwd(xyz, centres, idx, k, params, gout)
+    gots = [p.grad for conv in mlp.convs for p in (conv.conv_fn.weight, conv.conv_fn.bias)]
+    for name, got, ref in zip(('gw1', 'gb1', 'gw2', 'gb2', 'gw3', 'gb3'), gots, refs):
+        got = got.double().cpu().numpy().reshape(ref.shape)
+        err = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert err <= 2e-5, (name, err)

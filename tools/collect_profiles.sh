@@ -42,7 +42,7 @@ trace)
   # single-lane (CAMLI_OVERLAP=0): with the point branch on its second HIP stream the process stalls under
   # rocprofv3's queue interception on this image (host blocked in a library launch, r02 evidence runs); the bench
   # line printed by this very run (events, same single-lane setting) is kept next to the trace for comparison
-  CAMLI_OVERLAP=0 CAMLI_FAULT_DUMP=380 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench -o b -- \
+  CAMLI_OVERLAP=0 CAMLI_FAULT_DUMP=580 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_bench -o b -- \
       python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-isolated > $OUT/trace_bench.log 2>&1
   python $ROOT/tools/trace_stats.py $OUT/trace_bench/b_kernel_trace.csv --steps 5 --top 90 > $OUT/bench_steady_kernel_stats.csv 2>> $OUT/trace_bench.log
   grep '^{"metric"' $OUT/trace_bench.log > $OUT/bench_line_single_lane_traced.json
@@ -56,7 +56,7 @@ trace)
   ;;
 pmc)
   canary || continue
-  RX='pointconv_dw_fwd|pointconv_mix|corr2d_fwd|corr2d_bwd|allpairs_lookup|gather_cf|gemm_f32_mfma|gemm_gf2|segment_row_sum|knn_interp|corr3d_gather|weightnet|pointconv_dw_bwd|pointconv_dw_expand'
+  RX='fps_|knn_|conv3x3_co2|pointconv_dw_fwd|pointconv_mix|corr2d_fwd|corr2d_bwd|allpairs_lookup|gather_cf|gemm_f32_mfma|gemm_gf2|segment_row_sum|knn_interp|corr3d_gather|weightnet|pointconv_dw_bwd|pointconv_dw_expand'
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $OUT/pmc_$c -o p -- \
         python $ROOT/tools/kernel_bench.py --reps 2 > /dev/null 2>&1
@@ -72,11 +72,13 @@ pmc)
 pmcb)
   canary || continue
   for c in FETCH_SIZE WRITE_SIZE; do
-    CAMLI_OVERLAP=0 CAMLI_FAULT_DUMP=380 timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'pointconv_dw_fwd|pointconv_dw_bwd|allpairs_lookup' --output-format csv \
+    CAMLI_OVERLAP=0 CAMLI_FAULT_DUMP=580 timeout -k 10 600 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'pointconv_dw_fwd|pointconv_dw_bwd|allpairs_lookup' --output-format csv \
         -d $OUT/pmcb_$c -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated > /dev/null 2>&1
     python $ROOT/tools/pmc_summary.py $OUT/pmcb_$c/p_counter_collection.csv > $OUT/pmc_bench_$c.txt 2>&1
-    rm -rf $OUT/pmcb_$c
   done
+  python $ROOT/tools/pmc_traffic.py $OUT/pmcb_FETCH_SIZE/p_counter_collection.csv $OUT/pmcb_WRITE_SIZE/p_counter_collection.csv \
+      pointconv_dw_fwd camli_pointconv_dw_fwd > $OUT/traffic_pointconv_dw_fwd.json 2>&1
+  rm -rf $OUT/pmcb_FETCH_SIZE $OUT/pmcb_WRITE_SIZE
   ;;
 esac
 done

@@ -133,27 +133,29 @@ def cases(batch):
 
     # ---- A10 PointConvDW: fused gather * weight -> max, and the weight network on the matrix cores ---------------
     n = 2048
-    for (c, k) in [(128, 32), (128, 16), (128, 4)]:
+    # weights k-major [B,C,k,N] -- the layout of the product path (cores/setconv.py) -- and, as '(nk)' rows, the
+    # reference's [B,C,N,k] layout the other kernels of the file serve
+    for (c, k, k_major) in [(128, 32, True), (128, 16, True), (128, 4, True), (128, 32, False), (128, 16, False), (128, 4, False)]:
         feat = _randn(g, b, c, n).requires_grad_(True)
-        wgt = _rand(g, b, c, n, k).requires_grad_(True)
+        wgt = (_rand(g, b, c, k, n) if k_major else _rand(g, b, c, n, k)).requires_grad_(True)
         idx = torch.randint(0, n, (b, n, 32), generator=g).cuda()
         go = _randn(g, b, c, n)
 
-        def dw(feat=feat, wgt=wgt, idx=idx, go=go, k=k):
-            shared = fused.SharedSetConvWeights(wgt)
+        def dw(feat=feat, wgt=wgt, idx=idx, go=go, k=k, k_major=k_major):
+            shared = fused.SharedSetConvWeights(wgt, k_major=k_major)
             out = fused.pointconv_dw(feat, shared, idx, k)
             torch.autograd.grad(out, [feat, wgt], go)
-        yield 'pointconv_dw B%d C%d k%d' % (b, c, k), dw, {'camli_pointconv_dw_fwd': 'hbm', 'camli_pointconv_dw_bwd': 'hbm',
-                                                           'camli_pointconv_dw_expand': 'hbm'}
+        yield 'pointconv_dw B%d C%d k%d%s' % (b, c, k, '' if k_major else ' (nk)'), dw, {
+            'camli_pointconv_dw_fwd': 'hbm', 'camli_pointconv_dw_bwd': 'hbm', 'camli_pointconv_dw_expand': 'hbm'}
     from camliflow_amd.cores.blocks import MLP2d
     xyzc = _rand(g, b, 3, n, scale=10.0)
     for k in (16, 32):
         mlp = MLP2d(3, [8, 32, 128], act='relu').cuda()
         idx = torch.randint(0, n, (b, n, 32), generator=g).cuda()
-        go = _randn(g, b, 128, n, k)
+        go = _randn(g, b, 128, k, n)
 
         def wn(mlp=mlp, idx=idx, go=go, k=k):
-            out = fused.weightnet(xyzc, xyzc, idx, k, mlp)
+            out = fused.weightnet(xyzc, xyzc, idx, k, mlp, k_major=True)
             torch.autograd.grad(out, list(mlp.parameters()), go)
         yield 'weightnet B%d C128 k%d' % (b, k), wn, {'camli_weightnet_fwd': 'hbm', 'camli_weightnet_bwd': 'mfma_wn'}
 

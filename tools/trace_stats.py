@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('trace')
     ap.add_argument('--steps', type=int, required=True)
-    ap.add_argument('--marker', default='fps_kernel')
+    ap.add_argument('--marker', default='fps_')      # fps_kernel (full update) or fps_pruned_kernel: one launch per step
     ap.add_argument('--top', type=int, default=80)
     args = ap.parse_args()
     rows = []
