@@ -417,13 +417,14 @@ def roofline_report(summary, steps, args, step_ms):
     return roofline, table
 
 
-def write_detail(full):
+def write_detail(full, config='camliraft'):
     """The bulky parts of the report (per-kernel tables, isolated rows, census, long-form parity / baseline) go to a file;
     `gpurun_out/` is the directory that travels back from a GPU box."""
     out_dir = os.path.join(ROOT, 'gpurun_out')
     try:
         os.makedirs(out_dir, exist_ok=True)
-        path = os.path.join(out_dir, os.environ.get('CAMLI_BENCH_DETAIL', 'bench_detail.json'))
+        default = 'bench_detail.json' if config == 'camliraft' else 'bench_detail_%s.json' % config
+        path = os.path.join(out_dir, os.environ.get('CAMLI_BENCH_DETAIL', default))
         with open(path, 'w') as f:
             json.dump(full, f, indent=1)
         return os.path.relpath(path, ROOT)
@@ -694,7 +695,7 @@ def main():
             if autocast is None:
                 line['parity'] = parity_check(args, state_dict, sample, ref, device)
                 failed = not line['parity']['ok']
-        detail_path = write_detail(line)
+        detail_path = write_detail(line, args.config)
         # RCCL writes its version banner through C stdio when the communicator is created; flush it so that the JSON
         # line is the LAST line on stdout
         _flush_c_stdio()
