@@ -141,10 +141,8 @@ class SKFusion(nn.Module):
             state = fused.SkState()
             squeezed = fused.sk_pool(feat_2d, feat_3d, state)
             w_mid, w_out = self.fc_mid[0].weight, self.fc_out[0].weight
-            if not runtime.atomics_ok('sk_gate'):
-                weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)
-            elif w_mid.shape[1] <= 1024 and w_mid.shape[0] <= 512:
-                weight = fused.sk_gate(squeezed, w_mid, w_out)           # the whole gate in one launch each way
+            if w_mid.shape[1] <= 1024 and w_mid.shape[0] <= 512:
+                weight = fused.sk_gate(squeezed, w_mid, w_out)           # the whole gate: one launch forward, two backward (no atomics)
             else:
                 runtime.fallback('sk_gate', 'C=%d R=%d outside the gate kernel (C<=1024, R<=512)' % (w_mid.shape[1], w_mid.shape[0]))
                 weight = softmax(self.fc_out(self.fc_mid(squeezed)).reshape(bs, -1, 2), dim=-1)

@@ -92,11 +92,11 @@ def census():
 
 def atomics_ok(op):
     """False under ``torch.use_deterministic_algorithms(True)`` for the fused ops whose adjoint (or reduction)
-    accumulates with float atomics -- bias gradients, the masked-L2 sums, the SK gate's weight gradients, the
+    accumulates with float atomics -- bias gradients, the masked-L2 sums, the
     interpolation / max-pool / up-sampling scatters.  Those ops then run the torch composition, which torch makes
     deterministic (or refuses loudly); the switch is recorded in the census and is not a strict-mode violation.
     The atomic-free kernels (sorted gather adjoints, PointConv mixing, the all-pairs and point cost-volume lookups,
-    the weight network) stay on HIP: they are bit-reproducible by construction."""
+    the weight network, the SK gate since round 3) stay on HIP: they are bit-reproducible by construction."""
     import torch
     if not torch.are_deterministic_algorithms_enabled():
         return True

@@ -347,6 +347,51 @@ __global__ __launch_bounds__(256) void gather_scale_kernel(const float* __restri
     }
 }
 
+// Row-resident form (round 3): a workgroup owns TWO (b, c) rows of `data`, keeps them in LDS (2 * M floats) and walks all
+// P pixels: the index is read once per two channels, the gathers hit LDS instead of scattered 4-byte global loads
+// (8.4 M per call at [8,128] x 8160 pixels, 31.6 us per call, 54 calls per step), scale / out stream coalesced.
+// grid (ceil(C/2), B, PS pixel slices), block 256, dynamic LDS 2*M floats; four consecutive pixels per thread (16-byte
+// scale loads / out stores) when P % 4 == 0.
+__global__ __launch_bounds__(256) void gather_scale_rows_kernel(const float* __restrict__ data, const float* __restrict__ scale,
+                                                                const int64_t* __restrict__ idx, float* __restrict__ out,
+                                                                int C, int M, int P) {
+    extern __shared__ float rows_s[];      // [2][M]
+    const int c0 = blockIdx.x * 2, b = blockIdx.y;
+    const bool two = c0 + 1 < C;
+    const size_t r0 = (size_t)b * C + c0, r1 = r0 + (two ? 1 : 0);
+    for (int e = threadIdx.x; e < M; e += 256) {
+        rows_s[e] = data[r0 * M + e];
+        rows_s[M + e] = data[r1 * M + e];
+    }
+    __syncthreads();
+    const int64_t* __restrict__ ib = idx + (size_t)b * P;
+    const int per = (P + gridDim.z - 1) / gridDim.z;
+    const int lo = ((blockIdx.z * per) + 3) & ~3;                         // slice bounds on multiples of 4
+    const int hi = min(P, (((blockIdx.z + 1) * per) + 3) & ~3);
+    if ((P & 3) == 0) {
+        for (int p = lo + 4 * threadIdx.x; p < hi; p += 4 * 256) {
+            const longlong2 i01 = *reinterpret_cast<const longlong2*>(ib + p), i23 = *reinterpret_cast<const longlong2*>(ib + p + 2);
+            const int m0 = (int)i01.x, m1 = (int)i01.y, m2 = (int)i23.x, m3 = (int)i23.y;
+            const float4 s0 = *reinterpret_cast<const float4*>(scale + r0 * P + p);
+            float4 o0;
+            o0.x = s0.x * rows_s[m0]; o0.y = s0.y * rows_s[m1]; o0.z = s0.z * rows_s[m2]; o0.w = s0.w * rows_s[m3];
+            *reinterpret_cast<float4*>(out + r0 * P + p) = o0;
+            if (two) {
+                const float4 s1 = *reinterpret_cast<const float4*>(scale + r1 * P + p);
+                float4 o1;
+                o1.x = s1.x * rows_s[M + m0]; o1.y = s1.y * rows_s[M + m1]; o1.z = s1.z * rows_s[M + m2]; o1.w = s1.w * rows_s[M + m3];
+                *reinterpret_cast<float4*>(out + r1 * P + p) = o1;
+            }
+        }
+    } else {
+        for (int p = lo + threadIdx.x; p < hi; p += 256) {
+            const int m = (int)ib[p];
+            out[r0 * P + p] = scale[r0 * P + p] * rows_s[m];
+            if (two) out[r1 * P + p] = scale[r1 * P + p] * rows_s[M + m];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int camli_gather_cf_fwd(const float* data, const int64_t* idx, float* out, int B, int C, int M, int I,
@@ -542,6 +587,13 @@ extern "C" int camli_gather_scale_fwd(const float* data, const float* scale, con
     if (B < 0 || C < 1 || M < 1 || P < 0 || B > 65535 || C > 4 * 65535) {
         camli_set_error("camli_gather_scale_fwd: bad shape B=%d C=%d M=%d P=%d", B, C, M, P);
         return CAMLI_EINVAL;
+    }
+    if ((size_t)2 * M * sizeof(float) <= 64 * 1024 && P >= 1024) {
+        int ps = 1;
+        while ((long long)camli_divup(C, 2) * B * ps < 2048 && P / (ps * 2) >= 1024) ps *= 2;
+        hipLaunchKernelGGL(gather_scale_rows_kernel, dim3(camli_divup(C, 2), B, ps), dim3(256), (size_t)2 * M * sizeof(float),
+                           reinterpret_cast<hipStream_t>(stream), data, scale, idx, out, C, M, P);
+        return camli_check_launch("camli_gather_scale_fwd");
     }
     hipLaunchKernelGGL(gather_scale_kernel, dim3(camli_divup(P, 256), camli_divup(C, 4), B), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), data, scale, idx, out, C, M, P);

@@ -163,46 +163,92 @@ __global__ __launch_bounds__(256) void sk_gate_fwd_kernel(const float* __restric
     }
 }
 
-// grid B, block 256: one workgroup per batch row; the weight gradients are added into the callers'
-// accumulators with float atomics (8 x 24k of them: a single workgroup walking the batch serially took
-// ~270 us, 25x longer).  gs is fully written.
-__global__ __launch_bounds__(256) void sk_gate_bwd_kernel(const float* __restrict__ gw, const float* __restrict__ s,
-                                                          const float* __restrict__ m, const float* __restrict__ z,
-                                                          const float* __restrict__ w, const float* __restrict__ wmid,
-                                                          const float* __restrict__ wout, float* __restrict__ gs,
-                                                          float* __restrict__ gwmid, float* __restrict__ gwout, int C,
-                                                          int R) {
-    __shared__ float ss[SKG_MAXC], sm[SKG_MAXR], gp[2 * SKG_MAXC], gm[SKG_MAXR];
+// Gate adjoint, two kernels, no atomics (round 3; round 2 ran ONE workgroup per batch row that pushed 2*C*R + R*C float
+// atomics each: 8 workgroups on 256 CUs, 50 us per call, 54 calls per step, and a non-reproducible sum):
+//   sk_gate_bwd_s_kernel  grid B: gpre (softmax pair + sigmoid adjoint), gm = relu'(m) * Wout^T gpre, gs = Wmid^T gm
+//   sk_gate_bwd_w_kernel  grid R: hidden unit r recomputes gpre[b,:] and gm[b,r] for every b (a few hundred flops) and
+//                         ADDS  gWout[:,r] += sum_b gpre[b,:] m[b,r],  gWmid[r,:] += sum_b gm[b,r] s[b,:]  in batch order
+// (plain read-modify-write: the accumulators belong to one stream; the callers pass zero-filled or running buffers).
+__device__ __forceinline__ float sk_gpre(const float* __restrict__ gw, const float* __restrict__ w,
+                                         const float* __restrict__ z, int b, int o, int C) {
+    const int c = o >> 1;
+    const size_t e = ((size_t)b * C + c) * 2;
+    const float w0 = w[e], w1 = w[e + 1], g0 = gw[e], g1 = gw[e + 1];
+    const float dot = g0 * w0 + g1 * w1;                       // softmax over the pair
+    const float zz = z[(size_t)b * 2 * C + o];
+    const float wo = (o & 1) ? w1 : w0, go = (o & 1) ? g1 : g0;
+    return wo * (go - dot) * zz * (1.0f - zz);                 // ... then the sigmoid
+}
+
+__global__ __launch_bounds__(256) void sk_gate_bwd_s_kernel(const float* __restrict__ gw, const float* __restrict__ m,
+                                                            const float* __restrict__ z, const float* __restrict__ w,
+                                                            const float* __restrict__ wmid, const float* __restrict__ wout,
+                                                            float* __restrict__ gs, int C, int R) {
+    __shared__ float gp[2 * SKG_MAXC], gm[SKG_MAXR];
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int c = tid; c < C; c += 256) {
-        ss[c] = s[(size_t)b * C + c];
-        const size_t e = ((size_t)b * C + c) * 2;
-        const float w0 = w[e], w1 = w[e + 1], g0 = gw[e], g1 = gw[e + 1];
-        const float dot = g0 * w0 + g1 * w1;                       // softmax over the pair
-        const float z0 = z[(size_t)b * 2 * C + 2 * c], z1 = z[(size_t)b * 2 * C + 2 * c + 1];
-        gp[2 * c] = w0 * (g0 - dot) * z0 * (1.0f - z0);            // ... then the sigmoid
-        gp[2 * c + 1] = w1 * (g1 - dot) * z1 * (1.0f - z1);
-    }
-    for (int r = tid; r < R; r += 256) sm[r] = m[(size_t)b * R + r];
+    for (int o = tid; o < 2 * C; o += 256) gp[o] = sk_gpre(gw, w, z, b, o, C);
     __syncthreads();
-    for (int e = tid; e < 2 * C * R; e += 256) {                    // gWout[o,r] += gpre[o] * m[r]
-        const int o = e / R, r = e - o * R;
-        unsafeAtomicAdd(&gwout[e], gp[o] * sm[r]);
-    }
     for (int r = tid; r < R; r += 256) {                            // gm = Wout^T gpre, through the ReLU
         float a = 0.0f;
         for (int o = 0; o < 2 * C; ++o) a = __builtin_fmaf(wout[o * R + r], gp[o], a);
-        gm[r] = sm[r] > 0.0f ? a : 0.0f;
+        gm[r] = m[(size_t)b * R + r] > 0.0f ? a : 0.0f;
     }
     __syncthreads();
-    for (int e = tid; e < R * C; e += 256) {                        // gWmid[r,c] += gm[r] * s[c]
-        const int r = e / C, c = e - r * C;
-        unsafeAtomicAdd(&gwmid[e], gm[r] * ss[c]);
-    }
     for (int c = tid; c < C; c += 256) {                            // gs = Wmid^T gm
         float a = 0.0f;
         for (int r = 0; r < R; ++r) a = __builtin_fmaf(wmid[r * C + c], gm[r], a);
         gs[(size_t)b * C + c] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void sk_gate_bwd_w_kernel(const float* __restrict__ gw, const float* __restrict__ s,
+                                                            const float* __restrict__ m, const float* __restrict__ z,
+                                                            const float* __restrict__ w, const float* __restrict__ wout,
+                                                            float* __restrict__ gwmid, float* __restrict__ gwout, int B,
+                                                            int C, int R) {
+    __shared__ float red[4];
+    __shared__ float gm_b;
+    const int tid = threadIdx.x, r = blockIdx.x;
+    constexpr int OPT = 2 * SKG_MAXC / 256;      // output units per thread
+    float acc_out[OPT];
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) acc_out[i] = 0.0f;
+    constexpr int CPT = SKG_MAXC / 256;
+    float acc_mid[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) acc_mid[i] = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float mb = m[(size_t)b * R + r];
+        float part = 0.0f;
+#pragma unroll
+        for (int i = 0; i < OPT; ++i) {
+            const int o = tid + 256 * i;
+            if (o < 2 * C) {
+                const float g = sk_gpre(gw, w, z, b, o, C);
+                acc_out[i] = __builtin_fmaf(g, mb, acc_out[i]);
+                part = __builtin_fmaf(wout[o * R + r], g, part);
+            }
+        }
+        const float tot = block_sum_256(part, red);
+        if (tid == 0) gm_b = mb > 0.0f ? tot : 0.0f;
+        __syncthreads();
+        const float gmv = gm_b;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 256 * i;
+            if (c < C) acc_mid[i] = __builtin_fmaf(gmv, s[(size_t)b * C + c], acc_mid[i]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+        const int o = tid + 256 * i;
+        if (o < 2 * C) gwout[o * R + r] += acc_out[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = tid + 256 * i;
+        if (c < C) gwmid[r * C + c] += acc_mid[i];
     }
 }
 
@@ -284,7 +330,8 @@ extern "C" int camli_sk_gate_bwd(const float* gw, const float* s, const float* m
         camli_set_error("camli_sk_gate_bwd: bad shape B=%d C=%d (<= %d) R=%d (<= %d)", B, C, SKG_MAXC, R, SKG_MAXR);
         return C > SKG_MAXC || R > SKG_MAXR ? CAMLI_ENOTSUP : CAMLI_EINVAL;
     }
-    hipLaunchKernelGGL(sk_gate_bwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), gw, s, m, z, w,
-                       wmid, wout, gs, gwmid, gwout, C, R);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sk_gate_bwd_s_kernel, dim3(B), dim3(256), 0, st, gw, m, z, w, wmid, wout, gs, C, R);
+    hipLaunchKernelGGL(sk_gate_bwd_w_kernel, dim3(R), dim3(256), 0, st, gw, s, m, z, w, wout, gwmid, gwout, B, C, R);
     return camli_check_launch("camli_sk_gate_bwd");
 }

@@ -365,11 +365,12 @@ int camli_sk_mix_bwd_x(const float *g, const float *w, const float *gs, float *g
 
 /*
  * The SKFusion gate on [B,C] vectors (models/clfm.py:183-184,199-203): m = relu(s Wmid^T),
- * z = sigmoid(m Wout^T), w[b,c,:] = softmax(z[b,2c], z[b,2c+1]).  C <= 512, R <= 256.
+ * z = sigmoid(m Wout^T), w[b,c,:] = softmax(z[b,2c], z[b,2c+1]).  C <= 1024, R <= 512.
  *   s [B,C], wmid [R,C], wout [2C,R];  m [B,R], z [B,2C], w [B,C,2] (all fully written; m and z are kept
  *   for the backward).
- *   bwd: gw [B,C,2] -> gs [B,C] (fully written), gwmid [R,C] += , gwout [2C,R] += (float atomics, one
- *   workgroup per batch row; caller zero-fills or passes its running accumulators).
+ *   bwd: gw [B,C,2] -> gs [B,C] (fully written), gwmid [R,C] += , gwout [2C,R] += (plain read-modify-write in batch
+ *   order, one workgroup per hidden unit -- no atomics since round 3; the caller zero-fills or passes its running
+ *   accumulators, which must belong to the launch stream).
  */
 int camli_sk_gate_fwd(const float *s, const float *wmid, const float *wout, float *m, float *z, float *w,
                       int B, int C, int R, void *stream);
