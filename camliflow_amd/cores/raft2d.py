@@ -150,13 +150,15 @@ class GRU2D(nn.Module):
                 runtime.fallback('GRU2D', 'hidden plane is not a multiple of 4 elements')
             if fusable:
                 z, rh = fused.gru_gates(pre_zr, ctx_zr, h)
-                h = fused.gru_blend(conv2d(torch.cat([rh, motion], dim=1), w_q, None, padding=padding), ctx_q, z, h)
+                # the GRU's closing nan_to_num (raft_core.py:138) rides on the second half-step's blend kernel
+                h = fused.gru_blend(conv2d(torch.cat([rh, motion], dim=1), w_q, None, padding=padding), ctx_q, z, h,
+                                    nan_to_num=(suffix == '2'))
             else:
                 zr = torch.sigmoid(pre_zr + ctx_zr)
                 z, r = zr[:, :hd], zr[:, hd:]
                 q = torch.tanh(conv2d(torch.cat([r * h, motion], dim=1), w_q, None, padding=padding) + ctx_q)
                 h = (1 - z) * h + z * q
-        return torch.nan_to_num(h)
+        return h if fusable else torch.nan_to_num(h)
 
 
 def _conv(cin, cout, ksize):
@@ -180,7 +182,11 @@ class MotionEncoder2D(nn.Module):
         if epilogue_ok(corr):
             c = conv_bias_act(self.conv_c2, conv_bias_act(self.conv_c1, corr, 'relu'), 'relu')
             f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')
-            joint = torch.nan_to_num(conv_bias_act(self.conv, torch.cat([c, f], dim=1), 'relu'))
+            x = torch.cat([c, f], dim=1)
+            if (x.shape[2] * x.shape[3]) % 4 == 0:      # relu + nan_to_num in the epilogue pass (bias_act code 5)
+                joint = conv_bias_act(self.conv, x, 'relu_nan_to_num')
+            else:
+                joint = torch.nan_to_num(conv_bias_act(self.conv, x, 'relu'))
             return torch.cat([joint, flow], dim=1)
         c = self.relu(self.conv_c1(corr))
         c = self.relu(self.conv_c2(c))

@@ -1295,15 +1295,17 @@ class _GruGates(torch.autograd.Function):
 class _GruBlend(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, pre_q, ctx_q, z, h):
+    def forward(ctx, pre_q, ctx_q, z, h, sanitize=False):
         lib = _lib.load()
+        ctx.sanitize = bool(sanitize)
         pre_q, ctx_q, z, h = pre_q.contiguous(), ctx_q.contiguous(), z.contiguous(), h.contiguous()
         b, c = h.shape[0], h.shape[1]
         p = h[0, 0].numel()
         q, h_new = torch.empty_like(h), torch.empty_like(h)
         with _on_device(h):
             _lib.launch('camli_gru_blend_fwd', lib.camli_gru_blend_fwd, pre_q.data_ptr(), ctx_q.data_ptr(), z.data_ptr(),
-                        h.data_ptr(), q.data_ptr(), h_new.data_ptr(), b, c, p, _stream_ptr(h), work=(24.0 * b * c * p, 'B'))
+                        h.data_ptr(), q.data_ptr(), h_new.data_ptr(), b, c, p, int(ctx.sanitize), _stream_ptr(h),
+                        work=(24.0 * b * c * p, 'B'))
         ctx.save_for_backward(z, h, q)
         return h_new
 
@@ -1318,9 +1320,9 @@ class _GruBlend(torch.autograd.Function):
         gpre, gz, gh = torch.empty_like(h), torch.empty_like(h), torch.empty_like(h)
         with _on_device(h):
             _lib.launch('camli_gru_blend_bwd', lib.camli_gru_blend_bwd, g.data_ptr(), z.data_ptr(), h.data_ptr(),
-                        q.data_ptr(), gpre.data_ptr(), gz.data_ptr(), gh.data_ptr(), b, c, p, _stream_ptr(h),
+                        q.data_ptr(), gpre.data_ptr(), gz.data_ptr(), gh.data_ptr(), b, c, p, int(ctx.sanitize), _stream_ptr(h),
                         work=(28.0 * b * c * p, 'B'))
-        return gpre, gpre, gz, gh
+        return gpre, gpre, gz, gh, None
 
 
 def gru_gates(pre_zr, ctx_zr, h):
@@ -1330,16 +1332,18 @@ def gru_gates(pre_zr, ctx_zr, h):
     return z, rh
 
 
-def gru_blend(pre_q, ctx_q, z, h):
-    """h' = (1 - z) * h + z * tanh(pre_q + ctx_q)."""
+def gru_blend(pre_q, ctx_q, z, h, nan_to_num=False):
+    """h' = (1 - z) * h + z * tanh(pre_q + ctx_q); ``nan_to_num``: followed by torch.nan_to_num (raft_core.py:138) in the
+    same pass, its adjoint folded into the blend's."""
     _require_cuda('gru_blend', pre_q, ctx_q, z, h)
-    return _GruBlend.apply(pre_q, ctx_q, z, h)
+    return _GruBlend.apply(pre_q, ctx_q, z, h, bool(nan_to_num))
 
 
 # ------------------------------------------------------------------------------------------------
 # bias + activation epilogue (models/mlp.py:41-128, models/raft_core.py:155-197)
 # ------------------------------------------------------------------------------------------------
-ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh': 4}
+ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh': 4,
+             'relu_nan_to_num': 5}      # relu, then torch.nan_to_num (raft_core.py:163-164); needs a plane of 4k elements
 
 
 class _BiasAct(torch.autograd.Function):
@@ -1353,7 +1357,8 @@ class _BiasAct(torch.autograd.Function):
         p = x.numel() // (b * c)
         # relu / leaky_relu: keep one sign bit per element for the backward instead of re-reading y
         mask = None
-        if act in (1, 2) and p % 4 == 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+        assert act != 5 or p % 4 == 0, 'relu_nan_to_num exists in the sign-mask form only'
+        if act == 5 or (act in (1, 2) and p % 4 == 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])):
             mask = torch.empty(lib.camli_bias_act_mask_bytes(b, c, p) // 8, dtype=torch.int64, device=x.device)
         with _on_device(x):
             _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_fwd, x.data_ptr(), bias.data_ptr(),

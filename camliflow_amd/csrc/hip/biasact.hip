@@ -7,7 +7,9 @@
 //   fwd : y = act(x + bias[c])                     in place, one read + one write
 //   bwd : gx = gy * act'(y);  gbias[c] += sum gx   one pass; the per-channel sum is reduced in the
 //         same kernel (wave shuffle -> LDS -> one float atomic per workgroup)
-// act: 0 identity, 1 relu, 2 leaky_relu(0.1), 3 sigmoid, 4 tanh.  Layout [B, C, P] (P = spatial size).
+// act: 0 identity, 1 relu, 2 leaky_relu(0.1), 3 sigmoid, 4 tanh, 5 relu followed by torch.nan_to_num (round 3: the motion
+// encoder's last convolution, models/raft_core.py:163-164 -- NaN -> 0, +inf -> FLT_MAX, and a zero gradient wherever the
+// pre-activation was not finite; sign-mask form only).  Layout [B, C, P] (P = spatial size).
 #include "camli_common.h"
 
 namespace {
@@ -18,6 +20,7 @@ __device__ __forceinline__ float act_fwd(float v) {
     if (ACT == 2) return v > 0.0f ? v : 0.1f * v;
     if (ACT == 3) return 1.0f / (1.0f + __expf(-v));
     if (ACT == 4) return tanhf(v);
+    if (ACT == 5) return v > 0.0f ? fminf(v, 3.402823466e+38f) : 0.0f;     // NaN fails v > 0: 0, as nan_to_num(relu(NaN))
     return v;
 }
 
@@ -51,11 +54,16 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x
         float4* __restrict__ p4 = reinterpret_cast<float4*>(plane);
         unsigned long long* __restrict__ mrow = MASK ? mask + ((size_t)b * C + c) * mask_words(P) * 4 : nullptr;
         auto apply = [&](float4 v, int e) {
-            v.x = act_fwd<ACT>(v.x + bv); v.y = act_fwd<ACT>(v.y + bv); v.z = act_fwd<ACT>(v.z + bv); v.w = act_fwd<ACT>(v.w + bv);
+            const float4 raw = make_float4(v.x + bv, v.y + bv, v.z + bv, v.w + bv);
+            v.x = act_fwd<ACT>(raw.x); v.y = act_fwd<ACT>(raw.y); v.z = act_fwd<ACT>(raw.z); v.w = act_fwd<ACT>(raw.w);
             p4[e] = v;
             if (MASK) {
-                const unsigned long long mx = __ballot(v.x > 0.0f), my = __ballot(v.y > 0.0f);
-                const unsigned long long mz = __ballot(v.z > 0.0f), mw = __ballot(v.w > 0.0f);
+                // ACT 5: the gradient passes where the pre-activation is positive AND finite (relu, then nan_to_num)
+                constexpr float top = 3.402823466e+38f;
+                const unsigned long long mx = __ballot(ACT == 5 ? (raw.x > 0.0f && raw.x <= top) : v.x > 0.0f);
+                const unsigned long long my = __ballot(ACT == 5 ? (raw.y > 0.0f && raw.y <= top) : v.y > 0.0f);
+                const unsigned long long mz = __ballot(ACT == 5 ? (raw.z > 0.0f && raw.z <= top) : v.z > 0.0f);
+                const unsigned long long mw = __ballot(ACT == 5 ? (raw.w > 0.0f && raw.w <= top) : v.w > 0.0f);
                 if ((threadIdx.x & 63) == 0) {
                     unsigned long long* w = mrow + (size_t)(e >> 6) * 4;
                     w[0] = mx; w[1] = my; w[2] = mz; w[3] = mw;
@@ -181,7 +189,7 @@ int pick_chunk(int P) {
 }
 
 bool shape_ok(const char* what, int B, int C, int P, int act) {
-    if (B < 0 || C < 1 || P < 1 || act < 0 || act > 4 || B > 65535 || C > 65535) {
+    if (B < 0 || C < 1 || P < 1 || act < 0 || act > 5 || B > 65535 || C > 65535) {
         camli_set_error("%s: bad arguments B=%d C=%d P=%d act=%d", what, B, C, P, act);
         return false;
     }
@@ -200,8 +208,8 @@ extern "C" int camli_bias_act_fwd(float* x_inout, const float* bias, void* sign_
     if (B == 0) return CAMLI_OK;
     if (!x_inout || !bias) { camli_set_error("camli_bias_act_fwd: null pointer"); return CAMLI_EINVAL; }
     if (!shape_ok("camli_bias_act_fwd", B, C, P, act)) return CAMLI_EINVAL;
-    if (sign_mask && !((act == 1 || act == 2) && (P & 3) == 0)) {
-        camli_set_error("camli_bias_act_fwd: a sign mask needs act 1 or 2 and P %% 4 == 0 (act=%d P=%d)", act, P);
+    if ((sign_mask && !((act == 1 || act == 2 || act == 5) && (P & 3) == 0)) || (act == 5 && !sign_mask)) {
+        camli_set_error("camli_bias_act_fwd: a sign mask needs act 1, 2 or 5 and P %% 4 == 0, act 5 needs the mask (act=%d P=%d)", act, P);
         return CAMLI_EINVAL;
     }
     const int chunk = pick_chunk(P);
@@ -214,6 +222,7 @@ extern "C" int camli_bias_act_fwd(float* x_inout, const float* bias, void* sign_
         case 1: if (m) L(1, true); else L(1, false); break;
         case 2: if (m) L(2, true); else L(2, false); break;
         case 3: L(3, false); break;
+        case 5: L(5, true); break;
         default: L(4, false); break;
     }
 #undef L
@@ -232,8 +241,8 @@ extern "C" int camli_bias_act_bwd(const float* gy, const float* y, const void* s
         return camli_check_launch("camli_bias_act_bwd(identity)");
     }
     if (!gy || (!y && !sign_mask && act != 0) || !gx || !gbias) { camli_set_error("camli_bias_act_bwd: null pointer"); return CAMLI_EINVAL; }
-    if (sign_mask && !((act == 1 || act == 2) && (P & 3) == 0)) {
-        camli_set_error("camli_bias_act_bwd: a sign mask needs act 1 or 2 and P %% 4 == 0 (act=%d P=%d)", act, P);
+    if ((sign_mask && !((act == 1 || act == 2 || act == 5) && (P & 3) == 0)) || (act == 5 && !sign_mask)) {
+        camli_set_error("camli_bias_act_bwd: a sign mask needs act 1, 2 or 5 and P %% 4 == 0, act 5 needs the mask (act=%d P=%d)", act, P);
         return CAMLI_EINVAL;
     }
     const int chunk = pick_chunk(P);
@@ -246,6 +255,7 @@ extern "C" int camli_bias_act_bwd(const float* gy, const float* y, const void* s
         case 1: if (m) L(1, true); else L(1, false); break;
         case 2: if (m) L(2, true); else L(2, false); break;
         case 3: L(3, false); break;
+        case 5: L(1, true); break;       // the mask already holds "positive and finite": plain masked ReLU adjoint
         default: L(4, false); break;
     }
 #undef L

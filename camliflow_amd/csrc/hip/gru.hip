@@ -55,7 +55,15 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float4* __rest
     }
 }
 
-// blend: q = tanh(pre_q + ctx_q); h' = (1 - z) h + z q     all [B,C,P]
+// torch.nan_to_num: NaN -> 0, +-inf -> +-FLT_MAX
+__device__ __forceinline__ float nan_to_num_f(float v) {
+    return v != v ? 0.0f : fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f);
+}
+__device__ __forceinline__ bool finite_f(float v) { return fabsf(v) <= 3.402823466e+38f; }
+
+// blend: q = tanh(pre_q + ctx_q); h' = (1 - z) h + z q     all [B,C,P].  SANITIZE: h' = nan_to_num(h') (raft_core.py:138,
+// the GRU's last statement) folded in; the adjoint then zeroes the gradient where the un-sanitised h' was not finite.
+template <bool SANITIZE>
 __global__ __launch_bounds__(256) void gru_blend_fwd_kernel(const float4* __restrict__ pre, const float4* __restrict__ ctx,
                                                              const float4* __restrict__ z, const float4* __restrict__ h,
                                                              float4* __restrict__ q, float4* __restrict__ hn, size_t n4) {
@@ -65,18 +73,27 @@ __global__ __launch_bounds__(256) void gru_blend_fwd_kernel(const float4* __rest
         qo.x = tanhf(p.x + c.x); qo.y = tanhf(p.y + c.y); qo.z = tanhf(p.z + c.z); qo.w = tanhf(p.w + c.w);
         ho.x = (1.0f - zv.x) * hv.x + zv.x * qo.x; ho.y = (1.0f - zv.y) * hv.y + zv.y * qo.y;
         ho.z = (1.0f - zv.z) * hv.z + zv.z * qo.z; ho.w = (1.0f - zv.w) * hv.w + zv.w * qo.w;
+        if (SANITIZE) { ho.x = nan_to_num_f(ho.x); ho.y = nan_to_num_f(ho.y); ho.z = nan_to_num_f(ho.z); ho.w = nan_to_num_f(ho.w); }
         q[e] = qo;
         hn[e] = ho;
     }
 }
 
 // adjoint of blend: (g, z, h, q) -> gpre (= gradient of ctx_q), gz, gh
+template <bool SANITIZE>
 __global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ z,
                                                              const float4* __restrict__ h, const float4* __restrict__ q,
                                                              float4* __restrict__ gpre, float4* __restrict__ gz,
                                                              float4* __restrict__ gh, size_t n4) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
-        const float4 gv = g[e], zv = z[e], hv = h[e], qv = q[e];
+        float4 gv = g[e];
+        const float4 zv = z[e], hv = h[e], qv = q[e];
+        if (SANITIZE) {      // nan_to_num's adjoint: no gradient where its input (recomputed here) was not finite
+            gv.x = finite_f((1.0f - zv.x) * hv.x + zv.x * qv.x) ? gv.x : 0.0f;
+            gv.y = finite_f((1.0f - zv.y) * hv.y + zv.y * qv.y) ? gv.y : 0.0f;
+            gv.z = finite_f((1.0f - zv.z) * hv.z + zv.z * qv.z) ? gv.z : 0.0f;
+            gv.w = finite_f((1.0f - zv.w) * hv.w + zv.w * qv.w) ? gv.w : 0.0f;
+        }
         float4 a, b, c;
         a.x = gv.x * zv.x * (1.0f - qv.x * qv.x); a.y = gv.y * zv.y * (1.0f - qv.y * qv.y);
         a.z = gv.z * zv.z * (1.0f - qv.z * qv.z); a.w = gv.w * zv.w * (1.0f - qv.w * qv.w);
@@ -126,23 +143,31 @@ extern "C" int camli_gru_gates_bwd(const float* gz, const float* grh, const floa
 }
 
 extern "C" int camli_gru_blend_fwd(const float* pre_q, const float* ctx_q, const float* z, const float* h, float* q,
-                                   float* h_new, int B, int C, int P, void* stream) {
+                                   float* h_new, int B, int C, int P, int nan_to_num, void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!pre_q || !ctx_q || !z || !h || !q || !h_new) { camli_set_error("camli_gru_blend_fwd: null pointer"); return CAMLI_EINVAL; }
     if (!gru_shape_ok("camli_gru_blend_fwd", B, C, P)) return CAMLI_EINVAL;
     const size_t n4 = (size_t)B * C * P / 4;
-    hipLaunchKernelGGL(gru_blend_fwd_kernel, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       F4(pre_q), F4(ctx_q), F4(z), F4(h), F4W(q), F4W(h_new), n4);
+    if (nan_to_num)
+        hipLaunchKernelGGL(gru_blend_fwd_kernel<true>, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           F4(pre_q), F4(ctx_q), F4(z), F4(h), F4W(q), F4W(h_new), n4);
+    else
+        hipLaunchKernelGGL(gru_blend_fwd_kernel<false>, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           F4(pre_q), F4(ctx_q), F4(z), F4(h), F4W(q), F4W(h_new), n4);
     return camli_check_launch("camli_gru_blend_fwd");
 }
 
 extern "C" int camli_gru_blend_bwd(const float* g, const float* z, const float* h, const float* q, float* gpre_q, float* gz,
-                                   float* gh, int B, int C, int P, void* stream) {
+                                   float* gh, int B, int C, int P, int nan_to_num, void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!g || !z || !h || !q || !gpre_q || !gz || !gh) { camli_set_error("camli_gru_blend_bwd: null pointer"); return CAMLI_EINVAL; }
     if (!gru_shape_ok("camli_gru_blend_bwd", B, C, P)) return CAMLI_EINVAL;
     const size_t n4 = (size_t)B * C * P / 4;
-    hipLaunchKernelGGL(gru_blend_bwd_kernel, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       F4(g), F4(z), F4(h), F4(q), F4W(gpre_q), F4W(gz), F4W(gh), n4);
+    if (nan_to_num)
+        hipLaunchKernelGGL(gru_blend_bwd_kernel<true>, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           F4(g), F4(z), F4(h), F4(q), F4W(gpre_q), F4W(gz), F4W(gh), n4);
+    else
+        hipLaunchKernelGGL(gru_blend_bwd_kernel<false>, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                           F4(g), F4(z), F4(h), F4(q), F4W(gpre_q), F4W(gz), F4W(gh), n4);
     return camli_check_launch("camli_gru_blend_bwd");
 }

@@ -287,10 +287,12 @@ int camli_gru_gates_fwd(const float *pre_zr, const float *ctx_zr, const float *h
                         int B, int C, int P, void *stream);
 int camli_gru_gates_bwd(const float *gz, const float *grh, const float *z, const float *r, const float *h,
                         float *gpre_zr, float *gh, int B, int C, int P, void *stream);
+/* nan_to_num = 1 (round 3): h_new = torch.nan_to_num(h_new), the last statement of the GRU (raft_core.py:138), folded
+ * into the blend; its adjoint (zero gradient where the un-sanitised value was not finite) is folded into blend_bwd. */
 int camli_gru_blend_fwd(const float *pre_q, const float *ctx_q, const float *z, const float *h, float *q, float *h_new,
-                        int B, int C, int P, void *stream);
+                        int B, int C, int P, int nan_to_num, void *stream);
 int camli_gru_blend_bwd(const float *g, const float *z, const float *h, const float *q, float *gpre_q, float *gz,
-                        float *gh, int B, int C, int P, void *stream);
+                        float *gh, int B, int C, int P, int nan_to_num, void *stream);
 
 /*
  * Bias + activation epilogue of a convolution and its adjoint (the reference runs conv -> bias add ->

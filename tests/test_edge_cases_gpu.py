@@ -246,3 +246,49 @@ def test_adjoints_left_on_hip_under_deterministic_mode_are_bit_reproducible():
         assert (census['fused'].get('camli_pointconv_mix_bwd', 0) > 0) == stays, census
         if stays:
             assert torch.equal(first[0], second[0])
+
+
+def test_nan_to_num_folded_into_blend_and_epilogue():
+    """Round 3: the GRU's closing torch.nan_to_num (raft_core.py:138) rides on camli_gru_blend, the motion encoder's
+    (raft_core.py:163-164) on the bias/ReLU epilogue (code 5).  Values AND gradients must follow torch's composition on
+    inputs that contain NaN and +-inf (nan_to_num passes no gradient where its input was not finite)."""
+    from camliflow_amd.csrc import fused
+    g = torch.Generator().manual_seed(11)
+    b, c, h, w = 2, 8, 6, 10
+    bad = torch.tensor([float('nan'), float('inf'), float('-inf')])
+
+    def poisoned(*shape):
+        t = torch.randn(*shape, generator=g)
+        flat = t.view(-1)
+        pos = torch.randperm(flat.numel(), generator=g)[:9]
+        flat[pos] = bad.repeat(3)
+        return t.cuda()
+    # ---- blend
+    pre, ctx, hh = poisoned(b, c, h, w), torch.randn(b, c, h, w, generator=g).cuda(), poisoned(b, c, h, w)
+    z = torch.rand(b, c, h, w, generator=g).cuda()
+    go = torch.randn(b, c, h, w, generator=g).cuda()
+    leaves = [t.clone().requires_grad_(True) for t in (pre, ctx, z, hh)]
+    out = fused.gru_blend(*leaves, nan_to_num=True)
+    grads = torch.autograd.grad(out, leaves, go)
+    ref_leaves = [t.clone().requires_grad_(True) for t in (pre, ctx, z, hh)]
+    p_, c_, z_, h_ = ref_leaves
+    ref = torch.nan_to_num((1 - z_) * h_ + z_ * torch.tanh(p_ + c_))
+    ref_grads = torch.autograd.grad(ref, ref_leaves, go)
+    assert torch.isfinite(out).all() and torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    finite_out = torch.isfinite((1 - z) * hh + z * torch.tanh(pre + ctx))
+    for got, want in zip(grads, ref_grads):
+        # where the un-sanitised output is finite both are ordinary numbers; elsewhere both must be exactly zero or
+        # agree as NaN-free values (torch multiplies the zeroed gradient by finite local derivatives)
+        assert torch.allclose(got[finite_out], want[finite_out], rtol=1e-4, atol=1e-6)
+        assert (torch.nan_to_num(got[~finite_out]) == 0).all()
+    # ---- epilogue: relu + nan_to_num
+    x0, bias = poisoned(b, c, h, w), torch.randn(c, generator=g).cuda()
+    xa, ba = x0.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ya = fused.bias_act(xa * 1.0, ba, 'relu_nan_to_num')
+    gxa, gba = torch.autograd.grad(ya, [xa, ba], go)
+    xb, bb = x0.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yb = torch.nan_to_num(torch.relu(xb + bb.view(1, c, 1, 1)))
+    gxb, gbb = torch.autograd.grad(yb, [xb, bb], go)
+    assert torch.isfinite(ya).all() and torch.equal(ya, yb)
+    assert torch.equal(gxa, gxb)
+    assert torch.allclose(gba, gbb, rtol=1e-5, atol=1e-6)
