@@ -14,7 +14,7 @@ namespace {
 template <int C, bool BACKWARD>
 __global__ __launch_bounds__(256) void masked_l2_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                         int target_channels, float* __restrict__ out /* sum slot | gpred */,
-                                                        const float* __restrict__ coef, int P) {
+                                                        const float* __restrict__ coef, int P, int vec) {
     __shared__ float red[4];
     const int b = blockIdx.y;
     const float* __restrict__ pb = pred + (size_t)b * C * P;
@@ -22,7 +22,42 @@ __global__ __launch_bounds__(256) void masked_l2_kernel(const float* __restrict_
     const bool has_mask = target_channels > C;
     const float k = BACKWARD ? coef[0] : 0.0f;
     float acc = 0.0f;
-    const int p0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    // the forward walks several 1024-position chunks per workgroup: its sum ends in ONE float atomic per workgroup on a
+    // single address, and 4,050 of those in a row cost more (50 us) than streaming the tensors (15 us)
+    for (int chunk = blockIdx.x; chunk * 1024 < P; chunk += gridDim.x) {
+    const int p0 = (chunk * 256 + threadIdx.x) * 4;
+    if (vec && p0 < P) {
+        // four consecutive positions per thread as 16-byte accesses (the scalar form below issues four 4-byte loads
+        // per channel whose lanes are 16 bytes apart: every cache line is touched by four instructions)
+        float dv[C][4], sq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 a = *reinterpret_cast<const float4*>(pb + (size_t)c * P + p0);
+            const float4 t = *reinterpret_cast<const float4*>(tb + (size_t)c * P + p0);
+            dv[c][0] = a.x - t.x; dv[c][1] = a.y - t.y; dv[c][2] = a.z - t.z; dv[c][3] = a.w - t.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sq[j] += dv[c][j] * dv[c][j];
+        }
+        float mk[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (has_mask) {
+            const float4 m = *reinterpret_cast<const float4*>(tb + (size_t)C * P + p0);
+            mk[0] = m.x; mk[1] = m.y; mk[2] = m.z; mk[3] = m.w;
+        }
+        float sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = mk[j] > 0.0f;
+            const float err = sqrtf(sq[j]);
+            if (!BACKWARD) acc += on ? err : 0.0f;
+            sc[j] = (on && err > 0.0f) ? k / err : 0.0f;
+        }
+        if (BACKWARD) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * P + p0) =
+                    make_float4(sc[0] * dv[c][0], sc[1] * dv[c][1], sc[2] * dv[c][2], sc[3] * dv[c][3]);
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int p = p0 + j;
@@ -42,6 +77,8 @@ __global__ __launch_bounds__(256) void masked_l2_kernel(const float* __restrict_
 #pragma unroll
             for (int c = 0; c < C; ++c) out[((size_t)b * C + c) * P + p] = s * d[c];
         }
+    }
+    }
     }
     if (!BACKWARD) {
 #pragma unroll
@@ -64,12 +101,16 @@ int masked_l2_launch(const char* what, const float* pred, const float* target, i
         camli_set_error("%s: bad shape B=%d C=%d (2 or 3) P=%d target_channels=%d", what, B, C, P, target_channels);
         return CAMLI_EINVAL;
     }
-    dim3 grid(camli_divup(P, 1024), B);
+    const int chunks = camli_divup(P, 1024);
+    dim3 grid(BACKWARD ? chunks : (chunks < 64 ? chunks : 64), B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // 16-byte accesses need P % 4 == 0 (every channel plane then starts 16-byte aligned relative to its base) and aligned bases
+    const int vec = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) |
+                                      (BACKWARD ? reinterpret_cast<uintptr_t>(out) : 0)) & 15) == 0;
     if (C == 2)
-        hipLaunchKernelGGL((masked_l2_kernel<2, BACKWARD>), grid, dim3(256), 0, s, pred, target, target_channels, out, coef, P);
+        hipLaunchKernelGGL((masked_l2_kernel<2, BACKWARD>), grid, dim3(256), 0, s, pred, target, target_channels, out, coef, P, vec);
     else
-        hipLaunchKernelGGL((masked_l2_kernel<3, BACKWARD>), grid, dim3(256), 0, s, pred, target, target_channels, out, coef, P);
+        hipLaunchKernelGGL((masked_l2_kernel<3, BACKWARD>), grid, dim3(256), 0, s, pred, target, target_channels, out, coef, P, vec);
     return camli_check_launch(what);
 }
 
