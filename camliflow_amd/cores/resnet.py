@@ -44,8 +44,9 @@ class Bottleneck(nn.Module):
             shortcut = x if self.downsample is None else _conv_bn(self.downsample[0], self.downsample[1], x, None, folded)
             y = _conv_bn(self.conv1, self.bn1, x, 'relu', folded)
             y = _conv_bn(self.conv2, self.bn2, y, 'relu', folded)
-            y = _conv_bn(self.conv3, self.bn3, y, None, folded)
-            return self.relu(y + shortcut)
+            # bn3's bias, the shortcut and the block's closing ReLU in ONE pass over conv3's output (camli_bias_act_res_fwd);
+            # as bias pass + add + relu they were 7 tensor streams over the largest activations of the model
+            return _conv_bn(self.conv3, self.bn3, y, 'relu', folded, residual=shortcut)
         shortcut = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.relu(self.bn2(self.conv2(y)))
@@ -60,7 +61,7 @@ def _foldable(bn, x):
     return (not bn.training) and epilogue_ok(x)
 
 
-def _conv_bn(conv, bn, x, act, folded=None):
+def _conv_bn(conv, bn, x, act, folded=None, residual=None):
     """conv -> BatchNorm(eval) -> act as ONE convolution with folded weights plus the fused bias /
     activation epilogue:  y = conv(x, w * s) + (beta - mean * s),  s = gamma / sqrt(var + eps).
     gamma / beta stay trainable (the fold is differentiated by autograd on the small tensors); no
@@ -75,6 +76,8 @@ def _conv_bn(conv, bn, x, act, folded=None):
         bias = bn.bias - bn.running_mean * scale
     weight = conv.weight * scale.view(-1, 1, 1, 1)
     y = F.conv2d(x, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if residual is not None:
+        return fused.bias_act_res(y, bias, residual, act)
     return fused.bias_act(y, bias, act)
 
 

@@ -1397,6 +1397,49 @@ class _BiasAct(torch.autograd.Function):
         return gx, (None if deferred else gbias), None
 
 
+class _BiasActRes(torch.autograd.Function):
+    """y = act(x + bias[c] + res) in place on x: the closing statement of a residual block in one pass.  The adjoint is the
+    plain bias/activation adjoint; ``res`` receives the same gradient tensor as ``x``."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, bias, res, act):
+        lib = _lib.load()
+        if not x.is_contiguous():
+            x = x.contiguous()
+        res = res.contiguous()
+        b, c = x.shape[0], x.shape[1]
+        p = x.numel() // (b * c)
+        mask = None
+        if act == 1 and p % 4 == 0 and any(ctx.needs_input_grad[:3]):
+            mask = torch.empty(lib.camli_bias_act_mask_bytes(b, c, p) // 8, dtype=torch.int64, device=x.device)
+        with _on_device(x):
+            _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_res_fwd, x.data_ptr(), bias.data_ptr(), res.data_ptr(),
+                        mask.data_ptr() if mask is not None else None, b, c, p, act, _stream_ptr(x),
+                        work=(12.0 * b * c * p + (b * c * p / 8.0 if mask is not None else 0.0), 'B'))
+        ctx.mark_dirty(x)
+        if mask is not None:
+            ctx.save_for_backward(mask)
+        elif act != 0:
+            ctx.save_for_backward(x)
+        ctx.act, ctx.masked, ctx.dims = act, mask is not None, (b, c, p)
+        ctx.bias_param = _runtime.deferral_target(bias)
+        return x
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gy):
+        gx, gbias, _ = _BiasAct.backward(ctx, gy)
+        return gx, gbias, gx, None
+
+
+def bias_act_res(x, bias, res, act):
+    """act(x + bias[c] + res) in place on the fresh convolution output x; act None or 'relu'; res shaped like x."""
+    _require_cuda('bias_act_res', x, bias, res)
+    assert act in (None, 'relu') and res.shape == x.shape
+    return _BiasActRes.apply(x, bias.float(), res.float(), ACT_CODES[act])
+
+
 def bias_act(x, bias, act):
     """act(x + bias[c]) in place on the (fresh) convolution output x [B,C,...]; ``act`` as in ACT_CODES."""
     _require_cuda('bias_act', x, bias)

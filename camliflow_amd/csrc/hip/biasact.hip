@@ -42,19 +42,27 @@ __device__ __forceinline__ float act_grad(float y) {
 __host__ __device__ __forceinline__ int mask_words(int P) { return (P / 4 + 63) / 64; }
 
 // grid (chunks, C, B), block 256; each block walks its chunk of one (b, c) plane
-template <int ACT, bool MASK>
+// RES (round 3): y = act(x + bias[c] + res) -- the closing statement of a residual block, relu(bn3(conv3(.)) + shortcut)
+// (mmdet ResNet Bottleneck), in the same single pass; as bias pass + add + relu it was 7 tensor streams instead of 3.
+template <int ACT, bool MASK, bool RES = false>
 __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x, const float* __restrict__ bias,
                                                             unsigned long long* __restrict__ mask, int C, int P,
-                                                            int chunk) {
+                                                            int chunk, const float* __restrict__ res = nullptr) {
     const int c = blockIdx.y, b = blockIdx.z;
     const float bv = bias[c];
     float* __restrict__ plane = x + ((size_t)b * C + c) * P;
+    const float* __restrict__ rplane = RES ? res + ((size_t)b * C + c) * P : nullptr;
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
     if ((P & 3) == 0 && (chunk & 3) == 0) {
         float4* __restrict__ p4 = reinterpret_cast<float4*>(plane);
         unsigned long long* __restrict__ mrow = MASK ? mask + ((size_t)b * C + c) * mask_words(P) * 4 : nullptr;
+        const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rplane);
         auto apply = [&](float4 v, int e) {
-            const float4 raw = make_float4(v.x + bv, v.y + bv, v.z + bv, v.w + bv);
+            float4 raw = make_float4(v.x + bv, v.y + bv, v.z + bv, v.w + bv);
+            if (RES) {
+                const float4 r = r4[e];
+                raw.x += r.x; raw.y += r.y; raw.z += r.z; raw.w += r.w;
+            }
             v.x = act_fwd<ACT>(raw.x); v.y = act_fwd<ACT>(raw.y); v.z = act_fwd<ACT>(raw.z); v.w = act_fwd<ACT>(raw.w);
             p4[e] = v;
             if (MASK) {
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x
         }
         for (; e < e4; e += 256) apply(p4[e], e);
     } else {
-        for (int e = beg + threadIdx.x; e < end; e += 256) plane[e] = act_fwd<ACT>(plane[e] + bv);
+        for (int e = beg + threadIdx.x; e < end; e += 256) plane[e] = act_fwd<ACT>(plane[e] + bv + (RES ? rplane[e] : 0.0f));
     }
 }
 
@@ -227,6 +235,28 @@ extern "C" int camli_bias_act_fwd(float* x_inout, const float* bias, void* sign_
     }
 #undef L
     return camli_check_launch("camli_bias_act_fwd");
+}
+
+extern "C" int camli_bias_act_res_fwd(float* x_inout, const float* bias, const float* res, void* sign_mask, int B, int C,
+                                      int P, int act, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!x_inout || !bias || !res) { camli_set_error("camli_bias_act_res_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (!shape_ok("camli_bias_act_res_fwd", B, C, P, act)) return CAMLI_EINVAL;
+    if (!(act == 0 || act == 1) || (sign_mask && !(act == 1 && (P & 3) == 0)) ||
+        ((P & 3) == 0 && ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(x_inout)) & 15))) {
+        camli_set_error("camli_bias_act_res_fwd: act must be 0 or 1 (mask: act 1, P %% 4 == 0), tensors 16-byte aligned (act=%d P=%d)", act, P);
+        return CAMLI_EINVAL;
+    }
+    const int chunk = pick_chunk(P);
+    dim3 grid(camli_divup(P, chunk), C, B);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned long long* m = static_cast<unsigned long long*>(sign_mask);
+#define L(A, M) hipLaunchKernelGGL((bias_act_fwd_kernel<A, M, true>), grid, dim3(256), 0, s, x_inout, bias, m, C, P, chunk, res)
+    if (act == 0) L(0, false);
+    else if (m) L(1, true);
+    else L(1, false);
+#undef L
+    return camli_check_launch("camli_bias_act_res_fwd");
 }
 
 extern "C" int camli_bias_act_bwd(const float* gy, const float* y, const void* sign_mask, float* gx, float* gbias,

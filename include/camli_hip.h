@@ -310,6 +310,10 @@ int64_t camli_bias_act_mask_bytes(int B, int C, int P);
 int camli_bias_act_fwd(float *x_inout, const float *bias, void *sign_mask, int B, int C, int P, int act, void *stream);
 int camli_bias_act_bwd(const float *gy, const float *y, const void *sign_mask, float *gx, float *gbias,
                        int B, int C, int P, int act, void *stream);
+/* y = act(x + bias[c] + res) in place on x (round 3): the closing relu(bn3(conv3(.)) + shortcut) of a residual block in
+ * one pass; act 0 or 1, res [B,C,P] like x.  The adjoint is camli_bias_act_bwd (the gradient of res equals that of x). */
+int camli_bias_act_res_fwd(float *x_inout, const float *bias, const float *res, void *sign_mask, int B, int C, int P,
+                           int act, void *stream);
 
 /*
  * Neighbour-weight network of a depth-wise set-conv: weight_net = MLP2d(3 -> 8 -> 32 -> C, ReLU after

@@ -292,3 +292,49 @@ def test_nan_to_num_folded_into_blend_and_epilogue():
     assert torch.isfinite(ya).all() and torch.equal(ya, yb)
     assert torch.equal(gxa, gxb)
     assert torch.allclose(gba, gbb, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 12, 20), (1, 5, 3, 7), (3, 64, 34, 60)], ids=str)
+def test_residual_epilogue_vs_torch(shape):
+    """camli_bias_act_res_fwd (round 3): relu(conv_out + bias + shortcut) in one pass -- values equal to the three torch ops,
+    the gradient reaches the convolution output AND the shortcut, the bias gradient is the masked sum."""
+    from camliflow_amd.csrc import fused
+    g = torch.Generator().manual_seed(sum(shape))
+    x0, r0 = torch.randn(*shape, generator=g).cuda(), torch.randn(*shape, generator=g).cuda()
+    b0, go = torch.randn(shape[1], generator=g).cuda(), torch.randn(*shape, generator=g).cuda()
+    for act in ('relu', None):
+        xa, ra, ba = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        ya = fused.bias_act_res(xa * 1.0, ba, ra, act)
+        ga = torch.autograd.grad(ya, [xa, ra, ba], go)
+        xb, rb, bb = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        yb = xb + bb.view(1, -1, 1, 1) + rb
+        yb = torch.relu(yb) if act else yb
+        gb = torch.autograd.grad(yb, [xb, rb, bb], go)
+        assert torch.allclose(ya, yb, rtol=1e-6, atol=1e-6)
+        assert torch.equal(ga[0], gb[0]) and torch.equal(ga[1], gb[1])
+        assert torch.allclose(ga[2], gb[2], rtol=1e-4, atol=1e-4)
+
+
+def test_resnet_trunk_fused_residual_vs_composed():
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.raft2d import Encoder2D
+    from modelutils import hashed_fill_
+    torch.manual_seed(0)
+    enc = hashed_fill_(Encoder2D(50), scale=0.5).cuda().train()
+    x = torch.randn(2, 3, 64, 96, device='cuda')
+    res = {}
+    for backend in ('composed', 'hip'):
+        enc.zero_grad()
+        with runtime.use_backend(backend):
+            runtime.set_census(True)
+            runtime.reset_census()
+            out = enc(x)
+            out.square().mean().backward()
+            census = runtime.census()
+            runtime.set_census(False)
+        res[backend] = (out.detach(), {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None})
+    assert census['fused'].get('camli_bias_act_fwd', 0) > 7
+    assert torch.allclose(res['hip'][0], res['composed'][0], rtol=1e-4, atol=1e-4)
+    num = sum(((res['hip'][1][n] - res['composed'][1][n]).double() ** 2).sum().item() for n in res['hip'][1]) ** 0.5
+    den = sum((res['composed'][1][n].double() ** 2).sum().item() for n in res['hip'][1]) ** 0.5
+    assert res['hip'][1].keys() == res['composed'][1].keys() and num / den < 1e-3, num / den
