@@ -96,6 +96,8 @@ PROTOTYPES = {
     "camli_conv3x3_co2_bwd_data": (_int, [_c_float_p] * 3 + [_int] * 4 + [_stream]),
     "camli_conv3x3_co2_bwd_weight_workspace_bytes": (ctypes.c_longlong, [_int, _int, _int]),
     "camli_conv3x3_co2_bwd_weight": (_int, [_c_float_p] * 5 + [_int] * 5 + [_stream]),
+    "camli_maxpool3x3s2_fwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p] + [_int] * 5 + [_stream]),
+    "camli_maxpool3x3s2_bwd": (_int, [_c_float_p, ctypes.c_void_p, _c_float_p] + [_int] * 5 + [_stream]),
     "camli_pad_normalize": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _int,
                                    ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), _stream]),
     "camli_sk_gate_fwd": (_int, [_c_float_p] * 6 + [_int, _int, _int, _stream]),

@@ -1397,6 +1397,45 @@ class _BiasAct(torch.autograd.Function):
         return gx, (None if deferred else gbias), None
 
 
+class _MaxPool3x3S2(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((b, c, ho, wo), dtype=torch.float32, device=x.device)
+        arg = torch.empty((b, c, ho, wo), dtype=torch.uint8, device=x.device)
+        with _on_device(x):
+            _lib.launch('camli_maxpool3x3s2_fwd', lib.camli_maxpool3x3s2_fwd, x.data_ptr(), y.data_ptr(), arg.data_ptr(),
+                        b * c, h, w, ho, wo, _stream_ptr(x), work=(b * c * (4.0 * h * w + 5.0 * ho * wo), 'B'))
+        ctx.save_for_backward(arg)
+        ctx.in_hw = (h, w)
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gy):
+        lib = _lib.load()
+        (arg,) = ctx.saved_tensors
+        b, c, ho, wo = arg.shape
+        h, w = ctx.in_hw
+        gy = gy.contiguous().float()
+        gx = torch.empty((b, c, h, w), dtype=torch.float32, device=gy.device)
+        with _on_device(gy):
+            _lib.launch('camli_maxpool3x3s2_bwd', lib.camli_maxpool3x3s2_bwd, gy.data_ptr(), arg.data_ptr(), gx.data_ptr(),
+                        b * c, h, w, ho, wo, _stream_ptr(gy), work=(b * c * (4.0 * h * w + 5.0 * ho * wo), 'B'))
+        return gx
+
+
+def maxpool3x3s2(x):
+    """nn.MaxPool2d(3, stride=2, padding=1) on [B,C,H,W] (the ResNet stem): one byte of arg-max per output, gather adjoint."""
+    _require_cuda('maxpool3x3s2', x)
+    assert x.dim() == 4
+    return _MaxPool3x3S2.apply(x.float())
+
+
 class _BiasActRes(torch.autograd.Function):
     """y = act(x + bias[c] + res) in place on x: the closing statement of a residual block in one pass.  The adjoint is the
     plain bias/activation adjoint; ``res`` receives the same gradient tensor as ``x``."""

@@ -462,6 +462,17 @@ long long camli_conv3x3_co2_bwd_weight_workspace_bytes(int B, int Cin, int W);
 int camli_conv3x3_co2_bwd_weight(const float *gy, const float *x, float *workspace, float *gw, float *gb, int accumulate,
                                  int B, int Cin, int H, int W, void *stream);
 
+/*
+ * 3x3 / stride 2 / padding 1 max pooling (the ResNet stem's nn.MaxPool2d(3, 2, 1)) over `planes` = B*C planes of H x W,
+ * Ho = (H - 1) / 2 + 1, Wo likewise.  fwd: y [planes,Ho,Wo] and arg uint8 [planes,Ho,Wo] = window-local position 0..8 of the
+ * first maximum in row-major order (a NaN wins, as in torch).  bwd: gx [planes,H,W] fully written = sum of gy over the (at
+ * most four) windows whose arg points at the element: a gather, no atomics.
+ */
+int camli_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *arg, int planes, int H, int W, int Ho, int Wo,
+                           void *stream);
+int camli_maxpool3x3s2_bwd(const float *gy, const unsigned char *arg, float *gx, int planes, int H, int W, int Ho, int Wo,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -338,3 +338,23 @@ def test_resnet_trunk_fused_residual_vs_composed():
     num = sum(((res['hip'][1][n] - res['composed'][1][n]).double() ** 2).sum().item() for n in res['hip'][1]) ** 0.5
     den = sum((res['composed'][1][n].double() ** 2).sum().item() for n in res['hip'][1]) ** 0.5
     assert res['hip'][1].keys() == res['composed'][1].keys() and num / den < 1e-3, num / den
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 64, 96), (1, 3, 17, 33), (1, 2, 1, 1), (2, 4, 2, 300), (1, 1, 272, 480)], ids=str)
+def test_maxpool3x3s2_vs_torch(shape):
+    """camli_maxpool3x3s2 (the ResNet stem's pooling): values and gradients equal torch's, including ties (post-ReLU zeros:
+    the FIRST maximum in row-major window order takes the gradient), odd sizes and NaN propagation."""
+    from camliflow_amd.csrc import fused
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sum(shape))
+    x0 = torch.relu(torch.randn(*shape, generator=g)).cuda()          # many exact ties at 0
+    if x0.numel() > 50:
+        x0.view(-1)[7] = float('nan')
+    xa = x0.clone().requires_grad_(True)
+    ya = fused.maxpool3x3s2(xa)
+    xb = x0.clone().requires_grad_(True)
+    yb = F.max_pool2d(xb, 3, 2, 1)
+    go = torch.randn(yb.shape, generator=g).cuda()
+    assert ya.shape == yb.shape and torch.equal(torch.nan_to_num(ya, nan=-7.0), torch.nan_to_num(yb, nan=-7.0))
+    ga, gb = torch.autograd.grad(ya, xa, go)[0], torch.autograd.grad(yb, xb, go)[0]
+    assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-6), (ga - gb).abs().max().item()
