@@ -10,6 +10,8 @@ checkpoints load.  Parity for this sub-module is UNPINNED (the dependency's sour
 the reference tree); it is plain conv/BN/ReLU/max-pool executed by MIOpen and is not a HIP-kernel
 target.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -17,6 +19,7 @@ import torch.nn.functional as F
 from . import runtime
 
 _STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+_TRUNK_CHANNELS_LAST = os.environ.get('CAMLI_TRUNK_NHWC', '1') == '1'
 
 
 class Bottleneck(nn.Module):
@@ -75,6 +78,8 @@ def _conv_bn(conv, bn, x, act, folded=None, residual=None):
         scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         bias = bn.bias - bn.running_mean * scale
     weight = conv.weight * scale.view(-1, 1, 1, 1)
+    if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        weight = weight.contiguous(memory_format=torch.channels_last)
     y = F.conv2d(x, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if residual is not None:
         return fused.bias_act_res(y, bias, residual, act)
@@ -157,9 +162,17 @@ class ResNetTrunk(nn.Module):
                 x = fused.maxpool3x3s2(x)      # own kernels: torch's pooling adjoint alone took 1.5 ms of a step
             else:
                 x = pool(x)
+            if _TRUNK_CHANNELS_LAST:
+                # the bottleneck stages run channels-last: MIOpen's implicit-GEMM kernels are NHWC kernels and, fed NCHW
+                # tensors, wrap every call in layout transposes (profiles/r03_trunk_conv_layout_microbench.txt: 22.1 ->
+                # 18.1 ms per forward+backward of the stages at batch 16).  The stem stays NCHW (its 7x7 weight gradient
+                # is 2x slower channels-last); one conversion of the pooled map here, one back at the trunk's output.
+                x = x.contiguous(memory_format=torch.channels_last)
             for name in self.res_layers:
                 for block in getattr(self, name):
                     x = block(x, folded)
+            if _TRUNK_CHANNELS_LAST:
+                x = x.contiguous()
             return (x,)
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         for name in self.res_layers:

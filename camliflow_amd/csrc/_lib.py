@@ -80,6 +80,10 @@ PROTOTYPES = {
     "camli_gru_blend_bwd": (_int, [_c_float_p] * 7 + [_int, _int, _int, _int, _stream]),
     "camli_bias_act_mask_bytes": (ctypes.c_int64, [_int, _int, _int]),
     "camli_bias_act_fwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _stream]),
+    "camli_bias_act_nhwc_mask_bytes": (ctypes.c_int64, [ctypes.c_longlong, _int]),
+    "camli_bias_act_nhwc_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_longlong, _int, _int, _stream]),
+    "camli_bias_act_nhwc_bwd_workspace_bytes": (ctypes.c_int64, [ctypes.c_longlong, _int]),
+    "camli_bias_act_nhwc_bwd": (_int, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_longlong, _int, _int, _stream]),
     "camli_bias_act_res_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _stream]),
     "camli_bias_act_bwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_weightnet_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int] + [_c_float_p] * 7

@@ -1397,6 +1397,66 @@ class _BiasAct(torch.autograd.Function):
         return gx, (None if deferred else gbias), None
 
 
+def _is_nhwc(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+class _BiasActNHWC(torch.autograd.Function):
+    """act(x + bias[c] (+ res)) in place on a CHANNELS-LAST convolution output [B,C,H,W] (memory [B,H,W,C]); act 0 / 1.
+    The ResNet trunk runs channels-last (MIOpen's implicit-GEMM kernels are NHWC kernels), see biasact.hip."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, bias, res, act):
+        lib = _lib.load()
+        b, c, h, w = x.shape
+        n_pix = b * h * w
+        if res is not None and not _is_nhwc(res):
+            res = res.contiguous(memory_format=torch.channels_last)
+        mask = None
+        if act == 1 and any(ctx.needs_input_grad[:3]):
+            mask = torch.empty(lib.camli_bias_act_nhwc_mask_bytes(n_pix, c) // 8, dtype=torch.int64, device=x.device)
+        with _on_device(x):
+            _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_nhwc_fwd, x.data_ptr(), bias.data_ptr(),
+                        res.data_ptr() if res is not None else None, mask.data_ptr() if mask is not None else None, n_pix, c, act,
+                        _stream_ptr(x), work=((12.0 if res is not None else 8.0) * n_pix * c, 'B'))
+        ctx.mark_dirty(x)
+        if mask is not None:
+            ctx.save_for_backward(mask)
+        ctx.act, ctx.dims, ctx.has_res = act, (n_pix, c), res is not None
+        ctx.bias_param = _runtime.deferral_target(bias)
+        return x
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gy):
+        lib = _lib.load()
+        n_pix, c = ctx.dims
+        gy = gy.float()
+        if not _is_nhwc(gy):
+            gy = gy.contiguous(memory_format=torch.channels_last)
+        relu = ctx.act == 1
+        if relu and not ctx.saved_tensors:      # forward ran without a mask (no gradient was expected)
+            raise RuntimeError('bias_act (channels-last): backward without a saved sign mask')
+        gx = torch.empty_like(gy) if relu else gy
+        deferred = ctx.bias_param is not None
+        gbias = None
+        if deferred or ctx.needs_input_grad[1] or relu:
+            gbias = (_runtime.PARAM_GRADS.slot(ctx.bias_param, lambda: _zero_slice(c, gy), False) if deferred
+                     else _zero_slice(c, gy))
+            ws = torch.empty(lib.camli_bias_act_nhwc_bwd_workspace_bytes(n_pix, c) // 4, dtype=torch.float32, device=gy.device)
+            with _on_device(gy):
+                _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_nhwc_bwd, gy.data_ptr(),
+                            ctx.saved_tensors[0].data_ptr() if relu else None, gx.data_ptr() if relu else None, gbias.data_ptr(),
+                            ws.data_ptr(), n_pix, c, ctx.act, _stream_ptr(gy), work=((8.125 if relu else 4.0) * n_pix * c, 'B'))
+        return gx, (None if deferred else gbias), (gx if ctx.has_res else None), None
+
+
+def _nhwc_epilogue_ok(x, act):
+    c = x.shape[1]
+    return _is_nhwc(x) and act in (0, 1) and 4 <= c <= 1024 and (c & (c - 1)) == 0 and x.dtype == torch.float32
+
+
 class _MaxPool3x3S2(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
@@ -1476,12 +1536,16 @@ def bias_act_res(x, bias, res, act):
     """act(x + bias[c] + res) in place on the fresh convolution output x; act None or 'relu'; res shaped like x."""
     _require_cuda('bias_act_res', x, bias, res)
     assert act in (None, 'relu') and res.shape == x.shape
+    if _nhwc_epilogue_ok(x, ACT_CODES[act]):
+        return _BiasActNHWC.apply(x, bias.float().contiguous(), res.float(), ACT_CODES[act])
     return _BiasActRes.apply(x, bias.float(), res.float(), ACT_CODES[act])
 
 
 def bias_act(x, bias, act):
     """act(x + bias[c]) in place on the (fresh) convolution output x [B,C,...]; ``act`` as in ACT_CODES."""
     _require_cuda('bias_act', x, bias)
+    if _nhwc_epilogue_ok(x, ACT_CODES[act]):
+        return _BiasActNHWC.apply(x, bias.float().contiguous(), None, ACT_CODES[act])
     return _BiasAct.apply(x, bias.float(), ACT_CODES[act])
 
 

@@ -191,6 +191,140 @@ __global__ __launch_bounds__(256) void bias_sum_kernel(const float* __restrict__
     if (threadIdx.x == 0) unsafeAtomicAdd(gbias + c, (partial[0] + partial[1]) + (partial[2] + partial[3]));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// channels-last forms (round 3).  The ResNet trunk runs channels-last since MIOpen's implicit-GEMM kernels are NHWC
+// kernels: fed NCHW tensors it wraps them in layout transposes (15 ms per step) and, for the trunk's shapes, picks slower
+// solvers -- profiles/r03_trunk_conv_layout_microbench.txt: 22.1 -> 18.1 ms per forward+backward of the trunk at batch 16.
+// Tensor = [n_pix, C] with C fastest, C a power of two in [4, 1024]: a thread's 16-byte group always holds the same
+// four channels (the grid stride is a multiple of C), so its bias quad is loaded once and its bias-gradient partials
+// stay in registers.  Sign mask: word i holds the ballots of float4 groups 64 i .. 64 i + 63 (components x, y, z, w in
+// four consecutive words) of the FLAT tensor; forward and adjoint walk it identically.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int ACT, bool MASK, bool RES>
+__global__ __launch_bounds__(256) void bias_act_nhwc_fwd_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                                 const float* __restrict__ res,
+                                                                 unsigned long long* __restrict__ mask, size_t n4, int C) {
+    float4* __restrict__ p4 = reinterpret_cast<float4*>(x);
+    const float4* __restrict__ r4 = reinterpret_cast<const float4*>(res);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const float4 bv = *reinterpret_cast<const float4*>(bias + (int)((i * 4) % (size_t)C));
+    // four groups per trip, their loads requested together (one at a time the 535 MB activations of the first stage are a
+    // chain of 32 dependent load -> store round trips per thread); whole waves take a trip together: ballots complete
+    for (; i - (threadIdx.x & 63) < n4; i += 4 * stride) {
+        float4 v[4], r[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t e = i + u * stride;
+            in[u] = e < n4;
+            v[u] = in[u] ? p4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (RES) r[u] = in[u] ? r4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t e = i + u * stride;
+            if (e - (threadIdx.x & 63) >= n4) break;          // wave-uniform: this wave has no group in trip u
+            float4 raw = make_float4(v[u].x + bv.x, v[u].y + bv.y, v[u].z + bv.z, v[u].w + bv.w);
+            if (RES) { raw.x += r[u].x; raw.y += r[u].y; raw.z += r[u].z; raw.w += r[u].w; }
+            float4 o;
+            o.x = act_fwd<ACT>(raw.x); o.y = act_fwd<ACT>(raw.y); o.z = act_fwd<ACT>(raw.z); o.w = act_fwd<ACT>(raw.w);
+            if (in[u]) p4[e] = o;
+            if (MASK) {
+                const unsigned long long mx = __ballot(in[u] && o.x > 0.0f), my = __ballot(in[u] && o.y > 0.0f);
+                const unsigned long long mz = __ballot(in[u] && o.z > 0.0f), mw = __ballot(in[u] && o.w > 0.0f);
+                if ((threadIdx.x & 63) == 0) {
+                    unsigned long long* w = mask + (e >> 6) * 4;
+                    w[0] = mx; w[1] = my; w[2] = mz; w[3] = mw;
+                }
+            }
+        }
+    }
+}
+
+// adjoint: gx = gy * [mask bit] (RELU) or gx aliases gy (identity: gx == nullptr, only the sums); gbias[c] += sum gx
+template <bool RELU>
+__global__ __launch_bounds__(256) void bias_act_nhwc_bwd_kernel(const float* __restrict__ gy,
+                                                                 const unsigned long long* __restrict__ mask,
+                                                                 float* __restrict__ gx, float* __restrict__ gbias, size_t n4,
+                                                                 int C, float* __restrict__ partials) {
+    __shared__ float4 part[256];
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gy);
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(gx);
+    const size_t stride = (size_t)gridDim.x * 256;
+    const int lane = threadIdx.x & 63;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = i + u * stride < n4 ? g4[i + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t e = i + u * stride;
+            if (e >= n4) break;
+            if (RELU) {
+                const unsigned long long* w = mask + (e >> 6) * 4;
+                g[u].x = ((w[0] >> lane) & 1ull) ? g[u].x : 0.0f; g[u].y = ((w[1] >> lane) & 1ull) ? g[u].y : 0.0f;
+                g[u].z = ((w[2] >> lane) & 1ull) ? g[u].z : 0.0f; g[u].w = ((w[3] >> lane) & 1ull) ? g[u].w : 0.0f;
+                o4[e] = g[u];
+            }
+            acc.x += g[u].x; acc.y += g[u].y; acc.z += g[u].z; acc.w += g[u].w;
+        }
+    }
+    // threads tid, tid + C/4, tid + 2 C/4 ... of the block hold the same four channels
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    const int q = C >> 2;                     // channel quads; 256 % q == 0
+    if ((int)threadIdx.x < q) {
+        float4 s = part[threadIdx.x];
+        for (int t = threadIdx.x + q; t < 256; t += q) {
+            const float4 o = part[t];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        // the block's first float4 index is a multiple of 256, hence of q: thread t holds quad t
+        if (partials) {      // [gridDim.x][C]: summed in block order by bias_nhwc_reduce_kernel (no atomics, reproducible)
+            *reinterpret_cast<float4*>(partials + (size_t)blockIdx.x * C + 4 * threadIdx.x) = s;
+        } else {
+            float* dst = gbias + 4 * threadIdx.x;
+            unsafeAtomicAdd(dst + 0, s.x); unsafeAtomicAdd(dst + 1, s.y); unsafeAtomicAdd(dst + 2, s.z); unsafeAtomicAdd(dst + 3, s.w);
+        }
+    }
+}
+
+// gbias[c] += sum over the blocks' partial rows.  grid ceil(C/64), block (64, 16)
+__global__ __launch_bounds__(1024) void bias_nhwc_reduce_kernel(const float* __restrict__ partials, int n_rows, int C,
+                                                                 float* __restrict__ gbias) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    float acc = 0.0f;
+    if (c < C) {
+#pragma unroll 8
+        for (int r = threadIdx.y; r < n_rows; r += 16) acc += partials[(size_t)r * C + c];
+    }
+    red[threadIdx.y][threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < C) {
+        float v = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) v += red[g][threadIdx.x];
+        gbias[c] += v;
+    }
+}
+
+bool nhwc_ok(const char* what, long long n_pix, int C, int act) {
+    if (n_pix < 0 || C < 4 || C > 1024 || (C & (C - 1)) || (act != 0 && act != 1)) {
+        camli_set_error("%s: channels-last form needs C a power of two in [4, 1024] and act 0 or 1 (n_pix=%lld C=%d act=%d)", what,
+                        n_pix, C, act);
+        return false;
+    }
+    return true;
+}
+
+int nhwc_blocks(size_t n4) {
+    const size_t want = (n4 + 256 * 8 - 1) / (256 * 8);      // ~8 groups per thread, at most 16384 workgroups
+    return (int)(want < 1 ? 1 : (want > 16384 ? 16384 : want));
+}
+
 int pick_chunk(int P) {
     // ~8K elements per block, multiple of 1024 so float4 groups never straddle chunks
     return P <= 8192 ? ((P + 1023) / 1024) * 1024 : 8192;
@@ -257,6 +391,64 @@ extern "C" int camli_bias_act_res_fwd(float* x_inout, const float* bias, const f
     else L(1, false);
 #undef L
     return camli_check_launch("camli_bias_act_res_fwd");
+}
+
+extern "C" int64_t camli_bias_act_nhwc_mask_bytes(long long n_pix, int C) {
+    const long long n4 = n_pix * C / 4;
+    return ((n4 + 63) / 64) * 4 * (int64_t)sizeof(unsigned long long);
+}
+
+extern "C" int camli_bias_act_nhwc_fwd(float* x_inout, const float* bias, const float* res, void* sign_mask, long long n_pix,
+                                       int C, int act, void* stream) {
+    if (n_pix == 0) return CAMLI_OK;
+    if (!x_inout || !bias) { camli_set_error("camli_bias_act_nhwc_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (!nhwc_ok("camli_bias_act_nhwc_fwd", n_pix, C, act)) return CAMLI_EINVAL;
+    if ((sign_mask && act != 1) || ((reinterpret_cast<uintptr_t>(x_inout) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(bias)) & 15)) {
+        camli_set_error("camli_bias_act_nhwc_fwd: a sign mask needs act 1; pointers must be 16-byte aligned");
+        return CAMLI_EINVAL;
+    }
+    const size_t n4 = (size_t)n_pix * C / 4;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned long long* m = static_cast<unsigned long long*>(sign_mask);
+    const dim3 grid(nhwc_blocks(n4));
+#define L(A, M, R) hipLaunchKernelGGL((bias_act_nhwc_fwd_kernel<A, M, R>), grid, dim3(256), 0, s, x_inout, bias, res, m, n4, C)
+    if (act == 0) { if (res) L(0, false, true); else L(0, false, false); }
+    else if (m) { if (res) L(1, true, true); else L(1, true, false); }
+    else { if (res) L(1, false, true); else L(1, false, false); }
+#undef L
+    return camli_check_launch("camli_bias_act_nhwc_fwd");
+}
+
+static int nhwc_bwd_blocks(size_t n4, bool partial_rows) {
+    const int want = nhwc_blocks(n4), cap = partial_rows ? 4096 : 1024;
+    return want > cap ? cap : want;
+}
+
+extern "C" int64_t camli_bias_act_nhwc_bwd_workspace_bytes(long long n_pix, int C) {
+    if (n_pix < 0 || C < 4) return 0;
+    return (int64_t)nhwc_bwd_blocks((size_t)n_pix * C / 4, true) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int camli_bias_act_nhwc_bwd(const float* gy, const void* sign_mask, float* gx, float* gbias, float* workspace,
+                                       long long n_pix, int C, int act, void* stream) {
+    if (n_pix == 0) return CAMLI_OK;
+    if (!gy || !gbias || (act == 1 && (!sign_mask || !gx))) { camli_set_error("camli_bias_act_nhwc_bwd: null pointer"); return CAMLI_EINVAL; }
+    if (!nhwc_ok("camli_bias_act_nhwc_bwd", n_pix, C, act)) return CAMLI_EINVAL;
+    const size_t n4 = (size_t)n_pix * C / 4;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // with `workspace` (camli_bias_act_nhwc_bwd_workspace_bytes) every workgroup writes its C partial sums and a second
+    // kernel adds them in block order; without it the workgroups end in C float atomics each on the same C addresses
+    // (16,384 workgroups: 1.6 ms on a 535 MB activation, 7x its forward), so their number is capped at 1,024
+    const int blocks = nhwc_bwd_blocks(n4, workspace != nullptr);
+    const dim3 grid(blocks);
+    if (act == 1)
+        hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel<true>, grid, dim3(256), 0, s, gy, static_cast<const unsigned long long*>(sign_mask),
+                           gx, gbias, n4, C, workspace);
+    else
+        hipLaunchKernelGGL(bias_act_nhwc_bwd_kernel<false>, grid, dim3(256), 0, s, gy, nullptr, nullptr, gbias, n4, C, workspace);
+    if (workspace)
+        hipLaunchKernelGGL(bias_nhwc_reduce_kernel, dim3(camli_divup(C, 64)), dim3(64, 16), 0, s, workspace, blocks, C, gbias);
+    return camli_check_launch("camli_bias_act_nhwc_bwd");
 }
 
 extern "C" int camli_bias_act_bwd(const float* gy, const float* y, const void* sign_mask, float* gx, float* gbias,

@@ -312,6 +312,17 @@ int camli_bias_act_bwd(const float *gy, const float *y, const void *sign_mask, f
                        int B, int C, int P, int act, void *stream);
 /* y = act(x + bias[c] + res) in place on x (round 3): the closing relu(bn3(conv3(.)) + shortcut) of a residual block in
  * one pass; act 0 or 1, res [B,C,P] like x.  The adjoint is camli_bias_act_bwd (the gradient of res equals that of x). */
+/* channels-last forms (round 3, the ResNet trunk): tensor [n_pix, C] with C fastest, C a power of two in [4, 1024], act 0 or
+ * 1; res NULL or shaped like x; sign mask of camli_bias_act_nhwc_mask_bytes(n_pix, C) bytes (act 1).  bwd: act 1 writes
+ * gx = gy * mask, act 0 only adds the per-channel sums of gy into gbias (gx ignored). */
+int64_t camli_bias_act_nhwc_mask_bytes(long long n_pix, int C);
+int camli_bias_act_nhwc_fwd(float *x_inout, const float *bias, const float *res, void *sign_mask, long long n_pix, int C,
+                            int act, void *stream);
+int64_t camli_bias_act_nhwc_bwd_workspace_bytes(long long n_pix, int C);
+/* workspace: NULL (float atomics into gbias) or camli_bias_act_nhwc_bwd_workspace_bytes bytes (per-workgroup partial sums,
+ * added in a fixed order by a second kernel: reproducible, and faster on large tensors) */
+int camli_bias_act_nhwc_bwd(const float *gy, const void *sign_mask, float *gx, float *gbias, float *workspace, long long n_pix,
+                            int C, int act, void *stream);
 int camli_bias_act_res_fwd(float *x_inout, const float *bias, const float *res, void *sign_mask, int B, int C, int P,
                            int act, void *stream);
 

@@ -358,3 +358,31 @@ def test_maxpool3x3s2_vs_torch(shape):
     assert ya.shape == yb.shape and torch.equal(torch.nan_to_num(ya, nan=-7.0), torch.nan_to_num(yb, nan=-7.0))
     ga, gb = torch.autograd.grad(ya, xa, go)[0], torch.autograd.grad(yb, xb, go)[0]
     assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-6), (ga - gb).abs().max().item()
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 12, 20), (1, 4, 3, 7), (3, 256, 17, 30), (1, 1024, 2, 3)], ids=str)
+def test_channels_last_epilogue_vs_torch(shape):
+    """The channels-last bias / activation / residual epilogue of the ResNet trunk (round 3) against the torch ops on the
+    same channels-last tensors: values, the gradient of the convolution output and of the shortcut, the bias gradient; the
+    results stay channels-last."""
+    from camliflow_amd.csrc import fused
+    g = torch.Generator().manual_seed(sum(shape))
+    cl = torch.channels_last
+    x0 = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=cl)
+    r0 = torch.randn(*shape, generator=g).cuda().contiguous(memory_format=cl)
+    b0, go = torch.randn(shape[1], generator=g).cuda(), torch.randn(*shape, generator=g).cuda().contiguous(memory_format=cl)
+    for act in ('relu', None):
+        for with_res in (True, False):
+            xa, ra, ba = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            ya = fused.bias_act_res(xa * 1.0, ba, ra, act) if with_res else fused.bias_act(xa * 1.0, ba, act)
+            assert ya.is_contiguous(memory_format=cl)
+            ins_a = [xa, ra, ba] if with_res else [xa, ba]
+            ga = torch.autograd.grad(ya, ins_a, go)
+            xb, rb, bb = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+            yb = xb + bb.view(1, -1, 1, 1) + (rb if with_res else 0.0)
+            yb = torch.relu(yb) if act else yb
+            gb = torch.autograd.grad(yb, [xb, rb, bb] if with_res else [xb, bb], go)
+            assert torch.allclose(ya, yb, rtol=1e-6, atol=1e-6)
+            for u, v in zip(ga[:-1], gb[:-1]):
+                assert torch.equal(u, v)
+            assert torch.allclose(ga[-1], gb[-1], rtol=1e-4, atol=1e-4)

@@ -29,11 +29,57 @@ def timeit(fn, reps=10):
     return s.elapsed_time(e) / reps * 1e3
 
 
+TRUNK = [  # name, cin, cout, k, stride, H, W (input), batch: the ResNet-50 stem + stages 1-2 at 544x960, both frames in one batch
+    ('stem_7x7_s2', 3, 64, 7, 2, 544, 960, 16),
+    ('l1_c1_1x1', 64, 64, 1, 1, 136, 240, 16), ('l1_c2_3x3', 64, 64, 3, 1, 136, 240, 16), ('l1_c3_1x1', 64, 256, 1, 1, 136, 240, 16),
+    ('l1_c1b_1x1', 256, 64, 1, 1, 136, 240, 16),
+    ('l2_c1_1x1', 256, 128, 1, 1, 136, 240, 16), ('l2_c2_3x3_s2', 128, 128, 3, 2, 136, 240, 16), ('l2_c3_1x1', 128, 512, 1, 1, 68, 120, 16),
+    ('l2_ds_1x1_s2', 256, 512, 1, 2, 136, 240, 16), ('l2_c1b_1x1', 512, 128, 1, 1, 68, 120, 16), ('l2_c2b_3x3', 128, 128, 3, 1, 68, 120, 16),
+]
+
+
+def trunk(args):
+    print('%-14s %-13s %9s %9s %9s   %s' % ('conv', 'layout', 'fwd us', 'bwd us', 'TF/s f+b', 'GFLOP fwd'))
+    for name, cin, cout, k, stride, h, w, b in TRUNK:
+        ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+        flop = 2.0 * b * ho * wo * cin * cout * k * k
+        variants = ['nchw', 'nhwc'] + (['nhwc-gemm'] if k == 1 and stride == 1 else [])
+        for layout in variants:
+            fmt = torch.channels_last if layout.startswith('nhwc') else torch.contiguous_format
+            x = torch.randn(b, cin, h, w, device='cuda').contiguous(memory_format=fmt).requires_grad_(True)
+            wt = torch.randn(cout, cin, k, k, device='cuda').contiguous(memory_format=fmt).requires_grad_(True)
+            if layout == 'nhwc-gemm':      # a 1x1 convolution on channels-last data IS a plain GEMM over the pixels
+                def fwd():
+                    return torch.matmul(x.permute(0, 2, 3, 1).reshape(-1, cin), wt.view(cout, cin).t())
+            else:
+                def fwd():
+                    return F.conv2d(x, wt, None, stride=stride, padding=k // 2)
+            y = fwd()
+            gy = torch.randn_like(y)
+            t_f = timeit(fwd)
+            t_b = timeit(lambda: torch.autograd.grad(y, [x, wt], gy, retain_graph=True))
+            print('%-14s %-13s %9.1f %9.1f %9.1f   %.1f' % (name, layout, t_f, t_b, 3 * flop / (t_f + t_b) / 1e6, flop / 1e9))
+            if args.kernels:
+                from torch.profiler import ProfilerActivity, profile
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    for _ in range(3):
+                        yy = fwd()
+                        torch.autograd.grad(yy, [x, wt], gy)
+                    torch.cuda.synchronize()
+                for ev in sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:6]:
+                    print('      %8.1f us x%d  %s' % (ev.device_time_total / ev.count, ev.count // 3, ev.key[:110]))
+            sys.stdout.flush()
+            del x, wt, y, gy
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--kernels', action='store_true')
     ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--trunk', action='store_true', help='the ResNet trunk convolutions instead of the update block')
     args = ap.parse_args()
+    if args.trunk:
+        return trunk(args)
     b, h, w = args.batch, 68, 120
     print('%-14s %-13s %9s %9s %9s   %s' % ('conv', 'layout', 'fwd us', 'bwd us', 'TF/s f+b', 'GFLOP fwd'))
     for name, cin, cout, (kh, kw) in CASES:
