@@ -138,10 +138,41 @@ def _flush_c_stdio():
         pass
 
 
+_T_START = time.perf_counter()
+
+
 def _log(msg):
-    """Progress notes on stderr (never stdout: the one JSON line is the only thing there)."""
-    sys.stderr.write('bench.py: %s\n' % msg)
+    """Progress notes on stderr (never stdout: the one JSON line is the only thing there), stamped with the seconds
+    since the process started so that a run that is cut off shows which leg it was in."""
+    sys.stderr.write('bench.py [%6.1f s]: %s\n' % (time.perf_counter() - _T_START, msg))
     sys.stderr.flush()
+
+
+def _elapsed():
+    return time.perf_counter() - _T_START
+
+
+def run_with_deadline(fn, seconds):
+    """fn() on a worker thread, waited for at most `seconds`: (result, None) or (None, reason).  The CPU legs are single
+    long torch calls that cannot be interrupted; a thread that overruns is abandoned (daemon) and main() leaves through
+    os._exit after printing its line, so an overrun costs its leg, never the bench line."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            box['result'] = fn()
+        except BaseException as exc:      # noqa: BLE001 -- reported on the main thread
+            box['error'] = exc
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(max(seconds, 1.0))
+    if th.is_alive():
+        return None, 'not finished %.0f s after it started (time budget, --time-budget)' % seconds
+    if 'error' in box:
+        raise box['error']
+    return box['result'], None
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -257,13 +288,14 @@ def _cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline_and_reference(args, state_dict):
+def cpu_baseline_and_reference(args, state_dict, deadline=None):
     """The CPU restatement path (this repo's cores driven by the C oracle operators) on the host cores: one
     sample (batch 1) of the same workload.  1 warm-up + 2 timed training steps at 8 threads -- the thread count of the
     in-container reference timing and the port's best: measured on the 128-core GPU box in round 2,
     8 threads 6.9 s, 32 threads 8.6 s, 128 threads 50 s per step (CAMLI_CPU_THREAD_SWEEP=1 repeats that sweep).  The
     warm-up step's forward is also the parity reference: it returns the final flows of that sample.  Reported, not
-    the target."""
+    the target.  `deadline` (seconds on the _elapsed() clock): a timed step is only started when one more step of the
+    duration just seen fits before it; when not even one does, the warm-up step is the sample (and the line says so)."""
     from modelutils import oracle_boundary
     all_threads = torch.get_num_threads()
     model = build_model(args).train()
@@ -282,6 +314,9 @@ def cpu_baseline_and_reference(args, state_dict):
         for label, threads, reps in plan:
             torch.set_num_threads(threads)
             for _ in range(reps):
+                if deadline is not None and times and _elapsed() + 1.2 * max(t for runs in times.values() for t, _ in runs) > deadline:
+                    _log('CPU port: no room for another %s step before the time budget ends' % label)
+                    break
                 t0 = time.perf_counter()
                 if ref is None:       # the very first step: weights == state_dict, keep its forward as the reference
                     out = model(batch)
@@ -295,13 +330,18 @@ def cpu_baseline_and_reference(args, state_dict):
                 else:
                     train_step(model, opt, batch)
                 times.setdefault(label, []).append((time.perf_counter() - t0, threads))
+                _log('CPU port: %s step at %d threads took %.1f s' % (label, threads, times[label][-1][0]))
     torch.set_num_threads(all_threads)
     timed = [(t, n) for label, runs in times.items() if label != 'warmup' for t, n in runs]
+    cut = not timed
+    if cut:        # the time budget left no room after the warm-up step: it is the sample
+        timed = list(times['warmup'])
     best_t, best_n = min(timed)
     base = {'value': round(1.0 / best_t, 5), 'unit': 'frame-pairs/s', 'cores': best_n, 'kind': 'port',
             'sample': 'batch-1 training step (fwd+bwd+clip+AdamW) of the same workload, %dx%d + %d pts, %d iters: '
                       '1 warm-up (%.1f s) + %s; best taken'
                       % (args.width, args.height, args.points, args.iters, times['warmup'][0][0],
+                         'no timed step (time budget): the warm-up step is the sample' if cut else
                          ', '.join('%.1f s @ %d thr' % (t, n) for t, n in timed)),
             'cpu_model': _cpu_model_name(), 'os_cpu_count': os.cpu_count()}
     return base, batch, ref
@@ -485,6 +525,9 @@ def main():
     ap.add_argument('--mode', choices=['train', 'eval'], default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU port (cpu_baseline AND parity)')
     ap.add_argument('--no-isolated', action='store_true', help='skip the isolated per-kernel rows (roofline_rows)')
+    ap.add_argument('--time-budget', type=float, default=float(os.environ.get('CAMLI_BENCH_BUDGET_S', 420)),
+                    help='seconds the whole run may take: the legs after the timed region (isolated rows, CPU port, parity) '
+                         'are skipped / cut when they would not fit, and the line says so; the timed region never is')
     ap.add_argument('--graph', action='store_true', default=None,
                     help='capture the whole training step in one HIP graph and replay it (single GPU); default for the '
                          'batch-1 configurations camlipwc / kitti, whose steps are bound by host enqueue time')
@@ -684,22 +727,42 @@ def main():
             'census': {'fused_launches_per_step': {k: round(v / roofline_steps, 1) for k, v in sorted(census['fused'].items())},
                        'composed_calls_per_step': {k: round(v / roofline_steps, 1) for k, v in sorted(census['composed'].items())}},
         }
+        _log('timed region done: %.2f ms per step' % step_ms)
+        budget = args.time_budget
         if world == 1 and not args.no_isolated and args.config == 'camliraft':
-            import kernel_bench
-            line['roofline_rows'] = kernel_bench.run(batch=args.batch, reps=5)
+            if _elapsed() < 0.5 * budget:
+                import kernel_bench
+                line['roofline_rows'] = kernel_bench.run(batch=args.batch, reps=5)
+                _log('isolated kernel rows done')
+            else:
+                line['roofline_rows_skipped'] = 'time budget: %.0f of %.0f s were gone after the timed region' % (_elapsed(), budget)
+                _log('isolated kernel rows skipped (time budget)')
+        overrun = False
         if world == 1 and not args.no_cpu_baseline and args.model == 'camliraft':
             # free the bench model before the parity model is built
             del optimizer, graphed
-            base, sample, ref = cpu_baseline_and_reference(args, state_dict)
-            line['cpu_baseline'] = base
-            if autocast is None:
-                line['parity'] = parity_check(args, state_dict, sample, ref, device)
-                failed = not line['parity']['ok']
+            deadline = budget - 15.0
+            got, why = run_with_deadline(lambda: cpu_baseline_and_reference(args, state_dict, deadline), deadline - _elapsed())
+            if got is None:
+                overrun = True
+                line['cpu_baseline'] = {'value': None, 'unit': 'frame-pairs/s', 'cores': min(8, torch.get_num_threads()),
+                                        'kind': 'port', 'sample': 'CPU port %s' % why}
+                _log('CPU port abandoned: %s' % why)
+            else:
+                base, sample, ref = got
+                line['cpu_baseline'] = base
+                if autocast is None:
+                    line['parity'] = parity_check(args, state_dict, sample, ref, device)
+                    failed = not line['parity']['ok']
+                    _log('parity check done')
         detail_path = write_detail(line, args.config)
         # RCCL writes its version banner through C stdio when the communicator is created; flush it so that the JSON
         # line is the LAST line on stdout
         _flush_c_stdio()
         print(json.dumps(compact_line(line, detail_path)), flush=True)
+        if overrun:         # a CPU-port thread is still inside a torch call: leave without joining it
+            sys.stderr.flush()
+            os._exit(0)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

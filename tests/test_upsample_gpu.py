@@ -7,7 +7,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('case', [(2, 68, 120, 8, 0.25), (1, 17, 30, 8, 0.25), (2, 36, 60, 4, 1.0), (1, 5, 70, 8, 1.0)], ids=str)
+@pytest.mark.parametrize('case', [(2, 68, 120, 8, 0.25), (1, 17, 30, 8, 0.25), (2, 36, 60, 4, 1.0), (1, 5, 70, 8, 1.0), (1, 3, 193, 4, 0.5)], ids=str)
 def test_convex_upsample(case, oracle_lib):
     from camliflow_amd.cores import runtime
     from camliflow_amd.cores.geometry import convex_upsample
