@@ -150,11 +150,13 @@ def _is_pointwise(conv):
             and not isinstance(conv.padding, str))
 
 
-def conv_bias_act(conv, x, act):
+def conv_bias_act(conv, x, act, leave_bias=False):
     """``act(conv(x))`` with the bias add, the activation and (backward) the bias-gradient reduction
-    fused into one pass over the convolution output (camli_bias_act_fwd/bwd)."""
+    fused into one pass over the convolution output (camli_bias_act_fwd/bwd).  ``leave_bias`` (act None only): return
+    the bias-free convolution -- the caller's next kernel adds ``conv.bias`` itself (ConvexUpsampler2D)."""
     from ..csrc import fused
-    if act is None and fused.conv3x3_co2_supported(conv, x):
+    assert not leave_bias or act is None
+    if act is None and not leave_bias and fused.conv3x3_co2_supported(conv, x):
         # a flow head's last convolution (wide map -> 2 channels): own HBM-bound kernels, bias included
         return fused.conv3x3_co2(x, conv.weight, conv.bias)
     if _is_pointwise(conv) and x.dtype == torch.float32 and x.is_contiguous():
@@ -163,6 +165,8 @@ def conv_bias_act(conv, x, act):
         y = conv._conv_forward(x, conv.weight, None)
     if y.dtype != torch.float32:      # autocast: a fresh fp32 copy the epilogue may overwrite in place
         y = y.float()
+    if leave_bias:
+        return y
     if conv.bias is None:
         return y if act is None else fused.bias_act(y, torch.zeros(y.shape[1], device=y.device), act)
     return fused.bias_act(y, conv.bias, act)

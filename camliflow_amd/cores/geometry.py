@@ -183,14 +183,18 @@ def backwarp_2d(x, flow12, padding_mode):
     return grid_sample(x, norm.permute(0, 2, 3, 1), padding_mode=padding_mode, align_corners=True)
 
 
-def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0):
+def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0, mask_bias=None):
     """RAFT convex upsampling: softmax over the 3x3 neighbourhood (utils.py:191-204).  ``mask_scale``
-    is the factor the caller would otherwise multiply the mask by (RAFT: 0.25)."""
+    is the factor the caller would otherwise multiply the mask by (RAFT: 0.25); ``mask_bias`` [9*S*S] is added to the
+    mask first (a caller that leaves the bias of the mask head's last convolution to this op saves one pass over the
+    mask tensor on the product path)."""
     if runtime.fused() and flow.is_cuda and runtime.atomics_ok('convex_upsample'):
         if scale_factor in (4, 8):
             from ..csrc import fused
-            return fused.convex_upsample(flow, mask, scale_factor, mask_scale)
+            return fused.convex_upsample(flow, mask, scale_factor, mask_scale, mask_bias)
         runtime.fallback('convex_upsample', 'scale factor %d (kernels exist for 4 and 8)' % scale_factor)
+    if mask_bias is not None:
+        mask = mask + mask_bias.view(1, -1, 1, 1)
     if mask_scale != 1.0:
         mask = mask_scale * mask
     batch_size, _, image_h, image_w = flow.shape

@@ -70,9 +70,9 @@ PROTOTYPES = {
                                        _int, _int, _int, _int, _int, _int, _stream]),
     "camli_pointconv_mix_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p, _c_float_p,
                                        _int, _int, _int, _int, _int, _int, _stream]),
-    "camli_convex_upsample_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int,
+    "camli_convex_upsample_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int,
                                          ctypes.c_float, _stream]),
-    "camli_convex_upsample_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+    "camli_convex_upsample_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                          _int, _int, _int, _int, ctypes.c_float, _stream]),
     "camli_gru_gates_fwd": (_int, [_c_float_p] * 6 + [_int, _int, _int, _stream]),
     "camli_gru_gates_bwd": (_int, [_c_float_p] * 7 + [_int, _int, _int, _stream]),

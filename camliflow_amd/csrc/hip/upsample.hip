@@ -5,7 +5,9 @@
 // [B, 9*S*S, h, w] mask tensor forward, more backward) and the `0.25 *` pre-scaling of
 // models/raft_core.py:195.
 //
-//   p_k(i,j;y,x)  = softmax_k( mask_scale * mask[b, k*S*S + i*S + j, y, x] ),  k = (dy+1)*3 + (dx+1)
+//   p_k(i,j;y,x)  = softmax_k( mask_scale * (mask[b, ch, y, x] + mask_bias[ch]) ),  ch = k*S*S + i*S + j,  k = (dy+1)*3 + (dx+1)
+//   (mask_bias: optional, the bias of the mask head's last 1x1 convolution (raft_core.py:187-189) -- added here, the
+//   [B, 9*S*S, h, w] tensor is not passed over once more for it; its gradient is the per-channel sum of the mask gradient)
 //   out[b,c,y*S+i,x*S+j] = sum_k p_k * S * flow[b,c,y+dy_k,x+dx_k]           (zero outside the image)
 //
 // HBM-bound on streaming the mask once (4*9*S*S bytes per coarse pixel).  A workgroup owns 64
@@ -24,6 +26,7 @@ namespace {
 template <int S>
 __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __restrict__ flow,
                                                               const float* __restrict__ mask,
+                                                              const float* __restrict__ mask_bias,
                                                               float* __restrict__ out, int h, int w, float mask_scale,
                                                               int IG) {
     __shared__ float tile[2][S][64 + 1];    // [channel][j][x_local]
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __rest
             float mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                p[k] = mrow[(size_t)(k * S * S + i * S + j) * plane] * mask_scale;
+                p[k] = (mrow[(size_t)(k * S * S + i * S + j) * plane] + (mask_bias ? mask_bias[k * S * S + i * S + j] : 0.0f)) * mask_scale;
                 mx = fmaxf(mx, p[k]);
             }
             float den = 0.0f;
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __rest
 // the two columns next to its 64) instead of 18 * IG -- 4.7 M -> 0.43 M atomics at 8 x 68 x 120, S = 8.
 template <int S>
 __global__ __launch_bounds__(256) void convex_upsample_bwd_kernel(const float* __restrict__ flow, const float* __restrict__ mask,
+                                                                  const float* __restrict__ mask_bias,
                                                                   const float* __restrict__ gout, float* __restrict__ gflow,
                                                                   float* __restrict__ gmask, int h, int w, float mask_scale) {
     constexpr int MAXG = 4;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void convex_upsample_bwd_kernel(const float* _
             float mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                p[k] = mrow[(size_t)(k * S * S + i * S + j) * plane] * mask_scale;
+                p[k] = (mrow[(size_t)(k * S * S + i * S + j) * plane] + (mask_bias ? mask_bias[k * S * S + i * S + j] : 0.0f)) * mask_scale;
                 mx = fmaxf(mx, p[k]);
             }
             float den = 0.0f;
@@ -206,8 +210,8 @@ int upsample_row_groups(int B, int h, int w, int S, int cap) {
 
 }  // namespace
 
-extern "C" int camli_convex_upsample_fwd(const float* flow, const float* mask, float* out, int B, int h, int w,
-                                         int scale, float mask_scale, void* stream) {
+extern "C" int camli_convex_upsample_fwd(const float* flow, const float* mask, const float* mask_bias, float* out, int B,
+                                         int h, int w, int scale, float mask_scale, void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!flow || !mask || !out) { camli_set_error("camli_convex_upsample_fwd: null pointer"); return CAMLI_EINVAL; }
     if (!upsample_shape_ok("camli_convex_upsample_fwd", B, h, w, scale)) return CAMLI_EINVAL;
@@ -215,14 +219,14 @@ extern "C" int camli_convex_upsample_fwd(const float* flow, const float* mask, f
     const dim3 grid(camli_divup(w, 64), h, B * ig);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (scale == 8)
-        hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, dim3(64), 0, s, flow, mask, out, h, w, mask_scale, ig);
+        hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, dim3(64), 0, s, flow, mask, mask_bias, out, h, w, mask_scale, ig);
     else
-        hipLaunchKernelGGL(convex_upsample_kernel<4>, grid, dim3(64), 0, s, flow, mask, out, h, w, mask_scale, ig);
+        hipLaunchKernelGGL(convex_upsample_kernel<4>, grid, dim3(64), 0, s, flow, mask, mask_bias, out, h, w, mask_scale, ig);
     return camli_check_launch("camli_convex_upsample_fwd");
 }
 
-extern "C" int camli_convex_upsample_bwd(const float* gout, const float* flow, const float* mask, float* gflow,
-                                         float* gmask, int B, int h, int w, int scale, float mask_scale,
+extern "C" int camli_convex_upsample_bwd(const float* gout, const float* flow, const float* mask, const float* mask_bias,
+                                         float* gflow, float* gmask, int B, int h, int w, int scale, float mask_scale,
                                          void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!gout || !flow || !mask || !gflow || !gmask) {
@@ -233,8 +237,10 @@ extern "C" int camli_convex_upsample_bwd(const float* gout, const float* flow, c
     const dim3 grid(camli_divup(w, 64), h, B), block(64, upsample_row_groups(B, h, w, scale, 4));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (scale == 8)
-        hipLaunchKernelGGL(convex_upsample_bwd_kernel<8>, grid, block, 0, s, flow, mask, gout, gflow, gmask, h, w, mask_scale);
+        hipLaunchKernelGGL(convex_upsample_bwd_kernel<8>, grid, block, 0, s, flow, mask, mask_bias, gout, gflow, gmask, h, w,
+                           mask_scale);
     else
-        hipLaunchKernelGGL(convex_upsample_bwd_kernel<4>, grid, block, 0, s, flow, mask, gout, gflow, gmask, h, w, mask_scale);
+        hipLaunchKernelGGL(convex_upsample_bwd_kernel<4>, grid, block, 0, s, flow, mask, mask_bias, gout, gflow, gmask, h, w,
+                           mask_scale);
     return camli_check_launch("camli_convex_upsample_bwd");
 }

@@ -267,12 +267,14 @@ int camli_pointconv_mix_bwd_sorted(const float *gout, const float *feat_cl, cons
  * softmax / unfold / sum / permute, models/utils.py:191-204, with the mask pre-scaled at raft_core.py:195).
  *   flow [B,2,h,w]; mask [B, 9*S*S, h, w] (raw: mask_scale is applied inside); out [B,2,h*S,w*S]; S in {4,8}
  *   out[b,c,y*S+i,x*S+j] = sum_k softmax_k(mask_scale*mask[b,k*S*S+i*S+j,y,x]) * S * flow[b,c,y+dy_k,x+dx_k]
+ *   mask_bias: NULL, or [9*S*S] added to the mask before the scale (the bias of the mask head's last convolution,
+ *   raft_core.py:187-189, folded in: one pass less over the mask); its gradient = per-channel sum of gmask.
  *   bwd: gmask fully written; gflow += (float atomics, caller zero-fills).
  */
-int camli_convex_upsample_fwd(const float *flow, const float *mask, float *out,
+int camli_convex_upsample_fwd(const float *flow, const float *mask, const float *mask_bias, float *out,
                               int B, int h, int w, int scale, float mask_scale, void *stream);
-int camli_convex_upsample_bwd(const float *gout, const float *flow, const float *mask, float *gflow, float *gmask,
-                              int B, int h, int w, int scale, float mask_scale, void *stream);
+int camli_convex_upsample_bwd(const float *gout, const float *flow, const float *mask, const float *mask_bias, float *gflow,
+                              float *gmask, int B, int h, int w, int scale, float mask_scale, void *stream);
 
 /*
  * Elementwise halves of the convolutional GRU (models/raft_core.py:123-139 composes them from ~9 torch

@@ -80,3 +80,15 @@ def test_cli_refuses_more_ranks_than_gpus():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '64'], capture_output=True, text=True,
                          env=env, timeout=280)
     assert out.returncode == 2 and 'refusing to oversubscribe' in out.stderr
+
+
+def test_time_budget_helper():
+    """The legs after the timed region run under a deadline: a leg that overruns is abandoned with a reason (the line is
+    printed without it), one that finishes hands its result over, one that raises raises on the caller's thread."""
+    import time
+    import bench
+    assert bench.run_with_deadline(lambda: 7, 5.0) == (7, None)
+    got, why = bench.run_with_deadline(lambda: time.sleep(30), 1.0)
+    assert got is None and 'time budget' in why
+    with pytest.raises(ZeroDivisionError):
+        bench.run_with_deadline(lambda: 1 / 0, 5.0)

@@ -30,6 +30,35 @@ def test_convex_upsample(case, oracle_lib):
     assert torch.allclose(res['hip'][2], res['composed'][2], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('case', [(2, 17, 70, 8, 0.25), (1, 9, 130, 4, 1.0)], ids=str)
+@pytest.mark.parametrize('deferred', [False, True])
+def test_convex_upsample_with_folded_mask_bias(case, deferred):
+    """``mask_bias`` (the mask head's last bias added inside the kernel) against the torch composition on
+    ``mask + bias``: values, flow / mask gradients and the bias gradient (= per-channel sum of the mask gradient),
+    returned to autograd or accumulated through the deferred-parameter sink."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.geometry import convex_upsample
+    b, h, w, s, ms = case
+    g = torch.Generator(device='cpu').manual_seed(h * w + s)
+    flow = torch.randn(b, 2, h, w, generator=g).cuda().requires_grad_(True)
+    mask = (torch.randn(b, 9 * s * s, h, w, generator=g) * 3).cuda().requires_grad_(True)
+    bias = torch.nn.Parameter(torch.randn(9 * s * s, generator=g).cuda())
+    gout = torch.randn(b, 2, h * s, w * s, generator=g).cuda()
+    res = {}
+    for backend in ('hip', 'composed'):
+        flow.grad = mask.grad = bias.grad = None
+        runtime.set_deferred_param_grads(deferred and backend == 'hip')
+        try:
+            with runtime.use_backend(backend):
+                out = convex_upsample(flow, mask, scale_factor=s, mask_scale=ms, mask_bias=bias)
+            out.backward(gout)
+        finally:
+            runtime.set_deferred_param_grads(False)
+        res[backend] = (out.detach(), flow.grad.clone(), mask.grad.clone(), bias.grad.clone())
+    for got, want, tol in zip(res['hip'], res['composed'], (1e-5, 1e-4, 1e-5, 1e-3)):
+        assert torch.allclose(got, want, rtol=1e-4, atol=tol), (got - want).abs().max()
+
+
 @pytest.mark.parametrize('shape', [(2, 128, 68, 120), (1, 128, 16, 20), (3, 8, 5, 6)], ids=str)
 def test_gru_step_fused_vs_literal(shape):
     """GRU2D.step (hoisted context + fused gate / blend kernels) against the literal GRU2D.forward of
