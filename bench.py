@@ -59,6 +59,7 @@ NORTH_STAR = {
     'camli_weightnet_fwd': 'hbm', 'camli_weightnet_bwd': 'mfma',
     'camli_knn_interp_fwd': 'hbm', 'camli_knn_interp_bwd': 'hbm', 'camli_knn_interp_bwd_xyz': 'hbm',
     'camli_corr3d_gather_fwd': 'hbm', 'camli_corr3d_gather_bwd': 'hbm',
+    'camli_corr3d_mlp_fwd': 'fma', 'camli_corr3d_mlp_bwd': 'fma',      # plain fp32 FMA on the vector ALU (registers only)
     'camli_pwc3d_pair_fwd': 'hbm', 'camli_pwc3d_pair_bwd': 'hbm', 'camli_gather_wsum_fwd': 'hbm', 'camli_gather_wsum_bwd': 'hbm',
 }
 MFMA_F32_PEAK_TFLOPS = 157.3
@@ -436,6 +437,9 @@ def roofline_report(summary, steps, args, step_ms):
             else:
                 entry['tflops'] = round(rec['flop'] / secs / 1e12, 2)
                 entry['frac'] = round(entry['tflops'] / MFMA_F32_PEAK_TFLOPS, 4)
+        elif kind == 'fma' and rec.get('flop', 0) > 0:      # un-packed fp32 FMA: half the quoted (v_pk_fma_f32) vector peak
+            entry['tflops'] = round(rec['flop'] / secs / 1e12, 2)
+            entry['frac'] = round(entry['tflops'] / (MFMA_F32_PEAK_TFLOPS / 2), 4)
         elif kind == 'valu':
             entry['frac'] = round(rate / 1e9 / VALU_PAIR_PEAK_G, 4)
         if 'frac' in entry and kind in ('hbm', 'mfma'):

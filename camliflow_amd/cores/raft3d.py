@@ -9,6 +9,8 @@ Pieces, in data-flow order:
   CamLiRAFT_L_Core the point-only model built from them
 Module / parameter names are a checkpoint-compatibility surface and match the reference.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -122,6 +124,14 @@ class Correlation3D(nn.Module):
                 cross = knn_channel_first(xyzs2[lvl], xyz1, self.k, invariant_query=True)
                 columns.append(fused.corr3d_lookup_input(self.cost_volume_pyramid[lvl], xyz1, xyzs2[lvl], cross))
             lookup = torch.cat(columns, dim=3)
+        convs = [layer.conv_fn for layer in self.cost_mlp.convs]
+        if os.environ.get('CAMLI_CORR3D_MLP', 'fused') == 'fused':
+            if (all(layer._epilogue == 'relu' for layer in self.cost_mlp.convs)
+                    and fused.corr3d_cost_mlp_supported(lookup, convs, 4)):
+                # both layers, the ReLUs and the sum over the neighbours in one kernel each way (fp32 also under autocast,
+                # like every point op): the two [B,C/4,N,4k] activations stay in registers
+                return self.merge(fused.corr3d_cost_mlp(lookup, convs[0], convs[1], 4))
+            runtime.fallback('Correlation3D(RAFT).cost_mlp', 'outside the fused cost MLP (4 levels x 16 neighbours, width 32, N % 8 == 0)')
         cost = self.cost_mlp(lookup)                                                  # [B,C/4,N,4k]
         cost = cost.view(bs, -1, n_src, 4, self.k).sum(dim=-1)                        # [B,C/4,N,4]
         cost = cost.permute(0, 3, 1, 2).reshape(bs, -1, n_src)                        # level-major channels

@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(HERE, "libcamli_hip.so")
 # -ffp-contract=off: KNN / FPS distances are specified UNFUSED (oracle/camli_oracle.c); dot products
 # that may fuse say so explicitly with __builtin_fmaf.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# per-source additions.  corr3dmlp: the SLP vectoriser pairs the fmaf chains into v_pk_fma_f32, whose operands must be
+# vector registers -- the 1024 wave-uniform weights then leave the scalar registers (512 VGPRs + scratch instead of 168)
+EXTRA_FLAGS = {"corr3dmlp.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -47,7 +50,7 @@ def build(force=False, verbose=False):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
                 and os.path.getmtime(obj) > newest_header):
             return obj, None
-        cmd = [hipcc] + compile_flags + ["-c", "-I", HIP_DIR, "-I", INCLUDE_DIR, src, "-o", obj]
+        cmd = [hipcc] + compile_flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", "-I", HIP_DIR, "-I", INCLUDE_DIR, src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         res = subprocess.run(cmd, capture_output=True, text=True)

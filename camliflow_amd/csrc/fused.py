@@ -1011,6 +1011,74 @@ def corr3d_lookup_levels(pyr, xyz1, xyz2, knn_levels):
     return _Corr3DLookupLevels.apply(pyr.token, xyz1.float().contiguous(), xyz2.float().contiguous(), pyr, *knn_levels)
 
 
+class _Corr3DCostMLP(torch.autograd.Function):
+    """relu(W2 relu(W1 x + b1) + b2) summed over the k neighbours of every level, see csrc/hip/corr3dmlp.hip."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, lookup, w1, b1, w2, b2, levels):
+        lib = _lib.load()
+        b, _, n, lk = lookup.shape
+        hidden, k = w2.shape[0], lk // levels
+        out = torch.empty((b, levels * hidden, n), dtype=torch.float32, device=lookup.device)
+        cols = float(b) * n * lk
+        with _on_device(lookup):
+            _lib.launch('camli_corr3d_mlp_fwd', lib.camli_corr3d_mlp_fwd, lookup.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                        w2.data_ptr(), b2.data_ptr(), out.data_ptr(), b, n, levels, k, hidden, _stream_ptr(lookup),
+                        work=(16.0 * cols + 4.0 * out.numel(), 'B'), flop=2.0 * cols * (4 * hidden + hidden * hidden))
+        ctx.save_for_backward(lookup, w1, b1, w2, b2)
+        ctx.params = [_runtime.deferral_target(t) for t in (w1, b1, w2, b2)]
+        ctx.levels = levels
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        lib = _lib.load()
+        lookup, w1, b1, w2, b2 = ctx.saved_tensors
+        b, _, n, lk = lookup.shape
+        hidden, k = w2.shape[0], lk // ctx.levels
+        gout = gout.contiguous().float()
+        # only channel 3 (the cost-volume entry) is written and only channel 3 is read by the lookup's adjoint
+        glookup = torch.empty_like(lookup)
+        grads, deferred = [], []
+        for param, like in zip(ctx.params, (w1, b1, w2, b2)):
+            if param is not None:
+                grads.append(_runtime.PARAM_GRADS.slot(param, lambda like=like: torch.zeros_like(like), False))
+            else:
+                grads.append(torch.zeros_like(like))
+            deferred.append(param is not None)
+        ws = torch.empty(lib.camli_corr3d_mlp_bwd_workspace_bytes(b, n) // 4, dtype=torch.float32, device=lookup.device)
+        cols = float(b) * n * lk
+        with _on_device(lookup):
+            _lib.launch('camli_corr3d_mlp_bwd', lib.camli_corr3d_mlp_bwd, lookup.data_ptr(), gout.data_ptr(), w1.data_ptr(),
+                        b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), glookup.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
+                        grads[2].data_ptr(), grads[3].data_ptr(), ws.data_ptr(), b, n, ctx.levels, k, hidden, _stream_ptr(lookup),
+                        work=(20.0 * cols + 4.0 * gout.numel(), 'B'), flop=2.0 * cols * (2 * 4 * hidden + 3 * hidden * hidden))
+        return (glookup,) + tuple(None if d else g for g, d in zip(grads, deferred)) + (None,)
+
+
+def corr3d_cost_mlp_supported(lookup, convs, levels):
+    """The fused cost MLP covers the reference's configuration: two bias + ReLU layers 4 -> 32 -> 32, 4 levels x 16
+    neighbours, fp32 parameters, a point count that is a multiple of 8."""
+    if len(convs) != 2 or lookup.dim() != 4 or lookup.shape[1] != 4 or lookup.shape[3] % levels:
+        return False
+    c1, c2 = convs
+    if c1.bias is None or c2.bias is None or tuple(c1.weight.shape[:2]) != (c2.weight.shape[1], 4):
+        return False
+    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in (c1.weight, c1.bias, c2.weight, c2.bias)):
+        return False
+    return bool(_lib.load().camli_corr3d_mlp_supported(levels, lookup.shape[3] // levels, c2.weight.shape[0], lookup.shape[2])) \
+        and c2.weight.shape[0] == c2.weight.shape[1]
+
+
+def corr3d_cost_mlp(lookup, conv1, conv2, levels):
+    """lookup [B,4,N,levels*k] -> [B, levels*hidden, N] (level-major channels): ``cost_mlp(lookup).sum(-1)`` of every level,
+    camliraft_l_core.py:96-100, without the two [B,hidden,N,levels*k] activations."""
+    _require_cuda('corr3d_cost_mlp', lookup)
+    return _Corr3DCostMLP.apply(lookup.float().contiguous(), conv1.weight, conv1.bias, conv2.weight, conv2.bias, levels)
+
+
 # ------------------------------------------------------------------------------------------------
 # PointPWC learnable cost volume (models/camlipwc_l_core.py:53-106), see csrc/hip/pwc3d.hip
 # ------------------------------------------------------------------------------------------------

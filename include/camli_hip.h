@@ -213,6 +213,26 @@ int camli_corr3d_gather_bwd(const float *gout, const int64_t *knn, float *gcost,
                             void *stream);
 
 /*
+ * The cost MLP of that lookup and the sum over the neighbours in one pass (models/camliraft_l_core.py:96-100:
+ * `self.cost_mlp(lookup).sum(dim=-1)` per level; cost_mlp = MLP2d(4 -> hidden -> hidden, bias, ReLU)).  The hidden
+ * activations ([B,hidden,N,L*k] twice) never reach memory.
+ *   lookup [B,4,N,L*k] (camli_corr3d_gather_levels_fwd's output); w1 [hidden,4], b1 [hidden], w2 [hidden,hidden], b2 [hidden]
+ *   out [B, L*hidden, N], channel l*hidden + o = sum_j relu(b2[o] + w2[o,:] . relu(b1 + w1 lookup[b,:,n,l*k+j]))
+ *   bwd: glookup [B,4,N,L*k]: ONLY channel 3 (the cost-volume entry) is written -- the offsets are not differentiable
+ *        on this path and camli_corr3d_gather_levels_bwd reads channel 3 only;
+ *        gw1 / gb1 / gw2 / gb2 += the parameter gradients (per-workgroup partial tiles in `workspace`,
+ *        camli_corr3d_mlp_bwd_workspace_bytes, added in a fixed order: no atomics)
+ * Covered: L = 4, k = 16, hidden = 32, N % 8 == 0 (camli_corr3d_mlp_supported); anything else returns CAMLI_EINVAL.
+ */
+int camli_corr3d_mlp_supported(int levels, int k, int hidden, int N);
+int camli_corr3d_mlp_fwd(const float *lookup, const float *w1, const float *b1, const float *w2, const float *b2, float *out,
+                         int B, int N, int levels, int k, int hidden, void *stream);
+int64_t camli_corr3d_mlp_bwd_workspace_bytes(int B, int N);
+int camli_corr3d_mlp_bwd(const float *lookup, const float *gout, const float *w1, const float *b1, const float *w2,
+                         const float *b2, float *glookup, float *gw1, float *gb1, float *gw2, float *gb2, float *workspace,
+                         int B, int N, int levels, int k, int hidden, void *stream);
+
+/*
  * PointPWC learnable cost volume, PWC-style Correlation3D (internal composite op; the reference materialises
  * [B, 2C+3, N, k] = cat(f1 expanded, gather(f2), dxyz) and runs MLP2d over it: models/camlipwc_l_core.py:53-106).
  * The first MLP layer is split by input block (see csrc/hip/pwc3d.hip); tensors are [B,C,N,k] with k fastest, k a

@@ -180,6 +180,16 @@ def cases(batch):
         torch.autograd.grad(out, cost, go4)
     yield 'corr3d_gather B%d N2048 k16' % b, c3d, {'camli_corr3d_gather_fwd': 'hbm', 'camli_corr3d_gather_bwd': 'hbm'}
 
+    # ---- A12 cost MLP (4 -> 32 -> 32, ReLU) + neighbour sum of the lookup: fp32 FMA work, everything in registers ------
+    conv1, conv2 = torch.nn.Conv2d(4, 32, 1).cuda(), torch.nn.Conv2d(32, 32, 1).cuda()
+    look = _randn(g, b, 4, 2048, 64).requires_grad_(True)
+    go_mlp = _randn(g, b, 128, 2048)
+
+    def cost_mlp():
+        out = fused.corr3d_cost_mlp(look, conv1, conv2, 4)
+        torch.autograd.grad(out, [look, conv1.weight, conv1.bias, conv2.weight, conv2.bias], go_mlp)
+    yield 'corr3d_mlp B%d N2048 4x16' % b, cost_mlp, {'camli_corr3d_mlp_fwd': 'fma', 'camli_corr3d_mlp_bwd': 'fma'}
+
 
 def _row(case, name, kind, rec, fps_steps=None):
     us = rec['total_ms'] / rec['launches'] * 1e3
@@ -194,6 +204,12 @@ def _row(case, name, kind, rec, fps_steps=None):
         ach = flop / us / 1e6
         row.update(bound='mfma', achieved=round(ach, 2), peak=MFMA_F32_PEAK, unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK, 4),
                    flop_per_launch=flop)
+    elif kind == 'fma':
+        # plain (un-packed) fp32 FMA on the vector ALU: half the quoted 157.3 TFLOP/s, which counts v_pk_fma_f32
+        flop = rec.get('flop', 0.0) / rec['launches']
+        ach = flop / us / 1e6
+        row.update(bound='valu-fma', achieved=round(ach, 2), peak=MFMA_F32_PEAK / 2, unit='TFLOP/s',
+                   frac=round(ach / (MFMA_F32_PEAK / 2), 4), flop_per_launch=flop)
     elif kind == 'valu':
         ach = work / us / 1e3
         row.update(bound='valu', achieved=round(ach, 1), peak=VALU_PAIR_PEAK, unit='Gpairs/s', frac=round(ach / VALU_PAIR_PEAK, 4))

@@ -51,3 +51,22 @@ ka = prof.key_averages()
 rows = sorted(ka, key=lambda e: -e.self_device_time_total)[:45]
 for e in rows:
     print('%-60s calls %6d  %8.2f' % (e.key[:60], e.count, e.self_device_time_total / 1e3))
+
+# ---- per scope: which ops hold the forward GPU time (walk every op's parent chain up to its SCOPE range) ----
+per_scope = collections.defaultdict(collections.Counter)
+calls = collections.defaultdict(collections.Counter)
+for e in events:
+    if e.name.startswith('SCOPE:') or e.self_device_time_total <= 0:
+        continue
+    parent = e.cpu_parent
+    while parent is not None and not parent.name.startswith('SCOPE:'):
+        parent = parent.cpu_parent
+    if parent is not None:
+        per_scope[parent.name[6:]][e.name] += e.self_device_time_total
+        calls[parent.name[6:]][e.name] += 1
+want = sys.argv[2].split(',') if len(sys.argv) > 2 else ['core.clfm_corr', 'core.clfm_motion', 'core.branch_2d.motion_encoder',
+                                                          'core.branch_2d.convex_upsampler', 'core.branch_3d.correlation']
+for scope in want:
+    print('--- %s: forward ops by self GPU time (ms, calls)' % scope)
+    for name, t in per_scope[scope].most_common(14):
+        print('   %-70s %8.3f %5d' % (name[:70], t / 1e3, calls[scope][name]))
