@@ -8,8 +8,9 @@
 // hidden activations never leave the registers:
 //
 //   fwd : out[b, l*32 + o, n] = sum_j relu(b2[o] + W2[o,:] . relu(b1 + W1 x[b,:,n,l*16+j]))
-//         lane = column (level l = lane / 16, neighbour j = lane % 16) -> a wave is one point; the weights are
-//         wave-uniform (scalar loads), the neighbour sum is a 16-lane DPP rotation sum, two points share a weight row
+//         lane = column (level l = lane / 16, neighbour j = lane % 16) -> a wave is one point; layer 1 on the vector ALU
+//         with wave-uniform weights (scalar loads), layer 2 on the matrix cores (operands straight from registers,
+//         one v_permlane32_swap per K step), the neighbour sum is a 16-lane DPP rotation sum
 //   bwd : recomputes both layers from the 16-byte-per-column input, gives d/d(cost-volume entry) (the coordinates
 //         are not differentiable on this path) and the parameter gradients.  dW2 = G2 H1^T and [dW1 | db1] =
 //         G1 [X | 1]^T are contractions over the ~1 M columns of a call: they run on the matrix cores
@@ -42,8 +43,31 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ void layer1(const float* __restrict__ w1, const float* __restrict__ b1, const float (&x)[4],
+// Orders a wave's own LDS writes before its own later LDS reads of other lanes' slots.  The LDS executes one wave's
+// instructions in issue order, so no wait is needed -- only the compiler must not move the reads above the writes.
+// (The transposition buffers of the adjoint are private to a wave: a workgroup barrier there would only couple the waves.)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// The 1024 + 160 weights are wave-uniform and read-only: loads through the CONSTANT address space are scalar loads
+// (s_load_dwordx16, one per half row).  `opaque_zero()` is an offset the optimiser cannot see through: added to the
+// pointer inside the per-point loop it keeps the loads inside the loop -- hoisted out of it the 1184 values would have to
+// live in vector registers.
+typedef const float __attribute__((address_space(4))) * cfloat_ptr;
+__device__ __forceinline__ cfloat_ptr as_constant(const float* p) { return (cfloat_ptr)(p); }
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
+
+__device__ __forceinline__ void layer1(const float* w1_global, const float* b1_global, const float (&x)[4],
                                        float (&h1)[CM_H]) {
+    const int z = opaque_zero();
+    const cfloat_ptr w1 = as_constant(w1_global) + z, b1 = as_constant(b1_global) + z;
 #pragma unroll
     for (int i = 0; i < CM_H; ++i) {
         float a = b1[i];
@@ -55,7 +79,13 @@ __device__ __forceinline__ void layer1(const float* __restrict__ w1, const float
     }
 }
 
-// grid ceil(B * N / (4 * CH)), block 256: wave = CH consecutive points of one batch element (N % CH == 0)
+// grid ceil(B * N / (4 * CH)), block 256: wave = CH consecutive points of one batch element (N % CH == 0).
+// Layer 1 on the vector ALU in the column layout (lane = column, 32 units in registers); layer 2 on the matrix cores:
+// per 32-column tile D[o][col] = b2[o] + sum_i W2[o][i] H1[i][col] is 16 v_mfma_f32_32x32x2_f32 (bias in the
+// accumulator, then the i-ordered fmaf chain).  The A fragments (W2[o = lane % 32][i = 2s + lane / 32]) are 16 registers
+// loaded once per wave; the B fragment of step s wants H1[2s + lane / 32][col = 32 t + lane % 32], and ONE
+// v_permlane32_swap of (h1[2s], h1[2s + 1]) yields it for both tiles: [X.lo | Y.lo] and [X.hi | Y.hi].
+// D layout: lane holds column 32 t + lane % 32, units o = (r & 3) + 8 (r >> 2) + 4 (lane / 32), r = 0..15.
 template <int CH>
 __global__ __launch_bounds__(256) void corr3d_mlp_fwd_kernel(const float* __restrict__ lookup, const float* __restrict__ w1,
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
@@ -67,37 +97,38 @@ __global__ __launch_bounds__(256) void corr3d_mlp_fwd_kernel(const float* __rest
     const int chunk = blockIdx.x * 4 + wv;
     const bool live = chunk < B * chunks_per_b;
     const int b = live ? chunk / chunks_per_b : 0, n0 = live ? (chunk % chunks_per_b) * CH : 0;
-    const int l = lane >> 4, j = lane & 15;
+    const int half = lane >> 5, cl = lane & 31, q = cl >> 4, j = lane & 15;
     const float* __restrict__ xin = lookup + ((size_t)b * 4 * N + n0) * CM_COLS + lane;
     const size_t plane = (size_t)N * CM_COLS;
 
-    for (int p = 0; p < CH; p += 2) {
-        // the weights are re-fetched through the scalar cache per point pair: hoisted out of this loop the 1024 + 160
-        // values would have to live in vector registers
-        const float* __restrict__ w2p = w2;
-        asm volatile("" : "+s"(w2p));
-        float x0[4], x1[4], h0[CM_H], h1[CM_H];
+    float wa[CM_H / 2];
+    f32x16 bias;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            x0[c] = xin[c * plane + (size_t)p * CM_COLS];
-            x1[c] = xin[c * plane + (size_t)(p + 1) * CM_COLS];
+    for (int s = 0; s < CM_H / 2; ++s) wa[s] = w2[cl * CM_H + 2 * s + half];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = b2[(r & 3) + 8 * (r >> 2) + 4 * half];
+
+    for (int p = 0; p < CH; ++p) {
+        float x[4], h1[CM_H];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[c] = xin[c * plane + (size_t)p * CM_COLS];
+        layer1(w1, b1, x, h1);
+        f32x16 d0 = bias, d1 = bias;
+#pragma unroll
+        for (int s = 0; s < CM_H / 2; ++s) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(h1[2 * s]), __float_as_uint(h1[2 * s + 1]), false, false);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], __uint_as_float(sw[0]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s], __uint_as_float(sw[1]), d1, 0, 0, 0);
         }
-        layer1(w1, b1, x0, h0);
-        layer1(w1, b1, x1, h1);
+        // ReLU, sum over the 16 neighbours of a level (= one 16-lane row), lane j keeps value r = j
 #pragma unroll
-        for (int o = 0; o < CM_H; ++o) {
-            float a0 = b2[o], a1 = a0;
-#pragma unroll
-            for (int i = 0; i < CM_H; ++i) {
-                const float w = w2p[o * CM_H + i];
-                a0 = __builtin_fmaf(w, h0[i], a0);
-                a1 = __builtin_fmaf(w, h1[i], a1);
-            }
-            a0 = row16_sum(fmaxf(a0, 0.0f));
-            a1 = row16_sum(fmaxf(a1, 0.0f));
-            if (j == (o & 15)) {
-                stage[wv][l * CM_H + o][p] = a0;
-                stage[wv][l * CM_H + o][p + 1] = a1;
+        for (int r = 0; r < 16; ++r) {
+            const float v0 = row16_sum(fmaxf(d0[r], 0.0f));
+            const float v1 = row16_sum(fmaxf(d1[r], 0.0f));
+            if (j == r) {
+                const int o = (r & 3) + 8 * (r >> 2) + 4 * half;
+                stage[wv][q * CM_H + o][p] = v0;             // tile 0: levels 0, 1
+                stage[wv][(2 + q) * CM_H + o][p] = v1;       // tile 1: levels 2, 3
             }
         }
     }
@@ -113,87 +144,147 @@ __global__ __launch_bounds__(256) void corr3d_mlp_fwd_kernel(const float* __rest
 }
 
 // grid ceil(B * N / (BW * CH)), block 64 * BW (BW = 2 waves: the three transposition buffers are 19 KB per wave).
-// partials [gridDim.x][CM_PART]
+// partials [gridDim.x][CM_PART].  Per point (= 64 columns) 128 v_mfma_f32_32x32x2_f32:
+//   pre2 = b2 + W2 H1            32  (as in the forward; D layout: lane = column 32 t + lane % 32, 16 of the 32 units)
+//   G2   = gout where pre2 > 0       (D layout, in place; gout rows read in that layout)
+//   gH1  = W2^T G2               32  (B fragments from the D-layout registers: one v_permlane32_swap of registers
+//                                     (4m, 4m+1) gives the K steps o = 8m, 8m+1 and o = 8m+4, 8m+5; (4m+2, 4m+3) likewise)
+//   G1   = gH1 where h1 > 0          (the layer-1 sign bits travel as one 32-bit mask per column, swapped across the halves)
+//   dW2 += G2 H1^T, [dW1|db1] += G1 [X|1]^T   32 + 32  (contractions over the columns: operands transposed through LDS)
 constexpr int CM_BW = 2;
+__device__ __forceinline__ int unit_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
 template <int CH>
-__global__ __launch_bounds__(64 * CM_BW) void corr3d_mlp_bwd_kernel(const float* __restrict__ lookup, const float* __restrict__ gout,
+__global__ __launch_bounds__(64 * CM_BW) __attribute__((amdgpu_waves_per_eu(2))) void corr3d_mlp_bwd_kernel(const float* __restrict__ lookup, const float* __restrict__ gout,
                                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
                                                              float* __restrict__ glookup, float* __restrict__ partials, int B,
                                                              int N) {
     constexpr int LD = CM_H + 1;
-    __shared__ float bufA[CM_BW][CM_COLS][LD];     // G2^T, then G1^T: [column][channel]
+    __shared__ float bufA[CM_BW][CM_COLS][LD];     // G2^T, then G1^T: [column][unit]
     __shared__ float bufB[CM_BW][CM_COLS][LD];     // H1^T
     __shared__ float bufX[CM_BW][CM_COLS][8];      // x0..x3, 1, 0, 0, 0
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int chunks_per_b = N / CH;
     const int chunk = blockIdx.x * CM_BW + wv;
     const bool live = chunk < B * chunks_per_b;
+    const float livef = live ? 1.0f : 0.0f;
     const int b = live ? chunk / chunks_per_b : 0, n0 = live ? (chunk % chunks_per_b) * CH : 0;
-    const int l = lane >> 4;
-    const int half = lane >> 5, cl = lane & 31;
+    const int half = lane >> 5, cl = lane & 31, q = cl >> 4;
     const size_t plane = (size_t)N * CM_COLS;
     const float* __restrict__ xin = lookup + ((size_t)b * 4 * N + n0) * CM_COLS + lane;
-    const float* __restrict__ gin = gout + ((size_t)b * CM_OUT + l * CM_H) * N + n0;
+    // gout rows in the D layout: tile t -> level 2 t + q, unit unit_of(r, half)
+    const float* __restrict__ gin = gout + ((size_t)b * CM_OUT + q * CM_H) * N + n0;
 
+    // The A fragments (W2[o = cl][i = 2s + half] for pre2, W2^T[i = cl][o = 2s + half] for gH1), the bias and W1[:, 3] in
+    // the D layout are re-read per point (L1 hits): kept in registers they are 80 of them, and with the five accumulator
+    // tiles the kernel then holds one wave per SIMD -- nothing to overlap the matrix cores with.
     f32x16 acc_w2, acc_w1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_w2[r] = acc_w1[r] = 0.0f;
     float gb2 = 0.0f;       // lane (half, cl): sum of g2[o = cl] over the columns [32 half, 32 half + 32) of every point
 
     for (int p = 0; p < CH; ++p) {
-        const float* __restrict__ w2p = w2;       // see the forward kernel
-        asm volatile("" : "+s"(w2p));
-        float x[4], h1[CM_H], gh1[CM_H];
+        const int z = opaque_zero();
+        const float* __restrict__ w2v = w2 + z;
+        const float* __restrict__ b2v = b2 + z;
+        const float* __restrict__ w1v = w1 + z;
+        float x[4], h1[CM_H];
 #pragma unroll
         for (int c = 0; c < 4; ++c) x[c] = xin[c * plane + (size_t)p * CM_COLS];
         layer1(w1, b1, x, h1);
+        unsigned mask = 0u;                               // bit i: h1[i] > 0 for this lane's column
 #pragma unroll
-        for (int i = 0; i < CM_H; ++i) gh1[i] = 0.0f;
+        for (int i = 0; i < CM_H; ++i) {
+            mask |= h1[i] > 0.0f ? (1u << i) : 0u;
+            bufB[wv][lane][i] = h1[i];
+        }
+        const auto msw = __builtin_amdgcn_permlane32_swap(mask, mask, false, false);
+        const unsigned m0 = (unsigned)msw[0] >> (4 * half), m1 = (unsigned)msw[1] >> (4 * half);     // columns cl and 32 + cl
+
+        // ---- pre2, then G2 in place ----
+        f32x16 d0, d1;
 #pragma unroll
-        for (int o = 0; o < CM_H; ++o) {
-            float a = b2[o];
+        for (int r = 0; r < 16; ++r) d0[r] = d1[r] = b2v[unit_of(r, half)];
 #pragma unroll
-            for (int i = 0; i < CM_H; ++i) a = __builtin_fmaf(w2p[o * CM_H + i], h1[i], a);
-            const float go = gin[(size_t)o * N + p];
-            const float g = (live && a > 0.0f) ? go : 0.0f;
-#pragma unroll
-            for (int i = 0; i < CM_H; ++i) gh1[i] = __builtin_fmaf(w2p[o * CM_H + i], g, gh1[i]);
-            bufA[wv][lane][o] = g;
+        for (int s = 0; s < CM_H / 2; ++s) {
+            const float wa = w2v[cl * CM_H + 2 * s + half];
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(h1[2 * s]), __float_as_uint(h1[2 * s + 1]), false, false);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, __uint_as_float(sw[0]), d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, __uint_as_float(sw[1]), d1, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < CM_H; ++i) bufB[wv][lane][i] = h1[i];
-        __syncthreads();
-        // dW2[o][i] += sum over the 64 columns of g2[o] * h1[i]
+        for (int r = 0; r < 16; ++r) {
+            const int u = unit_of(r, half);
+            const float go0 = gin[(size_t)u * N + p] * livef;
+            const float go1 = gin[(size_t)(2 * CM_H + u) * N + p] * livef;
+            d0[r] = d0[r] > 0.0f ? go0 : 0.0f;
+            d1[r] = d1[r] > 0.0f ? go1 : 0.0f;
+            bufA[wv][cl][u] = d0[r];
+            bufA[wv][32 + cl][u] = d1[r];
+        }
+        // ---- gH1 = W2^T G2 ----
+        f32x16 e0, e1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e0[r] = e1[r] = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int r0 = 4 * m + 2 * pr, sa = 4 * m + pr, sb = 4 * m + 2 + pr;
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0[r0]), __float_as_uint(d0[r0 + 1]), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d1[r0]), __float_as_uint(d1[r0 + 1]), false, false);
+                const float wta = w2v[(2 * sa + half) * CM_H + cl], wtb = w2v[(2 * sb + half) * CM_H + cl];
+                e0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wta, __uint_as_float(s0[0]), e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wta, __uint_as_float(s1[0]), e1, 0, 0, 0);
+                e0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wtb, __uint_as_float(s0[1]), e0, 0, 0, 0);
+                e1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wtb, __uint_as_float(s1[1]), e1, 0, 0, 0);
+            }
+        }
+        wave_lds_fence();
+        // dW2[o][i] += sum over the 64 columns of g2[o] * h1[i];  db2[o] += sum of g2[o]
 #pragma unroll 8
         for (int s = 0; s < CM_COLS / 2; ++s)
             acc_w2 = __builtin_amdgcn_mfma_f32_32x32x2f32(bufA[wv][2 * s + half][cl], bufB[wv][2 * s + half][cl], acc_w2, 0, 0, 0);
 #pragma unroll 8
         for (int s = 0; s < CM_COLS / 2; ++s) gb2 += bufA[wv][32 * half + s][cl];
-        __syncthreads();
-        float gx3 = 0.0f;
+        wave_lds_fence();
+        // ---- layer-1 adjoint (D layout): G1, d/d(cost entry) ----
+        float part0 = 0.0f, part1 = 0.0f;
 #pragma unroll
-        for (int i = 0; i < CM_H; ++i) {
-            const float g1 = h1[i] > 0.0f ? gh1[i] : 0.0f;
-            bufA[wv][lane][i] = g1;
-            gx3 = __builtin_fmaf(w1[i * 4 + 3], g1, gx3);
+        for (int r = 0; r < 16; ++r) {
+            const int bit = (r & 3) + 8 * (r >> 2), u = unit_of(r, half);
+            const float g10 = (m0 >> bit) & 1u ? e0[r] : 0.0f;
+            const float g11 = (m1 >> bit) & 1u ? e1[r] : 0.0f;
+            bufA[wv][cl][u] = g10;
+            bufA[wv][32 + cl][u] = g11;
+            const float w13 = w1v[u * 4 + 3];
+            part0 = __builtin_fmaf(w13, g10, part0);
+            part1 = __builtin_fmaf(w13, g11, part1);
+        }
+        {   // a column's 32 units are split over the two lane halves: add the halves, lane L keeps column L
+            const auto t0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part0), __float_as_uint(part0), false, false);
+            const auto t1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part1), __float_as_uint(part1), false, false);
+            const float tot0 = __uint_as_float(t0[0]) + __uint_as_float(t0[1]);
+            const float tot1 = __uint_as_float(t1[0]) + __uint_as_float(t1[1]);
+            if (live) glookup[((size_t)b * 4 + 3) * plane + (size_t)(n0 + p) * CM_COLS + lane] = half == 0 ? tot0 : tot1;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) bufX[wv][lane][c] = x[c];
         bufX[wv][lane][4] = 1.0f;
         bufX[wv][lane][5] = bufX[wv][lane][6] = bufX[wv][lane][7] = 0.0f;
-        if (live) glookup[((size_t)b * 4 + 3) * plane + (size_t)(n0 + p) * CM_COLS + lane] = gx3;
-        __syncthreads();
+        wave_lds_fence();
         // [dW1 | db1][i][c] += sum over the columns of g1[i] * [x | 1][c]
 #pragma unroll 8
         for (int s = 0; s < CM_COLS / 2; ++s) {
             const float xb = cl < 8 ? bufX[wv][2 * s + half][cl & 7] : 0.0f;
             acc_w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(bufA[wv][2 * s + half][cl], xb, acc_w1, 0, 0, 0);
         }
-        __syncthreads();
+        wave_lds_fence();
     }
 
     // ---- the waves' tiles -> one partial row per workgroup, added in wave order ----
+    __syncthreads();
     float* red = &bufA[0][0][0];                 // CM_PART floats (bufA holds CM_BW * 64 * 33)
     static_assert(CM_BW * CM_COLS * LD >= CM_PART, "reduction row does not fit");
     for (int w = 0; w < CM_BW; ++w) {

@@ -39,6 +39,15 @@ def test_cost_mlp_vs_torch(shape, deferred):
     want = _reference(lookup64, *params64, 4)
     want.backward(gout.double())
     ref = [want.detach(), lookup64.grad[:, 3]] + [p.grad for p in params64]
+    # ... and the fp32 torch composition, to know what fp32 itself costs on this input: ReLU's derivative is discontinuous,
+    # among 33 M (column, unit) pairs a few pre-activations sit within one rounding of zero, and a gradient term that
+    # takes the other side there moves a parameter gradient by a whole term
+    want32 = _reference(lookup, conv1.weight, conv1.bias, conv2.weight, conv2.bias, 4)
+    want32.backward(gout)
+    ref32 = [want32.detach(), lookup.grad[:, 3].clone()] + [p.grad.clone() for p in (conv1.weight, conv1.bias, conv2.weight, conv2.bias)]
+    lookup.grad = None
+    conv1.zero_grad()
+    conv2.zero_grad()
 
     runtime.set_deferred_param_grads(deferred)
     try:
@@ -48,14 +57,13 @@ def test_cost_mlp_vs_torch(shape, deferred):
         runtime.set_deferred_param_grads(False)
     res = [got.detach(), lookup.grad[:, 3].clone()] + [p.grad.clone() for p in (conv1.weight, conv1.bias, conv2.weight, conv2.bias)]
     names = ('out', 'glookup[:,3]', 'gw1', 'gb1', 'gw2', 'gb2')
-    for name, a, w in zip(names, res, ref):
+    for name, a, w, t32 in zip(names, res, ref, ref32):
         scale = float(w.abs().max()) + 1e-6
         diff = (a.double() - w).abs()
-        bad = int((diff > 2e-5 * scale + 1e-6).sum())
-        # ReLU is discontinuous in its derivative: among 33 M (column, unit) pairs a few pre-activations sit within one
-        # fp32 rounding of zero, and there the fp32 and the fp64 evaluation may take different sides
-        allowed = a.numel() // 100000 if name == 'glookup[:,3]' else 0
-        assert bad <= allowed, (name, bad, allowed, float(diff.max()), scale)
+        tol = max(2e-5 * scale + 1e-6, 5.0 * float((t32.double() - w).abs().max()))
+        bad = int((diff > tol).sum())
+        allowed = a.numel() // 100000 if name == 'glookup[:,3]' else 0      # isolated sign flips, see above
+        assert bad <= allowed, (name, bad, allowed, float(diff.max()), tol, scale)
 
 
 def test_cost_mlp_is_reproducible():
