@@ -21,6 +21,7 @@
 // matrix cores.  Operands may be m-contiguous ([K][M], staged with 16-byte loads / ds_write_b128) or k-contiguous
 // ([M][K], transposed by the staging stores; row stride 130 floats keeps those stores on 32 distinct banks).
 #include "camli_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -36,19 +37,21 @@ constexpr int GB_K = 32;       // K step
 // CHECK = false: the tile is known to lie inside the operand and 16-byte loads are legal -- unconditional loads (a
 // per-element "in range?" select makes the compiler branch around every load and wait for each one in turn).
 // CHECK = true : out-of-range elements read as zero; `vec` = base and ld allow aligned 16-byte loads.
-template <bool KC>
+// KS = K step of the tile (32, or 16 for the unmarked loops: half the LDS image and two staging registers less per
+// operand -> three workgroups per CU instead of two); a tile is KS * 32 float4, KS / 8 per thread.
+template <bool KC, int KS = GB_K>
 struct TileGeom {
     static constexpr int LD = KC ? 130 : 132;      // LDS row stride in floats
-    static __device__ __forceinline__ int k_of(int f) { return KC ? 4 * (f & 7) : (f >> 5); }
-    static __device__ __forceinline__ int m_of(int f) { return KC ? (f >> 3) : 4 * (f & 31); }
+    static __device__ __forceinline__ int k_of(int f) { return KC ? 4 * (f & (KS / 4 - 1)) : (f >> 5); }
+    static __device__ __forceinline__ int m_of(int f) { return KC ? (f / (KS / 4)) : 4 * (f & 31); }
 };
 template <bool KC>
 using OperandTile = TileGeom<KC>;
 
-template <bool KC, bool CHECK>
+template <bool KC, bool CHECK, int KS = GB_K>
 __device__ __forceinline__ float4 tile_load_one(const float* __restrict__ base, int64_t ld, int m0, int k0, int M, int K,
                                                 bool vec, int f) {
-    const int gk = k0 + TileGeom<KC>::k_of(f), gm = m0 + TileGeom<KC>::m_of(f);
+    const int gk = k0 + TileGeom<KC, KS>::k_of(f), gm = m0 + TileGeom<KC, KS>::m_of(f);
     if (!CHECK) {
         const float* p = KC ? base + (int64_t)gm * ld + gk : base + (int64_t)gk * ld + gm;
         return *reinterpret_cast<const float4*>(p);
@@ -80,10 +83,10 @@ __device__ __forceinline__ float4 tile_load_one(const float* __restrict__ base, 
     return v;
 }
 
-template <bool KC>
+template <bool KC, int KS = GB_K>
 __device__ __forceinline__ void tile_store_one(float* __restrict__ s, const float4& v, int f) {
     constexpr int LD = TileGeom<KC>::LD;
-    float* d = s + TileGeom<KC>::k_of(f) * LD + TileGeom<KC>::m_of(f);
+    float* d = s + TileGeom<KC, KS>::k_of(f) * LD + TileGeom<KC, KS>::m_of(f);
     if (KC) {
         d[0] = v.x; d[LD] = v.y; d[2 * LD] = v.z; d[3 * LD] = v.w;
     } else {
@@ -101,6 +104,21 @@ __device__ __forceinline__ void tile_store_one(float* __restrict__ s, const floa
     tile_store_one<KCF>(s, R##1, tid + 256);                                                 \
     tile_store_one<KCF>(s, R##2, tid + 512);                                                 \
     tile_store_one<KCF>(s, R##3, tid + 768)
+// the same for a K step of KS (16: registers 2 and 3 stay unused and are dropped by the compiler)
+#define GB_LOADK(KCF, R, base, ld, x0, k0, X, K, vec)                                        \
+    R##0 = tile_load_one<KCF, CHECK, KS>(base, ld, x0, k0, X, K, vec, tid);                 \
+    R##1 = tile_load_one<KCF, CHECK, KS>(base, ld, x0, k0, X, K, vec, tid + 256);           \
+    if (KS == 32) {                                                                          \
+        R##2 = tile_load_one<KCF, CHECK, KS>(base, ld, x0, k0, X, K, vec, tid + 512);       \
+        R##3 = tile_load_one<KCF, CHECK, KS>(base, ld, x0, k0, X, K, vec, tid + 768);       \
+    }
+#define GB_STOREK(KCF, R, s)                                                                 \
+    tile_store_one<KCF, KS>(s, R##0, tid);                                                   \
+    tile_store_one<KCF, KS>(s, R##1, tid + 256);                                             \
+    if (KS == 32) {                                                                          \
+        tile_store_one<KCF, KS>(s, R##2, tid + 512);                                         \
+        tile_store_one<KCF, KS>(s, R##3, tid + 768);                                         \
+    }
 
 // The K loop of one 128x128 tile.  CHECK = false: interior tile, aligned operands, K a multiple of GB_K -- the loop
 // contains no bounds logic at all (a checked load anywhere in the loop makes the compiler wait for the whole
@@ -109,20 +127,20 @@ __device__ __forceinline__ void tile_store_one(float* __restrict__ s, const floa
 // iterations visited (a band around the flow field: ~15-20 % of the 128x32 tiles).  The staging pass already holds a
 // tile in registers, so "is any element non-zero" is one OR per thread folded into the step's barrier
 // (__syncthreads_or), and a zero tile skips its 64 MFMAs.  Values are unchanged (adding exact zeros).
-template <bool A_KC, bool B_KC, bool CHECK, bool SKIPZ>
+template <bool A_KC, bool B_KC, bool CHECK, bool SKIPZ, int KS>
 __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, const float* __restrict__ Bb, float* lds,
                                                f32x16 (&acc)[2][2], int M, int N, int K, int64_t lda, int64_t ldb, int m0,
                                                int n0, bool vec_a, bool vec_b, int tid, int wm, int wn) {
     constexpr int LDA = OperandTile<A_KC>::LD, LDB = OperandTile<B_KC>::LD;
     float* const sA = lds;                          // two buffers of [GB_K][LDA]
-    float* const sB = lds + 2 * GB_K * LDA;         // two buffers of [GB_K][LDB]
+    float* const sB = lds + 2 * KS * LDA;           // two buffers of [KS][LDB]
     const int lane = tid & 63;
     const int fk = lane >> 5, fm = lane & 31;
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    GB_LOAD4(A_KC, ra, Ab, lda, m0, 0, M, K, vec_a);
-    GB_LOAD4(B_KC, rb, Bb, ldb, n0, 0, N, K, vec_b);
-    GB_STORE4(A_KC, ra, sA);
-    GB_STORE4(B_KC, rb, sB);
+    float4 ra0, ra1, ra2 = make_float4(0.f, 0.f, 0.f, 0.f), ra3 = ra2, rb0, rb1, rb2 = ra2, rb3 = ra2;
+    GB_LOADK(A_KC, ra, Ab, lda, m0, 0, M, K, vec_a);
+    GB_LOADK(B_KC, rb, Bb, ldb, n0, 0, N, K, vec_b);
+    GB_STOREK(A_KC, ra, sA);
+    GB_STOREK(B_KC, rb, sB);
 #define GB_NONZERO(R) (((R##0).x != 0.f) | ((R##0).y != 0.f) | ((R##0).z != 0.f) | ((R##0).w != 0.f) | ((R##1).x != 0.f) | ((R##1).y != 0.f) | \
                        ((R##1).z != 0.f) | ((R##1).w != 0.f) | ((R##2).x != 0.f) | ((R##2).y != 0.f) | ((R##2).z != 0.f) | ((R##2).w != 0.f) | \
                        ((R##3).x != 0.f) | ((R##3).y != 0.f) | ((R##3).z != 0.f) | ((R##3).w != 0.f))
@@ -130,19 +148,19 @@ __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, con
     if (SKIPZ) live = __syncthreads_or(GB_NONZERO(rb) ? 1 : 0);
     else __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += GB_K) {
-        const bool more = k0 + GB_K < K;
+    for (int k0 = 0; k0 < K; k0 += KS) {
+        const bool more = k0 + KS < K;
         if (more) {     // next step's operands: in flight while this step runs on the matrix cores
-            GB_LOAD4(A_KC, ra, Ab, lda, m0, k0 + GB_K, M, K, vec_a);
-            GB_LOAD4(B_KC, rb, Bb, ldb, n0, k0 + GB_K, N, K, vec_b);
+            GB_LOADK(A_KC, ra, Ab, lda, m0, k0 + KS, M, K, vec_a);
+            GB_LOADK(B_KC, rb, Bb, ldb, n0, k0 + KS, N, K, vec_b);
         }
-        const float* a = sA + buf * (GB_K * LDA) + fk * LDA + wm + fm;
-        const float* b = sB + buf * (GB_K * LDB) + fk * LDB + wn + fm;
+        const float* a = sA + buf * (KS * LDA) + fk * LDA + wm + fm;
+        const float* b = sB + buf * (KS * LDB) + fk * LDB + wn + fm;
         // the fragments of a half step (8 k-pairs x 4 values) are read from LDS in one batch, then 32 MFMAs run
         // back to back: the matrix pipe never waits on an LDS round trip between its own instructions
         if (!SKIPZ || live)
 #pragma unroll
-        for (int kh = 0; kh < GB_K; kh += 16) {
+        for (int kh = 0; kh < KS; kh += 16) {
             float fa0[8], fa1[8], fb0[8], fb1[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -159,8 +177,8 @@ __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, con
             }
         }
         if (more) {
-            GB_STORE4(A_KC, ra, sA + (buf ^ 1) * (GB_K * LDA));     // the other buffer: its readers finished one barrier ago
-            GB_STORE4(B_KC, rb, sB + (buf ^ 1) * (GB_K * LDB));
+            GB_STOREK(A_KC, ra, sA + (buf ^ 1) * (KS * LDA));     // the other buffer: its readers finished one barrier ago
+            GB_STOREK(B_KC, rb, sB + (buf ^ 1) * (KS * LDB));
         }
         if (SKIPZ) live = __syncthreads_or((more && GB_NONZERO(rb)) ? 1 : 0);
         else __syncthreads();
@@ -264,7 +282,7 @@ __device__ __forceinline__ void gemm_tile_loop_marked(const float* __restrict__ 
 // C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
 // grid (ceil(N/128), ceil(M/128), batch), block 256
 // One 128x128 output tile (m0, n0) of one batch entry: Ab / Bb / Cb / mk already point at that entry.
-template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ>
+template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ, int KS = GB_K>
 __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const float* __restrict__ Bb, float* __restrict__ Cb,
                                            int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, int vec_a,
                                            int vec_b, const unsigned char* __restrict__ mk, int mark_mode, int mark_tb,
@@ -280,7 +298,7 @@ __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const bool fast = vec_a && vec_b && (m0 + GB_T <= M) && (n0 + GB_T <= N) && (K % GB_K == 0);    // block-uniform
+    const bool fast = vec_a && vec_b && (m0 + GB_T <= M) && (n0 + GB_T <= N) && (K % KS == 0);    // block-uniform
     if (SKIPZ && mk) {
         if (fast)
             gemm_tile_loop_marked<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn, mk,
@@ -289,9 +307,9 @@ __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const f
             gemm_tile_loop_marked<A_KC, B_KC, true>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm,
                                                     wn, mk, mark_mode, mark_tb, mark_src_blocks);
     } else if (fast)
-        gemm_tile_loop<A_KC, B_KC, false, SKIPZ>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
+        gemm_tile_loop<A_KC, B_KC, false, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
     else
-        gemm_tile_loop<A_KC, B_KC, true, SKIPZ>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn);
+        gemm_tile_loop<A_KC, B_KC, true, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn);
 
     const int fk = lane >> 5, fm = lane & 31;
     // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -312,7 +330,7 @@ __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const f
         }
 }
 
-template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ>
+template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ, int KS = GB_K>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                              float* __restrict__ C, int M, int N, int K, int64_t lda,
                                                              int64_t ldb, int64_t ldc, int64_t sa, int64_t sb, int64_t sc,
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                                                              int mark_tb, int mark_src_blocks) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 * GB_K * (LDA + LDB) floats (> 64 KB: dynamic)
     const unsigned char* mk = marks ? marks + (size_t)blockIdx.z * mark_src_blocks * mark_tb : nullptr;
-    gemm_block<A_KC, B_KC, ACC, SKIPZ>(A + (int64_t)blockIdx.z * sa, Bm + (int64_t)blockIdx.z * sb, C + (int64_t)blockIdx.z * sc,
+    gemm_block<A_KC, B_KC, ACC, SKIPZ, KS>(A + (int64_t)blockIdx.z * sa, Bm + (int64_t)blockIdx.z * sb, C + (int64_t)blockIdx.z * sc,
                                        M, N, K, lda, ldb, ldc, alpha, vec_a, vec_b, mk, mark_mode, mark_tb, mark_src_blocks,
                                        blockIdx.y * GB_T, blockIdx.x * GB_T, lds);
 }
@@ -365,6 +383,21 @@ void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K,
     const int vec_a = aligned16(A) && (lda % 4 == 0) && (sa % 4 == 0);
     const int vec_b = aligned16(Bm) && (ldb % 4 == 0) && (sb % 4 == 0);
     dim3 grid(camli_divup(N, GB_T), camli_divup(M, GB_T), batch);
+    if constexpr (!SKIPZ) {
+        // unmarked loops (the forward build): K step 16 -- 33 KB of LDS and <= 168 registers, three workgroups per CU
+        // (CAMLI_GEMM_KS=32 restores the 67 KB / two-workgroup form for A/B runs)
+        static const bool ks32 = []() { const char* e = getenv("CAMLI_GEMM_KS"); return e && atoi(e) == 32; }();
+        if (!ks32 && K % 16 == 0) {
+            constexpr size_t lds16 = (size_t)2 * 16 * (OperandTile<A_KC>::LD + OperandTile<B_KC>::LD) * sizeof(float);
+            if (accumulate)
+                hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, true, false, 16>), grid, dim3(256), lds16, stream, A, Bm, C,
+                                   M, N, K, lda, ldb, ldc, sa, sb, sc, alpha, vec_a, vec_b, nullptr, 0, 0, 0);
+            else
+                hipLaunchKernelGGL((gemm_f32_mfma_kernel<A_KC, B_KC, false, false, 16>), grid, dim3(256), lds16, stream, A, Bm, C,
+                                   M, N, K, lda, ldb, ldc, sa, sb, sc, alpha, vec_a, vec_b, nullptr, 0, 0, 0);
+            return;
+        }
+    }
     constexpr size_t lds = (size_t)2 * GB_K * (OperandTile<A_KC>::LD + OperandTile<B_KC>::LD) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

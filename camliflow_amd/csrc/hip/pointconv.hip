@@ -15,6 +15,8 @@
 // weight gradient (one thread per (w, j), a CH-long dot product), phase B the feature gradient
 // (lanes along ch again, Wn FMAs per neighbour) added with row-coalesced float atomics.
 #include "camli_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -265,6 +267,99 @@ __global__ __launch_bounds__(256) void pointconv_mix_bwd_point_kernel(const floa
     }
 }
 
+// (1, round 3 product path) the same two results on the matrix cores, no LDS: one wave per point, and both
+// contractions are 16x16 tiles of v_mfma_f32_16x16x4_f32 whose operands are exactly what a lane loads from memory:
+//   gwgt[w][j] = sum_c gout[w][c] * feat[idx_j][c]   A[i = w][k] and B[k][j]: lane (row = lane % 16, quad = lane / 16)
+//                reads 16 bytes (4 consecutive channels) of gout row w = row and of feature row idx_{j = row}; the four
+//                components are four K steps (the K index of an MFMA is arbitrary as long as A and B agree), so a load
+//                instruction fetches 64 contiguous bytes of each of the 16 rows and nothing is transposed
+//   T[j][c]    = sum_w wgt[w][j] * gout[w][c]        A[i = j][k = w] = the point's 16x16 weights (4 registers, loaded once),
+//                B[k = w][n = c]: lane (c = c0 + lane % 16, w = 4 s + lane / 16) reads gout again (L1 / L2 hit), D gives
+//                T[j = 4 (lane / 16) + r][c] -> 64-byte row segments
+// The LDS form above staged 32 rows per wave (68 KB per workgroup at CH = 131: 2 waves per SIMD) and spent its time in
+// ds_read_b128 + 512 fmaf per lane; here the arithmetic is 8 * ceil(CH / 16) matrix instructions per point and the
+// kernel is bound by its ~27 KB of memory traffic per point.  Rows are only 4-byte aligned (CH = 99, 131 ...): the
+// 16-byte loads are declared with 4-byte alignment (gfx950 global loads take any dword-aligned address).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ f32x4_t load_quad(const float* __restrict__ row, int q, int CH) {
+    const int c = 4 * q;
+    if (c + 3 < CH) return *reinterpret_cast<const f32x4_u*>(row + c);
+    f32x4_t v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (c < CH) v[0] = row[c];
+    if (c + 1 < CH) v[1] = row[c + 1];
+    if (c + 2 < CH) v[2] = row[c + 2];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void pointconv_mix_bwd_point_mfma_kernel(const float* __restrict__ gout,
+                                                                            const float* __restrict__ feat,
+                                                                            const float* __restrict__ wgt,
+                                                                            const int64_t* __restrict__ idx, int idx_stride,
+                                                                            float* __restrict__ trows /*[B,N,16,CH] or null*/,
+                                                                            float* __restrict__ gwgt /*[B,16,N,16] or null*/,
+                                                                            int B, int M, int N, int CH) {
+    const int lane = threadIdx.x & 63;
+    const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (p >= B * N) return;
+    const int b = p / N, n = p - b * N;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const float* __restrict__ g = gout + (size_t)p * PCW_WN * CH;
+    const float* __restrict__ wbase = wgt + (size_t)b * PCW_WN * N * PCW_K + (size_t)n * PCW_K;
+    if (gwgt) {
+        const int mrow = (int)idx[(size_t)p * idx_stride + r16];
+        const float* __restrict__ grow = g + (size_t)r16 * CH;
+        const float* __restrict__ frow = feat + ((size_t)b * M + mrow) * CH;
+        const int nq = (CH + 3) >> 2;
+        f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int q0 = 0; q0 < nq; q0 += 16) {       // four quads per lane and trip: eight 16-byte loads in flight
+            f32x4_t a[4], f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + 4 * u + g4;       // quads >= nq load zeros: they add nothing
+                a[u] = load_quad(grow, q, CH);
+                f[u] = load_quad(frow, q, CH);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], f[u][e], acc, 0, 0, 0);
+            }
+        }
+        // D[i = w = 4 g4 + r][j = r16]
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            gwgt[(((size_t)b * PCW_WN + 4 * g4 + r) * N + n) * PCW_K + r16] = acc[r];
+    }
+    if (trows) {
+        float wa[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wa[s] = wbase[(size_t)(4 * s + g4) * N * PCW_K + r16];    // wgt[w = 4 s + g4][j = r16]
+        float* __restrict__ t = trows + (size_t)p * PCW_K * CH;
+        for (int c0 = 0; c0 < CH; c0 += 64) {      // four 16-channel tiles per trip: sixteen loads in flight
+            float bv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 16 * u + r16;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bv[u][s] = c < CH ? g[(size_t)(4 * s + g4) * CH + c] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 16 * u + r16;
+                f32x4_t d = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], bv[u][s], d, 0, 0, 0);
+                if (c < CH) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t[(size_t)(4 * g4 + r) * CH + c] = d[r];    // T[j = 4 g4 + r][c]
+                }
+            }
+        }
+    }
+}
+
 // (2) grid ceil(B*M / 4), block 256 (one source point per wave): rows[pos] summed over the CSR segment of (b, m).
 // Used for the PointConv feature gradient (rows = T, RL = CH) -- positions index rows of length RL.
 __global__ __launch_bounds__(256) void segment_row_sum_kernel(const float* __restrict__ rows,
@@ -372,6 +467,11 @@ extern "C" int camli_pointconv_mix_bwd_sorted(const float* gout, const float* fe
         return CAMLI_EINVAL;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const bool lds_form = []() { const char* e = getenv("CAMLI_MIX_BWD"); return e && !strcmp(e, "lds"); }();
+    if (!lds_form) {
+        hipLaunchKernelGGL(pointconv_mix_bwd_point_mfma_kernel, dim3(camli_divup(B * N, 4)), dim3(256), 0, s, gout, feat_cl,
+                           wgt, idx, idx_stride, gfeat_cl ? scratch : nullptr, gwgt, B, M, N, CH);
+    } else {
     const int CHP = 4 * (camli_divup(CH, 4) | 1);
     const size_t lds = gwgt ? (size_t)4 * 32 * CHP * sizeof(float) : 0;
     if (lds > 150 * 1024) {
@@ -386,6 +486,7 @@ extern "C" int camli_pointconv_mix_bwd_sorted(const float* gout, const float* fe
     }
     hipLaunchKernelGGL(pointconv_mix_bwd_point_kernel, dim3(camli_divup(B * N, 4)), dim3(256), lds, s, gout, feat_cl, wgt,
                        idx, idx_stride, gfeat_cl ? scratch : nullptr, gwgt, B, M, N, CH, CHP);
+    }
     if (gfeat_cl)
         hipLaunchKernelGGL(segment_row_sum_kernel, dim3(camli_divup(B * M, 4)), dim3(256), 0, s, scratch, inv_order,
                            inv_offsets, gfeat_cl, B * M, CH);
