@@ -129,31 +129,94 @@ __global__ __launch_bounds__(256) void sk_mix_bwd_x_kernel(const float* __restri
 // this is ~5 launches forward and ~9 backward per SKFusion call, all on kilobyte-sized tensors. ----
 constexpr int SKG_MAXC = 1024, SKG_MAXR = 512;   // CamLiPWC fuses a 627-channel correlation feature (clfm.py:171-214 at configs[1])
 
-// grid B, block 256
-__global__ __launch_bounds__(256) void sk_gate_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wmid,
-                                                          const float* __restrict__ wout, float* __restrict__ m,
-                                                          float* __restrict__ z, float* __restrict__ w, int C, int R) {
+// The gate is two tiny matrix-vector products per batch row; round 2/3a ran them as one serial dot product per thread
+// (64 of 256 threads busy, every step a dependent global load: 18 us forward, 32 us for the s-adjoint, 54 calls per step).
+// Now a workgroup of 1024 threads per batch row and two access-shaped helpers:
+//   rows form : y[i] = sum_j W[i*ld + j] x[j]   (the contraction runs along the contiguous dimension) -- a group of G
+//               lanes per row, lanes stride over j (coalesced), butterfly sum inside the group
+//   cols form : y[j] = sum_i W[i*ld + j] x[i]   (the OUTPUT index is the contiguous one) -- lanes along j, the i range cut
+//               into NT / J parts whose partial sums meet in LDS, added in part order
+// Both are fixed-order sums (bit-reproducible); x lives in LDS.
+constexpr int SKG_NT = 1024;
+
+template <typename F>
+__device__ __forceinline__ void skg_rows(const float* __restrict__ W, int ld, const float* xs, int I, int J, F&& emit) {
+    // short rows take small groups (more rows in flight, fewer butterfly steps: a step is an LDS-crossbar round trip)
+    const int G = J > 128 ? 64 : (J > 64 ? 32 : 16);
+    const int lane = threadIdx.x & (G - 1), group = threadIdx.x / G, ngroups = SKG_NT / G;
+    for (int i = group; i < I; i += 2 * ngroups) {           // two rows per trip: their loads and butterflies overlap
+        const int i2 = i + ngroups;
+        const bool two = i2 < I;
+        const float* __restrict__ row = W + (size_t)i * ld;
+        const float* __restrict__ row2 = W + (size_t)(two ? i2 : i) * ld;
+        float a = 0.0f, a2 = 0.0f;
+        for (int j = lane; j < J; j += G) {
+            const float x = xs[j];
+            a = __builtin_fmaf(row[j], x, a);
+            a2 = __builtin_fmaf(row2[j], x, a2);
+        }
+        for (int off = G >> 1; off >= 1; off >>= 1) {
+            a += __shfl_xor(a, off, 64);
+            a2 += __shfl_xor(a2, off, 64);
+        }
+        if (lane == 0) {
+            emit(i, a);
+            if (two) emit(i2, a2);
+        }
+    }
+}
+
+// part_buf: SKG_NT floats of LDS.  Ends with the results handed to emit(j, sum) by the threads j < J (J <= SKG_NT) or
+// by thread j % SKG_NT (J > SKG_NT: one part, no LDS); the caller synchronises afterwards.
+template <typename F>
+__device__ __forceinline__ void skg_cols(const float* __restrict__ W, int ld, const float* xs, int I, int J, float* part_buf,
+                                         F&& emit) {
+    const int tid = threadIdx.x;
+    if (J >= SKG_NT) {
+        for (int j = tid; j < J; j += SKG_NT) {
+            float a = 0.0f;
+            for (int i = 0; i < I; ++i) a = __builtin_fmaf(W[(size_t)i * ld + j], xs[i], a);
+            emit(j, a);
+        }
+        return;
+    }
+    const int parts = SKG_NT / J, part = tid / J, j = tid - part * J;
+    float a = 0.0f;
+    if (part < parts) {
+        const int per = (I + parts - 1) / parts, lo = part * per, hi = min(I, lo + per);
+#pragma unroll 8
+        for (int i = lo; i < hi; ++i) a = __builtin_fmaf(W[(size_t)i * ld + j], xs[i], a);
+        part_buf[part * J + j] = a;
+    }
+    __syncthreads();
+    if (tid < J) {
+        float t = part_buf[tid];
+        for (int q = 1; q < parts; ++q) t += part_buf[q * J + tid];
+        emit(tid, t);
+    }
+}
+
+// grid B, block 1024
+__global__ __launch_bounds__(SKG_NT) void sk_gate_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wmid,
+                                                             const float* __restrict__ wout, float* __restrict__ m,
+                                                             float* __restrict__ z, float* __restrict__ w, int C, int R) {
     __shared__ float ss[SKG_MAXC], sm[SKG_MAXR], sz[2 * SKG_MAXC];
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) ss[c] = s[(size_t)b * C + c];
+    for (int c = tid; c < C; c += SKG_NT) ss[c] = s[(size_t)b * C + c];
     __syncthreads();
-    for (int r = tid; r < R; r += 256) {
-        float a = 0.0f;
-        for (int c = 0; c < C; ++c) a = __builtin_fmaf(wmid[r * C + c], ss[c], a);
+    skg_rows(wmid, C, ss, R, C, [&](int r, float a) {          // m = relu(Wmid s)
         a = fmaxf(a, 0.0f);
         sm[r] = a;
         m[(size_t)b * R + r] = a;
-    }
+    });
     __syncthreads();
-    for (int o = tid; o < 2 * C; o += 256) {
-        float a = 0.0f;
-        for (int r = 0; r < R; ++r) a = __builtin_fmaf(wout[o * R + r], sm[r], a);
+    skg_rows(wout, R, sm, 2 * C, R, [&](int o, float a) {      // z = sigmoid(Wout m)
         a = 1.0f / (1.0f + __expf(-a));
         sz[o] = a;
         z[(size_t)b * 2 * C + o] = a;
-    }
+    });
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += SKG_NT) {
         const float z0 = sz[2 * c], z1 = sz[2 * c + 1];
         const float mx = fmaxf(z0, z1);
         const float e0 = __expf(z0 - mx), e1 = __expf(z1 - mx);
@@ -180,25 +243,21 @@ __device__ __forceinline__ float sk_gpre(const float* __restrict__ gw, const flo
     return wo * (go - dot) * zz * (1.0f - zz);                 // ... then the sigmoid
 }
 
-__global__ __launch_bounds__(256) void sk_gate_bwd_s_kernel(const float* __restrict__ gw, const float* __restrict__ m,
-                                                            const float* __restrict__ z, const float* __restrict__ w,
-                                                            const float* __restrict__ wmid, const float* __restrict__ wout,
-                                                            float* __restrict__ gs, int C, int R) {
-    __shared__ float gp[2 * SKG_MAXC], gm[SKG_MAXR];
+__global__ __launch_bounds__(SKG_NT) void sk_gate_bwd_s_kernel(const float* __restrict__ gw, const float* __restrict__ m,
+                                                               const float* __restrict__ z, const float* __restrict__ w,
+                                                               const float* __restrict__ wmid, const float* __restrict__ wout,
+                                                               float* __restrict__ gs, int C, int R) {
+    __shared__ float gp[2 * SKG_MAXC], gm[SKG_MAXR], part_buf[SKG_NT];
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int o = tid; o < 2 * C; o += 256) gp[o] = sk_gpre(gw, w, z, b, o, C);
+    for (int o = tid; o < 2 * C; o += SKG_NT) gp[o] = sk_gpre(gw, w, z, b, o, C);
     __syncthreads();
-    for (int r = tid; r < R; r += 256) {                            // gm = Wout^T gpre, through the ReLU
-        float a = 0.0f;
-        for (int o = 0; o < 2 * C; ++o) a = __builtin_fmaf(wout[o * R + r], gp[o], a);
+    skg_cols(wout, R, gp, 2 * C, R, part_buf, [&](int r, float a) {       // gm = Wout^T gpre, through the ReLU
         gm[r] = m[(size_t)b * R + r] > 0.0f ? a : 0.0f;
-    }
+    });
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {                            // gs = Wmid^T gm
-        float a = 0.0f;
-        for (int r = 0; r < R; ++r) a = __builtin_fmaf(wmid[r * C + c], gm[r], a);
+    skg_cols(wmid, C, gm, R, C, part_buf, [&](int c, float a) {           // gs = Wmid^T gm
         gs[(size_t)b * C + c] = a;
-    }
+    });
 }
 
 __global__ __launch_bounds__(256) void sk_gate_bwd_w_kernel(const float* __restrict__ gw, const float* __restrict__ s,
@@ -313,7 +372,7 @@ extern "C" int camli_sk_gate_fwd(const float* s, const float* wmid, const float*
         camli_set_error("camli_sk_gate_fwd: bad shape B=%d C=%d (<= %d) R=%d (<= %d)", B, C, SKG_MAXC, R, SKG_MAXR);
         return C > SKG_MAXC || R > SKG_MAXR ? CAMLI_ENOTSUP : CAMLI_EINVAL;
     }
-    hipLaunchKernelGGL(sk_gate_fwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, wmid, wout, m, z,
+    hipLaunchKernelGGL(sk_gate_fwd_kernel, dim3(B), dim3(SKG_NT), 0, reinterpret_cast<hipStream_t>(stream), s, wmid, wout, m, z,
                        w, C, R);
     return camli_check_launch("camli_sk_gate_fwd");
 }
@@ -331,7 +390,7 @@ extern "C" int camli_sk_gate_bwd(const float* gw, const float* s, const float* m
         return C > SKG_MAXC || R > SKG_MAXR ? CAMLI_ENOTSUP : CAMLI_EINVAL;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sk_gate_bwd_s_kernel, dim3(B), dim3(256), 0, st, gw, m, z, w, wmid, wout, gs, C, R);
+    hipLaunchKernelGGL(sk_gate_bwd_s_kernel, dim3(B), dim3(SKG_NT), 0, st, gw, m, z, w, wmid, wout, gs, C, R);
     hipLaunchKernelGGL(sk_gate_bwd_w_kernel, dim3(R), dim3(256), 0, st, gw, s, m, z, w, wout, gwmid, gwout, B, C, R);
     return camli_check_launch("camli_sk_gate_bwd");
 }
