@@ -10,4 +10,16 @@ built and inspected on a machine without a GPU), but calling one without ``libca
 non-CUDA tensors raises -- there is no CPU fallback in this package.
 """
 
+import os as _os
+
+# hipBLASLt's stream-K GEMM kernels (the `SK3` Tensile solutions it picks for most fp32 shapes on gfx950) make their
+# workgroups wait for each other's partial tiles through flags in ONE synchroniser buffer per library handle, and torch
+# uses one handle per host thread for ALL streams.  Two such GEMMs running at the same time on two streams then wait on
+# flags the other one resets: the GPU spins at 100 % busy for good (round 3: reproduced 6 of 6 with the CLFM's two
+# directions on two streams, cured 2 of 2 by this switch; in hindsight also the "two-lane start-up dead-lock" that round 2
+# saw in 5 of 9 runs).  Data-parallel mode keeps the kernels but gives every workgroup whole tiles -- no cross-workgroup
+# waits -- and costs nothing measurable on this workload (248.3 vs 249.1 ms per step).  Must be in the environment before
+# the first GEMM creates the handle; an explicit user setting wins.
+_os.environ.setdefault('TENSILE_STREAMK_DATA_PARALLEL', '1')
+
 __version__ = "0.1.0"

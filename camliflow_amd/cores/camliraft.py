@@ -112,6 +112,7 @@ class CamLiRAFT_Core(nn.Module):
                 corr3d = b3d.correlation(xyz1, xyzs2_warp)
             if it > 0:
                 flow_2d_pred = flow_2d_pred.detach()
+            flow_branch = b2d.motion_encoder.begin(flow_2d_pred) if runtime.fused() else None     # aux stream (runtime.Branch)
             corr2d = b2d.correlation(grid_coords + flow_2d_pred)
             if cfgs.fuse_corr:
                 lanes.to_main(corr3d)
@@ -121,7 +122,7 @@ class CamLiRAFT_Core(nn.Module):
             # ---- motion features ---------------------------------------------------------------
             with lanes.side():
                 motion_feat3d = b3d.motion_encoder(xyz1, flow_3d_pred, corr3d, knn_indices=knn_indices)
-            motion_feat2d = b2d.motion_encoder(flow_2d_pred, corr2d)
+            motion_feat2d = b2d.motion_encoder(flow_2d_pred, corr2d, flow_branch=flow_branch)
             if cfgs.fuse_motion:
                 lanes.to_main(motion_feat3d)
                 motion_feat2d, motion_feat3d = self.clfm_motion(uv1, motion_feat2d, motion_feat3d)
@@ -143,8 +144,9 @@ class CamLiRAFT_Core(nn.Module):
             with lanes.side():
                 flow_3d_pred = flow_3d_pred + b3d.flow_head(xyz1, h_3d, knn_indices)
                 flow_3d_preds.append(knn_interpolation(xyz1, flow_3d_pred, pc1, k=3, invariant_input=True, invariant_query=True))
+            mask_branch = b2d.convex_upsampler.begin(h_2d) if runtime.fused() else None           # aux stream
             flow_2d_pred = flow_2d_pred + b2d.flow_head(h_2d)
-            flow_2d_preds.append(b2d.convex_upsampler(h_2d, flow_2d_pred))
+            flow_2d_preds.append(b2d.convex_upsampler.finish(mask_branch, h_2d, flow_2d_pred))
 
         lanes.to_main(flow_3d_preds)
         return flow_2d_preds, flow_3d_preds

@@ -170,8 +170,13 @@ class CLFM(nn.Module):
 
     def forward(self, uv, feat_2d, feat_3d):
         feat_2d, feat_3d = feat_2d.float(), feat_3d.float()
+        # the two directions are independent chains: 3D<-2D (a dozen kernels on [B,C,2048] tensors, latency-sized) goes to
+        # an auxiliary stream next to 2D<-3D (runtime.Branch; one stream when the lanes are off)
+        branch = runtime.Branch(feat_2d, feat_3d, uv, slot=2)
+        with branch:
+            feat_2d_sampled = grid_sample_wrapper(feat_2d.detach(), uv)
+            out3d = self.fuse3d(self.mlps3d(feat_2d_sampled.detach()), feat_3d)
         feat_3d_interp = self.interp(uv, feat_2d.detach(), feat_3d.detach())
         out2d = self.fuse2d(feat_2d, feat_3d_interp)
-        feat_2d_sampled = grid_sample_wrapper(feat_2d.detach(), uv)
-        out3d = self.fuse3d(self.mlps3d(feat_2d_sampled.detach()), feat_3d)
+        branch.join(out3d)
         return out2d, out3d

@@ -178,10 +178,26 @@ class MotionEncoder2D(nn.Module):
         self.conv = _conv(64 + 192, 128 - 2, 3)
         self.relu = nn.ReLU(inplace=True)
 
-    def forward(self, flow, corr):
+    def begin(self, flow):
+        """Issue the flow branch (conv_f1 7x7 2->128, conv_f2 3x3) on the auxiliary stream as soon as the flow estimate
+        exists -- it does not need the correlation features, and a 2-channel convolution leaves most of the chip to the
+        lookup / fusion / conv_c* kernels issued meanwhile.  Returns a handle for ``forward(..., flow_branch=handle)``;
+        None where the fused epilogue does not apply (the caller then runs the plain forward)."""
+        if not epilogue_ok(flow):
+            return None
+        branch = runtime.Branch(flow, slot=0)
+        with branch:
+            f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')
+        return branch, f
+
+    def forward(self, flow, corr, flow_branch=None):
         if epilogue_ok(corr):
             c = conv_bias_act(self.conv_c2, conv_bias_act(self.conv_c1, corr, 'relu'), 'relu')
-            f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')
+            if flow_branch is not None:
+                branch, f = flow_branch
+                branch.join(f)
+            else:
+                f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')
             x = torch.cat([c, f], dim=1)
             if (x.shape[2] * x.shape[3]) % 4 == 0:      # relu + nan_to_num in the epilogue pass (bias_act code 5)
                 joint = conv_bias_act(self.conv, x, 'relu_nan_to_num')
@@ -190,8 +206,12 @@ class MotionEncoder2D(nn.Module):
             return torch.cat([joint, flow], dim=1)
         c = self.relu(self.conv_c1(corr))
         c = self.relu(self.conv_c2(c))
-        f = self.relu(self.conv_f1(flow))
-        f = self.relu(self.conv_f2(f))
+        if flow_branch is not None:          # issued by begin(): same values, join before use
+            flow_branch[0].join(flow_branch[1])
+            f = flow_branch[1]
+        else:
+            f = self.relu(self.conv_f1(flow))
+            f = self.relu(self.conv_f2(f))
         joint = torch.nan_to_num(self.relu(self.conv(torch.cat([c, f], dim=1))))
         return torch.cat([joint, flow], dim=1)
 
@@ -218,6 +238,24 @@ class ConvexUpsampler2D(nn.Module):
     def __init__(self, input_dim):
         super().__init__()
         self.mask = nn.Sequential(_conv(input_dim, 256, 3), nn.ReLU(inplace=True), _conv(256, 64 * 9, 1))
+
+    def begin(self, h):
+        """Issue the mask head (3x3 + 1x1 convolution of the hidden state) on the auxiliary stream; the flow head, which
+        reads the same hidden state, follows on the current stream and the two chains meet in ``finish``.  Returns a
+        handle, or None where the fused path does not apply."""
+        if not (epilogue_ok(h) and runtime.atomics_ok('convex_upsample')):
+            return None
+        branch = runtime.Branch(h, slot=1)
+        with branch:
+            raw = conv_bias_act(self.mask[2], conv_bias_act(self.mask[0], h.float(), 'relu'), None, leave_bias=True)
+        return branch, raw
+
+    def finish(self, handle, h, flow):
+        if handle is None:
+            return self.forward(h, flow)
+        branch, raw = handle
+        branch.join(raw)
+        return convex_upsample(flow, raw, mask_scale=0.25, mask_bias=self.mask[2].bias)
 
     def forward(self, h, flow):
         if epilogue_ok(h) and runtime.atomics_ok('convex_upsample'):

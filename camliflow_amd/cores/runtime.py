@@ -266,6 +266,8 @@ class Lanes:
             if signature not in _PRIMED:        # first pass of this shape: one lane (see set_overlap)
                 _PRIMED.add(signature)
                 self.enabled = False
+        global _LANES_LIVE
+        _LANES_LIVE = self.enabled and os.environ.get('CAMLI_BRANCHES', '1') == '1'
         if self.enabled:
             self._torch = torch
             self.main = torch.cuda.current_stream(device)
@@ -290,6 +292,67 @@ class Lanes:
             self.main.wait_stream(self.side_stream)
             for t in _flatten(tensors):
                 t.record_stream(self.main)
+
+_LANES_LIVE = False     # the Lanes of the pass that is being issued are enabled (set by Lanes.__init__)
+_aux_streams = {}
+_BRANCH_MASK = int(os.environ.get('CAMLI_BRANCH_MASK', '7'))       # bit = slot: 1 motion encoder, 2 mask head, 4 CLFM
+_BRANCH_SHARE = os.environ.get('CAMLI_BRANCH_SHARE', '0') == '1'   # all slots on ONE auxiliary stream
+
+
+class Branch:
+    """A short independent chain of the IMAGE lane issued on an auxiliary stream (round 3): the 7x7 / 3x3 flow branch of
+    MotionEncoder2D next to the correlation lookup + its 1x1 / 3x3 branch, the mask head next to the flow head.  The
+    chains are independent until they are concatenated / consumed, one of them is a convolution that cannot fill the
+    chip (2 -> 128 channels) or a run of HBM-bound epilogues, the other one is bound by the matrix cores -- on one
+    stream they run one after the other.  autograd replays every node on the stream of its forward, so the adjoints
+    overlap the same way.  Usage:
+
+        br = runtime.Branch(x)            # fork here: the aux stream waits for what the current stream holds NOW
+        with br:
+            y = chain(x)                  # issued on the aux stream
+        ...                               # other work on the current stream
+        br.join(y)                        # the current stream waits for the chain; y may be used on it
+
+    Enabled only inside a pass whose Lanes are enabled (two-lane execution, not the priming pass), so the one-lane
+    configurations stay exactly one stream."""
+
+    def __init__(self, *inputs, slot=0):
+        import torch
+        first = next((t for t in _flatten(inputs) if t is not None), None)
+        self.enabled = bool(_LANES_LIVE and _BACKEND == 'hip' and first is not None and first.is_cuda
+                            and (_BRANCH_MASK >> slot) & 1)
+        if self.enabled:
+            self._torch = torch
+            dev = first.device
+            self.main = torch.cuda.current_stream(dev)
+            key = (dev.index, self.main.cuda_stream, 0 if _BRANCH_SHARE else slot)
+            if key not in _aux_streams:
+                _aux_streams[key] = torch.cuda.Stream(dev)
+            self.aux = _aux_streams[key]
+            self.aux.wait_stream(self.main)
+            for t in _flatten(inputs):
+                if t is not None:
+                    t.record_stream(self.aux)
+
+    def __enter__(self):
+        if self.enabled:
+            self._ctx = self._torch.cuda.stream(self.aux)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            return self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *outputs):
+        if self.enabled:
+            current = self._torch.cuda.current_stream(self.aux.device)
+            current.wait_stream(self.aux)
+            for t in _flatten(outputs):
+                if t is not None:
+                    t.record_stream(current)
+
 
 if _CENSUS_ON:
     set_census(True)

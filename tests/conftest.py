@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault('TENSILE_STREAMK_DATA_PARALLEL', '1')     # before torch creates a BLAS handle (camliflow_amd/__init__.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

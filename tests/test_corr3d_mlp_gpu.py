@@ -99,3 +99,22 @@ def test_cost_mlp_rejects_other_shapes():
     code = lib.camli_corr3d_mlp_fwd(x.data_ptr(), conv1.weight.data_ptr(), conv1.bias.data_ptr(), conv2.weight.data_ptr(),
                                     conv2.bias.data_ptr(), out.data_ptr(), 1, 12, 4, 16, 32, None)
     assert code == -22
+
+
+def test_isolated_rows_run_with_deferred_parameter_gradients():
+    """bench.py switches the deferred parameter gradients on for its step and then calls tools/kernel_bench.run(), whose
+    rows differentiate with torch.autograd.grad(): the run must switch the deferral off for its own duration and restore it
+    (round 3: the cost-MLP row raised "One of the differentiated Tensors appears to not have been used" and took the whole
+    bench line with it)."""
+    import os
+    import sys
+    from camliflow_amd.cores import runtime
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import kernel_bench
+    runtime.set_deferred_param_grads(True)
+    try:
+        rows = kernel_bench.run(batch=2, reps=1, only='corr3d_mlp')
+        assert runtime.deferred_param_grads()
+    finally:
+        runtime.set_deferred_param_grads(False)
+    assert {r['kernel'] for r in rows} == {'camli_corr3d_mlp_fwd', 'camli_corr3d_mlp_bwd'}

@@ -225,6 +225,18 @@ def run(batch=8, reps=10, only=None):
     from camliflow_amd.csrc import _lib
     _lib.load()
     runtime.set_backend('hip')
+    # the rows differentiate with torch.autograd.grad(), which the deferred parameter gradients bypass by design
+    # (bench.py switches them on for its step: "One of the differentiated Tensors appears to not have been used")
+    deferred = runtime.deferred_param_grads()
+    runtime.set_deferred_param_grads(False)
+    try:
+        return _run(batch, reps, only)
+    finally:
+        runtime.set_deferred_param_grads(deferred)
+
+
+def _run(batch, reps, only):
+    from camliflow_amd.csrc import _lib
     rows = []
     for case, fn, kinds in cases(batch):
         if only and only not in case:
