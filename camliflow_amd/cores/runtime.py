@@ -319,8 +319,11 @@ class Branch:
     def __init__(self, *inputs, slot=0):
         import torch
         first = next((t for t in _flatten(inputs) if t is not None), None)
+        # not under HIP-graph capture: hipStreamEndCapture segfaults on this image once a capture has forked into the
+        # auxiliary streams as well as the point lane (test_graph_gpu, --config kitti); the replayed configurations are
+        # the batch-1, enqueue-bound ones and keep their two lanes
         self.enabled = bool(_LANES_LIVE and _BACKEND == 'hip' and first is not None and first.is_cuda
-                            and (_BRANCH_MASK >> slot) & 1)
+                            and (_BRANCH_MASK >> slot) & 1 and not torch.cuda.is_current_stream_capturing())
         if self.enabled:
             self._torch = torch
             dev = first.device
