@@ -68,13 +68,18 @@ class CamLiRAFT_Core(nn.Module):
             xyz1, xyz2 = xyzs1[0], xyzs2[0]
             uv1 = self._project_to_feature_grid(xyz1, camera_info, feat_hw)
             uv2 = self._project_to_feature_grid(xyz2, camera_info, feat_hw)
+        # the context encoder is an independent chain (its own ResNet trunk on frame 1): auxiliary stream, so that its
+        # HBM-bound epilogues run under the feature encoder's convolutions and vice versa (runtime.Branch, slot 3)
+        cnet_branch = runtime.Branch(image1, slot=3)
+        with cnet_branch:
+            featc_2d = b2d.cnet(image1)
         if runtime.fused():
             # both frames through the feature encoder in one batch: its BatchNorms always run in eval
             # mode (norm_eval) and `align` has no norm, so per-sample results are unchanged
             feat1_2d, feat2_2d = torch.chunk(b2d.fnet(torch.cat([image1, image2], dim=0)), 2, dim=0)
         else:
             feat1_2d, feat2_2d = b2d.fnet(image1), b2d.fnet(image2)
-        featc_2d = b2d.cnet(image1)
+        cnet_branch.join(featc_2d)
         assert tuple(feat1_2d.shape[-2:]) == feat_hw
 
         lanes.to_main(feat1_3d, feat2_3d, featc_3d, uv1, uv2)

@@ -295,7 +295,7 @@ class Lanes:
 
 _LANES_LIVE = False     # the Lanes of the pass that is being issued are enabled (set by Lanes.__init__)
 _aux_streams = {}
-_BRANCH_MASK = int(os.environ.get('CAMLI_BRANCH_MASK', '7'))       # bit = slot: 1 motion encoder, 2 mask head, 4 CLFM
+_BRANCH_MASK = int(os.environ.get('CAMLI_BRANCH_MASK', '15'))      # bit = slot: 1 motion encoder, 2 mask head, 4 CLFM, 8 context encoder
 _BRANCH_SHARE = os.environ.get('CAMLI_BRANCH_SHARE', '0') == '1'   # all slots on ONE auxiliary stream
 
 
