@@ -1,0 +1,32 @@
+"""runtime.Branch off the GPU / with the lanes off: a transparent no-op (one stream, same results), so the CPU mirrors and the
+one-lane configurations are exactly what they were.  The enabled path is covered on the GPU by
+tests/test_model_gpu.py::test_two_lane_stream_overlap_matches_single_stream (its passes after the priming one run the point
+lane AND the auxiliary streams) and by the full-size parity tests."""
+import torch
+
+from camliflow_amd.cores import runtime
+
+
+def test_branch_is_a_no_op_without_cuda_lanes():
+    x = torch.randn(3, 4)
+    branch = runtime.Branch(x, None, [x, None], slot=2)
+    assert not branch.enabled
+    with branch as b:
+        assert b is branch
+        y = x * 2
+    branch.join(y, None)
+    assert torch.equal(y, x * 2)
+
+
+def test_motion_encoder_begin_handle_matches_plain_forward_on_cpu():
+    """begin() returns None off the fused path and forward() then computes the flow branch itself; a handle produced by an
+    (inactive) Branch gives the same values."""
+    from camliflow_amd.cores.raft2d import MotionEncoder2D
+    torch.manual_seed(0)
+    enc = MotionEncoder2D(4, 4)
+    flow, corr = torch.randn(1, 2, 8, 10), torch.randn(1, 4 * 81, 8, 10)
+    assert enc.begin(flow) is None
+    want = enc(flow, corr)
+    f = enc.relu(enc.conv_f2(enc.relu(enc.conv_f1(flow))))
+    got = enc(flow, corr, flow_branch=(runtime.Branch(flow), f))
+    assert torch.allclose(got, want, atol=1e-6)
