@@ -232,9 +232,11 @@ def set_overlap(enabled, prime_first_pass=True):
     of one.  Keeping that step on one stream costs nothing (it is never a timed step) and keeps a first-use problem
     from being confused with a stream-ordering problem again.  It lives here, not in a benchmark script, so that EVERY
     caller of ``set_overlap(True)`` gets it (training loops, tests, bench.py)."""
-    global _OVERLAP, _PRIME_FIRST_PASS
+    global _OVERLAP, _PRIME_FIRST_PASS, _LANES_LIVE
     _OVERLAP = bool(enabled)
     _PRIME_FIRST_PASS = bool(prime_first_pass)
+    if not _OVERLAP:
+        _LANES_LIVE = False     # a model without Lanes of its own must not inherit the auxiliary streams of an earlier pass
 
 
 def overlap():
@@ -322,7 +324,7 @@ class Branch:
         # not under HIP-graph capture: hipStreamEndCapture segfaults on this image once a capture has forked into the
         # auxiliary streams as well as the point lane (test_graph_gpu, --config kitti); the replayed configurations are
         # the batch-1, enqueue-bound ones and keep their two lanes
-        self.enabled = bool(_LANES_LIVE and _BACKEND == 'hip' and first is not None and first.is_cuda
+        self.enabled = bool(_LANES_LIVE and _OVERLAP and _BACKEND == 'hip' and first is not None and first.is_cuda
                             and (_BRANCH_MASK >> slot) & 1 and not torch.cuda.is_current_stream_capturing())
         if self.enabled:
             self._torch = torch

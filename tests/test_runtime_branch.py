@@ -30,3 +30,14 @@ def test_motion_encoder_begin_handle_matches_plain_forward_on_cpu():
     f = enc.relu(enc.conv_f2(enc.relu(enc.conv_f1(flow))))
     got = enc(flow, corr, flow_branch=(runtime.Branch(flow), f))
     assert torch.allclose(got, want, atol=1e-6)
+
+
+def test_set_overlap_false_switches_the_auxiliary_streams_off():
+    """_LANES_LIVE is set by the Lanes of a pass; a model that builds no Lanes (the image-only RAFT, CamLiPWC) must not
+    inherit it once the overlap is switched off."""
+    runtime._LANES_LIVE = True
+    try:
+        runtime.set_overlap(False)
+        assert runtime._LANES_LIVE is False
+    finally:
+        runtime._LANES_LIVE = False
