@@ -41,3 +41,13 @@ def test_set_overlap_false_switches_the_auxiliary_streams_off():
         assert runtime._LANES_LIVE is False
     finally:
         runtime._LANES_LIVE = False
+
+
+def test_upsampler_begin_finish_equal_forward_on_cpu():
+    """begin() yields no handle off the fused path; finish(None, h, flow) is forward(h, flow)."""
+    from camliflow_amd.cores.raft2d import ConvexUpsampler2D
+    torch.manual_seed(1)
+    up = ConvexUpsampler2D(16)
+    h, flow = torch.randn(1, 16, 6, 7), torch.randn(1, 2, 6, 7)
+    assert up.begin(h) is None
+    assert torch.equal(up.finish(None, h, flow), up(h, flow))
