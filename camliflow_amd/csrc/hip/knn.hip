@@ -538,6 +538,530 @@ __global__ __launch_bounds__(64) void knn_generic_kernel(const float* __restrict
     for (int i = 0; i < k; ++i) o[i] = (int64_t)ni[i];
 }
 
+// =====================================================================================================================
+// Round 4: candidates ACROSS the lanes.
+//
+// The lane-per-query kernels above spend 7/8 of their instructions on selection (queue test, insertion network,
+// partial-list merges) and need the candidate range split over waves to fill the chip when there are few queries.
+// Here a wave works on ONE query at a time and its 64 lanes hold the candidates:
+//
+//   * the wave keeps a chunk of J*64 candidates in registers for its whole life (lane l, slot j = candidate
+//     cbase + 64 j + l; 3 J VGPRs), the query coordinates are wave-uniform (scalar loads), so the distance
+//     arithmetic is 8 VALU operations per 64 pairs with no memory operand at all (same unfused fp32 expression);
+//   * phase 1 also keeps the minimum of each lane's J distances.  The k-th smallest of the 64 lane minima (one
+//     64-lane bitonic sort of the keys on DPP / v_permlane*_swap compare-exchanges, distances ordered as their bit
+//     patterns) is an upper bound T of the k-th neighbour distance: k different lanes hold a candidate within it;
+//   * phase 2 ballots `d <= T` per slot; the survivors (k + a few: 18 on average for k = 16, whatever M is) are
+//     compacted into a 64-entry LDS list with v_mbcnt prefix counts;
+//   * each survivor's final position is its rank by (distance, index) among the survivors -- counted against the
+//     list broadcast through v_readlane, no second sort -- and the lane stores its index at out[rank].
+//
+// Exactness.  Every candidate within the k-th distance survives, and sequential insertion
+// (k_nearest_neighbor_kernel.cu:52-95) leaves its list ordered by (distance, index) UNLESS a candidate tying the
+// final k-th distance is dropped (more ties at that distance than free slots) -- then which tied index stays depends
+// on the arrival order.  That case (rank k exists and has the k-th distance), a survivor list overflow, and a real
+// candidate at exactly the initial distance 1e9 send the query to an in-order lane-per-query scan (scan_range above)
+// after the wave's query loop, when the candidate registers are dead.  Unfilled slots (fewer than k candidates within
+// 1e9) keep index 0 like the reference's initial list.
+//
+// M > 2048: a TEAM of W = 2 / 4 / 8 waves (one workgroup) holds the candidates, 2048 per wave, and walks the queries
+// in step.  The lane minima are merged with one ds_min per wave into 64 class minima (class = candidate index mod 64
+// within a chunk), whose k-th smallest is again a bound with ~18 expected survivors; every wave sorts the classes
+// redundantly (no third barrier), appends its survivors to its own 64/W slots of the shared list, and the waves take
+// turns in ranking + storing a query.  Two barriers per query, LDS state double-buffered by query parity.
+namespace xl {
+
+constexpr uint32_t INIT_BITS = 0x4e6e6b28u;   // 1e9f
+constexpr int QPT_MAX = 64;                     // queries per team (redo list capacity)
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+// compare-exchange with the lane at a DPP-reachable position inside the 16-lane row; `lower` lanes keep the minimum
+template <int CTRL>
+__device__ __forceinline__ uint32_t cx_row(uint32_t x, bool lower) {
+    const uint32_t p = dpp<CTRL>(x);
+    const uint32_t lo = min(x, p), hi = max(x, p);
+    return lower ? lo : hi;
+}
+// partner lane ^ 4: banks 0, 2 of a row read four lanes up, banks 1, 3 four lanes down
+__device__ __forceinline__ uint32_t cx4(uint32_t x, bool lower) {
+    uint32_t p = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xf, 0x5, false);
+    p = (uint32_t)__builtin_amdgcn_update_dpp((int)p, (int)x, 0x114, 0xf, 0xA, false);
+    const uint32_t lo = min(x, p), hi = max(x, p);
+    return lower ? lo : hi;
+}
+struct LaneBits {
+    bool b1, b2, b4, b8, b16, b32;
+    __device__ __forceinline__ explicit LaneBits(int lane)
+        : b1(!(lane & 1)), b2(!(lane & 2)), b4(!(lane & 4)), b8(!(lane & 8)), b16(!(lane & 16)), b32(!(lane & 32)) {}
+};
+// ascending sort of one 32-bit key per lane across the 64 lanes of the wave: bitonic network in the form whose every
+// merge starts with a mirror (lane ^ (size - 1)) so that all comparators point the same way.  quad_perm / row_mirror /
+// row_half_mirror / row_ror:8 / row_sh[lr]:4 inside the rows, v_permlane16_swap and v_permlane32_swap across them.
+__device__ __forceinline__ uint32_t wave_sort_u32(uint32_t x, const LaneBits& lb) {
+    constexpr int X1 = 0xB1, X2 = 0x4E, X3 = 0x1B, HMIRROR = 0x141, MIRROR = 0x140, ROR8 = 0x128;
+    x = cx_row<X1>(x, lb.b1);
+    x = cx_row<X3>(x, lb.b2); x = cx_row<X1>(x, lb.b1);
+    x = cx_row<HMIRROR>(x, lb.b4); x = cx_row<X2>(x, lb.b2); x = cx_row<X1>(x, lb.b1);
+    x = cx_row<MIRROR>(x, lb.b8); x = cx4(x, lb.b4); x = cx_row<X2>(x, lb.b2); x = cx_row<X1>(x, lb.b1);
+    {   // lane ^ 31: mirror inside the row, then swap the rows of a pair
+        const uint32_t y = dpp<MIRROR>(x);
+        const auto r = __builtin_amdgcn_permlane16_swap(y, y, false, false);   // [y0 y0 y2 y2], [y1 y1 y3 y3]
+        const uint32_t p = lb.b16 ? r[1] : r[0];
+        x = lb.b16 ? min(x, p) : max(x, p);
+    }
+    x = cx_row<ROR8>(x, lb.b8); x = cx4(x, lb.b4); x = cx_row<X2>(x, lb.b2); x = cx_row<X1>(x, lb.b1);
+    {   // lane ^ 63
+        const uint32_t y = dpp<MIRROR>(x);
+        const auto r = __builtin_amdgcn_permlane16_swap(y, y, false, false);
+        const uint32_t y2 = lb.b16 ? r[1] : r[0];                                // x[lane ^ 31]
+        const auto s = __builtin_amdgcn_permlane32_swap(y2, y2, false, false);   // [lo lo], [hi hi]
+        const uint32_t p = lb.b32 ? s[1] : s[0];
+        x = lb.b32 ? min(x, p) : max(x, p);
+    }
+    {   // lane ^ 16
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        const uint32_t lo = min(r[0], r[1]), hi = max(r[0], r[1]);
+        x = lb.b16 ? lo : hi;
+    }
+    x = cx_row<ROR8>(x, lb.b8); x = cx4(x, lb.b4); x = cx_row<X2>(x, lb.b2); x = cx_row<X1>(x, lb.b1);
+    return x;
+}
+// minimum over the wave, in every lane
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+    x = min(x, dpp<0xB1>(x));
+    x = min(x, dpp<0x4E>(x));
+    x = min(x, dpp<0x141>(x));
+    x = min(x, dpp<0x140>(x));
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    x = min(r[0], r[1]);
+    const auto s = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return min(s[0], s[1]);
+}
+// the k-th smallest of the 64 lane values (wave-uniform), never above the initial distance of the reference's list
+__device__ __forceinline__ uint32_t kth_bound(uint32_t m, int k, const LaneBits& lb) {
+    uint32_t t;
+    if (k == 1) t = wave_min_u32(m);
+    else t = wave_sort_u32(m, lb);
+    t = (uint32_t)__builtin_amdgcn_readlane((int)t, k - 1);
+    return t < INIT_BITS ? t : INIT_BITS;
+}
+
+template <int D>
+__device__ __forceinline__ uint32_t dist_bits(float ux, float uy, float uz, float x, float y, float z) {
+    float d = (ux - x) * (ux - x) + (uy - y) * (uy - y);
+    if (D == 3) d = d + (uz - z) * (uz - z);
+    return __float_as_uint(d);
+}
+
+// LDS of one wave (dwords): survivor list 2 x 64 x (key lo, key hi) | class minima 2 x 64 | counts 2 x 8 |
+// redo lists 4 x 64 | queue of the redo scan 2 x QBUF x 64.  A team uses the region of its wave 0 for the shared parts.
+constexpr int L_SURV = 0, L_CLS = 256, L_CNT = 384, L_REDO = 400, L_QUEUE = 656;
+constexpr int L_WAVE = L_QUEUE + 2 * QBUF * 64;
+
+// in-order scans of the queries on a redo list (lane = query), candidates [0, hi)
+template <int D, int K>
+__device__ __forceinline__ void redo_scan(const float* __restrict__ in_b, const float* __restrict__ query_b,
+                                          int64_t* __restrict__ out_b, int hi, const uint32_t* list, int n, int q0,
+                                          float* wave_lds, int lane) {
+    const bool live = lane < n;
+    const int q = q0 + (int)(list[live ? lane : 0] & 0xffffu);
+    const float* qp = query_b + (size_t)q * D;
+    const float ux = qp[0], uy = qp[1], uz = (D == 3) ? qp[2] : 0.0f;
+    float dist[K];
+    int idx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        dist[j] = KNN_INIT;
+        idx[j] = 0;
+    }
+    float ev = INFINITY;
+    float* qd = wave_lds + L_QUEUE + lane;
+    int* qi = reinterpret_cast<int*>(wave_lds + L_QUEUE + QBUF * 64) + lane;
+    scan_range<D, K>(in_b, 0, hi, ux, uy, uz, dist, idx, ev, qd, qi, 64);
+    if (live) {
+        int64_t* o = out_b + (size_t)q * K;
+#pragma unroll
+        for (int j = 0; j < K; ++j) o[j] = (int64_t)idx[j];
+    }
+}
+template <int D>
+__device__ __forceinline__ void redo_dispatch(int k, const float* __restrict__ in_b, const float* __restrict__ query_b,
+                                              int64_t* __restrict__ out_b, int hi, const uint32_t* list, int n, int q0,
+                                              float* wave_lds, int lane) {
+    switch (k) {
+        case 1: redo_scan<D, 1>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
+        case 3: redo_scan<D, 3>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
+        case 4: redo_scan<D, 4>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
+        case 8: redo_scan<D, 8>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
+        case 16: redo_scan<D, 16>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
+        default: redo_scan<D, 32>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
+    }
+}
+
+// Rank + store one query from the survivor list.  slot l of the list belongs to team wave l / R, entry l % R;
+// cnt_of(w) = survivors wave w found (may exceed R: overflow).  Returns true when the query must be redone in order.
+template <typename CntOf>
+__device__ __forceinline__ bool finish_query(const uint32_t* surv, int W, int R, CntOf&& cnt_of, int k,
+                                             int64_t* __restrict__ o, int lane) {
+    const int sw = lane / R, st = lane - sw * R;
+    bool overflow = false;
+    int total = 0;
+    bool valid = false;
+    for (int w = 0; w < W; ++w) {
+        const int c = __builtin_amdgcn_readfirstlane(cnt_of(w));
+        overflow = overflow || c > R;
+        const int n = c < R ? c : R;
+        total += n;
+        valid = valid || (sw == w && st < n);
+    }
+    const uint32_t klo = valid ? surv[2 * lane] : 0xffffffffu;       // index
+    const uint32_t khi = valid ? surv[2 * lane + 1] : 0xffffffffu;   // distance bits
+    const uint64_t key = ((uint64_t)khi << 32) | klo;
+    int rank = 0;
+    for (int w = 0; w < W; ++w) {
+        const int c = __builtin_amdgcn_readfirstlane(cnt_of(w));
+        const int n = c < R ? c : R;
+        for (int t = 0; t < n; ++t) {
+            const int src = w * R + t;
+            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)klo, src);
+            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)khi, src);
+            const uint64_t s = ((uint64_t)shi << 32) | slo;
+            rank += (s < key) ? 1 : 0;
+        }
+    }
+    bool redo = overflow;
+    if (total >= k) {
+        const uint64_t mk = __ballot(valid && rank == k - 1);
+        const int src = (int)__builtin_ctzll(mk);
+        const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)khi, src);
+        redo = redo || __ballot(valid && rank >= k && khi == dk) != 0;
+    }
+    redo = redo || __ballot(valid && khi == INIT_BITS) != 0;
+    if (!redo) {
+        if (valid && rank < k) o[rank] = (int64_t)klo;
+        if (lane >= total && lane < k) o[lane] = 0;
+    }
+    return redo;
+}
+
+template <int D, int J, bool TEAM, int OCC>
+__global__ __launch_bounds__(TEAM ? 512 : 256, OCC) void knn_xlane_kernel(const float* __restrict__ input,
+                                                                     const float* __restrict__ query,
+                                                                     int64_t* __restrict__ out, int M, int Nq, int k,
+                                                                     int qpt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwb = blockDim.x >> 6;
+    const int W = TEAM ? nwb : 1;
+    const int tw = TEAM ? w : 0;
+    const int R = 64 / W;
+    const int b = blockIdx.y;
+    const int q0 = (TEAM ? blockIdx.x : blockIdx.x * nwb + w) * qpt;
+    if (q0 >= Nq) return;                       // TEAM: the whole workgroup leaves together
+    const int q1 = q0 + qpt < Nq ? q0 + qpt : Nq;
+    const LaneBits lb(lane);
+
+    float* wave_lds = smem + w * L_WAVE;
+    float* team_lds = smem + (TEAM ? 0 : w * L_WAVE);
+    uint32_t* surv = reinterpret_cast<uint32_t*>(team_lds + L_SURV);
+    uint32_t* cls = reinterpret_cast<uint32_t*>(team_lds + L_CLS);
+    volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(team_lds + L_CNT);
+    uint32_t* redo_list = reinterpret_cast<uint32_t*>(wave_lds + L_REDO);
+
+    const float* __restrict__ in_b = input + (size_t)b * M * D;
+    const float* __restrict__ query_b = query + (size_t)b * Nq * D;
+    int64_t* __restrict__ out_b = out + (size_t)b * Nq * k;
+
+    // the wave's candidates: slot j of lane l = candidate cbase + 64 j + l; a slot past the end gets an infinite
+    // coordinate, its distance is inf or NaN and never passes `<= T`
+    const int cbase = tw * (J * 64);
+    float cx[J], cy[J], cz[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = cbase + j * 64 + lane;
+        const bool in = c < M;
+        const float* p = in_b + (size_t)(in ? c : M - 1) * D;       // always a valid address: the loads stay unconditional
+        const float x = p[0], y = p[1], z = (D == 3) ? p[2] : 0.0f;
+        cx[j] = in ? x : INFINITY;
+        cy[j] = y;
+        cz[j] = z;
+    }
+    if (TEAM) {
+        if (w == 0) {
+            cls[lane] = 0xffffffffu;
+            cls[64 + lane] = 0xffffffffu;
+        }
+        __syncthreads();
+    }
+    const int cl = cbase + lane;
+    int nredo = 0;
+
+    float nx = query_b[(size_t)q0 * D], ny = query_b[(size_t)q0 * D + 1], nz = (D == 3) ? query_b[(size_t)q0 * D + 2] : 0.0f;
+    for (int qi = q0; qi < q1; ++qi) {
+        const float ux = nx, uy = ny, uz = nz;
+        if (qi + 1 < q1) {
+            const float* qp = query_b + (size_t)(qi + 1) * D;
+            nx = qp[0];
+            ny = qp[1];
+            nz = (D == 3) ? qp[2] : 0.0f;
+        }
+        const int par = (qi - q0) & 1;
+        // ---- phase 1: distances + lane minimum ----
+        uint32_t d[J];
+        uint32_t m = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            d[j] = dist_bits<D>(ux, uy, uz, cx[j], cy[j], cz[j]);
+            m = min(m, d[j]);
+        }
+        if (TEAM) {
+            atomicMin(&cls[par * 64 + lane], m);
+            __syncthreads();
+            m = cls[par * 64 + lane];
+        }
+        const uint32_t T = kth_bound(m, k, lb);
+        // ---- phase 2: survivors ----
+        int cnt = 0;
+        uint32_t* sv = surv + par * 128 + 2 * (tw * R);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const bool hit = d[j] <= T;
+            const uint64_t mask = __ballot(hit);
+            if (mask) {
+                const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)cnt));
+                if (hit && pos < R) {
+                    sv[2 * pos] = (uint32_t)(cl + j * 64);
+                    sv[2 * pos + 1] = d[j];
+                }
+                cnt += __builtin_popcountll(mask);
+            }
+        }
+        // ---- rank + store ----
+        bool redo = false;
+        if (TEAM) {
+            if (lane == 0) cnts[par * 8 + tw] = (uint32_t)cnt;
+            __syncthreads();
+            if (tw == ((qi - q0) & (W - 1))) {
+                redo = finish_query(surv + par * 128, W, R, [&](int ww) { return (int)cnts[par * 8 + ww]; }, k,
+                                    out_b + (size_t)qi * k, lane);
+                cls[par * 64 + lane] = 0xffffffffu;     // next use: two queries on, behind two barriers
+                if (redo && lane == 0) redo_list[nredo] = (uint32_t)(qi - q0);
+                nredo += redo ? 1 : 0;
+            }
+        } else {
+            redo = finish_query(surv + par * 128, 1, 64, [&](int) { return cnt; }, k, out_b + (size_t)qi * k, lane);
+            if (redo && lane == 0) redo_list[nredo] = (uint32_t)(qi - q0);
+            nredo += redo ? 1 : 0;
+        }
+    }
+    if (nredo > 0) redo_dispatch<D>(k, in_b, query_b, out_b, M, redo_list, nredo, q0, wave_lds, lane);
+}
+
+static int mode() {   // CAMLI_KNN=lane forces the lane-per-query kernels, =xlane the cross-lane ones wherever they apply
+    const char* e = getenv("CAMLI_KNN");      // read per call: tests and A/B tools flip it inside one process
+    if (!e) return 0;
+    return e[0] == 'l' ? 1 : (e[0] == 'x' ? 2 : 0);
+}
+static bool k_supported(int k) { return k == 1 || k == 3 || k == 4 || k == 8 || k == 16 || k == 32; }
+
+// waves per SIMD the D = 3, J = 32 kernels are compiled for: 3 (168 registers, a few spills) or 2 (CAMLI_KNN_XL_OCC=2)
+static long long target_waves() {     // waves a launch is cut into (1024 SIMDs x 3 by default)
+    const char* e = getenv("CAMLI_KNN_XL_WAVES");
+    const long long v = e ? atoll(e) : 3072LL;
+    return v > 0 ? v : 3072LL;
+}
+static int occ_choice() {
+    const char* e = getenv("CAMLI_KNN_XL_OCC");
+    return e ? atoi(e) : 3;
+}
+
+template <int D, int J, bool TEAM, int OCC>
+int launch(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k, int W, hipStream_t stream) {
+    const long long occ = target_waves();
+    const long long total = (long long)B * Nq;
+    const int nwb = TEAM ? W : 4;
+    const long long teams_wanted = TEAM ? occ / W : occ;
+    int qpt = (int)((total + teams_wanted - 1) / teams_wanted);
+    if (qpt < 4) qpt = 4;
+    if (qpt > QPT_MAX) qpt = QPT_MAX;
+    const int teams_per_block = TEAM ? 1 : nwb;
+    dim3 grid(camli_divup(Nq, qpt * teams_per_block), B);
+    const size_t lds = (size_t)nwb * L_WAVE * 4;
+    hipLaunchKernelGGL((knn_xlane_kernel<D, J, TEAM, OCC>), grid, dim3(64 * nwb), lds, stream, input, query, out, M, Nq, k, qpt);
+    return camli_check_launch("camli_knn(xlane)");
+}
+
+// returns 1 when the shape is not served here (the caller falls back to the lane-per-query kernels)
+template <int D>
+int dispatch(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k, hipStream_t stream, int* rc) {
+    if (!k_supported(k) || M > 16384) return 1;
+    if (M <= 256) *rc = launch<D, 4, false, 3>(input, query, out, B, M, Nq, k, 1, stream);
+    else if (M <= 512) *rc = launch<D, 8, false, 3>(input, query, out, B, M, Nq, k, 1, stream);
+    else if (M <= 1024) *rc = launch<D, 16, false, 3>(input, query, out, B, M, Nq, k, 1, stream);
+    else if (M <= 2048) {
+        if (occ_choice() == 2) *rc = launch<D, 32, false, 2>(input, query, out, B, M, Nq, k, 1, stream);
+        else *rc = launch<D, 32, false, 3>(input, query, out, B, M, Nq, k, 1, stream);
+    } else {
+        const int W = M <= 4096 ? 2 : (M <= 8192 ? 4 : 8);
+        if (occ_choice() == 2) *rc = launch<D, 32, true, 2>(input, query, out, B, M, Nq, k, W, stream);
+        else *rc = launch<D, 32, true, 3>(input, query, out, B, M, Nq, k, W, stream);
+    }
+    return 0;
+}
+
+// Nested prefixes (camli_knn_prefixes) in the cross-lane form: level l = the first M >> l candidates = the first J >> l
+// register slots of every lane, so ONE pass of distance arithmetic serves all levels; the lane minimum is snapshot where
+// a level ends, each level gets its own bound (one sort each; T_0 <= T_1 <= ...), phase 2 tests a slot against the
+// loosest bound of the levels that contain it and descends only on a hit.
+constexpr int P_SURV = 0, P_REDO = 512, P_QUEUE = 768;
+constexpr int P_WAVE = P_QUEUE + 2 * QBUF * 64;
+
+template <int J, int L, int OCC>
+__global__ __launch_bounds__(256, OCC) void knn_xlane_prefix_kernel(const float* __restrict__ input,
+                                                                      const float* __restrict__ query, KnnPrefixOut po,
+                                                                      int M, int Nq, int k, int qpt) {
+    constexpr int D = 3;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwb = blockDim.x >> 6;
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * nwb + w) * qpt;
+    if (q0 >= Nq) return;
+    const int q1 = q0 + qpt < Nq ? q0 + qpt : Nq;
+    const LaneBits lb(lane);
+    float* wave_lds = smem + w * P_WAVE;
+    uint32_t* surv = reinterpret_cast<uint32_t*>(wave_lds + P_SURV);        // [L][64][2]
+    uint32_t* redo_list = reinterpret_cast<uint32_t*>(wave_lds + P_REDO);   // [L][64]
+
+    const float* __restrict__ in_b = input + (size_t)b * M * D;
+    const float* __restrict__ query_b = query + (size_t)b * Nq * D;
+
+    float cx[J], cy[J], cz[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float* p = in_b + (size_t)(j * 64 + lane) * D;      // M = 64 J exactly
+        cx[j] = p[0];
+        cy[j] = p[1];
+        cz[j] = p[2];
+    }
+    int nredo[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) nredo[l] = 0;
+
+    float nx = query_b[(size_t)q0 * D], ny = query_b[(size_t)q0 * D + 1], nz = query_b[(size_t)q0 * D + 2];
+    for (int qi = q0; qi < q1; ++qi) {
+        const float ux = nx, uy = ny, uz = nz;
+        if (qi + 1 < q1) {
+            const float* qp = query_b + (size_t)(qi + 1) * D;
+            nx = qp[0];
+            ny = qp[1];
+            nz = qp[2];
+        }
+        uint32_t d[J];
+        uint32_t ml[L];
+        uint32_t m = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            d[j] = dist_bits<D>(ux, uy, uz, cx[j], cy[j], cz[j]);
+            m = min(m, d[j]);
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                if (j + 1 == (J >> l)) ml[l] = m;
+        }
+        uint32_t T[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) T[l] = kth_bound(ml[l], k, lb);
+        int cnt[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) cnt[l] = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            // levels that contain slot j: 0 .. lmax
+            int lmax = 0;
+#pragma unroll
+            for (int l = 1; l < L; ++l)
+                if (j < (J >> l)) lmax = l;
+            bool go = true;
+#pragma unroll
+            for (int l = L - 1; l >= 0; --l) {
+                if (l > lmax) continue;
+                if (go) {
+                    const bool hit = d[j] <= T[l];
+                    const uint64_t mask = __ballot(hit);
+                    if (mask) {
+                        const int pos = (int)__builtin_amdgcn_mbcnt_hi(
+                            (uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)cnt[l]));
+                        if (hit && pos < 64) {
+                            surv[l * 128 + 2 * pos] = (uint32_t)(lane + j * 64);
+                            surv[l * 128 + 2 * pos + 1] = d[j];
+                        }
+                        cnt[l] += __builtin_popcountll(mask);
+                    } else {
+                        go = false;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int c = cnt[l];
+            const bool redo = finish_query(surv + l * 128, 1, 64, [&](int) { return c; }, k,
+                                           po.out[l] + ((size_t)b * Nq + qi) * k, lane);
+            if (redo && lane == 0) redo_list[l * 64 + nredo[l]] = (uint32_t)(qi - q0);
+            nredo[l] += redo ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+        if (nredo[l] > 0)
+            redo_dispatch<D>(k, in_b, query_b, po.out[l] + (size_t)b * Nq * k, M >> l, redo_list + l * 64, nredo[l], q0,
+                             wave_lds + (P_QUEUE - L_QUEUE), lane);
+}
+
+template <int J, int L>
+int launch_prefix(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int k,
+                  hipStream_t stream) {
+    const long long occ = target_waves();
+    const long long total = (long long)B * Nq;
+    int qpt = (int)((total + occ - 1) / occ);
+    if (qpt < 4) qpt = 4;
+    if (qpt > QPT_MAX) qpt = QPT_MAX;
+    dim3 grid(camli_divup(Nq, qpt * 4), B);
+    const size_t lds = (size_t)4 * P_WAVE * 4;
+    if (J == 32 && occ_choice() == 2)
+        hipLaunchKernelGGL((knn_xlane_prefix_kernel<J, L, 2>), grid, dim3(256), lds, stream, input, query, po, M, Nq, k, qpt);
+    else
+        hipLaunchKernelGGL((knn_xlane_prefix_kernel<J, L, 3>), grid, dim3(256), lds, stream, input, query, po, M, Nq, k, qpt);
+    return camli_check_launch("camli_knn_prefixes(xlane)");
+}
+
+// 1 = shape not served here
+int dispatch_prefix(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int D, int k,
+                    hipStream_t stream, int* rc) {
+    if (D != 3 || !k_supported(k) || po.levels < 2) return 1;
+    const int L = po.levels;
+    for (int l = 0; l < L; ++l)
+        if (po.size[l] != (M >> l) || (po.size[l] & 63)) return 1;
+    if ((M >> (L - 1)) << (L - 1) != M) return 1;
+    const int J = M / 64;
+    if (J != 8 && J != 16 && J != 32) return 1;
+#define CAMLI_XL_PREFIX(JJ, LL) \
+    if (J == JJ && L == LL) { *rc = launch_prefix<JJ, LL>(input, query, po, B, M, Nq, k, stream); return 0; }
+    CAMLI_XL_PREFIX(32, 4) CAMLI_XL_PREFIX(32, 3) CAMLI_XL_PREFIX(32, 2)
+    CAMLI_XL_PREFIX(16, 4) CAMLI_XL_PREFIX(16, 3) CAMLI_XL_PREFIX(16, 2)
+    CAMLI_XL_PREFIX(8, 4) CAMLI_XL_PREFIX(8, 3) CAMLI_XL_PREFIX(8, 2)
+#undef CAMLI_XL_PREFIX
+    return 1;
+}
+
+}  // namespace xl
+
 // CAMLI_KNN_SHARE=0 switches the published bounds off (A/B runs)
 static int knn_share() {
     static const int v = [] { const char* e = getenv("CAMLI_KNN_SHARE"); return e ? atoi(e) : 1; }();
@@ -600,6 +1124,12 @@ extern "C" int camli_knn(const float* input, const float* query, int64_t* out_id
         return CAMLI_EINVAL;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (xl::mode() != 1) {
+        int rc = CAMLI_OK;
+        const int served = D == 2 ? xl::dispatch<2>(input, query, out_idx, B, M, Nq, k, s, &rc)
+                                  : xl::dispatch<3>(input, query, out_idx, B, M, Nq, k, s, &rc);
+        if (served == 0) return rc;
+    }
     return D == 2 ? dispatch_knn<2>(input, query, out_idx, B, M, Nq, k, s)
                   : dispatch_knn<3>(input, query, out_idx, B, M, Nq, k, s);
 }
@@ -620,6 +1150,16 @@ extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_
             camli_set_error("camli_knn_prefixes: level sizes must be strictly descending and positive");
             return CAMLI_EINVAL;
         }
+    if (xl::mode() != 1) {
+        KnnPrefixOut xpo;
+        xpo.levels = L;
+        for (int l = 0; l < 4; ++l) {
+            xpo.out[l] = l < L ? out_levels[l] : nullptr;
+            xpo.size[l] = l < L ? sizes[l] : 0;
+        }
+        int rc = CAMLI_OK;
+        if (xl::dispatch_prefix(input, query, xpo, B, M, Nq, D, k, reinterpret_cast<hipStream_t>(stream), &rc) == 0) return rc;
+    }
     const int chunk = sizes[L - 1];
     bool one_launch = (D == 3) && (k == 16 || k == 32) && chunk >= 64;
     for (int l = 0; l < L; ++l) one_launch = one_launch && (sizes[l] % chunk == 0);

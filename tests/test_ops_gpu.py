@@ -45,6 +45,10 @@ KNN_CASES = [
     (1, 256, 2048, 3, 16), (8, 2048, 2048, 3, 16), (3, 1000, 777, 3, 16), (2, 77, 130, 2, 3),
     (1, 5, 9, 3, 16), (1, 300, 300, 3, 8), (1, 300, 300, 3, 4), (1, 300, 64, 3, 5), (1, 100, 70, 2, 64),
     (1, 16384, 4096, 3, 16),
+    # round 4: the slot-count / team boundaries of the cross-lane kernels (M = 64 J, 2048 per team wave), k = 1 in 3-D,
+    # wide k in 2-D, fewer candidates than lanes
+    (2, 257, 100, 3, 16), (1, 2049, 300, 3, 16), (2, 3000, 500, 3, 32), (1, 5000, 333, 3, 3), (1, 12000, 200, 3, 8),
+    (2, 640, 640, 2, 16), (1, 2048, 2048, 3, 1), (1, 40, 64, 3, 32), (1, 4096, 4096, 3, 4),
 ]
 
 
@@ -63,6 +67,22 @@ def test_knn_bit_exact(case, kind, ops, oracle_lib):
     want = oracle_lib.knn(inp, qry, k)
     assert got.dtype == np.int64 and got.shape == (b, nq, k)
     assert np.array_equal(got, want), 'mismatching entries: %d of %d' % ((got != want).sum(), got.size)
+
+
+@pytest.mark.parametrize('case', [(2, 2048, 1024, 3, 16), (1, 8192, 512, 3, 16), (2, 2048, 700, 3, 3), (2, 1000, 300, 2, 1),
+                                  (1, 4096, 300, 3, 32)], ids=lambda c: 'B%d_M%d_N%d_D%d_k%d' % c)
+@pytest.mark.parametrize('mode', ['lane', 'xlane3', 'xlane2'])
+def test_knn_kernel_families_agree_with_the_oracle(case, mode, ops, oracle_lib, monkeypatch):
+    """Both kernel families behind camli_knn (lane-per-query, candidates-across-lanes in its two register budgets) on a
+    cloud with 25 % duplicates: bit-exact vs the oracle whichever one the dispatcher is told to take."""
+    b, m, nq, d, k = case
+    monkeypatch.setenv('CAMLI_KNN', 'lane' if mode == 'lane' else 'xlane')
+    monkeypatch.setenv('CAMLI_KNN_XL_OCC', '2' if mode == 'xlane2' else '3')
+    rng = np.random.default_rng(hash((case, 'fam')) % (2 ** 32))
+    inp, qry = _cloud(rng, b, m, d, 'dup'), _cloud(rng, b, nq, d, 'dup')
+    qry[:, :min(nq, m) // 2] = inp[:, :min(nq, m) // 2]
+    got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
+    assert np.array_equal(got, oracle_lib.knn(inp, qry, k))
 
 
 def test_knn_channel_first_layout_is_sniffed_like_the_reference(ops, oracle_lib):
