@@ -545,34 +545,40 @@ __global__ __launch_bounds__(64) void knn_generic_kernel(const float* __restrict
 // partial-list merges) and need the candidate range split over waves to fill the chip when there are few queries.
 // Here a wave works on ONE query at a time and its 64 lanes hold the candidates:
 //
-//   * the wave keeps a chunk of J*64 candidates in registers for its whole life (lane l, slot j = candidate
-//     cbase + 64 j + l; 3 J VGPRs), the query coordinates are wave-uniform (scalar loads), so the distance
-//     arithmetic is 8 VALU operations per 64 pairs with no memory operand at all (same unfused fp32 expression);
+//   * the candidates of the batch element sit in LDS as three coordinate planes (staged once per workgroup, shared by
+//     its four waves); a lane reads 4 consecutive candidates per 16-byte LDS access (slot 4g+u of lane l = candidate
+//     4 (64 g + l) + u), the query coordinates are wave-uniform (scalar loads), so the distance arithmetic is 8 VALU
+//     operations per 64 pairs (same unfused fp32 expression) next to 3/4 of an LDS read -- 24 KB of LDS traffic per
+//     query at M = 2048, a few % of the LDS rate.  (Round 4 first kept them in 96 registers: the kernel then sat at
+//     170-200 VGPRs, two waves per SIMD or spills with serialised scratch reloads, 40 us instead of 17.)
 //   * phase 1 also keeps the minimum of each lane's J distances.  The k-th smallest of the 64 lane minima (one
 //     64-lane bitonic sort of the keys on DPP / v_permlane*_swap compare-exchanges, distances ordered as their bit
 //     patterns) is an upper bound T of the k-th neighbour distance: k different lanes hold a candidate within it;
 //   * phase 2 ballots `d <= T` per slot; the survivors (k + a few: 18 on average for k = 16, whatever M is) are
-//     compacted into a 64-entry LDS list with v_mbcnt prefix counts;
+//     compacted into a 128-entry LDS list with v_mbcnt prefix counts;
 //   * each survivor's final position is its rank by (distance, index) among the survivors -- counted against the
-//     list broadcast through v_readlane, no second sort -- and the lane stores its index at out[rank].
+//     list read back as LDS broadcasts, no second sort -- and the lane stores its index at out[rank].
 //
-// Exactness.  Every candidate within the k-th distance survives, and sequential insertion
-// (k_nearest_neighbor_kernel.cu:52-95) leaves its list ordered by (distance, index) UNLESS a candidate tying the
-// final k-th distance is dropped (more ties at that distance than free slots) -- then which tied index stays depends
-// on the arrival order.  That case (rank k exists and has the k-th distance), a survivor list overflow, and a real
-// candidate at exactly the initial distance 1e9 send the query to an in-order lane-per-query scan (scan_range above)
-// after the wave's query loop, when the candidate registers are dead.  Unfilled slots (fewer than k candidates within
-// 1e9) keep index 0 like the reference's initial list.
+// Exactness.  Every candidate within the k-th distance D survives.  Sequential insertion
+// (k_nearest_neighbor_kernel.cu:52-95) keeps every candidate closer than D, ordered by (distance, index); of the
+// candidates AT distance D it keeps s = k - #closer, and which ones follows from the arrival order in closed form: once
+// the list holds k candidates within D it stays full, a later closer candidate pops the LAST tied entry and a later
+// tied candidate overwrites it (slot k-1), so the result is the first s-1 tied candidates by index followed by either
+// the last tied candidate of all (when no closer candidate arrives after it) or the s-th tied one.  Both are ranks in
+// the survivor list, so ties cost a few scalar operations, not a rescan.  Only a survivor-list overflow (more than
+// 128 / W survivors in one wave: duplicates-only clouds) and a real candidate at exactly the initial distance 1e9
+// send a query to an in-order lane-per-query scan (scan_range above) after the wave's query loop, when the candidate
+// registers are dead.  Unfilled slots (fewer than k candidates within 1e9) keep index 0 like the reference's list.
 //
-// M > 2048: a TEAM of W = 2 / 4 / 8 waves (one workgroup) holds the candidates, 2048 per wave, and walks the queries
-// in step.  The lane minima are merged with one ds_min per wave into 64 class minima (class = candidate index mod 64
-// within a chunk), whose k-th smallest is again a bound with ~18 expected survivors; every wave sorts the classes
-// redundantly (no third barrier), appends its survivors to its own 64/W slots of the shared list, and the waves take
-// turns in ranking + storing a query.  Two barriers per query, LDS state double-buffered by query parity.
+// M > 2048: the candidates pass through LDS in chunks of 2048 (knn_xlane_chunked_kernel below): the lane minima and the
+// survivor list of a query live across the chunks, the bound tightens chunk by chunk.  (Round 4 first tried TEAMS of
+// 2 / 4 / 8 waves holding 2048 candidates each in registers and walking the queries in step -- two barriers per query
+// at two waves per SIMD: 216 us at (8192, 4096, k 16) where the lane-per-query kernel takes 157.)
 namespace xl {
 
 constexpr uint32_t INIT_BITS = 0x4e6e6b28u;   // 1e9f
-constexpr int QPT_MAX = 64;                     // queries per team (redo list capacity)
+constexpr int QPT_MAX = 64;                     // queries per team
+constexpr int CAP = 128;                        // survivor list entries (two per lane)
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t x) {
@@ -656,210 +662,369 @@ __device__ __forceinline__ uint32_t dist_bits(float ux, float uy, float uz, floa
     return __float_as_uint(d);
 }
 
-// LDS of one wave (dwords): survivor list 2 x 64 x (key lo, key hi) | class minima 2 x 64 | counts 2 x 8 |
-// redo lists 4 x 64 | queue of the redo scan 2 x QBUF x 64.  A team uses the region of its wave 0 for the shared parts.
-constexpr int L_SURV = 0, L_CLS = 256, L_CNT = 384, L_REDO = 400, L_QUEUE = 656;
-constexpr int L_WAVE = L_QUEUE + 2 * QBUF * 64;
+// Survivor list: (CAP + 4 pad) entries of (index, distance bits); unused entries hold the sentinel ~0 (no real key
+// reaches it: distances stay <= 1e9).
+constexpr int LIST_DW = 2 * (CAP + 4);
+static_assert(LIST_DW % 4 == 0, "16-byte aligned LDS regions");
 
-// in-order scans of the queries on a redo list (lane = query), candidates [0, hi)
-template <int D, int K>
-__device__ __forceinline__ void redo_scan(const float* __restrict__ in_b, const float* __restrict__ query_b,
-                                          int64_t* __restrict__ out_b, int hi, const uint32_t* list, int n, int q0,
-                                          float* wave_lds, int lane) {
-    const bool live = lane < n;
-    const int q = q0 + (int)(list[live ? lane : 0] & 0xffffu);
-    const float* qp = query_b + (size_t)q * D;
-    const float ux = qp[0], uy = qp[1], uz = (D == 3) ? qp[2] : 0.0f;
-    float dist[K];
-    int idx[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        dist[j] = KNN_INIT;
-        idx[j] = 0;
-    }
-    float ev = INFINITY;
-    float* qd = wave_lds + L_QUEUE + lane;
-    int* qi = reinterpret_cast<int*>(wave_lds + L_QUEUE + QBUF * 64) + lane;
-    scan_range<D, K>(in_b, 0, hi, ux, uy, uz, dist, idx, ev, qd, qi, 64);
-    if (live) {
-        int64_t* o = out_b + (size_t)q * K;
-#pragma unroll
-        for (int j = 0; j < K; ++j) o[j] = (int64_t)idx[j];
-    }
-}
+// The exact in-order insertion of ONE query by a whole wave, for the two cases the closed forms do not cover (a
+// survivor list overflow: clouds that are mostly duplicates; a real candidate at exactly the initial distance).  Lane
+// j < k holds entry j of the reference's list; 64 candidates are tested per trip against the running k-th distance
+// and the accepted ones are inserted one by one in index order with the reference's own rule
+// (k_nearest_neighbor_kernel.cu:80-90: start at slot min(idx, k-1), move left past entries with dist > d).  Slow (a
+// dozen instructions per accepted candidate) and rare; needs no LDS and ~10 registers.
 template <int D>
-__device__ __forceinline__ void redo_dispatch(int k, const float* __restrict__ in_b, const float* __restrict__ query_b,
-                                              int64_t* __restrict__ out_b, int hi, const uint32_t* list, int n, int q0,
-                                              float* wave_lds, int lane) {
-    switch (k) {
-        case 1: redo_scan<D, 1>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
-        case 3: redo_scan<D, 3>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
-        case 4: redo_scan<D, 4>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
-        case 8: redo_scan<D, 8>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
-        case 16: redo_scan<D, 16>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
-        default: redo_scan<D, 32>(in_b, query_b, out_b, hi, list, n, q0, wave_lds, lane); break;
-    }
-}
-
-// Rank + store one query from the survivor list.  slot l of the list belongs to team wave l / R, entry l % R;
-// cnt_of(w) = survivors wave w found (may exceed R: overflow).  Returns true when the query must be redone in order.
-template <typename CntOf>
-__device__ __forceinline__ bool finish_query(const uint32_t* surv, int W, int R, CntOf&& cnt_of, int k,
-                                             int64_t* __restrict__ o, int lane) {
-    const int sw = lane / R, st = lane - sw * R;
-    bool overflow = false;
-    int total = 0;
-    bool valid = false;
-    for (int w = 0; w < W; ++w) {
-        const int c = __builtin_amdgcn_readfirstlane(cnt_of(w));
-        overflow = overflow || c > R;
-        const int n = c < R ? c : R;
-        total += n;
-        valid = valid || (sw == w && st < n);
-    }
-    const uint32_t klo = valid ? surv[2 * lane] : 0xffffffffu;       // index
-    const uint32_t khi = valid ? surv[2 * lane + 1] : 0xffffffffu;   // distance bits
-    const uint64_t key = ((uint64_t)khi << 32) | klo;
-    int rank = 0;
-    for (int w = 0; w < W; ++w) {
-        const int c = __builtin_amdgcn_readfirstlane(cnt_of(w));
-        const int n = c < R ? c : R;
-        for (int t = 0; t < n; ++t) {
-            const int src = w * R + t;
-            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)klo, src);
-            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)khi, src);
-            const uint64_t s = ((uint64_t)shi << 32) | slo;
-            rank += (s < key) ? 1 : 0;
+__device__ __noinline__ void redo_query(const float* __restrict__ in_b, int M, float ux, float uy, float uz, int k,
+                                        int64_t* __restrict__ o, int lane) {
+    float ld = KNN_INIT;
+    int li = 0;
+    for (int c0 = 0; c0 < M; c0 += 64) {
+        const int c = c0 + lane;
+        const bool in = c < M;
+        const float* p = in_b + (size_t)(in ? c : M - 1) * D;
+        float d = (ux - p[0]) * (ux - p[0]) + (uy - p[1]) * (uy - p[1]);
+        if (D == 3) d = d + (uz - p[2]) * (uz - p[2]);
+        float kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ld), k - 1));
+        uint64_t acc = __ballot(in && !(d > kth));
+        while (acc) {
+            const int src = (int)__builtin_ctzll(acc);
+            acc &= acc - 1;
+            const float dv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), src));
+            kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ld), k - 1));
+            if (dv > kth) continue;
+            const int ci = c0 + src;
+            const int j0 = ci < k - 1 ? ci : k - 1;
+            const int pos = __builtin_popcountll(__ballot(lane < j0 && !(ld > dv)));     // entries left of j0 that stay
+            const float up_d = __shfl_up(ld, 1, 64);
+            const int up_i = __shfl_up(li, 1, 64);
+            const bool shifted = lane > pos && lane <= j0;
+            ld = shifted ? up_d : (lane == pos ? dv : ld);
+            li = shifted ? up_i : (lane == pos ? ci : li);
         }
     }
-    bool redo = overflow;
-    if (total >= k) {
-        const uint64_t mk = __ballot(valid && rank == k - 1);
-        const int src = (int)__builtin_ctzll(mk);
-        const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)khi, src);
-        redo = redo || __ballot(valid && rank >= k && khi == dk) != 0;
-    }
-    redo = redo || __ballot(valid && khi == INIT_BITS) != 0;
-    if (!redo) {
-        if (valid && rank < k) o[rank] = (int64_t)klo;
-        if (lane >= total && lane < k) o[lane] = 0;
-    }
-    return redo;
+    if (lane < k) o[lane] = (int64_t)li;
 }
 
-template <int D, int J, bool TEAM, int OCC>
-__global__ __launch_bounds__(TEAM ? 512 : 256, OCC) void knn_xlane_kernel(const float* __restrict__ input,
-                                                                     const float* __restrict__ query,
-                                                                     int64_t* __restrict__ out, int M, int Nq, int k,
-                                                                     int qpt) {
+__device__ __forceinline__ int first_lane(uint64_t mask) { return (int)__builtin_ctzll(mask); }
+
+// Rank + store one query from its survivor list and leave the list all-sentinel again.  Entry t of team wave w sits
+// at slot t * W + w (lane l reads slots l and 64 + l); `nslots` = W * the largest per-wave count, `two` = some slot
+// >= 64 is in use, `total` = the number of entries.  Ties at the k-th distance in closed form (header).  Returns true when a real candidate sits at
+// exactly the reference's initial distance (nothing is stored then: the caller redoes the query in order).
+__device__ __forceinline__ bool finish_query(uint32_t* list, int nslots, int total, bool two, int k,
+                                             int64_t* __restrict__ o, int lane) {
+    const uint2 e0 = *reinterpret_cast<const uint2*>(list + 2 * lane);                 // (index, distance bits)
+    uint2 e1 = make_uint2(0xffffffffu, 0xffffffffu);
+    if (two) e1 = *reinterpret_cast<const uint2*>(list + 2 * (64 + lane));
+    const uint64_t key0 = ((uint64_t)e0.y << 32) | e0.x, key1 = ((uint64_t)e1.y << 32) | e1.x;
+    const bool v0 = e0.y != 0xffffffffu, v1 = e1.y != 0xffffffffu;
+    int rank0 = 0, rank1 = 0;
+    for (int s = 0; s < nslots; s += 4) {        // wave-uniform addresses: LDS broadcasts; the pad keeps s + 3 in range
+        const uint4 a = *reinterpret_cast<const uint4*>(list + 2 * s);
+        const uint4 b = *reinterpret_cast<const uint4*>(list + 2 * s + 4);
+        const uint64_t s0 = ((uint64_t)a.y << 32) | a.x, s1 = ((uint64_t)a.w << 32) | a.z;
+        const uint64_t s2 = ((uint64_t)b.y << 32) | b.x, s3 = ((uint64_t)b.w << 32) | b.z;
+        rank0 += (s0 < key0) + (s1 < key0) + (s2 < key0) + (s3 < key0);
+        if (two) rank1 += (s0 < key1) + (s1 < key1) + (s2 < key1) + (s3 < key1);
+    }
+    // every lane has its entries in registers: reset them for the next query
+    if (v0) *reinterpret_cast<uint2*>(list + 2 * lane) = make_uint2(0xffffffffu, 0xffffffffu);
+    if (v1) *reinterpret_cast<uint2*>(list + 2 * (64 + lane)) = make_uint2(0xffffffffu, 0xffffffffu);
+
+    if (__ballot((v0 && e0.y == INIT_BITS) || (v1 && e1.y == INIT_BITS)) != 0) return true;
+    if (total < k) {            // fewer than k candidates within 1e9: the rest of the reference's list keeps index 0
+        if (v0) o[rank0] = (int64_t)e0.x;
+        if (v1) o[rank1] = (int64_t)e1.x;
+        if (lane >= total && lane < k) o[lane] = 0;
+        return false;
+    }
+    uint32_t dk;                // the k-th distance = that of rank k - 1
+    {
+        const uint64_t m0 = __ballot(v0 && rank0 == k - 1);
+        if (m0) dk = (uint32_t)__builtin_amdgcn_readlane((int)e0.y, first_lane(m0));
+        else dk = (uint32_t)__builtin_amdgcn_readlane((int)e1.y, first_lane(__ballot(v1 && rank1 == k - 1)));
+    }
+    // the common case: nothing beyond rank k - 1 shares the k-th distance -> the ranks are the output slots
+    if (__ballot((v0 && rank0 >= k && e0.y == dk) || (v1 && rank1 >= k && e1.y == dk)) == 0) {
+        if (v0 && rank0 < k) o[rank0] = (int64_t)e0.x;
+        if (v1 && rank1 < k) o[rank1] = (int64_t)e1.x;
+        return false;
+    }
+    const bool less0 = v0 && e0.y < dk, less1 = v1 && e1.y < dk;
+    const bool tie0 = v0 && e0.y == dk, tie1 = v1 && e1.y == dk;
+    const int n_less = __builtin_popcountll(__ballot(less0)) + __builtin_popcountll(__ballot(less1));
+    const int n_tie = __builtin_popcountll(__ballot(tie0)) + __builtin_popcountll(__ballot(tie1));
+    int top_rank = k - 1;                         // rank of the entry that ends in slot k - 1
+    if (n_less + n_tie > k) {                     // more tied candidates than slots
+        const int last = n_less + n_tie - 1;      // rank of the tied candidate with the highest index
+        uint32_t last_idx;
+        const uint64_t m0 = __ballot(v0 && rank0 == last);
+        if (m0) last_idx = (uint32_t)__builtin_amdgcn_readlane((int)e0.x, first_lane(m0));
+        else last_idx = (uint32_t)__builtin_amdgcn_readlane((int)e1.x, first_lane(__ballot(v1 && rank1 == last)));
+        const bool closer_after = __ballot((less0 && e0.x > last_idx) || (less1 && e1.x > last_idx)) != 0;
+        if (!closer_after) top_rank = last;
+    }
+    if (v0) {
+        if (rank0 < k - 1) o[rank0] = (int64_t)e0.x;
+        else if (rank0 == top_rank) o[k - 1] = (int64_t)e0.x;
+    }
+    if (v1) {
+        if (rank1 < k - 1) o[rank1] = (int64_t)e1.x;
+        else if (rank1 == top_rank) o[k - 1] = (int64_t)e1.x;
+    }
+    return false;
+}
+
+// phase 2 of one wave: entries with d <= T go to slots (cnt + prefix) * W + tw of `list`, at most R per wave (the
+// count keeps running past R: the caller sees the overflow); returns the new count
+template <int J, typename IndexOf>
+__device__ __forceinline__ int collect(const uint32_t (&d)[J], uint32_t T, uint32_t* list, int W, int tw, int R,
+                                       IndexOf&& index_of, int cnt = 0) {
+    auto append = [&](uint64_t mask, bool hit, uint32_t dv, int j) {
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)cnt));
+        if (hit && pos < R) *reinterpret_cast<uint2*>(list + 2 * (pos * W + tw)) = make_uint2((uint32_t)index_of(j), dv);
+        cnt += __builtin_popcountll(mask);
+    };
+    static_assert(J % 4 == 0, "slots come in groups of four");
+#pragma unroll
+    for (int j = 0; j < J; j += 4) {
+        const bool h0 = d[j] <= T, h1 = d[j + 1] <= T, h2 = d[j + 2] <= T, h3 = d[j + 3] <= T;
+        const uint64_t m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+        if ((m0 | m1) | (m2 | m3)) {
+            if (m0) append(m0, h0, d[j], j);
+            if (m1) append(m1, h1, d[j + 1], j + 1);
+            if (m2) append(m2, h2, d[j + 2], j + 2);
+            if (m3) append(m3, h3, d[j + 3], j + 3);
+        }
+    }
+    return cnt;
+}
+
+// ---- M > 2048: the candidates pass through LDS in chunks of 2048 -----------------------------------------------------
+// A workgroup (4 waves x QB queries each) stages one chunk at a time; every wave runs phase 1 + bound + phase 2 of each
+// of its QB queries on the chunk before the next one is staged (two barriers per CHUNK, none per query).  A query's lane
+// minima accumulate over the chunks, so the bound after chunk c is the k-th smallest lane minimum of the first c + 1
+// chunks -- it only tightens, and every bound is above the final k-th distance, so the survivor list (one per query,
+// kept in LDS over the chunk loop) is a superset of what the single-chunk kernel would collect: ~18 + 9 + 6 + 5 entries
+// for four chunks at k = 16.  Ranking, ties and overflow as everywhere else.
+constexpr int CH_J = 32, CH_QB = 4;
+constexpr int CH_CAND_DW = 3 * 64 * CH_J, CH_WAVE_DW = CH_QB * LIST_DW;
+
+template <int D>
+__global__ __launch_bounds__(256) void knn_xlane_chunked_kernel(const float* __restrict__ input,
+                                                                const float* __restrict__ query,
+                                                                int64_t* __restrict__ out, int M, int Nq, int k, int qpt) {
+    constexpr int J = CH_J, QB = CH_QB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwb = blockDim.x >> 6;
-    const int W = TEAM ? nwb : 1;
-    const int tw = TEAM ? w : 0;
-    const int R = 64 / W;
     const int b = blockIdx.y;
-    const int q0 = (TEAM ? blockIdx.x : blockIdx.x * nwb + w) * qpt;
-    if (q0 >= Nq) return;                       // TEAM: the whole workgroup leaves together
+    const int q0 = (blockIdx.x * 4 + w) * qpt;
     const int q1 = q0 + qpt < Nq ? q0 + qpt : Nq;
     const LaneBits lb(lane);
-
-    float* wave_lds = smem + w * L_WAVE;
-    float* team_lds = smem + (TEAM ? 0 : w * L_WAVE);
-    uint32_t* surv = reinterpret_cast<uint32_t*>(team_lds + L_SURV);
-    uint32_t* cls = reinterpret_cast<uint32_t*>(team_lds + L_CLS);
-    volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(team_lds + L_CNT);
-    uint32_t* redo_list = reinterpret_cast<uint32_t*>(wave_lds + L_REDO);
+    float* cand = smem;
+    uint32_t* lists = reinterpret_cast<uint32_t*>(smem + CH_CAND_DW + w * CH_WAVE_DW);
 
     const float* __restrict__ in_b = input + (size_t)b * M * D;
     const float* __restrict__ query_b = query + (size_t)b * Nq * D;
     int64_t* __restrict__ out_b = out + (size_t)b * Nq * k;
+    for (int i = lane; i < QB * LIST_DW; i += 64) lists[i] = 0xffffffffu;
 
-    // the wave's candidates: slot j of lane l = candidate cbase + 64 j + l; a slot past the end gets an infinite
-    // coordinate, its distance is inf or NaN and never passes `<= T`
-    const int cbase = tw * (J * 64);
-    float cx[J], cy[J], cz[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int c = cbase + j * 64 + lane;
-        const bool in = c < M;
-        const float* p = in_b + (size_t)(in ? c : M - 1) * D;       // always a valid address: the loads stay unconditional
-        const float x = p[0], y = p[1], z = (D == 3) ? p[2] : 0.0f;
-        cx[j] = in ? x : INFINITY;
-        cy[j] = y;
-        cz[j] = z;
-    }
-    if (TEAM) {
-        if (w == 0) {
-            cls[lane] = 0xffffffffu;
-            cls[64 + lane] = 0xffffffffu;
-        }
-        __syncthreads();
-    }
-    const int cl = cbase + lane;
-    int nredo = 0;
+    const float4* X4 = reinterpret_cast<const float4*>(cand) + lane;
+    const float4* Y4 = reinterpret_cast<const float4*>(cand + 64 * J) + lane;
+    const float4* Z4 = reinterpret_cast<const float4*>(cand + 128 * J) + lane;
+    const int cl4 = 4 * lane;
+    const int nchunks = (M + 64 * J - 1) / (64 * J);
 
-    float nx = query_b[(size_t)q0 * D], ny = query_b[(size_t)q0 * D + 1], nz = (D == 3) ? query_b[(size_t)q0 * D + 2] : 0.0f;
-    for (int qi = q0; qi < q1; ++qi) {
-        const float ux = nx, uy = ny, uz = nz;
-        if (qi + 1 < q1) {
-            const float* qp = query_b + (size_t)(qi + 1) * D;
-            nx = qp[0];
-            ny = qp[1];
-            nz = (D == 3) ? qp[2] : 0.0f;
-        }
-        const int par = (qi - q0) & 1;
-        // ---- phase 1: distances + lane minimum ----
-        uint32_t d[J];
-        uint32_t m = 0xffffffffu;
+    for (int qb = 0; qb < qpt; qb += QB) {          // same trip count in every wave of the workgroup (barriers inside)
+        float ux[QB], uy[QB], uz[QB];
+        uint32_t m[QB];
+        int cnt[QB];
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            d[j] = dist_bits<D>(ux, uy, uz, cx[j], cy[j], cz[j]);
-            m = min(m, d[j]);
+        for (int u = 0; u < QB; ++u) {
+            const int q = q0 + qb + u < q1 ? q0 + qb + u : (q1 > 0 ? q1 - 1 : 0);
+            const float* qp = query_b + (size_t)q * D;
+            ux[u] = qp[0];
+            uy[u] = qp[1];
+            uz[u] = (D == 3) ? qp[2] : 0.0f;
+            m[u] = 0xffffffffu;
+            cnt[u] = 0;
         }
-        if (TEAM) {
-            atomicMin(&cls[par * 64 + lane], m);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();                        // every wave is done with the previous chunk
+            const int c0 = ch * 64 * J;
+            for (int c = threadIdx.x; c < 64 * J; c += 256) {
+                const bool in = c0 + c < M;
+                const float* p = in_b + (size_t)(in ? c0 + c : M - 1) * D;
+                cand[c] = in ? p[0] : INFINITY;      // past the end: distance inf / NaN, never <= T
+                cand[64 * J + c] = p[1];
+                if (D == 3) cand[128 * J + c] = p[2];
+            }
             __syncthreads();
-            m = cls[par * 64 + lane];
-        }
-        const uint32_t T = kth_bound(m, k, lb);
-        // ---- phase 2: survivors ----
-        int cnt = 0;
-        uint32_t* sv = surv + par * 128 + 2 * (tw * R);
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const bool hit = d[j] <= T;
-            const uint64_t mask = __ballot(hit);
-            if (mask) {
-                const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)cnt));
-                if (hit && pos < R) {
-                    sv[2 * pos] = (uint32_t)(cl + j * 64);
-                    sv[2 * pos + 1] = d[j];
+            for (int u = 0; u < QB; ++u) {
+                if (q0 + qb + u < q1) {             // wave-uniform
+                    uint32_t d[J];
+                    uint32_t mm = m[u];
+#pragma unroll
+                    for (int g = 0; g < J / 4; ++g) {
+                        const float4 x = X4[g * 64], y = Y4[g * 64];
+                        float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (D == 3) z = Z4[g * 64];
+                        d[4 * g + 0] = dist_bits<D>(ux[u], uy[u], uz[u], x.x, y.x, z.x);
+                        d[4 * g + 1] = dist_bits<D>(ux[u], uy[u], uz[u], x.y, y.y, z.y);
+                        d[4 * g + 2] = dist_bits<D>(ux[u], uy[u], uz[u], x.z, y.z, z.z);
+                        d[4 * g + 3] = dist_bits<D>(ux[u], uy[u], uz[u], x.w, y.w, z.w);
+                        mm = min(min(mm, d[4 * g]), min(d[4 * g + 1], min(d[4 * g + 2], d[4 * g + 3])));
+                    }
+                    m[u] = mm;
+                    const uint32_t T = kth_bound(mm, k, lb);
+                    cnt[u] = collect<J>(d, T, lists + u * LIST_DW, 1, 0, CAP,
+                                        [&](int slot) { return c0 + cl4 + 256 * (slot >> 2) + (slot & 3); }, cnt[u]);
                 }
-                cnt += __builtin_popcountll(mask);
             }
         }
-        // ---- rank + store ----
-        bool redo = false;
-        if (TEAM) {
-            if (lane == 0) cnts[par * 8 + tw] = (uint32_t)cnt;
-            __syncthreads();
-            if (tw == ((qi - q0) & (W - 1))) {
-                redo = finish_query(surv + par * 128, W, R, [&](int ww) { return (int)cnts[par * 8 + ww]; }, k,
-                                    out_b + (size_t)qi * k, lane);
-                cls[par * 64 + lane] = 0xffffffffu;     // next use: two queries on, behind two barriers
-                if (redo && lane == 0) redo_list[nredo] = (uint32_t)(qi - q0);
-                nredo += redo ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            if (q0 + qb + u < q1) {
+                const int n = cnt[u] < CAP ? cnt[u] : CAP;
+                int64_t* o = out_b + (size_t)(q0 + qb + u) * k;
+                const bool init_tie = finish_query(lists + u * LIST_DW, n, n, n > 64, k, o, lane);
+                if (cnt[u] > CAP || init_tie) redo_query<D>(in_b, M, ux[u], uy[u], uz[u], k, o, lane);
             }
-        } else {
-            redo = finish_query(surv + par * 128, 1, 64, [&](int) { return cnt; }, k, out_b + (size_t)qi * k, lane);
-            if (redo && lane == 0) redo_list[nredo] = (uint32_t)(qi - q0);
-            nredo += redo ? 1 : 0;
         }
     }
-    if (nredo > 0) redo_dispatch<D>(k, in_b, query_b, out_b, M, redo_list, nredo, q0, wave_lds, lane);
+}
+
+// ---- M <= 2048: one wave per query, candidates in LDS; L > 1 = the nested prefixes of camli_knn_prefixes ------------
+// Level l = the first M >> l candidates = the first (J / 4) >> l slot groups of every lane, so ONE pass of distance
+// arithmetic serves all levels: the lane minimum is snapshot where a level ends, each level gets its own bound (one
+// sort each; T_0 <= T_1 <= ...), phase 2 tests a slot against the loosest bound of the levels that contain it and
+// descends only on a hit.
+// LDS of a workgroup (dwords): candidate planes X | Y | Z of 64 J floats each | per wave: L survivor lists.
+template <int J>
+constexpr int cand_dw() { return 3 * 64 * J; }
+template <int L>
+constexpr int wave_dw() { return L * LIST_DW; }
+
+template <int D, int J, int L>
+__global__ __launch_bounds__(256) void knn_xlane_kernel(const float* __restrict__ input, const float* __restrict__ query,
+                                                        KnnPrefixOut po, int M, int Nq, int k, int qpt) {
+    static_assert(J % 4 == 0 && ((J / 4) >> (L - 1)) >= 1, "levels end on slot-group boundaries");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + w) * qpt;
+    const int q1 = q0 + qpt < Nq ? q0 + qpt : Nq;
+    const LaneBits lb(lane);
+    float* cand = smem;
+    float* wave_lds = smem + cand_dw<J>() + w * wave_dw<L>();
+    uint32_t* surv = reinterpret_cast<uint32_t*>(wave_lds);                    // [L] lists
+
+    const float* __restrict__ in_b = input + (size_t)b * M * D;
+    const float* __restrict__ query_b = query + (size_t)b * Nq * D;
+
+    // stage the candidates: plane p at cand + 64 J p; entries past M get an infinite x (distance inf / NaN: never <= T)
+    for (int c = threadIdx.x; c < 64 * J; c += 256) {
+        const bool in = c < M;
+        const float* p = in_b + (size_t)(in ? c : M - 1) * D;
+        cand[c] = in ? p[0] : INFINITY;
+        cand[64 * J + c] = p[1];
+        if (D == 3) cand[128 * J + c] = p[2];
+    }
+    for (int i = lane; i < L * LIST_DW; i += 64) surv[i] = 0xffffffffu;
+    __syncthreads();
+
+    const float4* X4 = reinterpret_cast<const float4*>(cand) + lane;
+    const float4* Y4 = reinterpret_cast<const float4*>(cand + 64 * J) + lane;
+    const float4* Z4 = reinterpret_cast<const float4*>(cand + 128 * J) + lane;
+    const int cl4 = 4 * lane;
+
+    if (q0 < Nq) {
+        float nx = query_b[(size_t)q0 * D], ny = query_b[(size_t)q0 * D + 1], nz = (D == 3) ? query_b[(size_t)q0 * D + 2] : 0.0f;
+        for (int qi = q0; qi < q1; ++qi) {
+            const float ux = nx, uy = ny, uz = nz;
+            {   // next query's coordinates: requested now, waited for at the end of the iteration
+                const int qn = qi + 1 < q1 ? qi + 1 : qi;
+                const float* qp = query_b + (size_t)qn * D;
+                nx = qp[0];
+                ny = qp[1];
+                nz = (D == 3) ? qp[2] : 0.0f;
+            }
+            // ---- phase 1: distances, lane minimum, its snapshots at the level ends ----
+            uint32_t d[J];
+            uint32_t ml[L];
+            uint32_t m = 0xffffffffu;
+#pragma unroll
+            for (int g = 0; g < J / 4; ++g) {
+                const float4 x = X4[g * 64], y = Y4[g * 64];
+                float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (D == 3) z = Z4[g * 64];
+                d[4 * g + 0] = dist_bits<D>(ux, uy, uz, x.x, y.x, z.x);
+                d[4 * g + 1] = dist_bits<D>(ux, uy, uz, x.y, y.y, z.y);
+                d[4 * g + 2] = dist_bits<D>(ux, uy, uz, x.z, y.z, z.z);
+                d[4 * g + 3] = dist_bits<D>(ux, uy, uz, x.w, y.w, z.w);
+                m = min(min(m, d[4 * g]), min(d[4 * g + 1], min(d[4 * g + 2], d[4 * g + 3])));
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    if (g + 1 == ((J / 4) >> l)) ml[l] = m;
+            }
+            uint32_t T[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) T[l] = kth_bound(ml[l], k, lb);
+            // ---- phase 2: survivors of every level ----
+            int cnt[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) cnt[l] = 0;
+            auto append = [&](int l, uint64_t mask, bool hit, uint32_t dv, int slot) {
+                const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)cnt[l]));
+                if (hit && pos < CAP)
+                    *reinterpret_cast<uint2*>(surv + l * LIST_DW + 2 * pos) =
+                        make_uint2((uint32_t)(cl4 + 256 * (slot >> 2) + (slot & 3)), dv);
+                cnt[l] += __builtin_popcountll(mask);
+            };
+#pragma unroll
+            for (int g = 0; g < J / 4; ++g) {
+                int lmax = 0;           // levels that contain group g: 0 .. lmax; T[lmax] is the loosest of their bounds
+#pragma unroll
+                for (int l = 1; l < L; ++l)
+                    if (g < ((J / 4) >> l)) lmax = l;
+                bool h[4];
+                uint64_t mk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    h[u] = d[4 * g + u] <= T[lmax];
+                    mk[u] = __ballot(h[u]);
+                }
+                if ((mk[0] | mk[1]) | (mk[2] | mk[3])) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (mk[u]) {
+                            append(lmax, mk[u], h[u], d[4 * g + u], 4 * g + u);
+#pragma unroll
+                            for (int l = L - 2; l >= 0; --l) {
+                                if (l >= lmax) continue;
+                                const bool hl = d[4 * g + u] <= T[l];
+                                const uint64_t ml2 = __ballot(hl);
+                                if (ml2) append(l, ml2, hl, d[4 * g + u], 4 * g + u);
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- rank + store ----
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int n = cnt[l] < CAP ? cnt[l] : CAP;
+                int64_t* o = po.out[l] + ((size_t)b * Nq + qi) * k;
+                const bool init_tie = finish_query(surv + l * LIST_DW, n, n, n > 64, k, o, lane);
+                if (cnt[l] > CAP || init_tie) redo_query<D>(in_b, M >> l, ux, uy, uz, k, o, lane);
+            }
+        }
+    }
 }
 
 static int mode() {   // CAMLI_KNN=lane forces the lane-per-query kernels, =xlane the cross-lane ones wherever they apply
@@ -867,195 +1032,75 @@ static int mode() {   // CAMLI_KNN=lane forces the lane-per-query kernels, =xlan
     if (!e) return 0;
     return e[0] == 'l' ? 1 : (e[0] == 'x' ? 2 : 0);
 }
-static bool k_supported(int k) { return k == 1 || k == 3 || k == 4 || k == 8 || k == 16 || k == 32; }
+static bool k_supported(int k) { return k >= 1 && k <= 32; }   // beyond 32 the lane-minimum bound admits too many survivors
 
-// waves per SIMD the D = 3, J = 32 kernels are compiled for: 3 (168 registers, a few spills) or 2 (CAMLI_KNN_XL_OCC=2)
-static long long target_waves() {     // waves a launch is cut into (1024 SIMDs x 3 by default)
+static long long target_waves() {     // waves a launch is cut into (two rounds of 1024 SIMDs x 4 by default: measured)
     const char* e = getenv("CAMLI_KNN_XL_WAVES");
-    const long long v = e ? atoll(e) : 3072LL;
-    return v > 0 ? v : 3072LL;
-}
-static int occ_choice() {
-    const char* e = getenv("CAMLI_KNN_XL_OCC");
-    return e ? atoi(e) : 3;
+    const long long v = e ? atoll(e) : 8192LL;
+    return v > 0 ? v : 8192LL;
 }
 
-template <int D, int J, bool TEAM, int OCC>
-int launch(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k, int W, hipStream_t stream) {
-    const long long occ = target_waves();
-    const long long total = (long long)B * Nq;
-    const int nwb = TEAM ? W : 4;
-    const long long teams_wanted = TEAM ? occ / W : occ;
-    int qpt = (int)((total + teams_wanted - 1) / teams_wanted);
-    if (qpt < 4) qpt = 4;
-    if (qpt > QPT_MAX) qpt = QPT_MAX;
-    const int teams_per_block = TEAM ? 1 : nwb;
-    dim3 grid(camli_divup(Nq, qpt * teams_per_block), B);
-    const size_t lds = (size_t)nwb * L_WAVE * 4;
-    hipLaunchKernelGGL((knn_xlane_kernel<D, J, TEAM, OCC>), grid, dim3(64 * nwb), lds, stream, input, query, out, M, Nq, k, qpt);
-    return camli_check_launch("camli_knn(xlane)");
-}
-
-// returns 1 when the shape is not served here (the caller falls back to the lane-per-query kernels)
 template <int D>
-int dispatch(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k, hipStream_t stream, int* rc) {
-    if (!k_supported(k) || M > 16384) return 1;
-    if (M <= 256) *rc = launch<D, 4, false, 3>(input, query, out, B, M, Nq, k, 1, stream);
-    else if (M <= 512) *rc = launch<D, 8, false, 3>(input, query, out, B, M, Nq, k, 1, stream);
-    else if (M <= 1024) *rc = launch<D, 16, false, 3>(input, query, out, B, M, Nq, k, 1, stream);
-    else if (M <= 2048) {
-        if (occ_choice() == 2) *rc = launch<D, 32, false, 2>(input, query, out, B, M, Nq, k, 1, stream);
-        else *rc = launch<D, 32, false, 3>(input, query, out, B, M, Nq, k, 1, stream);
-    } else {
-        const int W = M <= 4096 ? 2 : (M <= 8192 ? 4 : 8);
-        if (occ_choice() == 2) *rc = launch<D, 32, true, 2>(input, query, out, B, M, Nq, k, W, stream);
-        else *rc = launch<D, 32, true, 3>(input, query, out, B, M, Nq, k, W, stream);
-    }
-    return 0;
+int launch_chunked(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k, hipStream_t stream) {
+    const long long waves = target_waves() * 3 / 4;                     // 42 KB of LDS per workgroup: three per CU
+    const long long total = (long long)B * Nq;
+    int qpt = (int)((total + waves - 1) / waves);
+    qpt = (qpt + CH_QB - 1) / CH_QB * CH_QB;                            // whole batches of CH_QB queries
+    if (qpt < CH_QB) qpt = CH_QB;
+    if (qpt > QPT_MAX) qpt = QPT_MAX;
+    dim3 grid(camli_divup(Nq, qpt * 4), B);
+    const size_t lds = (size_t)(CH_CAND_DW + 4 * CH_WAVE_DW) * 4;
+    hipLaunchKernelGGL((knn_xlane_chunked_kernel<D>), grid, dim3(256), lds, stream, input, query, out, M, Nq, k, qpt);
+    return camli_check_launch("camli_knn(xlane chunked)");
 }
 
-// Nested prefixes (camli_knn_prefixes) in the cross-lane form: level l = the first M >> l candidates = the first J >> l
-// register slots of every lane, so ONE pass of distance arithmetic serves all levels; the lane minimum is snapshot where
-// a level ends, each level gets its own bound (one sort each; T_0 <= T_1 <= ...), phase 2 tests a slot against the
-// loosest bound of the levels that contain it and descends only on a hit.
-constexpr int P_SURV = 0, P_REDO = 512, P_QUEUE = 768;
-constexpr int P_WAVE = P_QUEUE + 2 * QBUF * 64;
-
-template <int J, int L, int OCC>
-__global__ __launch_bounds__(256, OCC) void knn_xlane_prefix_kernel(const float* __restrict__ input,
-                                                                      const float* __restrict__ query, KnnPrefixOut po,
-                                                                      int M, int Nq, int k, int qpt) {
-    constexpr int D = 3;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwb = blockDim.x >> 6;
-    const int b = blockIdx.y;
-    const int q0 = (blockIdx.x * nwb + w) * qpt;
-    if (q0 >= Nq) return;
-    const int q1 = q0 + qpt < Nq ? q0 + qpt : Nq;
-    const LaneBits lb(lane);
-    float* wave_lds = smem + w * P_WAVE;
-    uint32_t* surv = reinterpret_cast<uint32_t*>(wave_lds + P_SURV);        // [L][64][2]
-    uint32_t* redo_list = reinterpret_cast<uint32_t*>(wave_lds + P_REDO);   // [L][64]
-
-    const float* __restrict__ in_b = input + (size_t)b * M * D;
-    const float* __restrict__ query_b = query + (size_t)b * Nq * D;
-
-    float cx[J], cy[J], cz[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const float* p = in_b + (size_t)(j * 64 + lane) * D;      // M = 64 J exactly
-        cx[j] = p[0];
-        cy[j] = p[1];
-        cz[j] = p[2];
-    }
-    int nredo[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) nredo[l] = 0;
-
-    float nx = query_b[(size_t)q0 * D], ny = query_b[(size_t)q0 * D + 1], nz = query_b[(size_t)q0 * D + 2];
-    for (int qi = q0; qi < q1; ++qi) {
-        const float ux = nx, uy = ny, uz = nz;
-        if (qi + 1 < q1) {
-            const float* qp = query_b + (size_t)(qi + 1) * D;
-            nx = qp[0];
-            ny = qp[1];
-            nz = qp[2];
-        }
-        uint32_t d[J];
-        uint32_t ml[L];
-        uint32_t m = 0xffffffffu;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            d[j] = dist_bits<D>(ux, uy, uz, cx[j], cy[j], cz[j]);
-            m = min(m, d[j]);
-#pragma unroll
-            for (int l = 0; l < L; ++l)
-                if (j + 1 == (J >> l)) ml[l] = m;
-        }
-        uint32_t T[L];
-#pragma unroll
-        for (int l = 0; l < L; ++l) T[l] = kth_bound(ml[l], k, lb);
-        int cnt[L];
-#pragma unroll
-        for (int l = 0; l < L; ++l) cnt[l] = 0;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            // levels that contain slot j: 0 .. lmax
-            int lmax = 0;
-#pragma unroll
-            for (int l = 1; l < L; ++l)
-                if (j < (J >> l)) lmax = l;
-            bool go = true;
-#pragma unroll
-            for (int l = L - 1; l >= 0; --l) {
-                if (l > lmax) continue;
-                if (go) {
-                    const bool hit = d[j] <= T[l];
-                    const uint64_t mask = __ballot(hit);
-                    if (mask) {
-                        const int pos = (int)__builtin_amdgcn_mbcnt_hi(
-                            (uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)cnt[l]));
-                        if (hit && pos < 64) {
-                            surv[l * 128 + 2 * pos] = (uint32_t)(lane + j * 64);
-                            surv[l * 128 + 2 * pos + 1] = d[j];
-                        }
-                        cnt[l] += __builtin_popcountll(mask);
-                    } else {
-                        go = false;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int c = cnt[l];
-            const bool redo = finish_query(surv + l * 128, 1, 64, [&](int) { return c; }, k,
-                                           po.out[l] + ((size_t)b * Nq + qi) * k, lane);
-            if (redo && lane == 0) redo_list[l * 64 + nredo[l]] = (uint32_t)(qi - q0);
-            nredo[l] += redo ? 1 : 0;
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-        if (nredo[l] > 0)
-            redo_dispatch<D>(k, in_b, query_b, po.out[l] + (size_t)b * Nq * k, M >> l, redo_list + l * 64, nredo[l], q0,
-                             wave_lds + (P_QUEUE - L_QUEUE), lane);
-}
-
-template <int J, int L>
-int launch_prefix(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int k,
-                  hipStream_t stream) {
+template <int D, int J, int L>
+int launch(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int k, hipStream_t stream) {
     const long long occ = target_waves();
     const long long total = (long long)B * Nq;
     int qpt = (int)((total + occ - 1) / occ);
-    if (qpt < 4) qpt = 4;
+    if (qpt < 2) qpt = 2;
     if (qpt > QPT_MAX) qpt = QPT_MAX;
     dim3 grid(camli_divup(Nq, qpt * 4), B);
-    const size_t lds = (size_t)4 * P_WAVE * 4;
-    if (J == 32 && occ_choice() == 2)
-        hipLaunchKernelGGL((knn_xlane_prefix_kernel<J, L, 2>), grid, dim3(256), lds, stream, input, query, po, M, Nq, k, qpt);
-    else
-        hipLaunchKernelGGL((knn_xlane_prefix_kernel<J, L, 3>), grid, dim3(256), lds, stream, input, query, po, M, Nq, k, qpt);
-    return camli_check_launch("camli_knn_prefixes(xlane)");
+    const size_t lds = (size_t)(cand_dw<J>() + 4 * wave_dw<L>()) * 4;
+    hipLaunchKernelGGL((knn_xlane_kernel<D, J, L>), grid, dim3(256), lds, stream, input, query, po, M, Nq, k, qpt);
+    return camli_check_launch("camli_knn(xlane)");
+}
+
+// returns 1 when the shape is not served here (the caller falls back to the lane-per-query kernels).  Default choice
+// (CAMLI_KNN unset) from the A/B table of tools/ab_knn.py on the MI355X (profiles/r04_ab_knn.json): the cross-lane
+// kernels win wherever the per-query selection overhead of the lane-per-query form dominates -- k >= 2 up to 6144
+// candidates (2.4x at (2048, 2048, k 16), 3.6x at k 32, 1.5x at (4096, 2048)); from 8192 candidates on (an accepted
+// candidate is rare there: 11 VALU operations per pair) and for k = 1 (no selection at all) the lane-per-query scan stays.
+template <int D>
+int dispatch(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k, hipStream_t stream, int* rc) {
+    if (!k_supported(k)) return 1;
+    if (mode() == 0 && (k == 1 || M > 6144)) return 1;
+    KnnPrefixOut po;
+    po.levels = 1;
+    for (int l = 0; l < 4; ++l) po.out[l] = l == 0 ? out : nullptr, po.size[l] = l == 0 ? M : 0;
+    if (M <= 256) *rc = launch<D, 4, 1>(input, query, po, B, M, Nq, k, stream);
+    else if (M <= 512) *rc = launch<D, 8, 1>(input, query, po, B, M, Nq, k, stream);
+    else if (M <= 1024) *rc = launch<D, 16, 1>(input, query, po, B, M, Nq, k, stream);
+    else if (M <= 2048) *rc = launch<D, 32, 1>(input, query, po, B, M, Nq, k, stream);
+    else *rc = launch_chunked<D>(input, query, out, B, M, Nq, k, stream);
+    return 0;
 }
 
 // 1 = shape not served here
 int dispatch_prefix(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int D, int k,
                     hipStream_t stream, int* rc) {
     if (D != 3 || !k_supported(k) || po.levels < 2) return 1;
+    if (mode() == 0) return 1;      // measured: 64 us against 60 us for the lane-per-query prefix kernel (four bounds, four lists)
     const int L = po.levels;
     for (int l = 0; l < L; ++l)
-        if (po.size[l] != (M >> l) || (po.size[l] & 63)) return 1;
-    if ((M >> (L - 1)) << (L - 1) != M) return 1;
+        if (po.size[l] != (M >> l) || (po.size[l] & 255)) return 1;       // levels end on slot-group boundaries
     const int J = M / 64;
-    if (J != 8 && J != 16 && J != 32) return 1;
+    if (J * 64 != M) return 1;
 #define CAMLI_XL_PREFIX(JJ, LL) \
-    if (J == JJ && L == LL) { *rc = launch_prefix<JJ, LL>(input, query, po, B, M, Nq, k, stream); return 0; }
+    if (J == JJ && L == LL) { *rc = launch<3, JJ, LL>(input, query, po, B, M, Nq, k, stream); return 0; }
     CAMLI_XL_PREFIX(32, 4) CAMLI_XL_PREFIX(32, 3) CAMLI_XL_PREFIX(32, 2)
-    CAMLI_XL_PREFIX(16, 4) CAMLI_XL_PREFIX(16, 3) CAMLI_XL_PREFIX(16, 2)
-    CAMLI_XL_PREFIX(8, 4) CAMLI_XL_PREFIX(8, 3) CAMLI_XL_PREFIX(8, 2)
+    CAMLI_XL_PREFIX(16, 3) CAMLI_XL_PREFIX(16, 2) CAMLI_XL_PREFIX(8, 2)
 #undef CAMLI_XL_PREFIX
     return 1;
 }

@@ -71,16 +71,34 @@ def test_knn_bit_exact(case, kind, ops, oracle_lib):
 
 @pytest.mark.parametrize('case', [(2, 2048, 1024, 3, 16), (1, 8192, 512, 3, 16), (2, 2048, 700, 3, 3), (2, 1000, 300, 2, 1),
                                   (1, 4096, 300, 3, 32)], ids=lambda c: 'B%d_M%d_N%d_D%d_k%d' % c)
-@pytest.mark.parametrize('mode', ['lane', 'xlane3', 'xlane2'])
+@pytest.mark.parametrize('mode', ['lane', 'xlane'])
 def test_knn_kernel_families_agree_with_the_oracle(case, mode, ops, oracle_lib, monkeypatch):
-    """Both kernel families behind camli_knn (lane-per-query, candidates-across-lanes in its two register budgets) on a
-    cloud with 25 % duplicates: bit-exact vs the oracle whichever one the dispatcher is told to take."""
+    """Both kernel families behind camli_knn (lane-per-query, candidates-across-lanes) on a cloud with 25 % duplicates:
+    bit-exact vs the oracle whichever one the dispatcher is told to take."""
     b, m, nq, d, k = case
-    monkeypatch.setenv('CAMLI_KNN', 'lane' if mode == 'lane' else 'xlane')
-    monkeypatch.setenv('CAMLI_KNN_XL_OCC', '2' if mode == 'xlane2' else '3')
+    monkeypatch.setenv('CAMLI_KNN', mode)
     rng = np.random.default_rng(hash((case, 'fam')) % (2 ** 32))
     inp, qry = _cloud(rng, b, m, d, 'dup'), _cloud(rng, b, nq, d, 'dup')
     qry[:, :min(nq, m) // 2] = inp[:, :min(nq, m) // 2]
+    got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
+    assert np.array_equal(got, oracle_lib.knn(inp, qry, k))
+
+
+@pytest.mark.parametrize('k', [1, 2, 5, 16, 20, 32])
+def test_knn_initial_distance_and_far_candidates(k, ops, oracle_lib):
+    """The reference's list starts as k entries (1e9, index 0): candidates farther than 1e9 never enter, one at EXACTLY
+    1e9 ties the initial entries (start-slot rule of k_nearest_neighbor_kernel.cu:80), fewer than k candidates inside
+    leave index 0 in the tail.  sqrt(1e9) is not representable, 31622.7765^2 lands on both sides of 1e9 in fp32."""
+    rng = np.random.default_rng(k)
+    m, nq = 300, 130
+    inp = (rng.random((2, m, 3), dtype=np.float32) * 10).astype(np.float32)
+    qry = (rng.random((2, nq, 3), dtype=np.float32) * 10).astype(np.float32)
+    inp[0, ::3] += 1e6                       # farther than 1e9 (squared) from every query
+    inp[1, 5:] += 1e6                        # only five candidates inside: fewer than k for most k
+    qry[0, :16] = 0.0
+    inp[0, 1] = (31622.0, 6.0, 0.0)          # squared distance from the origin = 999950884 + 36 ... near 1e9
+    inp[0, 2] = (np.float32(np.sqrt(np.float32(1e9))), 0.0, 0.0)
+    inp[0, 4] = (0.0, np.float32(np.sqrt(np.float32(1e9))), 0.0)
     got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
     assert np.array_equal(got, oracle_lib.knn(inp, qry, k))
 

@@ -1,5 +1,4 @@
-"""A/B of the KNN kernels on one GPU: lane-per-query (CAMLI_KNN=lane) vs candidates-across-lanes (CAMLI_KNN=xlane, compiled
-for 3 or 2 waves per SIMD).  Every launch is bracketed by HIP events; rows = the KNN shapes of the headline step.
+"""A/B of the KNN kernels on one GPU: lane-per-query (CAMLI_KNN=lane) vs candidates-across-lanes (CAMLI_KNN=xlane).  Every launch is bracketed by HIP events; rows = the KNN shapes of the headline step.
 
   python tools/ab_knn.py [--batch 8] [--reps 30] [--json out.json]
 """
@@ -17,30 +16,37 @@ VALU_PAIR_PEAK = 7865.0
 SHAPES = [(8192, 4096, 3, 16), (4096, 2048, 3, 16), (2048, 2048, 3, 32), (2048, 2048, 3, 16), (1024, 2048, 3, 16),
           (512, 2048, 3, 16), (256, 2048, 3, 16), (2048, 2048, 3, 3), (2048, 1024, 3, 3), (2048, 8192, 3, 3),
           (2048, 8160, 2, 1), (16384, 4096, 3, 16), (2048, 16384, 3, 3)]
-MODES = [('lane', {'CAMLI_KNN': 'lane'}), ('xlane3', {'CAMLI_KNN': 'xlane', 'CAMLI_KNN_XL_OCC': '3'}),
-         ('xlane2', {'CAMLI_KNN': 'xlane', 'CAMLI_KNN_XL_OCC': '2'})]
+MODES = [('lane', {'CAMLI_KNN': 'lane'}), ('xlane', {'CAMLI_KNN': 'xlane'})]
 
 
-def timed(fn, reps):
+def timed(fn, reps, per_graph=20):
+    """median device time of one call: `per_graph` back-to-back launches captured in a HIP graph and replayed, so the
+    Python / ctypes launch path (15-30 us per call, more than most of these kernels) is not in the figure"""
     for _ in range(3):
         fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(per_graph):
+            fn()
+    graph.replay()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in evs:
         a.record()
-        fn()
+        graph.replay()
         b.record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    ts = sorted(a.elapsed_time(b) * 1e3 / per_graph for a, b in evs)
     return ts[len(ts) // 2]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8)
-    ap.add_argument('--reps', type=int, default=30)
+    ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--json', default=None)
-    ap.add_argument('--waves', default=None, help='comma list of CAMLI_KNN_XL_WAVES values to sweep for the xlane3 mode')
+    ap.add_argument('--waves', default=None, help='comma list of CAMLI_KNN_XL_WAVES values to sweep for the xlane mode')
     args = ap.parse_args()
     from camliflow_amd import csrc
     from camliflow_amd.csrc import wrapper
@@ -65,7 +71,7 @@ def main():
             os.environ.update(MODES[1][1])
             for wv in args.waves.split(','):
                 os.environ['CAMLI_KNN_XL_WAVES'] = wv
-                row['xlane3_w%s_us' % wv] = round(timed(lambda: csrc.k_nearest_neighbor(inp, qry, k), args.reps), 2)
+                row['xlane_w%s_us' % wv] = round(timed(lambda: csrc.k_nearest_neighbor(inp, qry, k), args.reps), 2)
             os.environ.pop('CAMLI_KNN_XL_WAVES')
         rows.append(row)
         print(json.dumps(row), flush=True)
@@ -87,7 +93,7 @@ def main():
         row[name + '_frac'] = round(row['pairs'] / us * 1e-3 / VALU_PAIR_PEAK, 4)
     rows.append(row)
     print(json.dumps(row), flush=True)
-    for k_ in ('CAMLI_KNN', 'CAMLI_KNN_XL_OCC'):
+    for k_ in ('CAMLI_KNN',):
         os.environ.pop(k_, None)
     if args.json:
         with open(args.json, 'w') as f:
