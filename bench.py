@@ -66,6 +66,7 @@ NORTH_STAR = {
 }
 MFMA_F32_PEAK_TFLOPS = 157.3
 VALU_PAIR_PEAK_G = 7865.0
+FPS_STEP_IDEAL_US = 0.35      # one dependent selection step with the cloud resident in registers (tools/kernel_bench.py)
 
 CONFIGS = {
     # name: (model, height, width, points, iters, batch, mode, autocast dtype, BASELINE config it stands for)
@@ -400,6 +401,35 @@ def parity_check(args, state_dict, batch, ref, device):
     return res
 
 
+SIDE_CONFIGS = ('camlipwc', 'kitti')       # BASELINE configs[1] and configs[4]: one short run each after the headline's legs
+
+
+def side_configs(budget):
+    """ms per step of the other two single-GPU configurations of BASELINE.json, each as its own process (its own model,
+    graph replay, library warm-up) with a hard time limit taken from what is left of the time budget; a configuration
+    that does not fit is reported as skipped.  < 300 bytes in the line."""
+    out = {}
+    for name in SIDE_CONFIGS:
+        left = budget - _elapsed()
+        if left < 75:
+            out[name] = {'skipped': 'time budget'}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', name, '--steps', '5', '--warmup', '2',
+               '--no-cpu-baseline', '--no-isolated']
+        env = dict(os.environ, CAMLI_BENCH_DETAIL='bench_detail_%s.json' % name)
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=left - 15)
+            rec = json.loads(res.stdout.strip().splitlines()[-1])
+            out[name] = {'ms_per_step': rec['ms_per_step'], 'value': rec['value'], 'dtype': rec['dtype'], 'steps': rec['steps']}
+        except subprocess.TimeoutExpired:
+            out[name] = {'skipped': 'did not finish in %.0f s' % (left - 15)}
+        except Exception as exc:      # noqa: BLE001 -- an optional leg never costs the line
+            out[name] = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:80])}
+        _log('side configuration %s: %s (%.0f s)' % (name, out[name], time.perf_counter() - t0))
+    return out
+
+
 def pmc_traffic(entry_point, args):
     """HBM bytes per launch of `entry_point` from the committed PMC measurement of this same workload
     (profiles/roofline_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
@@ -444,22 +474,42 @@ def roofline_report(summary, steps, args, step_ms):
             entry['frac'] = round(entry['tflops'] / (MFMA_F32_PEAK_TFLOPS / 2), 4)
         elif kind == 'valu':
             entry['frac'] = round(rate / 1e9 / VALU_PAIR_PEAK_G, 4)
-        if 'frac' in entry and kind in ('hbm', 'mfma'):
+        elif kind == 'fps':          # dependent selection steps: ideal time per step / achieved time per step
+            us_per_step = secs * 1e6 / rec['flop'] if rec.get('flop') else None     # `flop` carries the dependent steps (wrapper.py)
+            if us_per_step:
+                entry['us_per_step'] = round(us_per_step, 3)
+                entry['frac'] = round(min(FPS_STEP_IDEAL_US / us_per_step, 1.0), 4)
+        if 'frac' in entry:
             fracs[name] = rec['total_ms']
         table[name] = entry
     if not fracs:
         return None, table
+    # the DOMINANT north-star entry point (most device time in the timed region), whatever bounds it: round 3 admitted only
+    # hbm / mfma kinds here and camli_knn (valu) could never be named although it was the largest entry
     name = max(fracs, key=fracs.get)
     rec = summary[name]
     secs = rec['total_ms'] * 1e-3
-    if NORTH_STAR[name] == 'hbm':
+    kind = NORTH_STAR[name]
+    if kind == 'hbm':
         achieved, peak, unit, per_launch = rec['work'] / secs / 1e9, HBM_PEAK_GBS, 'GB/s', rec['work'] / rec['launches']
-    else:
+    elif kind == 'mfma':
         achieved, peak, unit, per_launch = rec['flop'] / secs / 1e12, MFMA_F32_PEAK_TFLOPS, 'TFLOP/s', rec['flop'] / rec['launches']
-    roofline = {'kernel': name, 'bound': NORTH_STAR[name], 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
+    elif kind == 'fma':
+        achieved, peak, unit, per_launch = rec['flop'] / secs / 1e12, MFMA_F32_PEAK_TFLOPS / 2, 'TFLOP/s', rec['flop'] / rec['launches']
+    elif kind == 'valu':     # candidate pairs per second against the fp32 vector rate at ~10 lane-operations per pair
+        achieved, peak, unit, per_launch = rec['work'] / secs / 1e9, VALU_PAIR_PEAK_G, 'Gpairs/s', rec['work'] / rec['launches']
+    else:                    # fps: fraction of the register-resident ideal step time
+        achieved, peak, unit, per_launch = table[name]['frac'] * 100.0, 100.0, '% of ideal step rate', rec['work'] / rec['launches']
+    roofline = {'kernel': name, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(kind, kind), 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
                 'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(name, args), 'launches': rec['launches'],
                 'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
                 'algorithmic_work_per_launch': round(per_launch), 'measured': 'in situ: HIP events on the launch stream, timed region'}
+    # the north-star entry point FURTHEST below its roofline among those that hold at least 1 % of the step
+    heavy = [n for n in fracs if summary[n]['total_ms'] / steps >= 0.01 * step_ms]
+    if heavy:
+        worst = min(heavy, key=lambda n: table[n]['frac'])
+        roofline['worst'] = {'kernel': worst, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(NORTH_STAR[worst], NORTH_STAR[worst]),
+                             'frac': table[worst]['frac'], 'ms_per_step': table[worst]['ms_per_step']}
     return roofline, table
 
 
@@ -495,14 +545,18 @@ def compact_line(full, detail_path=None):
         line['roofline'] = {k: roof[k] for k in keep if k in roof}
         if 'single_lane' in roof:
             line['roofline']['single_lane'] = {k: roof['single_lane'][k] for k in ('avg_launch_us', 'achieved', 'frac')}
+        if 'worst' in roof:
+            line['roofline']['worst'] = roof['worst']
         assert line['roofline']['frac'] <= 1.0, 'a roofline fraction above 1 is a mis-stated work figure'
     base = full.get('cpu_baseline')
     if base is not None:
-        line['cpu_baseline'] = {k: base[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model') if k in base}
+        line['cpu_baseline'] = {k: base[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model', 'os_cpu_count') if k in base}
     par = full.get('parity')
     if par is not None:
         line['parity'] = {k: par[k] for k in ('epe2d_abs_diff', 'epe3d_abs_diff', 'fps_equal', 'knn_equal', 'tolerance', 'ok')}
         line['parity']['vs'] = 'CPU port (cores + C oracle), batch-1 sample of the workload, shared post-IDS inputs'
+    if full.get('side_configs'):
+        line['side_configs'] = full['side_configs']
     if detail_path:
         line['detail'] = detail_path
     size = len(json.dumps(line))
@@ -531,6 +585,7 @@ def main():
     ap.add_argument('--mode', choices=['train', 'eval'], default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the CPU port (cpu_baseline AND parity)')
     ap.add_argument('--no-isolated', action='store_true', help='skip the isolated per-kernel rows (roofline_rows)')
+    ap.add_argument('--no-side-configs', action='store_true', help='skip the camlipwc / kitti side lines (side_configs)')
     ap.add_argument('--time-budget', type=float, default=float(os.environ.get('CAMLI_BENCH_BUDGET_S', 420)),
                     help='seconds the whole run may take: the legs after the timed region (isolated rows, CPU port, parity) '
                          'are skipped / cut when they would not fit, and the line says so; the timed region never is')
@@ -705,7 +760,9 @@ def main():
             rec = _lib.TIMER.summary().get(roofline['kernel'])
             if rec and rec['launches']:
                 secs = rec['total_ms'] * 1e-3
-                rate = (rec['work'] / secs / 1e9) if roofline['bound'] == 'hbm' else (rec['flop'] / secs / 1e12)
+                rate = (rec['flop'] / secs / 1e12) if roofline['unit'] == 'TFLOP/s' else (rec['work'] / secs / 1e9)
+                if roofline['bound'] == 'latency':
+                    rate = min(FPS_STEP_IDEAL_US / (secs * 1e6 / rec['flop']), 1.0) * 100.0
                 roofline['single_lane'] = {'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
                                            'achieved': round(rate, 2), 'frac': round(rate / roofline['peak'], 4),
                                            'launches': rec['launches'],
@@ -765,6 +822,8 @@ def main():
                     line['parity'] = parity_check(args, state_dict, sample, ref, device)
                     failed = not line['parity']['ok']
                     _log('parity check done')
+        if world == 1 and args.config == 'camliraft' and not args.no_side_configs:
+            line['side_configs'] = side_configs(budget)
         detail_path = write_detail(line, args.config)
         # RCCL writes its version banner through C stdio when the communicator is created; flush it so that the JSON
         # line is the LAST line on stdout

@@ -20,6 +20,23 @@ import os as _os
 # saw in 5 of 9 runs).  Data-parallel mode keeps the kernels but gives every workgroup whole tiles -- no cross-workgroup
 # waits -- and costs nothing measurable on this workload (248.3 vs 249.1 ms per step).  Must be in the environment before
 # the first GEMM creates the handle; an explicit user setting wins.
+import sys as _sys
+
+
+def _cuda_live():
+    """torch was imported AND has created its CUDA context (a GEMM, hence a BLAS handle, may already exist)."""
+    torch = _sys.modules.get('torch')
+    try:
+        return bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:      # noqa: BLE001 -- a torch without CUDA support
+        return False
+
+
+# what set_overlap(True) consults (cores/runtime.streamk_safe): was the switch already in the environment, or did this
+# import put it there BEFORE the process touched the GPU?  If torch had a live CUDA context and the variable was unset,
+# a handle in stream-K mode may exist and the variable lands too late.
+STREAMK_PRESET = 'TENSILE_STREAMK_DATA_PARALLEL' in _os.environ
+STREAMK_SET_BEFORE_CUDA = STREAMK_PRESET or not _cuda_live()
 _os.environ.setdefault('TENSILE_STREAMK_DATA_PARALLEL', '1')
 
 __version__ = "0.1.0"

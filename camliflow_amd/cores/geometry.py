@@ -240,9 +240,11 @@ def project_pc2image(pc, camera_info, grid_hw=None):
     mode = camera_info['projection_mode']
     if runtime.fused() and pc.is_cuda and mode in ('perspective', 'parallel'):
         scalar_camera = not any(isinstance(camera_info[k], torch.Tensor) for k in ('cx', 'cy'))
-        tensor_camera = all(isinstance(camera_info.get(k), torch.Tensor) and camera_info[k].dim() == 1 for k in ('f', 'cx', 'cy'))
+        tensor_camera = all(isinstance(camera_info.get(k), torch.Tensor) and camera_info[k].dim() == 1
+                            and camera_info[k].device == pc.device and camera_info[k].shape[0] == pc.shape[0]
+                            for k in ('f', 'cx', 'cy'))       # the kernel reads one value per batch element from device memory
         if (torch.is_grad_enabled() and pc.requires_grad) or not (scalar_camera if mode == 'parallel' else tensor_camera):
-            runtime.fallback('project_pc2image', 'differentiable cloud or mixed scalar / tensor camera constants')
+            runtime.fallback('project_pc2image', 'differentiable cloud, mixed scalar / tensor camera constants, or constants not [B] on the cloud\'s device')
         else:
             from ..csrc import fused
             return fused.project_pc2image(pc, camera_info, scale)

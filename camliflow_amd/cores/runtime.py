@@ -149,6 +149,7 @@ def deferral_target(tensor):
     dicts.  In all these cases the node returns its gradient to autograd in the ordinary way (correct, just not deferred)."""
     if not (_DEFER_PARAM_GRADS and tensor.is_leaf and tensor.requires_grad):
         return None
+    PARAM_GRADS.drop_stale()        # accumulators of backwards that raised (no backward is running now)
     if getattr(tensor, '_backward_hooks', None) or getattr(tensor, '_post_accumulate_grad_hooks', None):
         return None
     try:
@@ -163,7 +164,7 @@ def deferral_target(tensor):
 class _ParamGradSink:
     """Per-parameter accumulators, one table per running backward (graph task): a re-entrant backward (activation
     checkpointing) has its own table and flush, and does not disturb the outer one."""
-    MAX_TABLES = 4      # tables of backwards that raised are never flushed: the oldest are dropped beyond this
+    MAX_TABLES = 4      # depth guard; tables of backwards that raised are dropped by the next forward (drop_stale)
 
     def __init__(self):
         self.tables = {}        # graph-task id -> {id(param): [param, accumulator, reduce_batch, stream]}
@@ -183,13 +184,23 @@ class _ParamGradSink:
         if table is None:
             table = self.tables[task] = {}
             torch.autograd.variable.Variable._execution_engine.queue_callback(lambda task=task: self.flush(task))
-            while len(self.tables) > self.MAX_TABLES:       # leftovers of failed backwards (their callbacks never ran)
+            while len(self.tables) > self.MAX_TABLES:       # leftovers of failed backwards inside one running backward
                 del self.tables[min(self.tables)]
         entry = table.get(id(param))
         if entry is None:
             entry = table[id(param)] = [param, make(), reduce_batch, None]
         entry[3] = torch.cuda.current_stream(param.device) if param.is_cuda else None
         return entry[1]
+
+    def drop_stale(self):
+        """Called from the FORWARD of the deferring nodes (deferral_target).  A forward that runs while no backward is
+        executing (graph-task id -1) finds tables only if earlier backwards raised -- their flush callbacks never ran and
+        their accumulators ([B,Co,Ci] GEMM buffers, weight-sized tensors) would stay allocated for good, exactly in the
+        out-of-memory recovery case.  A forward inside a backward (activation checkpointing) leaves everything alone."""
+        if self.tables:
+            import torch
+            if torch._C._current_graph_task_id() == -1:
+                self.tables.clear()
 
     def flush(self, task):
         import torch
@@ -219,21 +230,46 @@ _PRIMED = set()
 _side_streams = {}
 
 
+def streamk_safe():
+    """Two GEMM-issuing streams are only safe when hipBLASLt's stream-K kernels run data-parallel: two stream-K GEMMs
+    of one handle on two streams spin on each other's flags for good (found in round 3).  True when
+    TENSILE_STREAMK_DATA_PARALLEL=1 is in the environment AND it got there before this process created its CUDA
+    context (preset by the user / launcher, or set by the package import ahead of the first GPU call)."""
+    import camliflow_amd
+    return os.environ.get('TENSILE_STREAMK_DATA_PARALLEL') == '1' and camliflow_amd.STREAMK_SET_BEFORE_CUDA
+
+
 def set_overlap(enabled, prime_first_pass=True):
-    """Run the 3-D (point) branch of the fused model on a second HIP stream.  The point kernels are
-    small (B*2048 points) and leave most CUs idle; the image branch's convolutions do not depend
-    on them between fusion points, so the two lanes overlap.  Results are unchanged.
+    """Run the 3-D (point) branch of the fused model on a second HIP stream (and, inside such a pass, the independent
+    chains of the image lane on auxiliary streams, ``Branch``).  The point kernels are small (B*2048 points) and leave
+    most CUs idle; the image branch's convolutions do not depend on them between fusion points, so the lanes overlap.
+    Results are unchanged.
+
+    REFUSED (one lane, with a RuntimeWarning) unless ``streamk_safe()``: the lanes both issue library GEMMs, and
+    hipBLASLt's stream-K GEMMs of one handle on two streams dead-lock the GPU (100 % busy for good).  The package import
+    sets TENSILE_STREAMK_DATA_PARALLEL=1, but that only helps before the first GEMM of the process: a host program that
+    initialised CUDA first, or a user who set the variable to 0, gets one lane.  CAMLI_OVERLAP_FORCE=1 overrides (for
+    a caller that knows no stream-K solution is in play).
 
     ``prime_first_pass`` (default): the FIRST pass of a process for a given (device, input signature) still runs on
     one stream -- forward and, because autograd replays a node on the stream of its forward, its backward.  The first
     step of a process is where the libraries do their first-use work (MIOpen / hipBLASLt solution look-ups, code-object
     loads): 20-60 s on most boxes of this pool, 231 s measured on a slow one, on ONE stream
-    (profiles/r03_first_step_probe.txt).  Round 2 read that stall as a two-stream dead-lock; round 3 found no evidence
-    of one.  Keeping that step on one stream costs nothing (it is never a timed step) and keeps a first-use problem
-    from being confused with a stream-ordering problem again.  It lives here, not in a benchmark script, so that EVERY
-    caller of ``set_overlap(True)`` gets it (training loops, tests, bench.py)."""
+    (profiles/r03_first_step_probe.txt).  Round 2 read that stall as a two-stream dead-lock; the real multi-stream
+    dead-lock (stream-K, above) was found and fixed later in round 3.  Keeping that step on one stream costs nothing (it
+    is never a timed step) and keeps a first-use problem from being confused with a stream-ordering problem again.  It
+    lives here, not in a benchmark script, so that EVERY caller of ``set_overlap(True)`` gets it."""
     global _OVERLAP, _PRIME_FIRST_PASS, _LANES_LIVE
-    _OVERLAP = bool(enabled)
+    enabled = bool(enabled)
+    if enabled and not streamk_safe() and os.environ.get('CAMLI_OVERLAP_FORCE') != '1':
+        import warnings
+        warnings.warn('camliflow_amd: multi-stream execution refused -- TENSILE_STREAMK_DATA_PARALLEL=1 was not in the '
+                      'environment before the CUDA context of this process existed (value now: %r); hipBLASLt stream-K '
+                      'GEMMs on two streams dead-lock the GPU.  Import camliflow_amd (or export the variable) before the '
+                      'first GPU call.  Running on one stream.' % os.environ.get('TENSILE_STREAMK_DATA_PARALLEL'),
+                      RuntimeWarning, stacklevel=2)
+        enabled = False
+    _OVERLAP = enabled
     _PRIME_FIRST_PASS = bool(prime_first_pass)
     if not _OVERLAP:
         _LANES_LIVE = False     # a model without Lanes of its own must not inherit the auxiliary streams of an earlier pass

@@ -1039,8 +1039,10 @@ class _Corr3DCostMLP(torch.autograd.Function):
         b, _, n, lk = lookup.shape
         hidden, k = w2.shape[0], lk // ctx.levels
         gout = gout.contiguous().float()
-        # only channel 3 (the cost-volume entry) is written and only channel 3 is read by the lookup's adjoint
+        # the kernel writes channel 3 only (the cost-volume entry; the coordinates are not differentiable on this path):
+        # channels 0-2 are zeros, not uninitialised memory (anomaly detection, any future consumer of the gradient)
         glookup = torch.empty_like(lookup)
+        glookup[:, :3].zero_()
         grads, deferred = [], []
         for param, like in zip(ctx.params, (w1, b1, w2, b2)):
             if param is not None:

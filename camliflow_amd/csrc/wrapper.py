@@ -179,7 +179,8 @@ def furthest_point_sampling(xyz: torch.Tensor, n_samples: int, cpp_impl=True):
     out = torch.empty((b, n_samples), dtype=torch.int64, device=xyz.device)
     with _on_device(xyz):
         _lib.launch('camli_fps', lib.camli_fps, xyz.data_ptr(), out.data_ptr(), b, n, n_samples, _stream_ptr(xyz),
-                        work=(float(b) * n * n_samples, 'point-updates'))
+                        work=(float(b) * n * n_samples, 'point-updates'),
+                        flop=float(n_samples))     # not flop: the DEPENDENT selection steps of the launch (latency roofline, bench.py)
     return out
 
 

@@ -127,3 +127,38 @@ def test_ddp_reducer_sees_every_gradient():
             runtime.set_deferred_param_grads(False)
     finally:
         dist.destroy_process_group()
+
+
+def test_accumulators_of_a_failed_backward_are_dropped_by_the_next_forward():
+    """a backward that raises never runs its flush callback; its table (and the accumulators it holds) must not
+    outlive the next forward, and the next step's gradients must be those of that step alone."""
+    torch.manual_seed(0)
+    net, x = _Net(), torch.randn(2, 6, 11, requires_grad=True)
+    want = _grads(net, x, False)
+
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('simulated out-of-memory in a backward')
+
+    runtime.set_deferred_param_grads(True)
+    try:
+        net.zero_grad()
+        # the failing node sits UPSTREAM of the deferring ones: their backwards have run (table filled) when it raises
+        loss = net(_Boom.apply(x)).square().sum()
+        try:
+            loss.backward()
+        except RuntimeError:
+            pass
+        assert runtime.PARAM_GRADS.tables, 'the failed backward left its table behind (nothing flushed it)'
+        net.zero_grad()
+        net(x).square().sum().backward()        # next step: forward drops the stale table, backward flushes its own
+        assert not runtime.PARAM_GRADS.tables
+    finally:
+        runtime.set_deferred_param_grads(False)
+    for p, w in zip(net.parameters(), want):
+        torch.testing.assert_close(p.grad, w, rtol=1e-5, atol=1e-6)

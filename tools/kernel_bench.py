@@ -104,6 +104,11 @@ def cases(batch):
         yield ('knn B%d M%d Nq%d D%d k%d' % (b, m, nq, d, k),
                (lambda inp=inp, qry=qry, k=k: csrc.k_nearest_neighbor(inp, qry, k)), {'camli_knn': 'valu'})
 
+    # the four nested cross searches of a GRU iteration, one launch (camli_knn_prefixes)
+    inp_p, qry_p = _rand(g, b, 2048, 3, scale=10.0), _rand(g, b, 2048, 3, scale=10.0)
+    yield ('knn prefixes B%d 2048/1024/512/256 Nq2048 k16' % b,
+           (lambda: wrapper.k_nearest_neighbor_prefixes(inp_p, qry_p, (2048, 1024, 512, 256), 16)), {'camli_knn': 'valu'})
+
     # the dense-query interpolation of kitti_submission.py:89-93 (every pixel of a 375x1242 map)
     inp1, qry1 = _rand(g, 1, 8192, 3, scale=10.0), _rand(g, 1, 465750, 3, scale=10.0)
     yield 'knn B1 M8192 Nq465750 D3 k3', (lambda: csrc.k_nearest_neighbor(inp1, qry1, 3)), {'camli_knn': 'valu'}
