@@ -42,3 +42,10 @@ def oracle_lib():
     import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(scope='session')
+def oracle_dense():
+    """oracle/dense.py: numpy restatement of the dense round-3 kernels' reference code (pinned by tests/test_dense_oracle.py)."""
+    from oracle import dense
+    return dense

@@ -1,0 +1,133 @@
+"""Golden vectors for oracle/dense.py from the REFERENCE's own modules, run unchanged with autograd on seeded inputs:
+
+  dense_cost_mlp        models/camliraft_l_core.py Correlation3D: cost_mlp (MLP2d 4 -> 32 -> 32, relu) + sum over the k
+                        neighbours (:96-98) for four levels, concatenated as forward() does (:86-93)
+  dense_flow_head       models/raft_core.py FlowHead2D (:169-182): input / output of its two-channel conv2, gradients
+  dense_allpairs_{even,odd}  models/raft_core.py Correlation2D.build_cost_volume_pyramid (:52-68): the aligned feature
+                        maps, the four levels, gradients back to the aligned maps
+  dense_resnet_glue     the stem max pooling and the bottleneck epilogue of the ResNet trunk the reference instantiates
+                        through mmdet (README.md:78-79, models/raft_core.py:10-38; mmdet itself is not under
+                        /root/reference -- SURVEY 8c): nn.MaxPool2d(3, 2, 1) and relu(bn-bias + conv + identity) from torch
+
+Run in the build container only:  python tests/golden/make_dense_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import refmodels  # noqa: E402
+
+refmodels.install(native_semantics=True)
+from models.camliraft_l_core import Correlation3D  # noqa: E402
+from models.raft_core import Correlation2D, FlowHead2D  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print('%-28s %7.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def fill(module, g, scale):
+    for p in module.parameters():
+        p.data = torch.randn(p.shape, generator=g) * scale
+
+
+def golden_cost_mlp():
+    g = torch.Generator().manual_seed(21)
+    b, n, k, levels = 2, 37, 16, 4
+    corr = Correlation3D(out_channels=128, k=k)
+    fill(corr.cost_mlp, g, 0.4)
+    lookups = [torch.randn(b, 4, n, k, generator=g, requires_grad=True) for _ in range(levels)]
+    # calc_matching_cost's tail (:96-98) per level, forward()'s concatenation (:93)
+    costs = torch.cat([torch.sum(corr.cost_mlp(x), dim=-1) for x in lookups], dim=1)
+    gout = torch.randn(costs.shape, generator=g)
+    costs.backward(gout)
+    convs = [m for m in corr.cost_mlp.modules() if isinstance(m, torch.nn.Conv2d)]
+    assert len(convs) == 2
+    save('dense_cost_mlp', lookup=torch.cat([x.detach() for x in lookups], dim=-1), levels=levels,
+         w1=convs[0].weight.detach().reshape(32, 4), b1=convs[0].bias.detach(), w2=convs[1].weight.detach().reshape(32, 32),
+         b2=convs[1].bias.detach(), out=costs.detach(), gout=gout,
+         glookup=torch.cat([x.grad for x in lookups], dim=-1),
+         gw1=convs[0].weight.grad.reshape(32, 4), gb1=convs[0].bias.grad, gw2=convs[1].weight.grad.reshape(32, 32),
+         gb2=convs[1].bias.grad)
+
+
+def golden_flow_head():
+    g = torch.Generator().manual_seed(22)
+    head = FlowHead2D(input_dim=12, hidden_dim=20)
+    fill(head, g, 0.2)
+    store = {}
+
+    def pre(_m, args):
+        args[0].retain_grad()
+        store['x'] = args[0]
+
+    def post(_m, _a, out):
+        out.retain_grad()
+        store['y'] = out
+    head.conv2.register_forward_pre_hook(pre)
+    head.conv2.register_forward_hook(post)
+    x = torch.randn(2, 12, 9, 11, generator=g)
+    out = head(x)
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+    save('dense_flow_head', x=store['x'].detach(), w=head.conv2.weight.detach(), b=head.conv2.bias.detach(), y=store['y'].detach(),
+         gy=store['y'].grad, gx=store['x'].grad, gw=head.conv2.weight.grad, gb=head.conv2.bias.grad, head_out=out.detach())
+
+
+def golden_allpairs(tag, hh, ww):
+    g = torch.Generator().manual_seed(23 + hh)
+    corr = Correlation2D(num_levels=4, radius=4)
+    fill(corr, g, 0.1)
+    store = []
+
+    def post(_m, _a, out):
+        out.retain_grad()
+        store.append(out)
+    corr.fnet_aligner.register_forward_hook(post)
+    fmap1 = torch.randn(2, 128, hh, ww, generator=g)
+    fmap2 = torch.randn(2, 128, hh, ww, generator=g)
+    corr.build_cost_volume_pyramid(fmap1, fmap2)
+    pyr = corr.cost_volume_pyramid
+    gpyr = [torch.randn(p.shape, generator=g) for p in pyr]
+    sum((p * q).sum() for p, q in zip(pyr, gpyr)).backward()
+    arrays = {'f1': store[0].detach(), 'f2': store[1].detach(), 'gf1': store[0].grad, 'gf2': store[1].grad}
+    for lvl, (p, q) in enumerate(zip(pyr, gpyr)):
+        arrays['pyr%d' % lvl] = p.detach().squeeze(1)
+        arrays['gpyr%d' % lvl] = q.squeeze(1)
+    save('dense_allpairs_' + tag, **arrays)
+
+
+def golden_resnet_glue():
+    g = torch.Generator().manual_seed(24)
+    x = torch.relu(torch.randn(2, 5, 13, 18, generator=g)).requires_grad_(True)     # post-ReLU stem output: zeros tie
+    pool = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    y = pool(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    conv_out = torch.randn(2, 6, 7, 9, generator=g, requires_grad=True)
+    identity = torch.randn(2, 6, 7, 9, generator=g, requires_grad=True)
+    bias = torch.randn(6, generator=g, requires_grad=True)
+    out = torch.relu(conv_out + bias[None, :, None, None] + identity)
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+    save('dense_resnet_glue', pool_x=x.detach(), pool_y=y.detach(), pool_gy=gy, pool_gx=x.grad,
+         conv_out=conv_out.detach(), identity=identity.detach(), bias=bias.detach(), out=out.detach(), gout=gout,
+         gconv=conv_out.grad, gbias=bias.grad)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(4)
+    golden_cost_mlp()
+    golden_flow_head()
+    golden_allpairs('even', 8, 12)
+    golden_allpairs('odd', 9, 15)
+    golden_resnet_glue()

@@ -117,6 +117,10 @@ MODEL_CASES = {
     'camlipwc_l': ('camlipwc_l', 'CamLiPWC_L', camlipwc_l_cfg, (1, 128, 192, 4608)),
     'pwc': ('pwc', 'PWC', pwc_cfg, (1, 128, 192, 4608)),
     'raft': ('raft', 'RAFT', raft_cfg, (1, 128, 160, 4608)),
+    # round 4: every golden above is batch 1 -- a batch-stride slip in an orchestration path would pass them.
+    # Two distinct samples per batch through the fused 2D+3D models of both families.
+    'camliraft_b2': ('camliraft', 'CamLiRAFT', lambda: camliraft_cfg(2), (2, 128, 160, 4608)),
+    'camlipwc_b2': ('camlipwc', 'CamLiPWC', camlipwc_cfg, (2, 128, 192, 4608)),
 }
 
 

@@ -1,0 +1,61 @@
+"""oracle/dense.py (numpy restatement, forward + hand-written adjoints, of the dense pieces the product path runs on its
+round-3 kernels) against tensors recorded from the REFERENCE's own modules with autograd
+(tests/golden/dense_*.npz, tests/golden/make_dense_golden.py).  CPU only."""
+import numpy as np
+
+from oracle import dense
+
+
+def _close(a, b, rtol=2e-5, atol=2e-6):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.allclose(a, b, rtol=rtol, atol=atol * max(1.0, np.abs(b).max())), np.abs(a - b).max()
+
+
+def test_cost_mlp_forward_and_adjoint_vs_reference_cost_mlp(golden):
+    g = golden('dense_cost_mlp')
+    levels = int(g['levels'])
+    params = (g['w1'], g['b1'], g['w2'], g['b2'])
+    _close(dense.cost_mlp_fwd(g['lookup'], *params, levels), g['out'])
+    gx, gw1, gb1, gw2, gb2 = dense.cost_mlp_bwd(g['gout'], g['lookup'], *params, levels)
+    for got, key in ((gx, 'glookup'), (gw1, 'gw1'), (gb1, 'gb1'), (gw2, 'gw2'), (gb2, 'gb2')):
+        _close(got, g[key], rtol=1e-4, atol=1e-5)
+
+
+def test_conv3x3_forward_and_adjoint_vs_reference_flow_head(golden):
+    g = golden('dense_flow_head')
+    y = dense.conv3x3_fwd(g['x'], g['w'], g['b'])
+    _close(y, g['y'])
+    _close(np.nan_to_num(y), g['head_out'])              # raft_core.py:180-181: .float() + nan_to_num
+    gx, gw, gb = dense.conv3x3_bwd(g['gy'], g['x'], g['w'])
+    _close(gx, g['gx'], rtol=1e-4, atol=1e-5)
+    _close(gw, g['gw'], rtol=1e-4, atol=1e-5)
+    _close(gb, g['gb'], rtol=1e-4, atol=1e-5)
+
+
+def test_allpairs_pyramid_forward_and_adjoint_vs_reference_build(golden):
+    for tag in ('even', 'odd'):
+        g = golden('dense_allpairs_' + tag)
+        pyr = dense.allpairs_pyramid_fwd(g['f1'], g['f2'], 4)
+        for lvl, p in enumerate(pyr):
+            _close(p, g['pyr%d' % lvl], rtol=1e-4, atol=1e-5)
+        gf1, gf2 = dense.allpairs_pyramid_bwd([g['gpyr%d' % lvl] for lvl in range(4)], g['f1'], g['f2'])
+        _close(gf1, g['gf1'], rtol=1e-4, atol=1e-5)
+        _close(gf2, g['gf2'], rtol=1e-4, atol=1e-5)
+
+
+def test_resnet_glue_vs_torch_modules_of_the_call_site(golden):
+    g = golden('dense_resnet_glue')
+    y, arg = dense.maxpool3x3s2_fwd(g['pool_x'])
+    assert np.array_equal(y, g['pool_y'])
+    gx = dense.maxpool3x3s2_bwd(g['pool_gy'], arg, g['pool_x'].shape[-2:])
+    # a window whose maximum is a tie of zeros (post-ReLU input) may route its gradient to another zero than torch does;
+    # those positions feed ReLU's flat side in the trunk -- compare where the input is positive, and the total mass
+    pos = g['pool_x'] > 0
+    _close(gx[pos], g['pool_gx'][pos])
+    assert abs(gx.sum() - g['pool_gx'].sum()) <= 1e-4 * np.abs(g['pool_gx']).sum()
+    out = dense.bias_act_res_fwd(g['conv_out'], g['bias'], g['identity'])
+    _close(out, g['out'])
+    gconv, gbias = dense.bias_act_res_bwd(g['gout'], out)
+    _close(gconv, g['gconv'])
+    _close(gbias, g['gbias'], rtol=1e-4, atol=1e-5)

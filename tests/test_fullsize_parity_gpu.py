@@ -13,11 +13,16 @@ of fused launches is printed.
   round 3 (parity chain): whole TRAINING steps against the CPU port at full size --
   configs[2]  CamLiRAFT 960x540 + 8192 pts (2 iterations: the CPU backward bounds the test)   flows, loss, every gradient
   configs[1]  CamLiPWC 960x540 + 8192 pts                                                    flows, loss, every gradient
+  round 4:
+  configs[2]  the same training step at BATCH 2 (two distinct samples: a batch-stride slip in an orchestration path
+              passes every batch-1 test)                                                    flows, loss, every gradient
+  configs[0]  CamLiRAFT-L at its restated size (N0 = 8192 -> working set 2048, 4 iterations; the model
+              ignores images, 256x256 only sizes the sensor), eval flows + the training step  vs CPU port
 """
 import pytest
 import torch
 
-from modelutils import camlipwc_cfg, camliraft_cfg, hashed_fill_, oracle_boundary, synthetic_inputs
+from modelutils import camlipwc_cfg, camliraft_cfg, camliraft_l_cfg, hashed_fill_, oracle_boundary, synthetic_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -167,7 +172,7 @@ def _train_step_vs_cpu_port(model_cls, cfg, inputs, monkeypatch):
     assert abs(loss_gpu.item() - loss_cpu.item()) <= 1e-4 * max(1.0, abs(loss_cpu.item())), (loss_gpu.item(), loss_cpu.item())
     gc = {n: p.grad for n, p in cpu_model.named_parameters() if p.grad is not None}
     gg = {n: p.grad.cpu() for n, p in gpu_model.named_parameters() if p.grad is not None}
-    assert gc.keys() == gg.keys() and len(gc) > 100
+    assert gc.keys() == gg.keys() and len(gc) > 40
     num = sum(((gg[n] - gc[n]).double() ** 2).sum().item() for n in gc) ** 0.5
     den = sum((gc[n].double() ** 2).sum().item() for n in gc) ** 0.5
     worst = max((abs(gg[n].norm().item() / gc[n].norm().item() - 1.0), n) for n in gc if gc[n].norm().item() > 1e-3 * den)
@@ -185,3 +190,35 @@ def test_config3_camliraft_960x540_training_step_gradients_vs_cpu_port(monkeypat
 def test_config2_camlipwc_960x540_training_step_vs_cpu_port(monkeypatch):
     from camliflow_amd.cores import CamLiPWC
     _train_step_vs_cpu_port(CamLiPWC, camlipwc_cfg(), synthetic_inputs(1, 540, 960, 8192), monkeypatch)
+
+
+def test_config3_camliraft_960x540_batch2_training_step_vs_cpu_port(monkeypatch):
+    from camliflow_amd.cores import CamLiRAFT
+    _train_step_vs_cpu_port(CamLiRAFT, camliraft_cfg(n_iters=2), synthetic_inputs(2, 540, 960, 8192), monkeypatch)
+
+
+def test_config1_camliraft_l_8192_points_4_iterations_vs_cpu_port(monkeypatch):
+    """BASELINE configs[0] as SURVEY 8d restates it (the literal 2048-point input cannot run: FPS needs N0 > 4096)."""
+    from camliflow_amd.cores import CamLiRAFT_L, runtime
+    from modelutils import share_clouds
+    inputs = synthetic_inputs(1, 256, 256, 8192)
+    _train_step_vs_cpu_port(CamLiRAFT_L, camliraft_l_cfg(4), inputs, monkeypatch)
+    # inference mode of the same pair of models (n_iters_eval = 4): every iterate's flow
+    torch.manual_seed(0)
+    cpu_model = hashed_fill_(CamLiRAFT_L(camliraft_l_cfg(4)), scale=0.5).eval()
+    gpu_model = CamLiRAFT_L(camliraft_l_cfg(4))
+    gpu_model.load_state_dict(cpu_model.state_dict())
+    gpu_model = gpu_model.cuda().eval()
+    share_clouds(monkeypatch)
+    with torch.no_grad():
+        with oracle_boundary():
+            out_cpu = cpu_model(inputs)
+        with runtime.use_backend('hip'):
+            runtime.set_strict(True)
+            try:
+                out_gpu = gpu_model({k: v.cuda() for k, v in inputs.items()})
+            finally:
+                runtime.set_strict(False)
+    for key in out_cpu:
+        epe = _epe(out_cpu[key], out_gpu[key].cpu())
+        assert epe <= 1e-4, (key, epe)
