@@ -23,6 +23,8 @@
 // (157 TFLOP/s): for C = 128 the write takes ~2x the MFMA time, so the kernel is HBM(write)-bound.
 #include "camli_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(256) void weightnet_fwd_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int WN_LD = 33;   // padded LDS row stride (conflict-free row-major <-> column access)
 
-template <int MT>
-__global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
+template <int MT, int OCC>
+__global__ __launch_bounds__(256, OCC) void weightnet_bwd_kernel(
     const float* __restrict__ xyz, const float* __restrict__ centres, const int64_t* __restrict__ idx, int idx_stride,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
             for (int i = 0; i < 8; ++i) a = __builtin_fmaf(s_w2[q * 8 + i], h1[i], a);
             s_h[q * WN_LD + cl] = fmaxf(a, 0.0f);
             h2_mask |= (a > 0.0f ? 1u : 0u) << r;
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);      // 16 weights in flight, not 128 (register budget)
         }
         __builtin_amdgcn_wave_barrier();
         float h2f[16];      // the column's h2 in the forward's K order, read back from the tile (other half's rows too)
@@ -230,14 +233,18 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = s_b3[32 * t + wn_row(r, half)];
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
+            for (int s = 0; s < 16; ++s) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w3[(32 * t + cl) * WN_LD + 2 * s + half], h2f[s], acc, 0, 0, 0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // operands of four steps in flight, not of sixteen
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.0f ? g[r] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r) {
                 gd = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w3[(32 * t + wn_row(r, half)) * WN_LD + cl], acc[r], gd, 0, 0, 0);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 16; ++r) s_g[wn_row(r, half) * WN_LD + cl] = acc[r];
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
                 const float ga = s_g[cl * WN_LD + 2 * s + half];   // A[i = c_local = cl][k = col = 2s + half]
                 gb[t] += ga;
                 gw[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, s_h[cl * WN_LD + 2 * s + half], gw[t], 0, 0, 0);
+                if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- g2 = gh2 * (h2 > 0) stays in gd ----
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(256, 2) void weightnet_bwd_kernel(
             const int q = wn_row(r, half);
 #pragma unroll
             for (int i = 0; i < 8; ++i) g1[i] = __builtin_fmaf(s_w2[q * 8 + i], gd[r], g1[i]);
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -438,13 +447,17 @@ extern "C" int camli_weightnet_bwd(const float* xyz, const float* centres, const
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long long tiles = (long long)B * (((long long)N * k + 31) / 32);   // 0 tiles: every slice is zero
     const int blocks = (int)(tiles / 4 + 1 < WN_BWD_BLOCKS ? tiles / 4 + 1 : WN_BWD_BLOCKS);
-#define CAMLI_WN_LAUNCH(MT)                                                                                       \
-    hipLaunchKernelGGL((weightnet_bwd_kernel<MT>), dim3(blocks), dim3(256), 0, s, xyz, centres, idx, idx_stride, \
+#define CAMLI_WN_LAUNCH(MT, OCC)                                                                                      \
+    hipLaunchKernelGGL((weightnet_bwd_kernel<MT, OCC>), dim3(blocks), dim3(256), 0, s, xyz, centres, idx, idx_stride, \
                        w1, b1, w2, b2, w3, b3, gout, workspace, B, C, M, N, k, k_major)
-    if (C <= 32) CAMLI_WN_LAUNCH(1);
-    else if (C <= 64) CAMLI_WN_LAUNCH(2);
-    else if (C <= 96) CAMLI_WN_LAUNCH(3);
-    else CAMLI_WN_LAUNCH(4);
+    // C > 64: 48-64 accumulator registers for dW3 on top of the rest do not fit 256 VGPRs (round 3 shipped the two-waves-
+    // per-SIMD build with 87 scratch instructions in its loop); one wave per SIMD, no spills.  CAMLI_WN_BWD_OCC=2: the old build
+    const char* occ_env = getenv("CAMLI_WN_BWD_OCC");
+    const int occ = occ_env ? atoi(occ_env) : 1;
+    if (C <= 32) CAMLI_WN_LAUNCH(1, 2);
+    else if (C <= 64) CAMLI_WN_LAUNCH(2, 2);
+    else if (C <= 96) { if (occ == 2) CAMLI_WN_LAUNCH(3, 2); else CAMLI_WN_LAUNCH(3, 1); }
+    else { if (occ == 2) CAMLI_WN_LAUNCH(4, 2); else CAMLI_WN_LAUNCH(4, 1); }
 #undef CAMLI_WN_LAUNCH
     int rc = camli_check_launch("camli_weightnet_bwd");
     if (rc != CAMLI_OK) return rc;
