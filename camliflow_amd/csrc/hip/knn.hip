@@ -709,17 +709,36 @@ __device__ __forceinline__ int first_lane(uint64_t mask) { return (int)__builtin
 
 // Rank + store one query from its survivor list and leave the list all-sentinel again.  Entry t of team wave w sits
 // at slot t * W + w (lane l reads slots l and 64 + l); `nslots` = W * the largest per-wave count, `two` = some slot
-// >= 64 is in use, `total` = the number of entries.  Ties at the k-th distance in closed form (header).  Returns true when a real candidate sits at
-// exactly the reference's initial distance (nothing is stored then: the caller redoes the query in order).
+// >= 64 is in use, `total` = the number of entries.  Ties at the k-th distance in closed form (header).  Returns true
+// when a real candidate sits at exactly the reference's initial distance (nothing is stored then: the caller redoes the
+// query in order).
+// CHAIN (nested prefixes, knn_xlane_chain_kernel): the list starts with the k results of the next smaller prefix -- the
+// reference's list after that prefix, from which its insertion simply continues -- followed by the new survivors
+// (index >= new_from).  The stored results also go to `next` (slot j = output j) as the start of the next larger
+// prefix's list; `fo` receives the k-th distance (the bound of that prefix) and the number of results.  Among the
+// carried-over entries "a closer candidate arrives after the last tied one" only holds for NEW candidates: the carried
+// ones arrive in list order, closer before tied, whatever their indices.
+struct FinishOut {
+    uint32_t dk;
+    int kept;
+};
+template <bool CHAIN = false>
 __device__ __forceinline__ bool finish_query(uint32_t* list, int nslots, int total, bool two, int k,
-                                             int64_t* __restrict__ o, int lane) {
+                                             int64_t* __restrict__ o, int lane, uint32_t new_from = 0,
+                                             uint32_t* next = nullptr, FinishOut* fo = nullptr) {
+    auto emit = [&](int slot, uint2 e) {
+        o[slot] = (int64_t)e.x;
+        if (CHAIN && next) *reinterpret_cast<uint2*>(next + 2 * slot) = e;
+    };
     const uint2 e0 = *reinterpret_cast<const uint2*>(list + 2 * lane);                 // (index, distance bits)
     uint2 e1 = make_uint2(0xffffffffu, 0xffffffffu);
     if (two) e1 = *reinterpret_cast<const uint2*>(list + 2 * (64 + lane));
     const uint64_t key0 = ((uint64_t)e0.y << 32) | e0.x, key1 = ((uint64_t)e1.y << 32) | e1.x;
     const bool v0 = e0.y != 0xffffffffu, v1 = e1.y != 0xffffffffu;
     int rank0 = 0, rank1 = 0;
-    for (int s = 0; s < nslots; s += 4) {        // wave-uniform addresses: LDS broadcasts; the pad keeps s + 3 in range
+    // wave-uniform addresses: LDS broadcasts, four entries per trip (the pad keeps s + 3 in range; sixteen per trip --
+    // fewer LDS round trips, more padding work -- measured slower: 24.0 vs 23.1 us at k 16, 12.2 vs 10.7 us at M = 256)
+    for (int s = 0; s < nslots; s += 4) {
         const uint4 a = *reinterpret_cast<const uint4*>(list + 2 * s);
         const uint4 b = *reinterpret_cast<const uint4*>(list + 2 * s + 4);
         const uint64_t s0 = ((uint64_t)a.y << 32) | a.x, s1 = ((uint64_t)a.w << 32) | a.z;
@@ -733,9 +752,10 @@ __device__ __forceinline__ bool finish_query(uint32_t* list, int nslots, int tot
 
     if (__ballot((v0 && e0.y == INIT_BITS) || (v1 && e1.y == INIT_BITS)) != 0) return true;
     if (total < k) {            // fewer than k candidates within 1e9: the rest of the reference's list keeps index 0
-        if (v0) o[rank0] = (int64_t)e0.x;
-        if (v1) o[rank1] = (int64_t)e1.x;
+        if (v0) emit(rank0, e0);
+        if (v1) emit(rank1, e1);
         if (lane >= total && lane < k) o[lane] = 0;
+        if (CHAIN && fo) fo->dk = INIT_BITS, fo->kept = total;
         return false;
     }
     uint32_t dk;                // the k-th distance = that of rank k - 1
@@ -744,10 +764,11 @@ __device__ __forceinline__ bool finish_query(uint32_t* list, int nslots, int tot
         if (m0) dk = (uint32_t)__builtin_amdgcn_readlane((int)e0.y, first_lane(m0));
         else dk = (uint32_t)__builtin_amdgcn_readlane((int)e1.y, first_lane(__ballot(v1 && rank1 == k - 1)));
     }
+    if (CHAIN && fo) fo->dk = dk, fo->kept = k;
     // the common case: nothing beyond rank k - 1 shares the k-th distance -> the ranks are the output slots
     if (__ballot((v0 && rank0 >= k && e0.y == dk) || (v1 && rank1 >= k && e1.y == dk)) == 0) {
-        if (v0 && rank0 < k) o[rank0] = (int64_t)e0.x;
-        if (v1 && rank1 < k) o[rank1] = (int64_t)e1.x;
+        if (v0 && rank0 < k) emit(rank0, e0);
+        if (v1 && rank1 < k) emit(rank1, e1);
         return false;
     }
     const bool less0 = v0 && e0.y < dk, less1 = v1 && e1.y < dk;
@@ -761,23 +782,24 @@ __device__ __forceinline__ bool finish_query(uint32_t* list, int nslots, int tot
         const uint64_t m0 = __ballot(v0 && rank0 == last);
         if (m0) last_idx = (uint32_t)__builtin_amdgcn_readlane((int)e0.x, first_lane(m0));
         else last_idx = (uint32_t)__builtin_amdgcn_readlane((int)e1.x, first_lane(__ballot(v1 && rank1 == last)));
-        const bool closer_after = __ballot((less0 && e0.x > last_idx) || (less1 && e1.x > last_idx)) != 0;
+        const bool closer_after = __ballot((less0 && e0.x > last_idx && e0.x >= new_from) ||
+                                           (less1 && e1.x > last_idx && e1.x >= new_from)) != 0;
         if (!closer_after) top_rank = last;
     }
     if (v0) {
-        if (rank0 < k - 1) o[rank0] = (int64_t)e0.x;
-        else if (rank0 == top_rank) o[k - 1] = (int64_t)e0.x;
+        if (rank0 < k - 1) emit(rank0, e0);
+        else if (rank0 == top_rank) emit(k - 1, e0);
     }
     if (v1) {
-        if (rank1 < k - 1) o[rank1] = (int64_t)e1.x;
-        else if (rank1 == top_rank) o[k - 1] = (int64_t)e1.x;
+        if (rank1 < k - 1) emit(rank1, e1);
+        else if (rank1 == top_rank) emit(k - 1, e1);
     }
     return false;
 }
 
 // phase 2 of one wave: entries with d <= T go to slots (cnt + prefix) * W + tw of `list`, at most R per wave (the
 // count keeps running past R: the caller sees the overflow); returns the new count
-template <int J, typename IndexOf>
+template <int J, int J0, int J1, typename IndexOf>
 __device__ __forceinline__ int collect(const uint32_t (&d)[J], uint32_t T, uint32_t* list, int W, int tw, int R,
                                        IndexOf&& index_of, int cnt = 0) {
     auto append = [&](uint64_t mask, bool hit, uint32_t dv, int j) {
@@ -786,9 +808,9 @@ __device__ __forceinline__ int collect(const uint32_t (&d)[J], uint32_t T, uint3
         if (hit && pos < R) *reinterpret_cast<uint2*>(list + 2 * (pos * W + tw)) = make_uint2((uint32_t)index_of(j), dv);
         cnt += __builtin_popcountll(mask);
     };
-    static_assert(J % 4 == 0, "slots come in groups of four");
+    static_assert(J0 % 4 == 0 && J1 % 4 == 0, "slots come in groups of four");
 #pragma unroll
-    for (int j = 0; j < J; j += 4) {
+    for (int j = J0; j < J1; j += 4) {
         const bool h0 = d[j] <= T, h1 = d[j + 1] <= T, h2 = d[j + 2] <= T, h3 = d[j + 3] <= T;
         const uint64_t m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
         if ((m0 | m1) | (m2 | m3)) {
@@ -880,7 +902,7 @@ __global__ __launch_bounds__(256) void knn_xlane_chunked_kernel(const float* __r
                     }
                     m[u] = mm;
                     const uint32_t T = kth_bound(mm, k, lb);
-                    cnt[u] = collect<J>(d, T, lists + u * LIST_DW, 1, 0, CAP,
+                    cnt[u] = collect<J, 0, J>(d, T, lists + u * LIST_DW, 1, 0, CAP,
                                         [&](int slot) { return c0 + cl4 + 256 * (slot >> 2) + (slot & 3); }, cnt[u]);
                 }
             }
@@ -897,20 +919,103 @@ __global__ __launch_bounds__(256) void knn_xlane_chunked_kernel(const float* __r
     }
 }
 
-// ---- M <= 2048: one wave per query, candidates in LDS; L > 1 = the nested prefixes of camli_knn_prefixes ------------
-// Level l = the first M >> l candidates = the first (J / 4) >> l slot groups of every lane, so ONE pass of distance
-// arithmetic serves all levels: the lane minimum is snapshot where a level ends, each level gets its own bound (one
-// sort each; T_0 <= T_1 <= ...), phase 2 tests a slot against the loosest bound of the levels that contain it and
-// descends only on a hit.
-// LDS of a workgroup (dwords): candidate planes X | Y | Z of 64 J floats each | per wave: L survivor lists.
+// ---- M <= 2048: one wave per query, candidates in LDS --------------------------------------------------------------
+// LDS of a workgroup (dwords): candidate planes X | Y | Z of 64 J floats each | per wave: survivor lists.
 template <int J>
 constexpr int cand_dw() { return 3 * 64 * J; }
-template <int L>
-constexpr int wave_dw() { return L * LIST_DW; }
 
-template <int D, int J, int L>
+// stage the candidates of batch element `in_b`: plane p at cand + 64 J p; entries past M get an infinite x (distance
+// inf / NaN: never <= T)
+template <int D, int J>
+__device__ __forceinline__ void stage_candidates(float* cand, const float* __restrict__ in_b, int M) {
+    for (int c = threadIdx.x; c < 64 * J; c += 256) {
+        const bool in = c < M;
+        const float* p = in_b + (size_t)(in ? c : M - 1) * D;
+        cand[c] = in ? p[0] : INFINITY;
+        cand[64 * J + c] = p[1];
+        if (D == 3) cand[128 * J + c] = p[2];
+    }
+}
+
+// phase 1 of one query: the J distances of every lane (slot 4g+u of lane l = candidate 4 (64 g + l) + u) and the lane
+// minimum over the first G_MIN slot groups
+template <int D, int J, int G_MIN>
+__device__ __forceinline__ uint32_t distances(const float4* X4, const float4* Y4, const float4* Z4, float ux, float uy,
+                                              float uz, uint32_t (&d)[J]) {
+    uint32_t m = 0xffffffffu;
+#pragma unroll
+    for (int g = 0; g < J / 4; ++g) {
+        const float4 x = X4[g * 64], y = Y4[g * 64];
+        float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (D == 3) z = Z4[g * 64];
+        d[4 * g + 0] = dist_bits<D>(ux, uy, uz, x.x, y.x, z.x);
+        d[4 * g + 1] = dist_bits<D>(ux, uy, uz, x.y, y.y, z.y);
+        d[4 * g + 2] = dist_bits<D>(ux, uy, uz, x.z, y.z, z.z);
+        d[4 * g + 3] = dist_bits<D>(ux, uy, uz, x.w, y.w, z.w);
+        if (g < G_MIN) m = min(min(m, d[4 * g]), min(d[4 * g + 1], min(d[4 * g + 2], d[4 * g + 3])));
+    }
+    return m;
+}
+
+template <int D, int J>
 __global__ __launch_bounds__(256) void knn_xlane_kernel(const float* __restrict__ input, const float* __restrict__ query,
-                                                        KnnPrefixOut po, int M, int Nq, int k, int qpt) {
+                                                        int64_t* __restrict__ out, int M, int Nq, int k, int qpt) {
+    static_assert(J % 4 == 0, "slot groups of four");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + w) * qpt;
+    const int q1 = q0 + qpt < Nq ? q0 + qpt : Nq;
+    const LaneBits lb(lane);
+    float* cand = smem;
+    uint32_t* list = reinterpret_cast<uint32_t*>(smem + cand_dw<J>() + w * LIST_DW);
+
+    const float* __restrict__ in_b = input + (size_t)b * M * D;
+    const float* __restrict__ query_b = query + (size_t)b * Nq * D;
+    int64_t* __restrict__ out_b = out + (size_t)b * Nq * k;
+    stage_candidates<D, J>(cand, in_b, M);
+    for (int i = lane; i < LIST_DW; i += 64) list[i] = 0xffffffffu;
+    __syncthreads();
+    if (q0 >= Nq) return;
+
+    const float4* X4 = reinterpret_cast<const float4*>(cand) + lane;
+    const float4* Y4 = reinterpret_cast<const float4*>(cand + 64 * J) + lane;
+    const float4* Z4 = reinterpret_cast<const float4*>(cand + 128 * J) + lane;
+    const int cl4 = 4 * lane;
+    float nx = query_b[(size_t)q0 * D], ny = query_b[(size_t)q0 * D + 1], nz = (D == 3) ? query_b[(size_t)q0 * D + 2] : 0.0f;
+    for (int qi = q0; qi < q1; ++qi) {
+        const float ux = nx, uy = ny, uz = nz;
+        {   // next query's coordinates: requested now, waited for at the end of the iteration
+            const int qn = qi + 1 < q1 ? qi + 1 : qi;
+            const float* qp = query_b + (size_t)qn * D;
+            nx = qp[0];
+            ny = qp[1];
+            nz = (D == 3) ? qp[2] : 0.0f;
+        }
+        uint32_t d[J];
+        const uint32_t m = distances<D, J, J / 4>(X4, Y4, Z4, ux, uy, uz, d);
+        const uint32_t T = kth_bound(m, k, lb);
+        const int cnt = collect<J, 0, J>(d, T, list, 1, 0, CAP, [&](int slot) { return cl4 + 256 * (slot >> 2) + (slot & 3); });
+        const int n = cnt < CAP ? cnt : CAP;
+        int64_t* o = out_b + (size_t)qi * k;
+        const bool init_tie = finish_query(list, n, n, n > 64, k, o, lane);
+        if (cnt > CAP || init_tie) redo_query<D>(in_b, M, ux, uy, uz, k, o, lane);
+    }
+}
+
+// ---- nested prefixes (camli_knn_prefixes): level l = the first M >> l candidates = the first (J / 4) >> l slot groups ----
+// ONE pass of distance arithmetic serves all levels, and only the SMALLEST prefix pays for a bound of its own (the sort of
+// its lane minima).  The reference's insertion over a larger prefix is the insertion over the smaller one continued with
+// the remaining candidates, so level l starts from the k results of level l + 1, takes their k-th distance -- an exact
+// upper bound of its own -- as T, and collects survivors from the INCREMENT slots only (~k of them: the increment holds as
+// many candidates as the smaller prefix).  finish_query<CHAIN> ranks results + survivors together (ties: see there).
+// Two lists per wave, used alternately by the levels.  (First form of this kernel, kept in the history: an own sorted
+// bound, a full-prefix collection and a list per level -- 64 us per call against 60 us for the lane-per-query prefix kernel.)
+template <int J, int L>
+__global__ __launch_bounds__(256) void knn_xlane_chain_kernel(const float* __restrict__ input, const float* __restrict__ query,
+                                                              KnnPrefixOut po, int M, int Nq, int k, int qpt) {
+    constexpr int D = 3;
     static_assert(J % 4 == 0 && ((J / 4) >> (L - 1)) >= 1, "levels end on slot-group boundaries");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -920,110 +1025,62 @@ __global__ __launch_bounds__(256) void knn_xlane_kernel(const float* __restrict_
     const int q1 = q0 + qpt < Nq ? q0 + qpt : Nq;
     const LaneBits lb(lane);
     float* cand = smem;
-    float* wave_lds = smem + cand_dw<J>() + w * wave_dw<L>();
-    uint32_t* surv = reinterpret_cast<uint32_t*>(wave_lds);                    // [L] lists
+    uint32_t* lists = reinterpret_cast<uint32_t*>(smem + cand_dw<J>() + w * 2 * LIST_DW);
 
     const float* __restrict__ in_b = input + (size_t)b * M * D;
     const float* __restrict__ query_b = query + (size_t)b * Nq * D;
-
-    // stage the candidates: plane p at cand + 64 J p; entries past M get an infinite x (distance inf / NaN: never <= T)
-    for (int c = threadIdx.x; c < 64 * J; c += 256) {
-        const bool in = c < M;
-        const float* p = in_b + (size_t)(in ? c : M - 1) * D;
-        cand[c] = in ? p[0] : INFINITY;
-        cand[64 * J + c] = p[1];
-        if (D == 3) cand[128 * J + c] = p[2];
-    }
-    for (int i = lane; i < L * LIST_DW; i += 64) surv[i] = 0xffffffffu;
+    stage_candidates<D, J>(cand, in_b, M);
+    for (int i = lane; i < 2 * LIST_DW; i += 64) lists[i] = 0xffffffffu;
     __syncthreads();
+    if (q0 >= Nq) return;
 
     const float4* X4 = reinterpret_cast<const float4*>(cand) + lane;
     const float4* Y4 = reinterpret_cast<const float4*>(cand + 64 * J) + lane;
     const float4* Z4 = reinterpret_cast<const float4*>(cand + 128 * J) + lane;
     const int cl4 = 4 * lane;
-
-    if (q0 < Nq) {
-        float nx = query_b[(size_t)q0 * D], ny = query_b[(size_t)q0 * D + 1], nz = (D == 3) ? query_b[(size_t)q0 * D + 2] : 0.0f;
-        for (int qi = q0; qi < q1; ++qi) {
-            const float ux = nx, uy = ny, uz = nz;
-            {   // next query's coordinates: requested now, waited for at the end of the iteration
-                const int qn = qi + 1 < q1 ? qi + 1 : qi;
-                const float* qp = query_b + (size_t)qn * D;
-                nx = qp[0];
-                ny = qp[1];
-                nz = (D == 3) ? qp[2] : 0.0f;
-            }
-            // ---- phase 1: distances, lane minimum, its snapshots at the level ends ----
-            uint32_t d[J];
-            uint32_t ml[L];
-            uint32_t m = 0xffffffffu;
-#pragma unroll
-            for (int g = 0; g < J / 4; ++g) {
-                const float4 x = X4[g * 64], y = Y4[g * 64];
-                float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (D == 3) z = Z4[g * 64];
-                d[4 * g + 0] = dist_bits<D>(ux, uy, uz, x.x, y.x, z.x);
-                d[4 * g + 1] = dist_bits<D>(ux, uy, uz, x.y, y.y, z.y);
-                d[4 * g + 2] = dist_bits<D>(ux, uy, uz, x.z, y.z, z.z);
-                d[4 * g + 3] = dist_bits<D>(ux, uy, uz, x.w, y.w, z.w);
-                m = min(min(m, d[4 * g]), min(d[4 * g + 1], min(d[4 * g + 2], d[4 * g + 3])));
-#pragma unroll
-                for (int l = 0; l < L; ++l)
-                    if (g + 1 == ((J / 4) >> l)) ml[l] = m;
-            }
-            uint32_t T[L];
-#pragma unroll
-            for (int l = 0; l < L; ++l) T[l] = kth_bound(ml[l], k, lb);
-            // ---- phase 2: survivors of every level ----
-            int cnt[L];
-#pragma unroll
-            for (int l = 0; l < L; ++l) cnt[l] = 0;
-            auto append = [&](int l, uint64_t mask, bool hit, uint32_t dv, int slot) {
-                const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)cnt[l]));
-                if (hit && pos < CAP)
-                    *reinterpret_cast<uint2*>(surv + l * LIST_DW + 2 * pos) =
-                        make_uint2((uint32_t)(cl4 + 256 * (slot >> 2) + (slot & 3)), dv);
-                cnt[l] += __builtin_popcountll(mask);
-            };
-#pragma unroll
-            for (int g = 0; g < J / 4; ++g) {
-                int lmax = 0;           // levels that contain group g: 0 .. lmax; T[lmax] is the loosest of their bounds
-#pragma unroll
-                for (int l = 1; l < L; ++l)
-                    if (g < ((J / 4) >> l)) lmax = l;
-                bool h[4];
-                uint64_t mk[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    h[u] = d[4 * g + u] <= T[lmax];
-                    mk[u] = __ballot(h[u]);
-                }
-                if ((mk[0] | mk[1]) | (mk[2] | mk[3])) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (mk[u]) {
-                            append(lmax, mk[u], h[u], d[4 * g + u], 4 * g + u);
-#pragma unroll
-                            for (int l = L - 2; l >= 0; --l) {
-                                if (l >= lmax) continue;
-                                const bool hl = d[4 * g + u] <= T[l];
-                                const uint64_t ml2 = __ballot(hl);
-                                if (ml2) append(l, ml2, hl, d[4 * g + u], 4 * g + u);
-                            }
-                        }
-                    }
-                }
-            }
-            // ---- rank + store ----
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int n = cnt[l] < CAP ? cnt[l] : CAP;
-                int64_t* o = po.out[l] + ((size_t)b * Nq + qi) * k;
-                const bool init_tie = finish_query(surv + l * LIST_DW, n, n, n > 64, k, o, lane);
-                if (cnt[l] > CAP || init_tie) redo_query<D>(in_b, M >> l, ux, uy, uz, k, o, lane);
-            }
+    auto index_of = [&](int slot) { return cl4 + 256 * (slot >> 2) + (slot & 3); };
+    float nx = query_b[(size_t)q0 * D], ny = query_b[(size_t)q0 * D + 1], nz = query_b[(size_t)q0 * D + 2];
+    for (int qi = q0; qi < q1; ++qi) {
+        const float ux = nx, uy = ny, uz = nz;
+        {
+            const int qn = qi + 1 < q1 ? qi + 1 : qi;
+            const float* qp = query_b + (size_t)qn * D;
+            nx = qp[0];
+            ny = qp[1];
+            nz = qp[2];
         }
+        constexpr int G_BASE = (J / 4) >> (L - 1);
+        uint32_t d[J];
+        const uint32_t m = distances<D, J, G_BASE>(X4, Y4, Z4, ux, uy, uz, d);
+        uint32_t T = kth_bound(m, k, lb);
+        int cnt = collect<J, 0, 4 * G_BASE>(d, T, lists, 1, 0, CAP, index_of);
+        bool broken = false;
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+            uint32_t* cur = lists + ((L - 1 - l) & 1) * LIST_DW;
+            uint32_t* nxt = lists + ((L - l) & 1) * LIST_DW;
+            int64_t* o = po.out[l] + ((size_t)b * Nq + qi) * k;
+            if (!broken) {
+                const int n = cnt < CAP ? cnt : CAP;
+                FinishOut fo;
+                const bool init_tie = finish_query<true>(cur, n, n, n > 64, k, o, lane, l == L - 1 ? 0u : (uint32_t)(M >> (l + 1)),
+                                                         l > 0 ? nxt : nullptr, &fo);
+                broken = init_tie || cnt > CAP;
+                if (!broken && l > 0) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    T = fo.dk;
+                    cnt = fo.kept;
+                    // the increment of level l - 1: slot groups [(J/4) >> l, (J/4) >> (l - 1))
+                    if (l == 1) cnt = collect<J, 4 * ((J / 4) >> 1), 4 * ((J / 4) >> 0)>(d, T, nxt, 1, 0, CAP, index_of, cnt);
+                    if (L >= 3 && l == 2) cnt = collect<J, 4 * ((J / 4) >> 2), 4 * ((J / 4) >> 1)>(d, T, nxt, 1, 0, CAP, index_of, cnt);
+                    if (L >= 4 && l == 3) cnt = collect<J, 4 * ((J / 4) >> 3), 4 * ((J / 4) >> 2)>(d, T, nxt, 1, 0, CAP, index_of, cnt);
+                }
+            }
+            if (broken) redo_query<D>(in_b, M >> l, ux, uy, uz, k, o, lane);      // this level and every larger one, in order
+        }
+        if (broken)       // rare: whatever the chain left in the two lists must not reach the next query
+            for (int i = lane; i < 2 * LIST_DW; i += 64) lists[i] = 0xffffffffu;
     }
 }
 
@@ -1054,17 +1111,30 @@ int launch_chunked(const float* input, const float* query, int64_t* out, int B, 
     return camli_check_launch("camli_knn(xlane chunked)");
 }
 
-template <int D, int J, int L>
-int launch(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int k, hipStream_t stream) {
+static int queries_per_wave(int B, int Nq) {
     const long long occ = target_waves();
     const long long total = (long long)B * Nq;
     int qpt = (int)((total + occ - 1) / occ);
     if (qpt < 2) qpt = 2;
-    if (qpt > QPT_MAX) qpt = QPT_MAX;
+    return qpt > QPT_MAX ? QPT_MAX : qpt;
+}
+
+template <int D, int J>
+int launch(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k, hipStream_t stream) {
+    const int qpt = queries_per_wave(B, Nq);
     dim3 grid(camli_divup(Nq, qpt * 4), B);
-    const size_t lds = (size_t)(cand_dw<J>() + 4 * wave_dw<L>()) * 4;
-    hipLaunchKernelGGL((knn_xlane_kernel<D, J, L>), grid, dim3(256), lds, stream, input, query, po, M, Nq, k, qpt);
+    const size_t lds = (size_t)(cand_dw<J>() + 4 * LIST_DW) * 4;
+    hipLaunchKernelGGL((knn_xlane_kernel<D, J>), grid, dim3(256), lds, stream, input, query, out, M, Nq, k, qpt);
     return camli_check_launch("camli_knn(xlane)");
+}
+
+template <int J, int L>
+int launch_chain(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int k, hipStream_t stream) {
+    const int qpt = queries_per_wave(B, Nq);
+    dim3 grid(camli_divup(Nq, qpt * 4), B);
+    const size_t lds = (size_t)(cand_dw<J>() + 4 * 2 * LIST_DW) * 4;
+    hipLaunchKernelGGL((knn_xlane_chain_kernel<J, L>), grid, dim3(256), lds, stream, input, query, po, M, Nq, k, qpt);
+    return camli_check_launch("camli_knn_prefixes(xlane chain)");
 }
 
 // returns 1 when the shape is not served here (the caller falls back to the lane-per-query kernels).  Default choice
@@ -1076,13 +1146,10 @@ template <int D>
 int dispatch(const float* input, const float* query, int64_t* out, int B, int M, int Nq, int k, hipStream_t stream, int* rc) {
     if (!k_supported(k)) return 1;
     if (mode() == 0 && (k == 1 || M > 6144)) return 1;
-    KnnPrefixOut po;
-    po.levels = 1;
-    for (int l = 0; l < 4; ++l) po.out[l] = l == 0 ? out : nullptr, po.size[l] = l == 0 ? M : 0;
-    if (M <= 256) *rc = launch<D, 4, 1>(input, query, po, B, M, Nq, k, stream);
-    else if (M <= 512) *rc = launch<D, 8, 1>(input, query, po, B, M, Nq, k, stream);
-    else if (M <= 1024) *rc = launch<D, 16, 1>(input, query, po, B, M, Nq, k, stream);
-    else if (M <= 2048) *rc = launch<D, 32, 1>(input, query, po, B, M, Nq, k, stream);
+    if (M <= 256) *rc = launch<D, 4>(input, query, out, B, M, Nq, k, stream);
+    else if (M <= 512) *rc = launch<D, 8>(input, query, out, B, M, Nq, k, stream);
+    else if (M <= 1024) *rc = launch<D, 16>(input, query, out, B, M, Nq, k, stream);
+    else if (M <= 2048) *rc = launch<D, 32>(input, query, out, B, M, Nq, k, stream);
     else *rc = launch_chunked<D>(input, query, out, B, M, Nq, k, stream);
     return 0;
 }
@@ -1091,14 +1158,13 @@ int dispatch(const float* input, const float* query, int64_t* out, int B, int M,
 int dispatch_prefix(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int D, int k,
                     hipStream_t stream, int* rc) {
     if (D != 3 || !k_supported(k) || po.levels < 2) return 1;
-    if (mode() == 0) return 1;      // measured: 64 us against 60 us for the lane-per-query prefix kernel (four bounds, four lists)
     const int L = po.levels;
     for (int l = 0; l < L; ++l)
         if (po.size[l] != (M >> l) || (po.size[l] & 255)) return 1;       // levels end on slot-group boundaries
     const int J = M / 64;
     if (J * 64 != M) return 1;
 #define CAMLI_XL_PREFIX(JJ, LL) \
-    if (J == JJ && L == LL) { *rc = launch<3, JJ, LL>(input, query, po, B, M, Nq, k, stream); return 0; }
+    if (J == JJ && L == LL) { *rc = launch_chain<JJ, LL>(input, query, po, B, M, Nq, k, stream); return 0; }
     CAMLI_XL_PREFIX(32, 4) CAMLI_XL_PREFIX(32, 3) CAMLI_XL_PREFIX(32, 2)
     CAMLI_XL_PREFIX(16, 3) CAMLI_XL_PREFIX(16, 2) CAMLI_XL_PREFIX(8, 2)
 #undef CAMLI_XL_PREFIX
