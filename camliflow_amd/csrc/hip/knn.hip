@@ -1158,6 +1158,7 @@ int dispatch(const float* input, const float* query, int64_t* out, int B, int M,
 int dispatch_prefix(const float* input, const float* query, const KnnPrefixOut& po, int B, int M, int Nq, int D, int k,
                     hipStream_t stream, int* rc) {
     if (D != 3 || !k_supported(k) || po.levels < 2) return 1;
+    if (mode() == 0) return 1;      // measured (profiles/r04_ab_knn.json): 67 us against 60 us for the lane-per-query prefix kernel
     const int L = po.levels;
     for (int l = 0; l < L; ++l)
         if (po.size[l] != (M >> l) || (po.size[l] & 255)) return 1;       // levels end on slot-group boundaries
