@@ -2,6 +2,7 @@
 pyramid with radius-4 lookup, conv-GRU update block, flow head and convex upsampler.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -133,6 +134,11 @@ class GRU2D(nn.Module):
             # contiguous once per pass: the gate kernels would otherwise copy these channel slices every iteration
             state[suffix] = (torch.cat(keep[:2], dim=0), keep[2], ctx[:, :2 * hd].contiguous(),
                              ctx[:, 2 * hd:].contiguous(), padding)
+            if runtime.fused() and context.is_cuda and not torch.is_grad_enabled() and os.environ.get('CAMLI_CONV5', '1') == '1':
+                # inference: the half-steps run on the implicit-GEMM kernels with the gate arithmetic in their epilogues
+                # (csrc/hip/conv5.hip; no adjoint, so not under autograd) -- weights packed once per pass
+                from ..csrc import fused
+                state['packed' + suffix] = (fused.pack_conv5_weight(state[suffix][0]), fused.pack_conv5_weight(state[suffix][1]))
         return state
 
     def step(self, h, motion, state):
@@ -145,6 +151,12 @@ class GRU2D(nn.Module):
         fusable = h.is_cuda and (hd * h.shape[2] * h.shape[3]) % 4 == 0
         for suffix in ('1', '2'):
             w_zr, w_q, ctx_zr, ctx_q, padding = state[suffix]
+            packed = state.get('packed' + suffix)
+            if packed is not None and not torch.is_grad_enabled() and h.dtype == torch.float32 and motion.dtype == torch.float32 \
+                    and not torch.is_autocast_enabled():
+                z, rh = fused.conv5_gru_gates(h, motion, packed[0], ctx_zr, vertical=(suffix == '2'))
+                h = fused.conv5_gru_blend(rh, motion, packed[1], ctx_q, z, h, vertical=(suffix == '2'), nan_to_num=(suffix == '2'))
+                continue
             pre_zr = conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding)
             if not fusable and h.is_cuda:
                 runtime.fallback('GRU2D', 'hidden plane is not a multiple of 4 elements')
@@ -158,7 +170,7 @@ class GRU2D(nn.Module):
                 z, r = zr[:, :hd], zr[:, hd:]
                 q = torch.tanh(conv2d(torch.cat([r * h, motion], dim=1), w_q, None, padding=padding) + ctx_q)
                 h = (1 - z) * h + z * q
-        return h if fusable else torch.nan_to_num(h)
+        return h if (fusable or state.get('packed2') is not None and not torch.is_grad_enabled()) else torch.nan_to_num(h)
 
 
 def _conv(cin, cout, ksize):

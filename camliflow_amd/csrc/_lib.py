@@ -100,6 +100,8 @@ PROTOTYPES = {
     "camli_ids_flow_bwd": (_int, [_c_float_p] * 7 + [ctypes.c_float] * 5 + [_int, _int, _stream]),
     "camli_persp2paral": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int] + [ctypes.c_float] * 5 + [_stream]),
     "camli_project_pc2image": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int] + [ctypes.c_float] * 4 + [_stream]),
+    "camli_conv5_fwd": (_int, [_c_float_p, _int, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                               _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _int, _int, _stream]),
     "camli_conv3x3_co2_fwd": (_int, [_c_float_p] * 4 + [_int] * 4 + [_stream]),
     "camli_conv3x3_co2_bwd_data": (_int, [_c_float_p] * 3 + [_int] * 4 + [_stream]),
     "camli_conv3x3_co2_bwd_weight_workspace_bytes": (ctypes.c_longlong, [_int, _int, _int]),

@@ -87,6 +87,25 @@ def conv3x3_bwd(gy, x, w):
     return gxp[:, :, 1:-1, 1:-1].astype(np.float32), gw.astype(np.float32), gy.sum(axis=(0, 2, 3)).astype(np.float32)
 
 
+# ---- 1x5 / 5x1 convolution, zero padding 2 along the kernel: GRU2D's gates, models/raft_core.py:110-122 -----------------
+
+def conv5_fwd(x, w, bias=None):
+    """x [B,Ci,H,W], w [Co,Ci,1,5] (horizontal) or [Co,Ci,5,1] (vertical), bias [Co] or None -> [B,Co,H,W] (as nn.Conv2d with
+    padding (0,2) / (2,0): cross-correlation)."""
+    x, w = _f64(x, w)
+    vertical = w.shape[2] == 5
+    taps = w.reshape(w.shape[0], w.shape[1], 5)
+    b, ci, hh, ww = x.shape
+    xp = np.pad(x, ((0, 0), (0, 0), (2, 2), (0, 0)) if vertical else ((0, 0), (0, 0), (0, 0), (2, 2)))
+    out = np.zeros((b, w.shape[0], hh, ww))
+    for t in range(5):
+        win = xp[:, :, t:t + hh, :] if vertical else xp[:, :, :, t:t + ww]
+        out += np.einsum('oc,bchw->bohw', taps[:, :, t], win)
+    if bias is not None:
+        out += np.asarray(bias, dtype=np.float64)[None, :, None, None]
+    return out.astype(np.float32)
+
+
 # ---- all-pairs volume pyramid, models/raft_core.py:52-68 (after fnet_aligner) -----------------------------------------
 # cost_volume = f1^T f2 / sqrt(C) as [B*P, 1, h, w]; then avg_pool2d(2, stride 2) over the TARGET dims, num_levels - 1
 # times (floor: an odd trailing row / column is dropped).

@@ -5,6 +5,8 @@
   dense_flow_head       models/raft_core.py FlowHead2D (:169-182): input / output of its two-channel conv2, gradients
   dense_allpairs_{even,odd}  models/raft_core.py Correlation2D.build_cost_volume_pyramid (:52-68): the aligned feature
                         maps, the four levels, gradients back to the aligned maps
+  dense_gru2d           models/raft_core.py GRU2D (:110-140): weights, inputs (h, x = [context | motion]), the input and
+                        output of each of its six 1x5 / 5x1 convolutions, the new hidden state
   dense_resnet_glue     the stem max pooling and the bottleneck epilogue of the ResNet trunk the reference instantiates
                         through mmdet (README.md:78-79, models/raft_core.py:10-38; mmdet itself is not under
                         /root/reference -- SURVEY 8c): nn.MaxPool2d(3, 2, 1) and relu(bn-bias + conv + identity) from torch
@@ -25,7 +27,7 @@ import refmodels  # noqa: E402
 
 refmodels.install(native_semantics=True)
 from models.camliraft_l_core import Correlation3D  # noqa: E402
-from models.raft_core import Correlation2D, FlowHead2D  # noqa: E402
+from models.raft_core import GRU2D, Correlation2D, FlowHead2D  # noqa: E402
 
 
 def save(name, **arrays):
@@ -106,6 +108,27 @@ def golden_allpairs(tag, hh, ww):
     save('dense_allpairs_' + tag, **arrays)
 
 
+def golden_gru2d():
+    g = torch.Generator().manual_seed(25)
+    hd, cd, md = 16, 8, 24                       # hidden, context and motion channels: x = cat([context, motion])
+    gru = GRU2D(hidden_dim=hd, input_dim=cd + md)
+    fill(gru, g, 0.15)
+    store = {}
+    for name in ('convz1', 'convr1', 'convq1', 'convz2', 'convr2', 'convq2'):
+        mod = getattr(gru, name)
+        mod.register_forward_hook(lambda _m, args, out, name=name: store.update({name + '_in': args[0].detach(), name + '_out': out.detach()}))
+    h0 = torch.tanh(torch.randn(2, hd, 11, 13, generator=g))
+    x = torch.randn(2, cd + md, 11, 13, generator=g)
+    with torch.no_grad():
+        out = gru(h0, x)
+    arrays = {'h0': h0, 'x': x, 'out': out, 'hidden': hd, 'context': cd}
+    for name in ('convz1', 'convr1', 'convq1', 'convz2', 'convr2', 'convq2'):
+        arrays[name + '_w'] = getattr(gru, name).weight.detach()
+        arrays[name + '_b'] = getattr(gru, name).bias.detach()
+    arrays.update(store)
+    save('dense_gru2d', **arrays)
+
+
 def golden_resnet_glue():
     g = torch.Generator().manual_seed(24)
     x = torch.relu(torch.randn(2, 5, 13, 18, generator=g)).requires_grad_(True)     # post-ReLU stem output: zeros tie
@@ -130,4 +153,5 @@ if __name__ == '__main__':
     golden_flow_head()
     golden_allpairs('even', 8, 12)
     golden_allpairs('odd', 9, 15)
+    golden_gru2d()
     golden_resnet_glue()

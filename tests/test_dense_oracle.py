@@ -59,3 +59,21 @@ def test_resnet_glue_vs_torch_modules_of_the_call_site(golden):
     gconv, gbias = dense.bias_act_res_bwd(g['gout'], out)
     _close(gconv, g['gconv'])
     _close(gbias, g['gbias'], rtol=1e-4, atol=1e-5)
+
+
+def test_conv5_and_gate_arithmetic_vs_reference_gru2d(golden):
+    """oracle/dense.conv5_fwd against every 1x5 / 5x1 convolution the reference's GRU2D ran, and the whole update (conv5 +
+    the gate arithmetic of oracle/glue.py) against its new hidden state."""
+    from oracle import glue
+    g = golden('dense_gru2d')
+    for name in ('convz1', 'convr1', 'convq1', 'convz2', 'convr2', 'convq2'):
+        _close(dense.conv5_fwd(g[name + '_in'], g[name + '_w'], g[name + '_b']), g[name + '_out'], rtol=1e-5, atol=1e-6)
+    h, x = g['h0'], g['x']
+    for suffix in ('1', '2'):
+        hx = np.concatenate([h, x], axis=1)
+        pre_zr = np.concatenate([dense.conv5_fwd(hx, g['convz' + suffix + '_w'], g['convz' + suffix + '_b']),
+                                 dense.conv5_fwd(hx, g['convr' + suffix + '_w'], g['convr' + suffix + '_b'])], axis=1)
+        z, rh, _ = glue.gru_gates_fwd(pre_zr, np.zeros_like(pre_zr), h)
+        pre_q = dense.conv5_fwd(np.concatenate([rh, x], axis=1), g['convq' + suffix + '_w'], g['convq' + suffix + '_b'])
+        h, _ = glue.gru_blend_fwd(pre_q, np.zeros_like(pre_q), z, h, nan_to_num=(suffix == '2'))
+    _close(h, g['out'], rtol=1e-5, atol=1e-6)
