@@ -134,9 +134,13 @@ class GRU2D(nn.Module):
             # contiguous once per pass: the gate kernels would otherwise copy these channel slices every iteration
             state[suffix] = (torch.cat(keep[:2], dim=0), keep[2], ctx[:, :2 * hd].contiguous(),
                              ctx[:, 2 * hd:].contiguous(), padding)
-            if runtime.fused() and context.is_cuda and not torch.is_grad_enabled() and os.environ.get('CAMLI_CONV5', '1') == '1':
-                # inference: the half-steps run on the implicit-GEMM kernels with the gate arithmetic in their epilogues
-                # (csrc/hip/conv5.hip; no adjoint, so not under autograd) -- weights packed once per pass
+            if runtime.fused() and context.is_cuda and not torch.is_grad_enabled() and os.environ.get('CAMLI_CONV5', '0') == '1':
+                # CAMLI_CONV5=1, inference only: the half-steps run on the implicit-GEMM kernels with the gate arithmetic
+                # in their epilogues (csrc/hip/conv5.hip; no adjoint, so not under autograd), weights packed once per
+                # pass.  OFF by default -- measured in the step (bench.py --config eval, alternating runs on one box):
+                # 121.3 / 121.7 ms with them against 117.8 / 117.8 ms with the library convolutions + gate kernels
+                # (profiles/r04_conv5_experiments.txt): the bare contraction is 0.9 x MIOpen's and what the epilogues
+                # save does not pay for it.
                 from ..csrc import fused
                 state['packed' + suffix] = (fused.pack_conv5_weight(state[suffix][0]), fused.pack_conv5_weight(state[suffix][1]))
         return state

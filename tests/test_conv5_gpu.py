@@ -78,10 +78,11 @@ def _gru_from_golden(g):
     return gru, hd, cd
 
 
-def test_gru2d_inference_path_vs_reference_module_golden(golden):
+def test_gru2d_inference_path_vs_reference_module_golden(golden, monkeypatch):
     """prepare() + step() of this repo's GRU2D under no_grad on the 'hip' backend = the conv5 kernels; expected: the
     REFERENCE GRU2D's recorded new hidden state."""
     from camliflow_amd.cores import runtime
+    monkeypatch.setenv('CAMLI_CONV5', '1')          # opt-in: the step is faster on the library convolutions (raft2d.GRU2D.prepare)
     g = golden('dense_gru2d')
     gru, hd, cd = _gru_from_golden(g)
     h0, x = dev(g['h0']), dev(g['x'])
@@ -96,11 +97,12 @@ def test_gru2d_inference_path_vs_reference_module_golden(golden):
     _close(out, g['out'], what='h1')
 
 
-def test_gru2d_inference_path_equals_training_path_formulation():
+def test_gru2d_inference_path_equals_training_path_formulation(monkeypatch):
     """Same weights, same inputs at the step's real channel counts: conv5 kernels (no_grad) vs library convolutions + gate
     kernels (grad enabled), 1/8-resolution size with a ragged edge."""
     from camliflow_amd.cores import runtime
     from camliflow_amd.cores.raft2d import GRU2D
+    monkeypatch.setenv('CAMLI_CONV5', '1')
     torch.manual_seed(0)
     gru = GRU2D(hidden_dim=128, input_dim=128 + 128).cuda()
     ctx = torch.randn(2, 128, 34, 60, device='cuda')
