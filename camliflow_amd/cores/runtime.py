@@ -357,11 +357,16 @@ class Branch:
     def __init__(self, *inputs, slot=0):
         import torch
         first = next((t for t in _flatten(inputs) if t is not None), None)
-        # not under HIP-graph capture: hipStreamEndCapture segfaults on this image once a capture has forked into the
-        # auxiliary streams as well as the point lane (test_graph_gpu, --config kitti); the replayed configurations are
-        # the batch-1, enqueue-bound ones and keep their two lanes
+        # not under HIP-graph capture.  Round 4 bisected it per slot on --config kitti (CAMLI_BRANCH_IN_CAPTURE=1 lifts this
+        # guard, CAMLI_BRANCH_MASK picks the slots): the motion-encoder, mask-head and context-encoder branches capture and
+        # replay correctly but make the replayed batch-1 step SLOWER (143.7 / 144.2 / 150.1 ms against 142.1 ms without:
+        # a replayed graph is not enqueue-bound and these chains are too short to pay for their fork / join at batch 1);
+        # with the CLFM direction forked in, hipStreamEndCapture itself crashes (SIGSEGV inside torch's capture_end where
+        # an un-joinable fork should come back as hipErrorStreamCaptureUnjoined) -- profiles/r04_branch_capture_bisect.txt.
+        # So the replayed configurations keep exactly their two lanes.
         self.enabled = bool(_LANES_LIVE and _OVERLAP and _BACKEND == 'hip' and first is not None and first.is_cuda
-                            and (_BRANCH_MASK >> slot) & 1 and not torch.cuda.is_current_stream_capturing())
+                            and (_BRANCH_MASK >> slot) & 1
+                            and (os.environ.get('CAMLI_BRANCH_IN_CAPTURE') == '1' or not torch.cuda.is_current_stream_capturing()))
         if self.enabled:
             self._torch = torch
             dev = first.device
