@@ -97,7 +97,10 @@ class PointConvDW(nn.Module):
         self.weight_net = MLP2d(3, [8, 32, out_channels], act='relu')
 
     def forward(self, xyz, features, sampled_xyz=None, knn_indices=None):
-        if runtime.fused() and xyz.is_cuda and runtime.atomics_ok('PointConvDW'):
+        # round 4: under torch.use_deterministic_algorithms(True) the adjoint's scatter runs on the ordered row kernel (no float
+        # atomics, camli_pointconv_dw_bwd_ordered) while a feature row and its two side arrays fit 64 KB of LDS -- up to 5461
+        # source points, every PointConvDW of the models; longer rows would need global float atomics and leave HIP
+        if runtime.fused() and xyz.is_cuda and (features.shape[-1] * 12 <= 64 * 1024 or runtime.atomics_ok('PointConvDW')):
             return self._forward_fused(xyz, features, sampled_xyz, knn_indices)
         sampled_xyz, knn_indices, knn_offset = _neighbourhood(xyz, sampled_xyz, knn_indices, self.k)
         features = batch_indexing(self.mlp(features), knn_indices)            # [B,Cout,n,k]

@@ -313,8 +313,11 @@ class _PointConvDW(torch.autograd.Function):
         gout = gout.contiguous().float()
         gfeat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None   # fully written by the kernel
         gwsel = torch.empty_like(wsel)
+        # torch.use_deterministic_algorithms(True): the ordered form (no float atomics, fixed summation order; 1.7x the time)
+        ordered = torch.are_deterministic_algorithms_enabled() and 12 * m <= 64 * 1024
         with _on_device(feat):
-            _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd, gout.data_ptr(), feat.data_ptr(),
+            _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd_ordered if ordered else lib.camli_pointconv_dw_bwd,
+                        gout.data_ptr(), feat.data_ptr(),
                         wsel.data_ptr(), msel.data_ptr(), gfeat.data_ptr() if gfeat is not None else None,
                         gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat),
                         work=(16.0 * b * c * n + 8.0 * b * c * m, 'B'))

@@ -149,6 +149,10 @@ int camli_pointconv_dw_fwd_kmajor(const float *feat, const float *weight_kn, con
                                   void *stream);
 int camli_pointconv_dw_bwd(const float *gout, const float *feat, const float *wsel, const int *msel,
                            float *gfeat, float *gwsel, int B, int C, int M, int N, void *stream);
+/* the same adjoint with a FIXED summation order (no float atomics: integer LDS tickets decide whose turn it is to add into a
+ * target): bit-reproducible, ~1.7x the time; selected under torch.use_deterministic_algorithms(True).  M <= 5461. */
+int camli_pointconv_dw_bwd_ordered(const float *gout, const float *feat, const float *wsel, const int *msel,
+                           float *gfeat, float *gwsel, int B, int C, int M, int N, void *stream);
 int camli_pointconv_dw_expand(const float *const *gwsel_list, const unsigned char *const *arg_list, int n_calls,
                               float *gweight, int B, int C, int N, int k, int k_major, void *stream);
 

@@ -163,8 +163,10 @@ def test_deterministic_algorithms_route_atomic_adjoints_to_torch():
             census = runtime.census()
             runtime.set_census(False)
     switched = [k for k in census['composed'] if 'deterministic' in k]
-    assert any(k.startswith('bias_act') for k in switched) and any(k.startswith('PointConvDW') for k in switched), switched
-    assert 'camli_bias_act_bwd' not in census['fused'] and 'camli_pointconv_dw_bwd' not in census['fused']
+    assert any(k.startswith('bias_act') for k in switched), switched
+    assert 'camli_bias_act_bwd' not in census['fused']
+    # round 4: PointConvDW's adjoint is atomic-free (ordered row kernel) and stays on HIP
+    assert not any(k.startswith('PointConvDW') for k in switched) and census['fused'].get('camli_pointconv_dw_bwd', 0) > 0
     assert census['fused'].get('camli_knn', 0) > 0 and census['fused'].get('camli_allpairs_lookup_bwd', 0) > 0
     assert abs(det_loss - base_loss) <= 1e-4 * max(1.0, abs(base_loss))
     for key in base_out:
@@ -223,6 +225,31 @@ def test_adjoints_left_on_hip_under_deterministic_mode_are_bit_reproducible():
             (torch.arange(b * 256, device='cuda')[:, None].expand(-1, kk), cross.view(b * 256, kk)),
             go[:, 3].reshape(b * 256, kk), accumulate=True).view(b, 256, mm)
         torch.testing.assert_close(first, want, rtol=1e-5, atol=1e-5)
+
+    # PointConvDW adjoint (round 4: ordered row kernel, no float atomics): twice the same bits, both gradients, on neighbour
+    # tables with heavy collisions (few distinct targets) as well as the usual ones; and equal to the round-3 atomic
+    # kernel up to fp32 summation order
+    for targets in (m, 37):
+        featd = torch.randn(b, c, m, generator=g).cuda()
+        goutd = torch.randn(b, c, n, generator=g).cuda()
+        wsel = torch.randn(b, c, n, generator=g).cuda()
+        msel = torch.randint(0, targets, (b, c, n), generator=g, dtype=torch.int32).cuda()
+        lib = fused._lib.load()
+
+        def dw_bwd(entry=lib.camli_pointconv_dw_bwd_ordered):
+            gfeat, gwsel = torch.empty_like(featd), torch.empty_like(goutd)
+            fused._lib.check(entry(goutd.data_ptr(), featd.data_ptr(), wsel.data_ptr(), msel.data_ptr(), gfeat.data_ptr(),
+                                   gwsel.data_ptr(), b, c, m, n, torch.cuda.current_stream().cuda_stream), 'camli_pointconv_dw_bwd')
+            return gfeat, gwsel
+        first, second = _twice(dw_bwd)
+        assert torch.equal(first[0], second[0]) and torch.equal(first[1], second[1])
+        atomic = dw_bwd(lib.camli_pointconv_dw_bwd)
+        assert torch.equal(first[1], atomic[1])
+        torch.testing.assert_close(first[0], atomic[0], rtol=1e-4, atol=1e-4)
+        want = torch.zeros(b * c, m, device='cuda').index_put_(
+            (torch.arange(b * c, device='cuda')[:, None].expand(-1, n), msel.view(b * c, n).long()),
+            (goutd * wsel).view(b * c, n), accumulate=True).view(b, c, m)
+        torch.testing.assert_close(first[0], want, rtol=1e-4, atol=1e-4)
 
     # PointConv mixing: k = 16 stays on HIP (sorted adjoint) and is reproducible; k = 8 leaves HIP in deterministic mode
     feat = torch.randn(b, 32, m, generator=g).cuda().requires_grad_(True)
