@@ -4,7 +4,8 @@
 #   bench    headline bench line (parity, roofline rows, cpu baseline) + the other configurations
 #   trace    rocprofv3 --kernel-trace --stats of the bench step and of tools/kernel_bench.py
 #   pmc      HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and MFMA busy of the isolated north-star kernels
-#   pmcb     HBM traffic of the roofline kernel over the bench command itself
+#   pmcv     SQ issue / wait counters of the VALU-bound kernels (KNN, FPS) over tools/kernel_bench.py --only knn
+#   pmcb     HBM traffic of the set-conv forward / adjoint and the all-pairs lookup over the bench command itself
 # PMC counters are collected in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never together with a
 # sys / hip / hsa trace), as MI355X_MICROARCH.md prescribes.  Every rocprofv3 command runs under its own `timeout`; a
 # canary (a two-kernel trace) guards each stage so a box whose profiler hangs costs one minute, not the whole call
@@ -12,7 +13,7 @@
 set -u
 TAG=${1:-r02}
 shift
-STAGES="${*:-bench trace pmc pmcb}"
+STAGES="${*:-bench trace pmc pmcv pmcb}"
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -68,6 +69,16 @@ pmc)
       python $ROOT/tools/kernel_bench.py --reps 2 --only 'a' > /dev/null 2>&1
   python $ROOT/tools/pmc_summary.py $OUT/pmc_mfma/p_counter_collection.csv > $OUT/pmc_kernel_bench_mfma.txt 2>&1
   rm -rf $OUT/pmc_mfma
+  ;;
+pmcv)
+  canary || continue
+  # issue-side counters of the VALU-bound north-star kernels (KNN, FPS): how much of a wave's life is VALU issue, how much
+  # is waiting (SQ counters; their own pass, as every PMC set)
+  timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU \
+      --kernel-trace --kernel-include-regex 'knn_|fps_' --output-format csv -d $OUT/pmc_valu -o p -- \
+      python $ROOT/tools/kernel_bench.py --reps 2 --only 'knn' > /dev/null 2>&1
+  python $ROOT/tools/pmc_summary.py $OUT/pmc_valu/p_counter_collection.csv > $OUT/pmc_kernel_bench_valu.txt 2>&1
+  rm -rf $OUT/pmc_valu
   ;;
 pmcb)
   canary || continue
