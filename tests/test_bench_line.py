@@ -92,3 +92,44 @@ def test_time_budget_helper():
     assert got is None and 'time budget' in why
     with pytest.raises(ZeroDivisionError):
         bench.run_with_deadline(lambda: 1 / 0, 5.0)
+
+
+def test_compact_line_round4_fields():
+    """Round 4: the line of the round (profiles/r04_a_bench_line.json) names a VALU-bound kernel when it dominates, carries
+    `roofline.worst`, `side_configs` and `cpu_baseline.os_cpu_count`, and the compaction keeps all of them below the limit."""
+    import bench
+    with open(os.path.join(ROOT, 'profiles', 'r04_a_bench_line.json')) as f:
+        line = json.loads(f.read().strip().splitlines()[-1])
+    assert line['roofline']['bound'] in ('hbm', 'mfma', 'valu', 'latency') and 0 < line['roofline']['frac'] <= 1.0
+    assert set(line['roofline']['worst']) == {'kernel', 'bound', 'frac', 'ms_per_step'}
+    assert set(line['side_configs']) == {'camlipwc', 'kitti'} and line['cpu_baseline']['os_cpu_count'] > 0
+    full = dict(_full_line(), side_configs=line['side_configs'])
+    full['roofline']['worst'] = line['roofline']['worst']
+    full['cpu_baseline']['os_cpu_count'] = 256
+    out = bench.compact_line(full, 'gpurun_out/bench_detail.json')
+    assert out['side_configs'] == line['side_configs'] and out['roofline']['worst'] == line['roofline']['worst']
+    assert out['cpu_baseline']['os_cpu_count'] == 256 and len(json.dumps(out)) < bench.LINE_LIMIT_BYTES
+
+
+def test_roofline_report_lets_every_kind_compete():
+    """camli_knn (valu) could never be the roofline kernel.  Now the entry point with the most device time wins
+    whatever bounds it, and `worst` is the lowest fraction among those holding >= 1 % of the step."""
+    import types
+    import bench
+    summary = {
+        'camli_knn': {'total_ms': 40.0, 'launches': 170, 'work': 170 * 5.0e7, 'unit': 'pairs', 'flop': 0.0},
+        'camli_pointconv_dw_fwd': {'total_ms': 30.0, 'launches': 540, 'work': 540 * 1.2e8, 'unit': 'B', 'flop': 0.0},
+        'camli_fps': {'total_ms': 25.0, 'launches': 5, 'work': 5 * 16 * 8192 * 4096.0, 'unit': 'point-updates', 'flop': 5 * 4096.0},
+        'camli_allpairs_build_fwd': {'total_ms': 20.0, 'launches': 5, 'work': 5 * 3.0e9, 'unit': 'B', 'flop': 5 * 3.6e11},
+    }
+    args = types.SimpleNamespace(batch=8, iters=12, height=540, width=960, points=8192)
+    roof, table = bench.roofline_report(summary, 5, args, step_ms=233.0)
+    assert roof['kernel'] == 'camli_knn' and roof['bound'] == 'valu' and roof['unit'] == 'Gpairs/s'
+    assert abs(roof['frac'] - (170 * 5.0e7 / 0.040 / 1e9) / bench.VALU_PAIR_PEAK_G) < 1e-3
+    assert table['camli_fps']['frac'] == round(bench.FPS_STEP_IDEAL_US / (25.0e3 / (5 * 4096.0)), 4)
+    assert roof['worst']['kernel'] == min(table, key=lambda n: table[n]['frac'])
+    # with the KNN entry gone the FPS launch dominates: a latency-bound roofline object
+    del summary['camli_knn']
+    summary['camli_fps']['total_ms'] = 50.0
+    roof, _ = bench.roofline_report(summary, 5, args, step_ms=233.0)
+    assert roof['kernel'] == 'camli_fps' and roof['bound'] == 'latency' and roof['frac'] <= 1.0
