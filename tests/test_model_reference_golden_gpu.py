@@ -3,7 +3,7 @@ against the flows, losses and gradient fingerprints RECORDED FROM THE REFERENCE'
 (tests/golden/model_*.npz, tests/golden/make_model_golden.py).  The clouds the reference handed to build_pc_pyramid --
 after its IDS transform, recorded in model_*_core_inputs.npz -- are fed to the HIP cores bit-for-bit: FPS is a chain of
 thousands of arg-max decisions and only reproducible on identical inputs, while the IDS transform's log / divide differ
-in the last ulp between CPU and GPU.  Tolerances: EPE <= 1e-4 (north star), loss 1e-4 relative, gradient norms 5e-3
+in the last ulp between CPU and GPU.  Tolerances: EPE <= 1e-4 (north star), loss 1e-4 relative, gradient norms 1e-3 (measured worst 2.8e-4)
 relative (float atomics in a few adjoints)."""
 import numpy as np
 import pytest
@@ -12,6 +12,8 @@ import torch
 from modelutils import MODEL_CASES, grad_fingerprint, hashed_fill_, synthetic_inputs
 
 pytestmark = pytest.mark.gpu
+# measured worst relative deviation of any norm over three runs: 2.8e-4 (camliraft_b2; float-atomic ordering)
+GRAD_RTOL = 1e-3
 
 
 def _share_reference_clouds(monkeypatch, core_inputs):
@@ -61,7 +63,9 @@ def test_hip_model_matches_reference_recording(name, golden, monkeypatch):
                     loss.backward()
                     names, norms = grad_fingerprint(model)
                     assert names == list(g['grad_names'])
-                    assert np.allclose(norms, g['grad_norms'], rtol=5e-3, atol=1e-6), np.abs(norms / g['grad_norms'] - 1).max()
+                    dev = np.abs(norms - g['grad_norms']) / np.maximum(np.abs(g['grad_norms']), 1e-6)
+                    print(name, 'gradient fingerprint: worst relative deviation %.2e over %d norms' % (dev.max(), len(dev)))
+                    assert np.allclose(norms, g['grad_norms'], rtol=GRAD_RTOL, atol=1e-6), dev.max()
         finally:
             census = runtime.census()
             runtime.set_census(False)
