@@ -55,7 +55,7 @@ NORTH_STAR = {
     'camli_allpairs_build_fwd': 'mfma', 'camli_allpairs_build_bwd': 'mfma', 'camli_allpairs_fold_bwd': 'hbm',
     'camli_allpairs_lookup_fwd': 'hbm', 'camli_allpairs_lookup_bwd': 'hbm',
     'camli_knn': 'valu', 'camli_fps': 'fps',
-    'camli_gather_cf_fwd': 'hbm', 'camli_gather_cf_bwd': 'hbm',
+    'camli_gather_cf_fwd': 'hbm', 'camli_gather_cf_bwd': 'hbm', 'camli_gather_cl_fwd': 'hbm', 'camli_gather_cl_bwd': 'hbm',
     'camli_pointconv_mix_fwd': 'hbm', 'camli_pointconv_mix_bwd': 'hbm',
     'camli_pointconv_dw_fwd': 'hbm', 'camli_pointconv_dw_bwd': 'hbm', 'camli_pointconv_dw_expand': 'hbm',
     'camli_weightnet_fwd': 'hbm', 'camli_weightnet_bwd': 'mfma',

@@ -46,8 +46,11 @@ def batch_indexing(batched_data, batched_indices, layout='channel_first'):
         flat = batched_indices.reshape(bs, 1, -1).expand(bs, n_channels, -1).to(torch.int64)
         return torch.gather(batched_data, 2, flat).view([bs, n_channels] + idx_shape)
     if layout == 'channel_last':
-        if batched_data.is_cuda:
-            runtime.fallback('batch_indexing', 'channel-last layout (its only product-path user, PointConv, is fused)')
+        if runtime.fused() and batched_data.is_cuda:
+            if batched_data.dim() in (2, 3) and batched_data.is_floating_point():
+                from ..csrc import fused
+                return fused.gather_rows(batched_data, batched_indices)
+            runtime.fallback('batch_indexing', 'channel-last data of rank %d / dtype %s' % (batched_data.dim(), batched_data.dtype))
         rows = torch.arange(bs, dtype=torch.long, device=batched_data.device)
         rows = rows.view([bs] + [1] * len(idx_shape)).expand([bs] + idx_shape)
         if batched_data.dim() == 2:

@@ -70,11 +70,16 @@ class Correlation3D(nn.Module):
     def build_cost_volume_pyramid(self, feat1, feat2, xyzs2, k=3, nested=False):
         """``nested``: the caller guarantees that xyzs2[l+1] is the first n_{l+1} points of xyzs2[l] (the FPS pyramid,
         models/utils.py:121-125); the lookups of the pass then search and gather all levels in one launch each."""
-        dense = torch.bmm(feat1.float().transpose(1, 2), feat2.float()) / feat1.shape[1]
-        levels = [dense]
-        for coarse, fine in zip(xyzs2[1:], xyzs2[:-1]):
-            parents = _ops.k_nearest_neighbor(fine, coarse, k=k)               # [B,M_l,k] into level l-1
-            levels.append(batch_indexing(levels[-1], parents).mean(dim=-1))
+        parents = [_ops.k_nearest_neighbor(fine, coarse, k=k)                  # [B,M_l,k] into level l-1
+                   for coarse, fine in zip(xyzs2[1:], xyzs2[:-1])]
+        if runtime.fused() and feat1.is_cuda and len(parents) < 8:
+            from ..csrc import fused
+            levels = fused.point_volume_pyramid(feat1, feat2, parents)
+        else:
+            levels = [torch.bmm(feat1.float().transpose(1, 2), feat2.float()) / feat1.shape[1]]
+            for idx in parents:
+                levels.append(batch_indexing(levels[-1], idx).mean(dim=-1))
+        dense = levels[0]
         self.cost_volume_pyramid = levels
         self._nested = None
         if nested and runtime.fused() and dense.is_cuda and len(levels) <= 4 and min(lvl.shape[2] for lvl in levels) >= self.k:

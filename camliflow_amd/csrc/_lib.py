@@ -44,6 +44,8 @@ PROTOTYPES = {
     "camli_gather_cf_fwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_gather_cf_bwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_gather_cf_bwd_sorted": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_gather_cl_fwd": (_int, [_c_float_p, _c_i64_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_gather_cl_bwd_sorted": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_pointconv_mix_bwd_scratch_bytes": (ctypes.c_int64, [_int, _int, _int, _int]),
     "camli_pointconv_mix_bwd_sorted": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, ctypes.c_void_p, ctypes.c_void_p,
                                               _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _int, _stream]),

@@ -843,6 +843,49 @@ def gather_points(data, indices):
     return out.view([b, c] + list(indices.shape[1:]))
 
 
+class _GatherCL(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, data, idx_flat):
+        lib = _lib.load()
+        b, m, c = data.shape
+        i = idx_flat.shape[1]
+        out = torch.empty((b, i, c), dtype=torch.float32, device=data.device)
+        with _on_device(data):
+            _lib.launch('camli_gather_cl_fwd', lib.camli_gather_cl_fwd, data.data_ptr(), idx_flat.data_ptr(),
+                        out.data_ptr(), b, c, m, i, _stream_ptr(data), work=(8.0 * b * c * i + 8.0 * b * i, 'B'))
+        ctx.save_for_backward(idx_flat)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        lib = _lib.load()
+        (idx_flat,) = ctx.saved_tensors
+        gout = gout.contiguous().float()
+        b, i, c = gout.shape
+        order, offsets = inverse_map(idx_flat, ctx.m)
+        gdata = torch.empty((b, ctx.m, c), dtype=torch.float32, device=gout.device)
+        with _on_device(gout):
+            _lib.launch('camli_gather_cl_bwd', lib.camli_gather_cl_bwd_sorted, gout.data_ptr(), order.data_ptr(),
+                        offsets.data_ptr(), gdata.data_ptr(), b, c, ctx.m, i, _stream_ptr(gout),
+                        work=(4.0 * b * c * (i + ctx.m) + 4.0 * b * (i + ctx.m), 'B'))
+        return gdata, None
+
+
+def gather_rows(data, indices):
+    """batch_indexing, channel-last: data [B,M,C] or [B,M], indices [B,I1..Im] -> [B,I1..Im,C] or [B,I1..Im]
+    (utils.py:85-104)."""
+    _require_cuda('gather_rows', data, indices)
+    b = data.shape[0]
+    flat = indices.reshape(b, -1).to(torch.int64).contiguous()
+    rows = data.float().contiguous()
+    if data.dim() == 2:
+        return _GatherCL.apply(rows.unsqueeze(-1), flat).view([b] + list(indices.shape[1:]))
+    return _GatherCL.apply(rows, flat).view([b] + list(indices.shape[1:]) + [data.shape[2]])
+
+
 class _KnnInterp(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
@@ -935,6 +978,62 @@ def corr3d_lookup_input(cost_volume, xyz1, xyz2, knn_indices):
     assert not xyz1.requires_grad and not xyz2.requires_grad
     return _Corr3DGather.apply(cost_volume.float().contiguous(), xyz1.float().contiguous(),
                                xyz2.float().contiguous(), knn_indices.contiguous())
+
+
+class _PointVolumes(torch.autograd.Function):
+    """V_l = f1^T . f2_l / C for every level of the point cost-volume pyramid, one launch per level forward and the
+    grouped adjoint GEMMs backward (camli_allpairs_build_fwd / _bwd, the fp32 matrix-core kernel of the 2-D all-pairs
+    volume with scale 1/C).  The reference builds level 0 with torch.bmm + a division over the volume and every coarser
+    level by gathering and averaging VOLUME columns (camliraft_l_core.py:51-60); the KNN mean acts on the target point
+    only and is linear, so level l is the same GEMM against the KNN-averaged target FEATURES (equal up to fp32 summation
+    order), each volume element is written once, and the adjoint never scatters into volume-sized tensors."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, feat1, *feat2_levels):
+        lib = _lib.load()
+        feat1 = feat1.contiguous()
+        feat2_levels = [t.contiguous() for t in feat2_levels]
+        b, c, n = feat1.shape
+        sizes = [t.shape[2] for t in feat2_levels]
+        vols = [torch.empty((b, n, m), dtype=torch.float32, device=feat1.device) for m in sizes]
+        total = sum(sizes)
+        with _on_device(feat1):
+            _lib.launch('camli_allpairs_build_fwd', lib.camli_allpairs_build_fwd, feat1.data_ptr(), _ptr_array(feat2_levels),
+                        _ptr_array(vols), (ctypes.c_int * len(sizes))(*sizes), len(sizes), b, c, n, 1.0 / c, _stream_ptr(feat1),
+                        work=(4.0 * b * n * total + 4.0 * b * c * (n + total), 'B'), flop=2.0 * b * n * total * c)
+        ctx.save_for_backward(feat1, *feat2_levels)
+        return tuple(vols)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, *gvols):
+        lib = _lib.load()
+        feat1, *feat2_levels = ctx.saved_tensors
+        b, c, n = feat1.shape
+        sizes = [t.shape[2] for t in feat2_levels]
+        gvols = [torch.zeros((b, n, m), dtype=torch.float32, device=feat1.device) if g is None else g.contiguous().float()
+                 for g, m in zip(gvols, sizes)]
+        g1 = torch.empty_like(feat1)
+        g2_levels = [torch.empty_like(t) for t in feat2_levels]
+        total = sum(sizes)
+        with _on_device(feat1):
+            _lib.launch('camli_allpairs_build_bwd', lib.camli_allpairs_build_bwd, feat1.data_ptr(), _ptr_array(feat2_levels),
+                        _ptr_array(gvols), (ctypes.c_int * len(sizes))(*sizes), len(sizes), g1.data_ptr(), _ptr_array(g2_levels),
+                        b, c, n, 1.0 / c, _stream_ptr(feat1),
+                        work=(4.0 * b * n * total + 4.0 * b * c * 2 * (n + total), 'B'), flop=4.0 * b * n * total * c)
+        return (g1, *g2_levels)
+
+
+def point_volume_pyramid(feat1, feat2, parents):
+    """Correlation3D.build_cost_volume_pyramid (camliraft_l_core.py:51-60) on the matrix cores: feat1 [B,C,N],
+    feat2 [B,C,M0], parents[l] int64 [B,M_{l+1},k] = the k nearest level-l targets of every level-(l+1) target.
+    Returns the list of [B,N,M_l] volumes."""
+    _require_cuda('point_volume_pyramid', feat1, feat2)
+    levels = [feat2.float()]
+    for idx in parents:
+        levels.append(gather_points(levels[-1], idx).mean(dim=-1))          # [B,C,M_l]: tiny next to the volumes
+    return list(_PointVolumes.apply(feat1.float(), *levels))
 
 
 class Corr3DPyramid:

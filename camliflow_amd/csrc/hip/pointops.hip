@@ -4,6 +4,7 @@
 // scatter_add / index_put(accumulate) with one atomic per gathered element.
 //
 //   gather_cf      models/utils.py:61-83   data [B,C,M], idx [B,I]          -> out [B,C,I]
+//   gather_cl      models/utils.py:85-104  data [B,M,C], idx [B,I]          -> out [B,I,C]
 //   knn_interp     models/utils.py:130-146 IDW of the k nearest             -> out [B,C,Nq]
 //   corr3d_gather  models/camliraft_l_core.py:62-76 (dxyz, cost entry)      -> out [B,4,N,k]
 //
@@ -115,6 +116,55 @@ void launch_gather_cf_bwd_lds(const float* gout, const int32_t* order, const int
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((gather_cf_bwd_lds_kernel<TC>), dim3(camli_divup(C, TC), B), dim3(threads), lds, stream, gout,
                        order, offsets, gdata, C, M, I, vec);
+}
+
+// ---- gather along the point axis, channel-last (models/utils.py:85-104) -----------------------------
+// data [B,M,C] -> out [B,I,C] = data[b, idx[b,i], :]: a row copy.  One thread per V consecutive channels of one output
+// row (V = 4 when rows are 16-byte multiples, else 1), channels fastest: a row is read and written in whole lines, the
+// int64 index of a row is one load shared by the C/V lanes that copy it.  C = 1 is the reference's rank-2 form
+// (data [B,M], models/camliraft_l_core.py:70-74): coalesced writes, 4-byte gathers.
+template <int V>
+__global__ __launch_bounds__(256) void gather_cl_fwd_kernel(const float* __restrict__ data, const int64_t* __restrict__ idx,
+                                                             float* __restrict__ out, int CV, int M, int64_t rows_b) {
+    // rows_b = I * CV work items per batch entry
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= rows_b) return;
+    const int64_t i = t / CV;
+    const int c = (int)(t - i * CV);
+    const int I = (int)(rows_b / CV);
+    const int64_t m = idx[(int64_t)b * I + i];
+    if (V == 4)
+        reinterpret_cast<float4*>(out)[((int64_t)b * I + i) * CV + c] = reinterpret_cast<const float4*>(data)[((int64_t)b * M + m) * CV + c];
+    else
+        out[((int64_t)b * I + i) * CV + c] = data[((int64_t)b * M + m) * CV + c];
+}
+
+// adjoint through the inverse map (see gather_cf_bwd_sorted_kernel): gdata[b,m,:] = sum of the gout rows whose index
+// is m, in ascending flat position; every output written once, no atomics.  `order` holds global row numbers b*I + i.
+template <int V>
+__global__ __launch_bounds__(256) void gather_cl_bwd_sorted_kernel(const float* __restrict__ gout, const int32_t* __restrict__ order,
+                                                                    const int32_t* __restrict__ offsets, float* __restrict__ gdata,
+                                                                    int CV, int64_t rows_b) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= rows_b) return;
+    const int64_t m = t / CV;
+    const int c = (int)(t - m * CV);
+    const int M = (int)(rows_b / CV);
+    const int beg = offsets[(int64_t)b * M + m], end = offsets[(int64_t)b * M + m + 1];
+    if (V == 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = beg; e < end; ++e) {
+            const float4 g = reinterpret_cast<const float4*>(gout)[(int64_t)order[e] * CV + c];
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        }
+        reinterpret_cast<float4*>(gdata)[((int64_t)b * M + m) * CV + c] = acc;
+    } else {
+        float acc = 0.0f;
+        for (int e = beg; e < end; ++e) acc += gout[(int64_t)order[e] * CV + c];
+        gdata[((int64_t)b * M + m) * CV + c] = acc;
+    }
 }
 
 // ---- inverse-distance interpolation from precomputed k nearest neighbours -------------------------
@@ -445,6 +495,42 @@ extern "C" int camli_gather_cf_bwd_sorted(const float* gout, const int32_t* inv_
                            inv_order, inv_offsets, gdata, C, M, I);
     }
     return camli_check_launch("camli_gather_cf_bwd_sorted");
+}
+
+extern "C" int camli_gather_cl_fwd(const float* data, const int64_t* idx, float* out, int B, int C, int M, int I,
+                                   void* stream) {
+    if (B == 0 || I == 0) return CAMLI_OK;
+    if (!data || !idx || !out) { camli_set_error("camli_gather_cl_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || C < 1 || M < 1 || I < 0 || B > 65535 || (int64_t)I * C > ((int64_t)1 << 38)) {
+        camli_set_error("camli_gather_cl_fwd: bad shape B=%d C=%d M=%d I=%d", B, C, M, I);
+        return CAMLI_EINVAL;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const int cv = vec ? C / 4 : C;
+    const int64_t rows_b = (int64_t)I * cv;
+    const dim3 grid((unsigned)((rows_b + 255) / 256), B);
+    if (vec) hipLaunchKernelGGL(gather_cl_fwd_kernel<4>, grid, dim3(256), 0, s, data, idx, out, cv, M, rows_b);
+    else hipLaunchKernelGGL(gather_cl_fwd_kernel<1>, grid, dim3(256), 0, s, data, idx, out, cv, M, rows_b);
+    return camli_check_launch("camli_gather_cl_fwd");
+}
+
+extern "C" int camli_gather_cl_bwd_sorted(const float* gout, const int32_t* inv_order, const int32_t* inv_offsets,
+                                          float* gdata, int B, int C, int M, int I, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!gout || !inv_order || !inv_offsets || !gdata) { camli_set_error("camli_gather_cl_bwd_sorted: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || C < 1 || M < 1 || I < 0 || B > 65535 || (int64_t)B * I > 2147483647LL || (int64_t)M * C > ((int64_t)1 << 38)) {
+        camli_set_error("camli_gather_cl_bwd_sorted: bad shape B=%d C=%d M=%d I=%d", B, C, M, I);
+        return CAMLI_EINVAL;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(gdata)) & 15) == 0;
+    const int cv = vec ? C / 4 : C;
+    const int64_t rows_b = (int64_t)M * cv;
+    const dim3 grid((unsigned)((rows_b + 255) / 256), B);
+    if (vec) hipLaunchKernelGGL(gather_cl_bwd_sorted_kernel<4>, grid, dim3(256), 0, s, gout, inv_order, inv_offsets, gdata, cv, rows_b);
+    else hipLaunchKernelGGL(gather_cl_bwd_sorted_kernel<1>, grid, dim3(256), 0, s, gout, inv_order, inv_offsets, gdata, cv, rows_b);
+    return camli_check_launch("camli_gather_cl_bwd_sorted");
 }
 
 static int knn_interp_args_ok(const char* what, const void* a, const void* b, const void* c, const void* d,

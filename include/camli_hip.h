@@ -174,6 +174,16 @@ int camli_gather_cf_bwd_sorted(const float *gout, const int32_t *inv_order, cons
                                int B, int C, int M, int I, void *stream);
 
 /*
+ * batch_indexing, channel-last (models/utils.py:85-104): out[b,i,:] = data[b,idx[b,i],:].
+ *   data [B,M,C] (C = 1: the rank-2 form [B,M] of models/camliraft_l_core.py:70-74), idx int64 [B,I], out [B,I,C].
+ *   bwd through the inverse map of idx (see camli_gather_cf_bwd_sorted): gdata [B,M,C] fully written, no atomics,
+ *   fixed summation order (ascending i).
+ */
+int camli_gather_cl_fwd(const float *data, const int64_t *idx, float *out, int B, int C, int M, int I, void *stream);
+int camli_gather_cl_bwd_sorted(const float *gout, const int32_t *inv_order, const int32_t *inv_offsets, float *gdata,
+                               int B, int C, int M, int I, void *stream);
+
+/*
  * knn_interpolation tail (models/utils.py:138-146) given the k <= 8 nearest inputs of every query:
  *   w_j = (1/max(|in_xyz[:,knn_j] - q|, 1e-8)) / sum_j(...);  out[b,c,q] = sum_j feat[b,c,knn_j] * w_j
  *   in_xyz [B,3,M], feat [B,C,M], q_xyz [B,3,Nq] channel-first; knn int64 rows of stride knn_stride.

@@ -127,6 +127,28 @@ def scatter_add_cf(gout, idx, N):
     return out
 
 
+def gather_cl(data, idx):
+    """channel-last batch_indexing: data [B,N,C] (or [B,N]), idx int64 [B,I] -> [B,I,C] (or [B,I])"""
+    data, idx = _f32(data), _i64(idx)
+    flat = data.ndim == 2
+    B, N = data.shape[:2]
+    C = 1 if flat else data.shape[2]
+    I = idx.shape[1]
+    out = np.zeros((B, I) if flat else (B, I, C), dtype=np.float32)
+    _chk(_load().oracle_gather_cl(_p(data), _p(idx), _p(out), B, C, N, I), "gather_cl")
+    return out
+
+
+def scatter_add_cl(gout, idx, N):
+    gout, idx = _f32(gout), _i64(idx)
+    flat = gout.ndim == 2
+    B, I = gout.shape[:2]
+    C = 1 if flat else gout.shape[2]
+    out = np.zeros((B, N) if flat else (B, N, C), dtype=np.float32)
+    _chk(_load().oracle_scatter_add_cl(_p(gout), _p(idx), _p(out), B, C, N, I), "scatter_add_cl")
+    return out
+
+
 def knn_interp_fwd(in_xyz, feat, q_xyz, knn_idx):
     """channel-first: in_xyz [B,3,M], feat [B,C,M], q_xyz [B,3,Nq], knn_idx [B,Nq,k] -> [B,C,Nq]"""
     in_xyz, feat, q_xyz, knn_idx = _f32(in_xyz), _f32(feat), _f32(q_xyz), _i64(knn_idx)

@@ -300,6 +300,33 @@ int oracle_scatter_add_cf(const float *gout, const int64_t *idx, float *gdata, i
     return 0;
 }
 
+/*   channel-last (models/utils.py:85-104): data [B,N,C] (C = 1 for the rank-2 form [B,N]), idx int64 [B,I]
+ *   -> out [B,I,C] = data[b, idx[b,i], :]; the adjoint adds gout rows into gdata rows in ascending i. */
+int oracle_gather_cl(const float *data, const int64_t *idx, float *out, int B, int C, int N, int I)
+{
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < I; ++i) {
+            const int64_t m = idx[(size_t)b * I + i];
+            if (m < 0 || m >= N) return -1;
+            memcpy(out + ((size_t)b * I + i) * C, data + ((size_t)b * N + m) * C, sizeof(float) * (size_t)C);
+        }
+    return 0;
+}
+
+int oracle_scatter_add_cl(const float *gout, const int64_t *idx, float *gdata, int B, int C, int N, int I)
+{
+    memset(gdata, 0, sizeof(float) * (size_t)B * N * C);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < I; ++i) {
+            const int64_t m = idx[(size_t)b * I + i];
+            if (m < 0 || m >= N) return -1;
+            float *row = gdata + ((size_t)b * N + m) * C;
+            const float *g = gout + ((size_t)b * I + i) * C;
+            for (int c = 0; c < C; ++c) row[c] += g[c];
+        }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------
  * knn_interpolation  (k nearest + inverse-distance weights)
  * follows models/utils.py:130-146.

@@ -150,6 +150,45 @@ def allpairs_pyramid_bwd(gpyr, f1, f2):
     return gf1.astype(np.float32), gf2.astype(np.float32)
 
 
+# ---- point cost-volume pyramid, models/camliraft_l_core.py:51-60 -------------------------------------------------------
+# cost_volume = bmm(f1^T, f2) / C  [B,N,M0]; level i = mean over the k nearest level-(i-1) targets of every level-i target
+# of the level-(i-1) volume's columns (batch_indexing(volume, knn) -> [B,N,M_i,k], mean over k).  The neighbour tables
+# are inputs here (k_nearest_neighbor has its own oracle).
+
+def point_volume_pyramid_fwd(f1, f2, parents):
+    """f1 [B,C,N], f2 [B,C,M0], parents[i] int [B,M_{i+1},k] -> list of [B,N,M_i]."""
+    f1, f2 = _f64(f1, f2)
+    b, c, _ = f1.shape
+    pyr = [np.einsum('bcn,bcm->bnm', f1, f2) / np.float64(c)]
+    for idx in parents:
+        idx = np.asarray(idx, dtype=np.int64)
+        prev = pyr[-1]
+        cols = np.stack([prev[bi][:, idx[bi]] for bi in range(b)])          # [B,N,M_i,k]
+        pyr.append(cols.mean(axis=-1))
+    return [p.astype(np.float32) for p in pyr]
+
+
+def point_volume_pyramid_bwd(gpyr, f1, f2, parents):
+    """adjoint of the above: gradients of the levels -> (d/d f1, d/d f2).  The mean's adjoint adds g / k into each of
+    the k gathered columns (repeated parents add repeatedly)."""
+    f1, f2 = _f64(f1, f2)
+    b, c, _ = f1.shape
+    g = None
+    for lvl in reversed(range(len(gpyr))):
+        cur = np.asarray(gpyr[lvl], dtype=np.float64).copy()
+        if g is not None:
+            idx = np.asarray(parents[lvl], dtype=np.int64)                   # [B,M_{lvl+1},k] into level lvl
+            k = idx.shape[-1]
+            for bi in range(b):
+                for j in range(k):
+                    np.add.at(cur[bi], (slice(None), idx[bi, :, j]), g[bi] / k)
+        g = cur
+    gvol = g / np.float64(c)
+    gf1 = np.einsum('bnm,bcm->bcn', gvol, f2)
+    gf2 = np.einsum('bnm,bcn->bcm', gvol, f1)
+    return gf1.astype(np.float32), gf2.astype(np.float32)
+
+
 # ---- ResNet stem max pooling (kernel 3, stride 2, padding 1) and the bottleneck epilogue -------------------------------
 # mmdet 2.14 ResNet (README.md:78-79; call site models/raft_core.py:10-38): self.maxpool = nn.MaxPool2d(3, 2, 1);
 # Bottleneck.forward ends with  out = bn3(conv3(.)) ; out += identity ; out = relu(out)  -- with the frozen / folded

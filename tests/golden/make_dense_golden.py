@@ -5,6 +5,9 @@
   dense_flow_head       models/raft_core.py FlowHead2D (:169-182): input / output of its two-channel conv2, gradients
   dense_allpairs_{even,odd}  models/raft_core.py Correlation2D.build_cost_volume_pyramid (:52-68): the aligned feature
                         maps, the four levels, gradients back to the aligned maps
+  dense_point_volume    models/camliraft_l_core.py Correlation3D.build_cost_volume_pyramid (:51-60): features, the
+                        neighbour tables it computed, the four levels, gradients back to the features; and
+                        models/utils.py batch_indexing(layout='channel_last') (:85-104), rank-3 and rank-2 data
   dense_gru2d           models/raft_core.py GRU2D (:110-140): weights, inputs (h, x = [context | motion]), the input and
                         output of each of its six 1x5 / 5x1 convolutions, the new hidden state
   dense_resnet_glue     the stem max pooling and the bottleneck epilogue of the ResNet trunk the reference instantiates
@@ -108,6 +111,58 @@ def golden_allpairs(tag, hh, ww):
     save('dense_allpairs_' + tag, **arrays)
 
 
+def golden_point_volume():
+    """Correlation3D.build_cost_volume_pyramid (:51-60) on an FPS-like nested target pyramid; the neighbour tables it
+    computes internally are recorded by wrapping the module's k_nearest_neighbor; batch_indexing's channel-last form
+    (models/utils.py:85-104) on the same data."""
+    import models.camliraft_l_core as core
+    from models.utils import batch_indexing
+    g = torch.Generator().manual_seed(26)
+    b, c, n = 2, 24, 72
+    sizes = [72, 40, 20, 12]
+    corr = Correlation3D(out_channels=128, k=16)
+    feat1 = torch.randn(b, c, n, generator=g, requires_grad=True)
+    feat2 = torch.randn(b, c, sizes[0], generator=g, requires_grad=True)
+    cloud = torch.randn(b, 3, sizes[0], generator=g)
+    xyzs2 = [cloud[:, :, :m].contiguous() for m in sizes]
+    tables = []
+    inner = core.k_nearest_neighbor
+
+    def recording(*args, **kwargs):
+        out = inner(*args, **kwargs)
+        tables.append(out.detach().clone())
+        return out
+    core.k_nearest_neighbor = recording
+    try:
+        corr.build_cost_volume_pyramid(feat1, feat2, xyzs2, k=3)
+    finally:
+        core.k_nearest_neighbor = inner
+    pyr = corr.cost_volume_pyramid
+    gpyr = [torch.randn(p.shape, generator=g) for p in pyr]
+    sum((p * q).sum() for p, q in zip(pyr, gpyr)).backward()
+    arrays = {'f1': feat1.detach(), 'f2': feat2.detach(), 'gf1': feat1.grad, 'gf2': feat2.grad}
+    for lvl, (p, q) in enumerate(zip(pyr, gpyr)):
+        arrays['pyr%d' % lvl] = p.detach()
+        arrays['gpyr%d' % lvl] = q
+        arrays['xyz%d' % lvl] = xyzs2[lvl]
+    for lvl, t in enumerate(tables):
+        arrays['parents%d' % lvl] = t
+    # channel-last batch_indexing: rank-3 rows and the rank-2 form calc_matching_cost uses (:70-74)
+    rows = torch.randn(b, 30, 7, generator=g, requires_grad=True)
+    picks = torch.randint(0, 30, (b, 11, 5), generator=g)
+    got = batch_indexing(rows, picks, layout='channel_last')
+    grow = torch.randn(got.shape, generator=g)
+    got.backward(grow)
+    flat = torch.randn(b * 9, 30, generator=g, requires_grad=True)
+    fpicks = torch.randint(0, 30, (b * 9, 16), generator=g)
+    fgot = batch_indexing(flat, fpicks, layout='channel_last')
+    fg = torch.randn(fgot.shape, generator=g)
+    fgot.backward(fg)
+    arrays.update(cl_data=rows.detach(), cl_idx=picks, cl_out=got.detach(), cl_gout=grow, cl_gdata=rows.grad,
+                  cl2_data=flat.detach(), cl2_idx=fpicks, cl2_out=fgot.detach(), cl2_gout=fg, cl2_gdata=flat.grad)
+    save('dense_point_volume', **arrays)
+
+
 def golden_gru2d():
     g = torch.Generator().manual_seed(25)
     hd, cd, md = 16, 8, 24                       # hidden, context and motion channels: x = cat([context, motion])
@@ -155,3 +210,4 @@ if __name__ == '__main__':
     golden_allpairs('odd', 9, 15)
     golden_gru2d()
     golden_resnet_glue()
+    golden_point_volume()

@@ -6,6 +6,8 @@
   camli_allpairs_build_fwd/bwd        all-pairs volume pyramid          models/raft_core.py:52-68
   camli_maxpool3x3s2_fwd/bwd          ResNet stem pooling               mmdet ResNet (call site raft_core.py:10-38)
   camli_bias_act_res_fwd, camli_bias_act_nhwc_fwd/bwd                   bottleneck epilogue, NCHW and channels-last
+  camli_allpairs_build_fwd/bwd (scale 1/C, KNN-averaged target features) point cost-volume pyramid  models/camliraft_l_core.py:51-60
+  camli_gather_cl_fwd/bwd_sorted      channel-last batch_indexing       models/utils.py:85-104
 
 and against the committed golden tensors of the reference modules themselves (tests/golden/dense_*.npz)."""
 import numpy as np
@@ -200,3 +202,106 @@ def test_epilogue_kernels_vs_oracle(shape, channels_last, oracle_dense):
             _close(grads[1], wgb, what='gbias')
             if with_res:
                 _close(grads[2], wgx, rtol=1e-6, atol=1e-6, what='gres')
+
+
+# ---- point cost-volume pyramid build (camliraft_l_core.py:51-60) and channel-last batch_indexing (utils.py:85-104) ----
+def _run_point_volumes(f1, f2, parents, gpyr):
+    from camliflow_amd.csrc import fused
+    a, b = dev(f1).requires_grad_(True), dev(f2).requires_grad_(True)
+    pyr = fused.point_volume_pyramid(a, b, [dev(p) for p in parents])
+    sum((p * dev(q)).sum() for p, q in zip(pyr, gpyr)).backward()
+    return pyr, a.grad, b.grad
+
+
+def test_point_volume_build_vs_reference_golden(golden):
+    g = golden('dense_point_volume')
+    parents = [g['parents%d' % lvl] for lvl in range(3)]
+    pyr, gf1, gf2 = _run_point_volumes(g['f1'], g['f2'], parents, [g['gpyr%d' % lvl] for lvl in range(4)])
+    for lvl, p in enumerate(pyr):
+        _close(p, g['pyr%d' % lvl], what='level %d' % lvl)
+    _close(gf1, g['gf1'], what='gf1')
+    _close(gf2, g['gf2'], what='gf2')
+
+
+def test_point_volume_module_build_matches_reference_golden(golden):
+    """the module path: Correlation3D.build_cost_volume_pyramid computes the neighbour tables itself (camli_knn)."""
+    from camliflow_amd.cores.raft3d import Correlation3D
+    g = golden('dense_point_volume')
+    corr = Correlation3D(out_channels=128, k=16).cuda()
+    xyzs2 = [dev(g['xyz%d' % lvl]) for lvl in range(4)]
+    f1, f2 = dev(g['f1']).requires_grad_(True), dev(g['f2']).requires_grad_(True)
+    corr.build_cost_volume_pyramid(f1, f2, xyzs2, k=3)
+    for lvl, p in enumerate(corr.cost_volume_pyramid):
+        _close(p, g['pyr%d' % lvl], what='level %d' % lvl)
+    sum((p * dev(g['gpyr%d' % lvl])).sum() for lvl, p in enumerate(corr.cost_volume_pyramid)).backward()
+    _close(f1.grad, g['gf1'], what='gf1')
+    _close(f2.grad, g['gf2'], what='gf2')
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 2048, (2048, 1024, 512, 256)), (1, 64, 300, (257, 130, 33)), (3, 20, 129, (129,))],
+                         ids=lambda s: 'b%dc%dn%d' % s[:3])
+def test_point_volume_build_vs_oracle(shape, oracle_dense):
+    b, c, n, sizes = shape
+    rng = np.random.default_rng(n)
+    f1 = rng.standard_normal((b, c, n)).astype(np.float32)
+    f2 = rng.standard_normal((b, c, sizes[0])).astype(np.float32)
+    parents = [rng.integers(0, fine, size=(b, coarse, 3)) for fine, coarse in zip(sizes[:-1], sizes[1:])]
+    gpyr = [rng.standard_normal((b, n, m)).astype(np.float32) for m in sizes]
+    pyr, gf1, gf2 = _run_point_volumes(f1, f2, parents, gpyr)
+    want = oracle_dense.point_volume_pyramid_fwd(f1, f2, parents)
+    for lvl, (p, w) in enumerate(zip(pyr, want)):
+        _close(p, w, what='level %d' % lvl)
+    if n <= 300:        # the numpy adjoint scatters column by column: small cases only
+        wf1, wf2 = oracle_dense.point_volume_pyramid_bwd(gpyr, f1, f2, parents)
+        _close(gf1, wf1, what='gf1')
+        _close(gf2, wf2, what='gf2')
+
+
+def test_point_volume_build_full_size_adjoint_property():
+    """<V(f1, f2), G> is bilinear in (f1, f2): <G, V> = <f1, dV/df1^T G> = <f2, dV/df2^T G> at the configs[2] size."""
+    b, c, n, sizes = 2, 128, 2048, (2048, 1024, 512, 256)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    f1 = torch.randn(b, c, n, device='cuda', generator=gen)
+    f2 = torch.randn(b, c, sizes[0], device='cuda', generator=gen)
+    parents = [torch.randint(0, fine, (b, coarse, 3), device='cuda', generator=gen) for fine, coarse in zip(sizes[:-1], sizes[1:])]
+    gpyr = [torch.randn(b, n, m, device='cuda', generator=gen).numpy(force=True) for m in sizes]
+    pyr, gf1, gf2 = _run_point_volumes(f1.numpy(force=True), f2.numpy(force=True), [p.numpy(force=True) for p in parents], gpyr)
+    total = sum((p.double() * dev(q).double()).sum() for p, q in zip(pyr, gpyr)).item()
+    assert abs((f1.double() * gf1.double()).sum().item() - total) <= 1e-5 * abs(total) + 1e-3
+    assert abs((f2.double() * gf2.double()).sum().item() - total) <= 1e-5 * abs(total) + 1e-3
+
+
+def test_channel_last_gather_vs_reference_golden(golden):
+    from camliflow_amd.cores.geometry import batch_indexing
+    g = golden('dense_point_volume')
+    for tag in ('cl', 'cl2'):
+        data = dev(g[tag + '_data']).requires_grad_(True)
+        out = batch_indexing(data, dev(g[tag + '_idx']), layout='channel_last')
+        assert np.array_equal(out.detach().cpu().numpy(), g[tag + '_out'])
+        out.backward(dev(g[tag + '_gout']))
+        _close(data.grad, g[tag + '_gdata'], what=tag)
+
+
+@pytest.mark.parametrize('case', [(2, 100, 1, (37,)), (3, 513, 7, (40, 3)), (2, 2048, 64, (1024, 16)), (1, 5, 4, (1,)),
+                                  (2, 4096, 128, (33,))], ids=lambda c: 'b%dm%dc%d' % c[:3])
+@pytest.mark.parametrize('rank2', [False, True], ids=['rows', 'flat'])
+def test_channel_last_gather_vs_oracle(case, rank2, oracle_lib):
+    """forward bit-exact; the adjoint sums a row's contributions in ascending position like the oracle: bit-exact too."""
+    from camliflow_amd.csrc import fused
+    b, m, c, ishape = case
+    if rank2 and c != 1:
+        pytest.skip('rank-2 data is the C = 1 form')
+    rng = np.random.default_rng(m + c)
+    data = rng.standard_normal((b, m) if rank2 else (b, m, c)).astype(np.float32)
+    idx = rng.integers(0, m, size=(b,) + ishape)
+    if m > 8:
+        idx[0].flat[:5] = 3                      # repeated targets: the adjoint has to add
+    t = dev(data).requires_grad_(True)
+    out = fused.gather_rows(t, dev(idx))
+    flat = idx.reshape(b, -1)
+    want = oracle_lib.gather_cl(data, flat)
+    assert out.shape == (b,) + ishape + (() if rank2 else (c,))
+    assert np.array_equal(out.detach().cpu().numpy().reshape(want.shape), want)
+    gout = rng.standard_normal(want.shape).astype(np.float32)
+    out.backward(dev(gout).view_as(out))
+    assert np.array_equal(t.grad.cpu().numpy(), oracle_lib.scatter_add_cl(gout, flat, m))

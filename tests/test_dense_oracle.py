@@ -77,3 +77,25 @@ def test_conv5_and_gate_arithmetic_vs_reference_gru2d(golden):
         pre_q = dense.conv5_fwd(np.concatenate([rh, x], axis=1), g['convq' + suffix + '_w'], g['convq' + suffix + '_b'])
         h, _ = glue.gru_blend_fwd(pre_q, np.zeros_like(pre_q), z, h, nan_to_num=(suffix == '2'))
     _close(h, g['out'], rtol=1e-5, atol=1e-6)
+
+
+def test_point_volume_pyramid_and_channel_last_gather_vs_reference(golden, oracle_lib):
+    """camliraft_l_core.py:51-60 (build + its autograd adjoint) and utils.py:85-104 (channel-last batch_indexing)."""
+    g = golden('dense_point_volume')
+    parents = [g['parents%d' % lvl] for lvl in range(3)]
+    # the reference's k_nearest_neighbor on the recorded level clouds gives the recorded tables (KNN oracle, fp32 ties aside)
+    for lvl in range(3):
+        fine = np.ascontiguousarray(g['xyz%d' % lvl].transpose(0, 2, 1))
+        coarse = np.ascontiguousarray(g['xyz%d' % (lvl + 1)].transpose(0, 2, 1))
+        assert np.array_equal(oracle_lib.knn(fine, coarse, 3), parents[lvl])
+    pyr = dense.point_volume_pyramid_fwd(g['f1'], g['f2'], parents)
+    for lvl, p in enumerate(pyr):
+        _close(p, g['pyr%d' % lvl], rtol=1e-4, atol=1e-5)
+    gf1, gf2 = dense.point_volume_pyramid_bwd([g['gpyr%d' % lvl] for lvl in range(4)], g['f1'], g['f2'], parents)
+    _close(gf1, g['gf1'], rtol=1e-4, atol=1e-5)
+    _close(gf2, g['gf2'], rtol=1e-4, atol=1e-5)
+    idx = g['cl_idx'].reshape(g['cl_idx'].shape[0], -1)
+    assert np.array_equal(oracle_lib.gather_cl(g['cl_data'], idx).reshape(g['cl_out'].shape), g['cl_out'])
+    _close(oracle_lib.scatter_add_cl(g['cl_gout'].reshape(idx.shape + (-1,)), idx, g['cl_data'].shape[1]), g['cl_gdata'])
+    assert np.array_equal(oracle_lib.gather_cl(g['cl2_data'], g['cl2_idx']), g['cl2_out'])
+    _close(oracle_lib.scatter_add_cl(g['cl2_gout'], g['cl2_idx'], g['cl2_data'].shape[1]), g['cl2_gdata'])
