@@ -164,28 +164,12 @@ class CamLiPWC(_FreezableBN, FlowModel):
         flows_2d, flows_3d = self.core.decode(xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, paral)
         flows_3d = [flows_paral2persp(xyz1, [f], persp, paral)[0] for xyz1, f in zip(xyzs1, flows_3d)]
 
-        final_flow_2d = resize_flow2d(flows_2d[0], origin_h, origin_w)
-        final_flow_3d = flows_3d[0]
-        outputs = {'flow_2d': final_flow_2d, 'flow_3d': final_flow_3d}
-        if 'flow_2d' not in inputs or 'flow_3d' not in inputs:
-            return outputs
+        final = {'flow_2d': resize_flow2d(flows_2d[0], origin_h, origin_w), 'flow_3d': flows_3d[0]}
+        return self.supervise(inputs, final, {
+            'flow_2d': lambda target: calc_pyramid_loss_2d(flows_2d, target, self.cfgs.loss2d),
+            'flow_3d': lambda target: calc_pyramid_loss_3d(flows_3d, target, self.cfgs.loss3d, sample_indices1)})
 
-        target_2d, target_3d = inputs['flow_2d'].float(), inputs['flow_3d'].float()
-        loss_2d = calc_pyramid_loss_2d(flows_2d, target_2d, self.cfgs.loss2d)
-        loss_3d = calc_pyramid_loss_3d(flows_3d, target_3d, self.cfgs.loss3d, sample_indices1)
-        self.loss = loss_2d + loss_3d
-        self.update_metrics('loss', self.loss)
-        self.update_metrics('loss2d', loss_2d)
-        self.update_metrics('loss3d', loss_3d)
-        self.update_2d_metrics(final_flow_2d, target_2d)
-        self.update_3d_metrics(final_flow_3d, target_3d)
-        if 'occ_mask_3d' in inputs:
-            self.update_3d_metrics(final_flow_3d, target_3d, inputs['occ_mask_3d'])
-        return outputs
-
-    @staticmethod
-    def is_better(curr_metrics, best_metrics):
-        return best_metrics is None or curr_metrics['epe2d'] < best_metrics['epe2d']
+    RANKED_BY = 'epe2d'
 
 
 class CamLiPWC_L(FlowModel):
@@ -206,18 +190,11 @@ class CamLiPWC_L(FlowModel):
         flows_3d = self.core.decode(xyzs1, xyzs2, self.core.encode(xyzs1), self.core.encode(xyzs2))
         if use_ids:
             flows_3d = [flows_paral2persp(xyz1, [f], persp, paral)[0] for xyz1, f in zip(xyzs1, flows_3d)]
-        final_flow_3d = flows_3d[0]
-        if 'flow_3d' not in inputs:
-            return {'flow_3d': final_flow_3d}
-        target_3d = inputs['flow_3d']
-        self.loss = calc_pyramid_loss_3d(flows_3d, target_3d, self.cfgs.loss, sample_indices1)
-        self.update_metrics('loss3d', self.loss)
-        self.update_3d_metrics(final_flow_3d, target_3d)
-        return {'flow_3d': final_flow_3d}
+        return self.supervise(inputs, {'flow_3d': flows_3d[0]}, {
+            'flow_3d': lambda target: calc_pyramid_loss_3d(flows_3d, target, self.cfgs.loss, sample_indices1)},
+            targets={'flow_3d': inputs['flow_3d']} if 'flow_3d' in inputs else None)
 
-    @staticmethod
-    def is_better(curr_metrics, best_metrics):
-        return best_metrics is None or curr_metrics['epe3d'] < best_metrics['epe3d']
+    RANKED_BY = 'epe3d'
 
 
 class PWC(FlowModel):
@@ -233,18 +210,10 @@ class PWC(FlowModel):
         origin_h, origin_w = images.shape[2:]
         images = resize_to_64x(images, None)[0]
         flows = self.core.decode(self.core.encode(images[:, :3]), self.core.encode(images[:, 3:]))
-        final_flow = resize_flow2d(flows[0], origin_h, origin_w)
-        if 'flow_2d' not in inputs:
-            return {'flow_2d': final_flow}
-        target_2d = inputs['flow_2d'].float()
-        self.loss = calc_pyramid_loss_2d(flows, target_2d, self.cfgs.loss)
-        self.update_metrics('loss2d', self.loss)
-        self.update_2d_metrics(final_flow, target_2d)
-        return {'flow_2d': final_flow}
+        return self.supervise(inputs, {'flow_2d': resize_flow2d(flows[0], origin_h, origin_w)}, {
+            'flow_2d': lambda target: calc_pyramid_loss_2d(flows, target, self.cfgs.loss)})
 
-    @staticmethod
-    def is_better(curr_metrics, best_metrics):
-        return best_metrics is None or curr_metrics['epe2d'] < best_metrics['epe2d']
+    RANKED_BY = 'epe2d'
 
 
 class RAFT(FlowModel):
@@ -260,15 +229,7 @@ class RAFT(FlowModel):
         padder = InputPadder(images.shape, x=8)
         image1, image2 = padder.pad(images[:, :3], images[:, 3:])
         flow_preds = [padder.unpad(f) for f in self.core(image1, image2)]
-        final_flow = flow_preds[-1]
-        if 'flow_2d' not in inputs:
-            return {'flow_2d': final_flow}
-        target_2d = inputs['flow_2d'].float()
-        self.loss = calc_sequence_loss_2d(flow_preds, target_2d, self.cfgs.loss)
-        self.update_metrics('loss2d', self.loss)
-        self.update_2d_metrics(final_flow, target_2d)
-        return {'flow_2d': final_flow}
+        return self.supervise(inputs, {'flow_2d': flow_preds[-1]}, {
+            'flow_2d': lambda target: calc_sequence_loss_2d(flow_preds, target, self.cfgs.loss)})
 
-    @staticmethod
-    def is_better(curr_metrics, best_metrics):
-        return best_metrics is None or curr_metrics['epe2d'] < best_metrics['epe2d']
+    RANKED_BY = 'epe2d'

@@ -221,28 +221,11 @@ class CamLiRAFT(_FreezableBN, FlowModel):
         flow_2d_preds = [padder.unpad(f) for f in flow_2d_preds]
         flow_3d_preds = flows_paral2persp(pc1, flow_3d_preds, persp, paral)
 
-        final_flow_2d, final_flow_3d = flow_2d_preds[-1], flow_3d_preds[-1]
-        outputs = {'flow_2d': final_flow_2d, 'flow_3d': final_flow_3d}
-        if 'flow_2d' not in inputs or 'flow_3d' not in inputs:
-            return outputs
+        return self.supervise(inputs, {'flow_2d': flow_2d_preds[-1], 'flow_3d': flow_3d_preds[-1]}, {
+            'flow_2d': lambda target: calc_sequence_loss_2d(flow_2d_preds, target, cfgs=self.cfgs.loss2d),
+            'flow_3d': lambda target: calc_sequence_loss_3d(flow_3d_preds, target, cfgs=self.cfgs.loss3d)})
 
-        target_2d, target_3d = inputs['flow_2d'].float(), inputs['flow_3d'].float()
-        loss_2d = calc_sequence_loss_2d(flow_2d_preds, target_2d, cfgs=self.cfgs.loss2d)
-        loss_3d = calc_sequence_loss_3d(flow_3d_preds, target_3d, cfgs=self.cfgs.loss3d)
-        self.loss = loss_2d + loss_3d
-
-        self.update_metrics('loss', self.loss)
-        self.update_metrics('loss2d', loss_2d)
-        self.update_metrics('loss3d', loss_3d)
-        self.update_2d_metrics(final_flow_2d, target_2d)
-        self.update_3d_metrics(final_flow_3d, target_3d)
-        if 'occ_mask_3d' in inputs:
-            self.update_3d_metrics(final_flow_3d, target_3d, inputs['occ_mask_3d'])
-        return outputs
-
-    @staticmethod
-    def is_better(curr_metrics, best_metrics):
-        return best_metrics is None or curr_metrics['epe2d'] < best_metrics['epe2d']
+    RANKED_BY = 'epe2d'
 
 
 class CamLiRAFT_L(FlowModel):
@@ -282,16 +265,9 @@ class CamLiRAFT_L(FlowModel):
         if use_ids:
             flow_preds = flows_paral2persp(pc1, flow_preds, persp, paral)
 
-        final_flow_3d = flow_preds[-1]
-        if 'flow_3d' not in inputs:
-            return {'flow_3d': final_flow_3d}
+        # the ground truth may carry a validity channel: this model trains and scores on the first three (camliraft_l.py:70)
+        return self.supervise(inputs, {'flow_3d': flow_preds[-1]}, {
+            'flow_3d': lambda target: calc_sequence_loss_3d(flow_preds, target, self.cfgs.loss)},
+            targets={'flow_3d': inputs['flow_3d'][:, :3]} if 'flow_3d' in inputs else None)
 
-        target_3d = inputs['flow_3d'][:, :3]
-        self.loss = calc_sequence_loss_3d(flow_preds, target_3d, self.cfgs.loss)
-        self.update_metrics('loss3d', self.loss)
-        self.update_3d_metrics(final_flow_3d, target_3d)
-        return {'flow_3d': final_flow_3d}
-
-    @staticmethod
-    def is_better(curr_metrics, best_metrics):
-        return best_metrics is None or curr_metrics['epe3d'] < best_metrics['epe3d']
+    RANKED_BY = 'epe3d'

@@ -135,9 +135,41 @@ class FlowModel(nn.Module):
             raise ValueError('Loss is empty.')
         return self.loss
 
-    @staticmethod
-    def is_better(curr_metrics, best_metrics):
-        raise RuntimeError('Function `is_better` must be implemented.')
+    RANKED_BY = None        # the metric that ranks checkpoints ('epe2d' / 'epe3d'); lower is better
+
+    @classmethod
+    def is_better(cls, curr_metrics, best_metrics):
+        if cls.RANKED_BY is None:
+            raise RuntimeError('%s does not name the metric that ranks its checkpoints' % cls.__name__)
+        return best_metrics is None or curr_metrics[cls.RANKED_BY] < best_metrics[cls.RANKED_BY]
+
+    def supervise(self, inputs, final, terms, targets=None):
+        """The supervised tail all models share (the reference repeats it in every forward: camliraft.py:70-92,
+        camliraft_l.py:66-77, camlipwc.py:62-85, camlipwc_l.py, pwc.py, raft.py).  ``final`` maps 'flow_2d' / 'flow_3d'
+        to the full-resolution predictions and is what forward returns.  When the inputs hold a ground truth for every
+        entry, ``terms[key](target)`` is that modality's loss, ``self.loss`` their sum, and the running metrics take
+        the per-modality losses, the end-point metrics and -- with an occlusion mask -- the non-occluded 3-D ones."""
+        if any(key not in inputs for key in final):
+            return final
+        if targets is None:
+            targets = {key: inputs[key].float() for key in final}
+        parts = [(key, terms[key](targets[key])) for key in final]
+        total = parts[0][1]
+        for _, value in parts[1:]:
+            total = total + value
+        self.loss = total
+        if len(parts) > 1:
+            self.update_metrics('loss', total)
+        for key, value in parts:
+            self.update_metrics('loss' + key[len('flow_'):], value)
+        if 'flow_2d' in final:
+            self.update_2d_metrics(final['flow_2d'], targets['flow_2d'])
+        if 'flow_3d' in final:
+            self.update_3d_metrics(final['flow_3d'], targets['flow_3d'])
+            # only the two fused models score the non-occluded subset (camliraft.py:95-96, camlipwc.py:97-98)
+            if 'occ_mask_3d' in inputs and len(parts) > 1:
+                self.update_3d_metrics(final['flow_3d'], targets['flow_3d'], inputs['occ_mask_3d'])
+        return final
 
     @torch.no_grad()
     def update_2d_metrics(self, pred, target):
