@@ -61,6 +61,7 @@ NORTH_STAR = {
     'camli_weightnet_fwd': 'hbm', 'camli_weightnet_bwd': 'mfma',
     'camli_knn_interp_fwd': 'hbm', 'camli_knn_interp_bwd': 'hbm', 'camli_knn_interp_bwd_xyz': 'hbm',
     'camli_corr3d_gather_fwd': 'hbm', 'camli_corr3d_gather_bwd': 'hbm',
+    'camli_corr3d_cost_levels_fwd': 'fma', 'camli_corr3d_cost_levels_bwd': 'fma',
     'camli_corr3d_mlp_fwd': 'fma', 'camli_corr3d_mlp_bwd': 'fma',      # plain fp32 FMA on the vector ALU (registers only)
     'camli_pwc3d_pair_fwd': 'hbm', 'camli_pwc3d_pair_bwd': 'hbm', 'camli_gather_wsum_fwd': 'hbm', 'camli_gather_wsum_bwd': 'hbm',
 }

@@ -79,6 +79,61 @@ __device__ __forceinline__ void layer1(const float* w1_global, const float* b1_g
     }
 }
 
+// The lookup's gather folded into the MLP kernels (GATHER = true): the column of lane L = (level L / 16, neighbour L % 16)
+// of point n is built in place -- x[0..2] = xyz2[:, m] - xyz1[:, n], x[3] = volume_l[n, m], m = knn_l[n, L % 16] -- instead of
+// being read from a materialised [B,4,N,64] tensor (camli_corr3d_gather_levels_fwd: one launch, 16.8 MB written and read
+// back per GRU iteration at batch 8); the adjoint adds d/d(volume entry) straight into the persistent gradient volumes
+// (a point's 16 neighbours of a level are distinct and launches on one stream are ordered: plain read-modify-write).
+// Nested target levels: level l is the first size[l] points of xyz2 [B,3,M0].
+struct CmGather {
+    const float* xyz1;         // [B,3,N]
+    const float* xyz2;         // [B,3,M0]
+    const float* vol[4];       // [B,N,size[l]] cost volumes
+    const int64_t* knn[4];     // [B,N,16]
+    int size[4];
+    int m0;
+};
+struct CmGradVols {
+    float* vol[4];             // [B,N,size[l]] gradient volumes, accumulated
+};
+
+// One column = (level lane / 16, neighbour lane % 16) of one point.  The gathers of a point form a two-deep dependent chain
+// (neighbour index -> coordinates / volume entry) on top of a loop that works through CH points one after the other, so both
+// kernels run them as a software pipeline: the index of point p + 2 and the gathers of point p + 1 are in flight while point
+// p is on the matrix cores.
+struct CmColumn {
+    float x[4];
+    size_t entry;      // offset of the volume entry inside its level: where the adjoint adds
+};
+// what a lane needs of its level (lane / 16), picked once per kernel: inside the per-point loop the selects would be
+// re-evaluated as vector loads of the kernel-argument fields -- a third link in front of the index -> gather chain
+struct CmLane {
+    const int64_t* knn;
+    const float* vol;
+    int size;
+};
+__device__ __forceinline__ CmLane lane_level(const CmGather& ga, int lane) {
+    const int l = lane >> 4;
+    const int64_t* k0 = ga.knn[0]; const int64_t* k1 = ga.knn[1]; const int64_t* k2 = ga.knn[2]; const int64_t* k3 = ga.knn[3];
+    const float* v0 = ga.vol[0]; const float* v1 = ga.vol[1]; const float* v2 = ga.vol[2]; const float* v3 = ga.vol[3];
+    const int s0 = ga.size[0], s1 = ga.size[1], s2 = ga.size[2], s3 = ga.size[3];
+    CmLane ll;
+    ll.knn = l == 0 ? k0 : l == 1 ? k1 : l == 2 ? k2 : k3;
+    ll.vol = l == 0 ? v0 : l == 1 ? v1 : l == 2 ? v2 : v3;
+    ll.size = l == 0 ? s0 : l == 1 ? s1 : l == 2 ? s2 : s3;
+    return ll;
+}
+__device__ __forceinline__ int column_index(const CmLane& ll, int b, int n, int N, int lane) {
+    return (int)ll.knn[((size_t)b * N + n) * 16 + (lane & 15)];
+}
+__device__ __forceinline__ void column_gather(const CmGather& ga, const CmLane& ll, int b, int n, int N, int m, CmColumn& col) {
+    col.entry = ((size_t)b * N + n) * ll.size + m;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        col.x[a] = ga.xyz2[((size_t)b * 3 + a) * ga.m0 + m] - ga.xyz1[((size_t)b * 3 + a) * N + n];
+    col.x[3] = ll.vol[col.entry];
+}
+
 // grid ceil(B * N / (4 * CH)), block 256: wave = CH consecutive points of one batch element (N % CH == 0).
 // Layer 1 on the vector ALU in the column layout (lane = column, 32 units in registers); layer 2 on the matrix cores:
 // per 32-column tile D[o][col] = b2[o] + sum_i W2[o][i] H1[i][col] is 16 v_mfma_f32_32x32x2_f32 (bias in the
@@ -86,8 +141,9 @@ __device__ __forceinline__ void layer1(const float* w1_global, const float* b1_g
 // loaded once per wave; the B fragment of step s wants H1[2s + lane / 32][col = 32 t + lane % 32], and ONE
 // v_permlane32_swap of (h1[2s], h1[2s + 1]) yields it for both tiles: [X.lo | Y.lo] and [X.hi | Y.hi].
 // D layout: lane holds column 32 t + lane % 32, units o = (r & 3) + 8 (r >> 2) + 4 (lane / 32), r = 0..15.
-template <int CH>
-__global__ __launch_bounds__(256) void corr3d_mlp_fwd_kernel(const float* __restrict__ lookup, const float* __restrict__ w1,
+template <int CH, bool GATHER>
+__global__ __launch_bounds__(256) void corr3d_mlp_fwd_kernel(const float* __restrict__ lookup, CmGather ga,
+                                                             const float* __restrict__ w1,
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
                                                              const float* __restrict__ b2, float* __restrict__ out, int B,
                                                              int N) {
@@ -98,7 +154,7 @@ __global__ __launch_bounds__(256) void corr3d_mlp_fwd_kernel(const float* __rest
     const bool live = chunk < B * chunks_per_b;
     const int b = live ? chunk / chunks_per_b : 0, n0 = live ? (chunk % chunks_per_b) * CH : 0;
     const int half = lane >> 5, cl = lane & 31, q = cl >> 4, j = lane & 15;
-    const float* __restrict__ xin = lookup + ((size_t)b * 4 * N + n0) * CM_COLS + lane;
+    const float* __restrict__ xin = GATHER ? nullptr : lookup + ((size_t)b * 4 * N + n0) * CM_COLS + lane;
     const size_t plane = (size_t)N * CM_COLS;
 
     float wa[CM_H / 2];
@@ -108,10 +164,25 @@ __global__ __launch_bounds__(256) void corr3d_mlp_fwd_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias[r] = b2[(r & 3) + 8 * (r >> 2) + 4 * half];
 
+    CmColumn nxt;
+    int m_nxt = 0;
+    CmLane ll = {};
+    if (GATHER) {
+        ll = lane_level(ga, lane);
+        column_gather(ga, ll, b, n0, N, column_index(ll, b, n0, N, lane), nxt);
+        m_nxt = column_index(ll, b, n0 + (CH > 1 ? 1 : 0), N, lane);
+    }
     for (int p = 0; p < CH; ++p) {
         float x[4], h1[CM_H];
+        if (GATHER) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) x[c] = xin[c * plane + (size_t)p * CM_COLS];
+            for (int c = 0; c < 4; ++c) x[c] = nxt.x[c];
+            if (p + 1 < CH) column_gather(ga, ll, b, n0 + p + 1, N, m_nxt, nxt);
+            m_nxt = column_index(ll, b, n0 + min(p + 2, CH - 1), N, lane);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = xin[c * plane + (size_t)p * CM_COLS];
+        }
         layer1(w1, b1, x, h1);
         f32x16 d0 = bias, d1 = bias;
 #pragma unroll
@@ -154,8 +225,8 @@ __global__ __launch_bounds__(256) void corr3d_mlp_fwd_kernel(const float* __rest
 constexpr int CM_BW = 2;
 __device__ __forceinline__ int unit_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <int CH>
-__global__ __launch_bounds__(64 * CM_BW) __attribute__((amdgpu_waves_per_eu(2))) void corr3d_mlp_bwd_kernel(const float* __restrict__ lookup, const float* __restrict__ gout,
+template <int CH, bool GATHER>
+__global__ __launch_bounds__(64 * CM_BW) __attribute__((amdgpu_waves_per_eu(2))) void corr3d_mlp_bwd_kernel(const float* __restrict__ lookup, CmGather ga, CmGradVols gvols, const float* __restrict__ gout,
                                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
                                                              float* __restrict__ glookup, float* __restrict__ partials, int B,
@@ -172,7 +243,7 @@ __global__ __launch_bounds__(64 * CM_BW) __attribute__((amdgpu_waves_per_eu(2)))
     const int b = live ? chunk / chunks_per_b : 0, n0 = live ? (chunk % chunks_per_b) * CH : 0;
     const int half = lane >> 5, cl = lane & 31, q = cl >> 4;
     const size_t plane = (size_t)N * CM_COLS;
-    const float* __restrict__ xin = lookup + ((size_t)b * 4 * N + n0) * CM_COLS + lane;
+    const float* __restrict__ xin = GATHER ? nullptr : lookup + ((size_t)b * 4 * N + n0) * CM_COLS + lane;
     // gout rows in the D layout: tile t -> level 2 t + q, unit unit_of(r, half)
     const float* __restrict__ gin = gout + ((size_t)b * CM_OUT + q * CM_H) * N + n0;
 
@@ -184,14 +255,35 @@ __global__ __launch_bounds__(64 * CM_BW) __attribute__((amdgpu_waves_per_eu(2)))
     for (int r = 0; r < 16; ++r) acc_w2[r] = acc_w1[r] = 0.0f;
     float gb2 = 0.0f;       // lane (half, cl): sum of g2[o = cl] over the columns [32 half, 32 half + 32) of every point
 
+    CmColumn nxt;
+    int m_nxt = 0;
+    float gold_nxt = 0.0f;      // the gradient-volume entry the lane adds into travels with the column (read early, written late)
+    float* const gbase = !GATHER ? nullptr
+                         : (lane >> 4) == 0 ? gvols.vol[0] : (lane >> 4) == 1 ? gvols.vol[1] : (lane >> 4) == 2 ? gvols.vol[2] : gvols.vol[3];
+    CmLane ll = {};
+    if (GATHER) {
+        ll = lane_level(ga, lane);
+        column_gather(ga, ll, b, n0, N, column_index(ll, b, n0, N, lane), nxt);
+        gold_nxt = live ? gbase[nxt.entry] : 0.0f;
+        m_nxt = column_index(ll, b, n0 + (CH > 1 ? 1 : 0), N, lane);
+    }
     for (int p = 0; p < CH; ++p) {
         const int z = opaque_zero();
         const float* __restrict__ w2v = w2 + z;
         const float* __restrict__ b2v = b2 + z;
         const float* __restrict__ w1v = w1 + z;
         float x[4], h1[CM_H];
+        float* gslot = nullptr;
+        float gold = 0.0f;
+        if (GATHER) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) x[c] = xin[c * plane + (size_t)p * CM_COLS];
+            for (int c = 0; c < 4; ++c) x[c] = nxt.x[c];
+            gslot = gbase + nxt.entry;
+            gold = gold_nxt;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = xin[c * plane + (size_t)p * CM_COLS];
+        }
         layer1(w1, b1, x, h1);
         unsigned mask = 0u;                               // bit i: h1[i] > 0 for this lane's column
 #pragma unroll
@@ -267,13 +359,30 @@ __global__ __launch_bounds__(64 * CM_BW) __attribute__((amdgpu_waves_per_eu(2)))
             const auto t1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part1), __float_as_uint(part1), false, false);
             const float tot0 = __uint_as_float(t0[0]) + __uint_as_float(t0[1]);
             const float tot1 = __uint_as_float(t1[0]) + __uint_as_float(t1[1]);
-            if (live) glookup[((size_t)b * 4 + 3) * plane + (size_t)(n0 + p) * CM_COLS + lane] = half == 0 ? tot0 : tot1;
+            const float mine = half == 0 ? tot0 : tot1;
+            if (GATHER) {
+                if (live) *gslot = gold + mine;
+            } else if (live) {
+                glookup[((size_t)b * 4 + 3) * plane + (size_t)(n0 + p) * CM_COLS + lane] = mine;
+            }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) bufX[wv][lane][c] = x[c];
         bufX[wv][lane][4] = 1.0f;
         bufX[wv][lane][5] = bufX[wv][lane][6] = bufX[wv][lane][7] = 0.0f;
         wave_lds_fence();
+        if (GATHER) {
+            // the next point's gathers go out HERE: every other global load of the iteration (the per-point re-reads of the
+            // weights, L1 hits) is behind us, so no in-order vmcnt wait stands between these and the 32 LDS-fed MFMAs below.
+            // Measured (tools/ab_corr3d.py, batch 8, 2048 points): 152 us against 114 us for the kernel fed from a
+            // materialised lookup tensor + 19 us gather adjoint + 5 us zero fill: the 15 extra live registers cost the
+            // weight re-reads their batching (20 full vmcnt waits per point instead of 5) -- the forward gains 17 us
+            if (p + 1 < CH) {
+                column_gather(ga, ll, b, n0 + p + 1, N, m_nxt, nxt);
+                gold_nxt = live ? gbase[nxt.entry] : 0.0f;
+            }
+            m_nxt = column_index(ll, b, n0 + min(p + 2, CH - 1), N, lane);
+        }
         // [dW1 | db1][i][c] += sum over the columns of g1[i] * [x | 1][c]
 #pragma unroll 8
         for (int s = 0; s < CM_COLS / 2; ++s) {
@@ -361,9 +470,43 @@ extern "C" int camli_corr3d_mlp_fwd(const float* lookup, const float* w1, const 
     if (!lookup || !w1 || !b1 || !w2 || !b2 || !out) { camli_set_error("camli_corr3d_mlp_fwd: null pointer"); return CAMLI_EINVAL; }
     if (!mlp_shape_ok("camli_corr3d_mlp_fwd", B, N, levels, k, hidden)) return CAMLI_EINVAL;
     const int blocks = camli_divup(B * (N / CM_CH), 4);
-    hipLaunchKernelGGL(corr3d_mlp_fwd_kernel<CM_CH>, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), lookup, w1,
-                       b1, w2, b2, out, B, N);
+    hipLaunchKernelGGL((corr3d_mlp_fwd_kernel<CM_CH, false>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       lookup, CmGather{}, w1, b1, w2, b2, out, B, N);
     return camli_check_launch("camli_corr3d_mlp_fwd");
+}
+
+static int gather_pack(const char* what, CmGather& ga, const float* xyz1, const float* xyz2, const float* const* vols,
+                       const int64_t* const* knn_levels, const int* sizes, int M0) {
+    if (!xyz1 || !xyz2 || !vols || !knn_levels || !sizes) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    ga.xyz1 = xyz1;
+    ga.xyz2 = xyz2;
+    ga.m0 = M0;
+    for (int l = 0; l < 4; ++l) {
+        if (!vols[l] || !knn_levels[l] || sizes[l] < 1 || sizes[l] > M0) {
+            camli_set_error("%s: level %d: null pointer or size %d outside [1, %d]", what, l, sizes[l], M0);
+            return CAMLI_EINVAL;
+        }
+        ga.vol[l] = vols[l];
+        ga.knn[l] = knn_levels[l];
+        ga.size[l] = sizes[l];
+    }
+    return CAMLI_OK;
+}
+
+extern "C" int camli_corr3d_cost_levels_fwd(const float* xyz1, const float* xyz2, const float* const* cost_levels,
+                                            const int64_t* const* knn_levels, const int* sizes, const float* w1,
+                                            const float* b1, const float* w2, const float* b2, float* out, int B, int N,
+                                            int M0, int levels, int k, int hidden, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!w1 || !b1 || !w2 || !b2 || !out) { camli_set_error("camli_corr3d_cost_levels_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (!mlp_shape_ok("camli_corr3d_cost_levels_fwd", B, N, levels, k, hidden) || M0 < 1) return CAMLI_EINVAL;
+    CmGather ga;
+    const int rc = gather_pack("camli_corr3d_cost_levels_fwd", ga, xyz1, xyz2, cost_levels, knn_levels, sizes, M0);
+    if (rc != CAMLI_OK) return rc;
+    const int blocks = camli_divup(B * (N / CM_CH), 4);
+    hipLaunchKernelGGL((corr3d_mlp_fwd_kernel<CM_CH, true>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       nullptr, ga, w1, b1, w2, b2, out, B, N);
+    return camli_check_launch("camli_corr3d_cost_levels_fwd");
 }
 
 extern "C" int64_t camli_corr3d_mlp_bwd_workspace_bytes(int B, int N) {
@@ -382,9 +525,45 @@ extern "C" int camli_corr3d_mlp_bwd(const float* lookup, const float* gout, cons
     if (!mlp_shape_ok("camli_corr3d_mlp_bwd", B, N, levels, k, hidden)) return CAMLI_EINVAL;
     const int blocks = camli_divup(B * (N / CM_CH), CM_BW);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(corr3d_mlp_bwd_kernel<CM_CH>, dim3(blocks), dim3(64 * CM_BW), 0, s, lookup, gout, w1, b1, w2, b2, glookup, workspace,
-                       B, N);
+    hipLaunchKernelGGL((corr3d_mlp_bwd_kernel<CM_CH, false>), dim3(blocks), dim3(64 * CM_BW), 0, s, lookup, CmGather{}, CmGradVols{}, gout, w1, b1,
+                       w2, b2, glookup, workspace, B, N);
     hipLaunchKernelGGL(corr3d_mlp_reduce_kernel, dim3(camli_divup(CM_PART, 64)), dim3(64, 16), 0, s, workspace, blocks, gw1, gb1, gw2,
                        gb2);
     return camli_check_launch("camli_corr3d_mlp_bwd");
+}
+
+// adjoint of camli_corr3d_cost_levels_fwd: gcost_levels[l] [B,N,sizes[l]] += d/d(volume entry) (caller zero-fills once per
+// pass, then calls once per GRU iteration); gw1 / gb1 / gw2 / gb2 += as camli_corr3d_mlp_bwd; same workspace.
+extern "C" int camli_corr3d_cost_levels_bwd(const float* xyz1, const float* xyz2, const float* const* cost_levels,
+                                            const int64_t* const* knn_levels, const int* sizes, const float* gout,
+                                            const float* w1, const float* b1, const float* w2, const float* b2,
+                                            float* const* gcost_levels, float* gw1, float* gb1, float* gw2, float* gb2,
+                                            float* workspace, int B, int N, int M0, int levels, int k, int hidden,
+                                            void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!gout || !w1 || !b1 || !w2 || !b2 || !gw1 || !gb1 || !gw2 || !gb2 || !workspace || !cost_levels) {
+        camli_set_error("camli_corr3d_cost_levels_bwd: null pointer");
+        return CAMLI_EINVAL;
+    }
+    if (!mlp_shape_ok("camli_corr3d_cost_levels_bwd", B, N, levels, k, hidden) || M0 < 1) return CAMLI_EINVAL;
+    CmGather ga;
+    const int rc = gather_pack("camli_corr3d_cost_levels_bwd", ga, xyz1, xyz2, cost_levels, knn_levels, sizes, M0);
+    if (rc != CAMLI_OK) return rc;
+    if (!gcost_levels) { camli_set_error("camli_corr3d_cost_levels_bwd: null pointer"); return CAMLI_EINVAL; }
+    CmGradVols gv;
+    for (int l = 0; l < 4; ++l) {
+        if (!gcost_levels[l]) { camli_set_error("camli_corr3d_cost_levels_bwd: null gradient volume %d", l); return CAMLI_EINVAL; }
+        if (sizes[l] < 16) {      // fewer candidates than neighbours: the unfilled slots repeat index 0 and would race
+            camli_set_error("camli_corr3d_cost_levels_bwd: level %d has %d < 16 points", l, sizes[l]);
+            return CAMLI_ENOTSUP;
+        }
+        gv.vol[l] = gcost_levels[l];
+    }
+    const int blocks = camli_divup(B * (N / CM_CH), CM_BW);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL((corr3d_mlp_bwd_kernel<CM_CH, true>), dim3(blocks), dim3(64 * CM_BW), 0, s, nullptr, ga, gv, gout, w1, b1, w2, b2,
+                       nullptr, workspace, B, N);
+    hipLaunchKernelGGL(corr3d_mlp_reduce_kernel, dim3(camli_divup(CM_PART, 64)), dim3(64, 16), 0, s, workspace, blocks, gw1, gb1, gw2,
+                       gb2);
+    return camli_check_launch("camli_corr3d_cost_levels_bwd");
 }

@@ -247,6 +247,26 @@ int camli_corr3d_mlp_bwd(const float *lookup, const float *gout, const float *w1
                          int B, int N, int levels, int k, int hidden, void *stream);
 
 /*
+ * The same MLP with the lookup's gather folded in (camliraft_l_core.py:62-101 for the four NESTED target levels of a pass in
+ * one launch each way): the column (level l, neighbour j) of point n is built in the kernel,
+ *   x = (xyz2[:, m] - xyz1[:, n], cost_levels[l][b, n, m]),  m = knn_levels[l][b, n, j],
+ * instead of being read from camli_corr3d_gather_levels_fwd's [B,4,N,L*k] tensor.
+ *   xyz1 [B,3,N], xyz2 [B,3,M0] (level l = its first sizes[l] points), cost_levels[l] [B,N,sizes[l]], knn_levels[l] int64
+ *   [B,N,k] (HOST arrays of DEVICE pointers); out as camli_corr3d_mlp_fwd.
+ *   bwd: gcost_levels[l] [B,N,sizes[l]] += d/d(volume entry) (the caller zero-fills once per pass, then calls once per GRU
+ *        iteration; needs sizes[l] >= k, else CAMLI_ENOTSUP); parameter gradients and workspace as camli_corr3d_mlp_bwd.
+ */
+int camli_corr3d_cost_levels_fwd(const float *xyz1, const float *xyz2, const float *const *cost_levels,
+                                 const int64_t *const *knn_levels, const int *sizes, const float *w1, const float *b1,
+                                 const float *w2, const float *b2, float *out, int B, int N, int M0, int levels, int k,
+                                 int hidden, void *stream);
+int camli_corr3d_cost_levels_bwd(const float *xyz1, const float *xyz2, const float *const *cost_levels,
+                                 const int64_t *const *knn_levels, const int *sizes, const float *gout, const float *w1,
+                                 const float *b1, const float *w2, const float *b2, float *const *gcost_levels, float *gw1,
+                                 float *gb1, float *gw2, float *gb2, float *workspace, int B, int N, int M0, int levels,
+                                 int k, int hidden, void *stream);
+
+/*
  * PointPWC learnable cost volume, PWC-style Correlation3D (internal composite op; the reference materialises
  * [B, 2C+3, N, k] = cat(f1 expanded, gather(f2), dxyz) and runs MLP2d over it: models/camlipwc_l_core.py:53-106).
  * The first MLP layer is split by input block (see csrc/hip/pwc3d.hip); tensors are [B,C,N,k] with k fastest, k a
