@@ -95,6 +95,10 @@ def epilogue_ok(x):
 _PW_DX_GEMM = os.environ.get('CAMLI_PW_DX', 'gemm') != 'lib'
 
 
+def _is_nhwc(x):
+    return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+
+
 class _PointwiseConv(torch.autograd.Function):
     """1x1, stride-1 convolution without bias.  The forward stays on the library (a GEMM, no layout
     change); the data gradient is a batched GEMM (see backward); the WEIGHT gradient is taken as a batched GEMM over the positions
@@ -108,6 +112,15 @@ class _PointwiseConv(torch.autograd.Function):
         ctx.param = runtime.deferral_target(w)      # identity of the Parameter, for deferral
         nd = x.dim() - 2
         ctx.conv_args = ([1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1)
+        ctx.nhwc_in = _is_nhwc(x)
+        if ctx.nhwc_in:
+            # channels-last input (the ResNet trunk's output), channel-first output: y_b = W x_b with x_b read as the
+            # [P, C] matrix it is in memory -- the layout change rides on the GEMM's transposed operand instead of a
+            # 0.5 ms transposing copy of the [16, 512, 68, 120] map (and another one for its gradient)
+            w2 = w.flatten(1).unsqueeze(0).expand(x.shape[0], -1, -1)
+            y = torch.empty((x.shape[0], w.shape[0]) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+            torch.bmm(w2, x.flatten(2), out=y.flatten(2))       # y itself is returned: the epilogue works in place on it
+            return y
         return torch.ops.aten.convolution(x, w, None, *ctx.conv_args)
 
     @staticmethod
@@ -120,7 +133,11 @@ class _PointwiseConv(torch.autograd.Function):
             x, w = x.to(gy.dtype), w.to(gy.dtype)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if _PW_DX_GEMM:
+            if ctx.nhwc_in:
+                # dx in the layout x came in: dx_b^T [P, C] = gy_b^T W, a channels-last tensor without a copy
+                gx = torch.matmul(gy.flatten(2).transpose(1, 2), w.flatten(1))                    # [B, P, C]
+                gx = gx.view(x.shape[0], *x.shape[2:], x.shape[1]).permute(0, 3, 1, 2)
+            elif _PW_DX_GEMM:
                 # dx_b = W^T gy_b: one strided-batched GEMM.  The library's data-gradient entry costs ~340 us of HOST
                 # time per call here (solution lookup on every call + a zero-fill launch, 304 calls per step =
                 # 100 ms of the step's enqueue time) for the same GEMM on the device.
@@ -159,7 +176,7 @@ def conv_bias_act(conv, x, act, leave_bias=False):
     if act is None and not leave_bias and fused.conv3x3_co2_supported(conv, x):
         # a flow head's last convolution (wide map -> 2 channels): own HBM-bound kernels, bias included
         return fused.conv3x3_co2(x, conv.weight, conv.bias)
-    if _is_pointwise(conv) and x.dtype == torch.float32 and x.is_contiguous():
+    if _is_pointwise(conv) and x.dtype == torch.float32 and (x.is_contiguous() or _is_nhwc(x)):
         y = _PointwiseConv.apply(x, conv.weight)
     else:
         y = conv._conv_forward(x, conv.weight, None)

@@ -29,7 +29,10 @@ class Encoder2D(ResNetTrunk):
                 self.load_state_dict(state.get('state_dict', state), strict=False)
 
     def forward(self, x):
-        return self.align(super().forward(x)[0])
+        # on the product path ``align`` (1x1, fp32) takes the trunk's channels-last map directly
+        direct = (runtime.fused() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+                  and self.align._epilogue is not False and os.environ.get('CAMLI_ALIGN_NHWC', '1') == '1')
+        return self.align(super().forward(x, keep_channels_last=direct)[0])
 
 
 def _window_offsets(radius, device):

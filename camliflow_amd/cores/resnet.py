@@ -152,7 +152,9 @@ class ResNetTrunk(nn.Module):
         sizes = [bn.num_features for bn in bns]
         return {id(bn): pair for bn, pair in zip(bns, zip(torch.split(scale, sizes), torch.split(bias, sizes)))}
 
-    def forward(self, x):
+    def forward(self, x, keep_channels_last=False):
+        """``keep_channels_last``: the caller's next op reads the channels-last map as it is (Encoder2D's 1x1 ``align``,
+        a GEMM): the conversion back at the trunk's output is skipped."""
         if _foldable(self.bn1, x):
             folded = self._fold_table()
             from ..csrc import fused
@@ -171,7 +173,7 @@ class ResNetTrunk(nn.Module):
             for name in self.res_layers:
                 for block in getattr(self, name):
                     x = block(x, folded)
-            if _TRUNK_CHANNELS_LAST:
+            if _TRUNK_CHANNELS_LAST and not keep_channels_last:
                 x = x.contiguous()
             return (x,)
         x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
