@@ -16,7 +16,7 @@ from torch.nn.functional import avg_pool2d
 
 from . import _lib
 from ..cores import runtime as _runtime
-from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_slice, _zero_token
+from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_slice
 
 
 # ------------------------------------------------------------------------------------------------
@@ -173,7 +173,9 @@ class _Lookup(torch.autograd.Function):
             else:       # gradient pyramid supplied from outside: no marks to maintain
                 _lib.launch('camli_allpairs_lookup_bwd', lib.camli_allpairs_lookup_bwd, ptrs, hs, ws, n, coords.data_ptr(),
                             gout.data_ptr(), bs, h, w, ctx.radius, _stream_ptr(coords), work=work)
-        return _zero_token(gout), None, None, None
+        # no gradient for the token: the engine still runs the token's producer once every consumer has run (it hands it
+        # materialised zeros), and a None costs no accumulation -- a shared zero tensor here was one add launch per lookup
+        return None, None, None, None
 
 
 def allpairs_pyramid(fmap1, fmap2, num_levels=4):
@@ -322,7 +324,7 @@ class _PointConvDW(torch.autograd.Function):
                         gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat),
                         work=(16.0 * b * c * n + 8.0 * b * c * m, 'B'))
         shared.records.append((gwsel, arg))
-        return gfeat, _zero_token(gout), None, None, None
+        return gfeat, None, None, None, None
 
 
 def pointconv_dw(feat, shared, knn_indices, k):
@@ -1101,7 +1103,7 @@ class _Corr3DLookupLevels(torch.autograd.Function):
             _lib.launch('camli_corr3d_gather_bwd', lib.camli_corr3d_gather_levels_bwd, gout.data_ptr(), _ptr_array(knn_levels),
                         _ptr_array(pyr.grads), sizes, nl, b, n, m0, k, _stream_ptr(gout),
                         work=(b * n * nl * k * (8.0 + 4.0 + 8.0), 'B'))
-        return (_zero_token(gout), None, None, None) + (None,) * nl
+        return (None, None, None, None) + (None,) * nl
 
 
 def corr3d_lookup_levels(pyr, xyz1, xyz2, knn_levels):
@@ -1211,7 +1213,7 @@ class _Corr3DCostLevels(torch.autograd.Function):
                         grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), ws.data_ptr(), b, n, m0, nl, k, hidden,
                         _stream_ptr(xyz1), work=(cols * (8.0 + 16.0 + 4.0 + 8.0) + 4.0 * gout.numel(), 'B'),
                         flop=2.0 * cols * (2 * 4 * hidden + 3 * hidden * hidden))
-        return (_zero_token(gout), None, None, None) + tuple(None if d else g for g, d in zip(grads, deferred)) + (None,) * nl
+        return (None, None, None, None) + tuple(None if d else g for g, d in zip(grads, deferred)) + (None,) * nl
 
 
 def corr3d_cost_levels_supported(pyr, knn_levels, convs, n_points):

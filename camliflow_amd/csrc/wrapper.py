@@ -49,20 +49,6 @@ def _on_device(t):
     return torch.cuda.device(t.device)
 
 
-_zero_tokens = {}
-
-
-def _zero_token(t):
-    """A shared, never-written 1-element zero: the gradient handed to the token inputs of the
-    accumulate-outside-autograd Functions (saves one fill launch per backward call).  Created once per
-    device and synchronised then, so every stream may read it afterwards."""
-    z = _zero_tokens.get(t.device)
-    if z is None:
-        z = _zero_tokens[t.device] = torch.zeros(1, dtype=torch.float32, device=t.device)
-        torch.cuda.current_stream(t.device).synchronize()
-    return z
-
-
 _zero_arena = {}            # device -> [chunk, used]
 _ARENA_FLOATS = 1 << 20
 
