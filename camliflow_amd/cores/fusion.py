@@ -67,7 +67,8 @@ class FusionAwareInterp(nn.Module):
             knn_indices, score = self._geometry(uv, grid, image_h, image_w)
             if self.k == 1 and feat_3d.is_cuda and not feat_3d.requires_grad:
                 from ..csrc import fused          # gather * score in one launch (its own adjoint wrt the score)
-                final = fused.gather_scale(feat_3d, score[..., 0], knn_indices[..., 0])
+                # squeeze, not [..., 0]: a view's adjoint is free, a select's is a zero fill + a copy of the [B,C,HW] score
+                final = fused.gather_scale(feat_3d, score.squeeze(-1), knn_indices[..., 0])
                 return self.out_conv(final.reshape(bs, -1, image_h, image_w))
             knn_feat3d = batch_indexing(feat_3d, knn_indices)                       # [B,C,HW,k]
         else:

@@ -88,6 +88,7 @@ PROTOTYPES = {
                                          _int, _int, _int, _int, ctypes.c_float, _stream]),
     "camli_gru_gates_fwd": (_int, [_c_float_p] * 6 + [_int, _int, _int, _stream]),
     "camli_gru_gates_bwd": (_int, [_c_float_p] * 7 + [_int, _int, _int, _stream]),
+    "camli_gru_gates_bwd_strided": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int64] + [_c_float_p] * 5 + [_int, _int, _int, _stream]),
     "camli_gru_blend_fwd": (_int, [_c_float_p] * 6 + [_int, _int, _int, _int, _stream]),
     "camli_gru_blend_bwd": (_int, [_c_float_p] * 7 + [_int, _int, _int, _int, _stream]),
     "camli_bias_act_mask_bytes": (ctypes.c_int64, [_int, _int, _int]),
@@ -98,6 +99,7 @@ PROTOTYPES = {
     "camli_bias_act_nhwc_bwd": (_int, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_longlong, _int, _int, _stream]),
     "camli_bias_act_res_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _stream]),
     "camli_bias_act_bwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_bias_act_bwd_strided": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_weightnet_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int] + [_c_float_p] * 7
                             + [_int, _int, _int, _int, _int, _int, _stream]),
     "camli_bilinear_sample_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),

@@ -1551,13 +1551,19 @@ class _GruGates(torch.autograd.Function):
         z, r, h = ctx.saved_tensors
         b, c = h.shape[0], h.shape[1]
         p = h[0, 0].numel()
-        gz = gz.contiguous().float() if gz is not None else torch.zeros_like(h)
-        grh = grh.contiguous().float() if grh is not None else torch.zeros_like(h)
+        gz = gz.float() if gz is not None else torch.zeros_like(h)
+        grh = grh.float() if grh is not None else torch.zeros_like(h)
+        # grh is a channel slice of the gradient of cat([r*h, x]): read in place (camli_gru_gates_bwd_strided)
+        gz_bs, grh_bs = _batch_strided(gz), _batch_strided(grh)
+        if gz_bs is None:
+            gz, gz_bs = gz.contiguous(), c * p
+        if grh_bs is None:
+            grh, grh_bs = grh.contiguous(), c * p
         gpre = torch.empty((b, 2 * c) + tuple(h.shape[2:]), dtype=torch.float32, device=h.device)
         gh = torch.empty_like(h)
         with _on_device(h):
-            _lib.launch('camli_gru_gates_bwd', lib.camli_gru_gates_bwd, gz.data_ptr(), grh.data_ptr(), z.data_ptr(),
-                        r.data_ptr(), h.data_ptr(), gpre.data_ptr(), gh.data_ptr(), b, c, p, _stream_ptr(h),
+            _lib.launch('camli_gru_gates_bwd', lib.camli_gru_gates_bwd_strided, gz.data_ptr(), gz_bs, grh.data_ptr(), grh_bs,
+                        z.data_ptr(), r.data_ptr(), h.data_ptr(), gpre.data_ptr(), gh.data_ptr(), b, c, p, _stream_ptr(h),
                         work=(32.0 * b * c * p, 'B'))
         return gpre, gpre, gh
 
@@ -1669,6 +1675,26 @@ ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh
              'relu_nan_to_num': 5}      # relu, then torch.nan_to_num (raft_core.py:163-164); needs a plane of 4k elements
 
 
+_STRIDED_GRADS = os.environ.get('CAMLI_STRIDED_GRADS', '1') != '0'      # 0: copy sliced gradients out first (A/B)
+
+
+def _batch_strided(t):
+    """t [B,C,...] fp32 whose batch entries are dense [C,...] blocks a fixed stride apart -- a contiguous tensor or a channel
+    slice of one (the adjoint of a cat hands those over) -> its batch stride in floats, usable by the *_strided entry points
+    (16-byte aligned, stride a multiple of 4); else None."""
+    if t.dtype != torch.float32 or t.dim() < 2 or not _STRIDED_GRADS:
+        return None
+    inner = 1
+    for size, stride in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+        if size != 1 and stride != inner:
+            return None
+        inner *= size
+    bs = t.stride(0) if t.shape[0] > 1 else inner
+    if bs < inner or bs % 4 or (t.data_ptr() % 16):
+        return None
+    return bs
+
+
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
@@ -1702,9 +1728,13 @@ class _BiasAct(torch.autograd.Function):
         lib = _lib.load()
         saved = ctx.saved_tensors[0] if ctx.saved_tensors else None
         b, c, p = ctx.dims
-        gy = gy.contiguous().float()
         identity = ctx.act == 0
-        gx = gy if identity else torch.empty_like(gy)       # identity: the input gradient IS gy, only the bias sums are reduced
+        gy = gy.float()
+        gy_bs = None if identity else _batch_strided(gy)     # a channel slice of a wider gradient is read where it lies
+        if gy_bs is None:
+            gy = gy.contiguous()
+            gy_bs = c * p
+        gx = gy if identity else torch.empty(gy.shape, dtype=torch.float32, device=gy.device)   # identity: the input gradient IS gy
         deferred = ctx.bias_param is not None
         if identity and not (deferred or ctx.needs_input_grad[1]):
             return gx, None, None
@@ -1713,7 +1743,7 @@ class _BiasAct(torch.autograd.Function):
         else:
             gbias = _zero_slice(c, gy)
         with _on_device(gy):
-            _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gy.data_ptr(),
+            _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd_strided, gy.data_ptr(), gy_bs,
                         None if (ctx.masked or identity) else saved.data_ptr(), saved.data_ptr() if ctx.masked else None,
                         None if identity else gx.data_ptr(), gbias.data_ptr(), b, c, p, ctx.act, _stream_ptr(gy),
                         work=((4.0 if identity else (8.125 if ctx.masked else 12.0)) * b * c * p, 'B'))

@@ -98,14 +98,17 @@ template <int ACT, bool MASK>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                             const unsigned long long* __restrict__ mask,
                                                             float* __restrict__ gx, float* __restrict__ gbias, int C,
-                                                            int P, int chunk) {
+                                                            int P, int chunk, size_t gy_bs) {
+    // gy_bs: batch stride of gy in floats (C * P, or more when gy is a channel slice of a wider gradient -- the adjoint of a
+    // cat hands those over, and copying them out first cost a pass per slice)
     __shared__ float partial[4];
     const int c = blockIdx.y, b = blockIdx.z;
     const size_t base = ((size_t)b * C + c) * P;
+    const size_t gbase = (size_t)b * gy_bs + (size_t)c * P;
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
     float acc = 0.0f;
     if ((P & 3) == 0 && (chunk & 3) == 0) {
-        const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gy + base);
+        const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gy + gbase);
         float4* __restrict__ o4 = reinterpret_cast<float4*>(gx + base);
         if (MASK) {
             const unsigned long long* __restrict__ mrow = mask + ((size_t)b * C + c) * mask_words(P) * 4;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
         }
     } else {
         for (int e = beg + threadIdx.x; e < end; e += 256) {
-            const float o = gy[base + e] * act_grad<ACT>(y[base + e]);
+            const float o = gy[gbase + e] * act_grad<ACT>(y[base + e]);
             gx[base + e] = o;
             acc += o;
         }
@@ -160,10 +163,10 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
 // Identity activation: gx == gy, so the adjoint only needs the per-channel sum of gy (4 B/elem read, nothing
 // written but the C bias sums).  Same grid / reduction as the general kernel.
 __global__ __launch_bounds__(256) void bias_sum_kernel(const float* __restrict__ gy, float* __restrict__ gbias, int C,
-                                                        int P, int chunk) {
+                                                        int P, int chunk, size_t gy_bs) {
     __shared__ float partial[4];
     const int c = blockIdx.y, b = blockIdx.z;
-    const size_t base = ((size_t)b * C + c) * P;
+    const size_t base = (size_t)b * gy_bs + (size_t)c * P;
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
     float acc = 0.0f;
     if ((P & 3) == 0 && (chunk & 3) == 0) {
@@ -451,15 +454,29 @@ extern "C" int camli_bias_act_nhwc_bwd(const float* gy, const void* sign_mask, f
     return camli_check_launch("camli_bias_act_nhwc_bwd");
 }
 
+extern "C" int camli_bias_act_bwd_strided(const float* gy, int64_t gy_batch_stride, const float* y, const void* sign_mask,
+                                          float* gx, float* gbias, int B, int C, int P, int act, void* stream);
+
 extern "C" int camli_bias_act_bwd(const float* gy, const float* y, const void* sign_mask, float* gx, float* gbias,
                                   int B, int C, int P, int act, void* stream) {
+    return camli_bias_act_bwd_strided(gy, (int64_t)C * P, y, sign_mask, gx, gbias, B, C, P, act, stream);
+}
+
+// gy [B,C,P] with batch stride gy_batch_stride floats (>= C*P): a channel slice of a wider gradient is read in place
+extern "C" int camli_bias_act_bwd_strided(const float* gy, int64_t gy_batch_stride, const float* y, const void* sign_mask,
+                                          float* gx, float* gbias, int B, int C, int P, int act, void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!shape_ok("camli_bias_act_bwd", B, C, P, act)) return CAMLI_EINVAL;
+    if (gy_batch_stride < (int64_t)C * P || ((P & 3) == 0 && ((gy_batch_stride & 3) || (reinterpret_cast<uintptr_t>(gy) & 15)))) {
+        camli_set_error("camli_bias_act_bwd: batch stride %lld (needs >= C*P = %lld, and with P %% 4 == 0 a multiple of 4 and a 16-byte aligned pointer)",
+                        (long long)gy_batch_stride, (long long)C * P);
+        return CAMLI_EINVAL;
+    }
     if (act == 0 && !gx) {   // identity: the caller aliases gx to gy, only the bias sums are produced
         if (!gy || !gbias) { camli_set_error("camli_bias_act_bwd: null pointer"); return CAMLI_EINVAL; }
         const int chunk0 = pick_chunk(P);
         hipLaunchKernelGGL(bias_sum_kernel, dim3(camli_divup(P, chunk0), C, B), dim3(256), 0,
-                           reinterpret_cast<hipStream_t>(stream), gy, gbias, C, P, chunk0);
+                           reinterpret_cast<hipStream_t>(stream), gy, gbias, C, P, chunk0, (size_t)gy_batch_stride);
         return camli_check_launch("camli_bias_act_bwd(identity)");
     }
     if (!gy || (!y && !sign_mask && act != 0) || !gx || !gbias) { camli_set_error("camli_bias_act_bwd: null pointer"); return CAMLI_EINVAL; }
@@ -471,7 +488,7 @@ extern "C" int camli_bias_act_bwd(const float* gy, const float* y, const void* s
     dim3 grid(camli_divup(P, chunk), C, B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned long long* m = static_cast<const unsigned long long*>(sign_mask);
-#define L(A, M) hipLaunchKernelGGL((bias_act_bwd_kernel<A, M>), grid, dim3(256), 0, s, gy, y, m, gx, gbias, C, P, chunk)
+#define L(A, M) hipLaunchKernelGGL((bias_act_bwd_kernel<A, M>), grid, dim3(256), 0, s, gy, y, m, gx, gbias, C, P, chunk, (size_t)gy_batch_stride)
     switch (act) {
         case 0: L(0, false); break;
         case 1: if (m) L(1, true); else L(1, false); break;

@@ -12,6 +12,8 @@
 // HBM-bound, 16-byte accesses, one pass over each operand.
 #include "camli_common.h"
 
+#include <stdint.h>
+
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -39,11 +41,13 @@ __global__ __launch_bounds__(256) void gru_gates_fwd_kernel(const float4* __rest
 __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float4* __restrict__ gz, const float4* __restrict__ grh,
                                                              const float4* __restrict__ z, const float4* __restrict__ r,
                                                              const float4* __restrict__ h, float4* __restrict__ gpre,
-                                                             float4* __restrict__ gh, size_t n4, size_t cp4) {
+                                                             float4* __restrict__ gh, size_t n4, size_t cp4, size_t gz_bs4,
+                                                             size_t grh_bs4) {
+    // gz / grh may be channel slices of wider gradients (what the adjoint of cat([rh, x]) hands over): batch strides in float4
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
         const size_t b = e / cp4, off = e - b * cp4;
         const size_t iz = b * 2 * cp4 + off, ir = iz + cp4;
-        const float4 g1 = gz[e], g2 = grh[e], zv = z[e], rv = r[e], hv = h[e];
+        const float4 g1 = gz[b * gz_bs4 + off], g2 = grh[b * grh_bs4 + off], zv = z[e], rv = r[e], hv = h[e];
         float4 a, c, d;
         a.x = g1.x * zv.x * (1.0f - zv.x); a.y = g1.y * zv.y * (1.0f - zv.y); a.z = g1.z * zv.z * (1.0f - zv.z); a.w = g1.w * zv.w * (1.0f - zv.w);
         c.x = g2.x * hv.x * rv.x * (1.0f - rv.x); c.y = g2.y * hv.y * rv.y * (1.0f - rv.y);
@@ -131,15 +135,29 @@ extern "C" int camli_gru_gates_fwd(const float* pre_zr, const float* ctx_zr, con
     return camli_check_launch("camli_gru_gates_fwd");
 }
 
-extern "C" int camli_gru_gates_bwd(const float* gz, const float* grh, const float* z, const float* r, const float* h,
-                                   float* gpre_zr, float* gh, int B, int C, int P, void* stream) {
+extern "C" int camli_gru_gates_bwd_strided(const float* gz, int64_t gz_batch_stride, const float* grh, int64_t grh_batch_stride,
+                                           const float* z, const float* r, const float* h, float* gpre_zr, float* gh, int B,
+                                           int C, int P, void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!gz || !grh || !z || !r || !h || !gpre_zr || !gh) { camli_set_error("camli_gru_gates_bwd: null pointer"); return CAMLI_EINVAL; }
     if (!gru_shape_ok("camli_gru_gates_bwd", B, C, P)) return CAMLI_EINVAL;
-    const size_t cp4 = (size_t)C * P / 4, n4 = cp4 * B;
+    const int64_t cp = (int64_t)C * P;
+    if (gz_batch_stride < cp || grh_batch_stride < cp || (gz_batch_stride & 3) || (grh_batch_stride & 3) ||
+        (reinterpret_cast<uintptr_t>(gz) & 15) || (reinterpret_cast<uintptr_t>(grh) & 15)) {
+        camli_set_error("camli_gru_gates_bwd: batch strides %lld / %lld must be multiples of 4 floats >= C*P = %lld, pointers 16-byte aligned",
+                        (long long)gz_batch_stride, (long long)grh_batch_stride, (long long)cp);
+        return CAMLI_EINVAL;
+    }
+    const size_t cp4 = (size_t)cp / 4, n4 = cp4 * B;
     hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       F4(gz), F4(grh), F4(z), F4(r), F4(h), F4W(gpre_zr), F4W(gh), n4, cp4);
+                       F4(gz), F4(grh), F4(z), F4(r), F4(h), F4W(gpre_zr), F4W(gh), n4, cp4, (size_t)gz_batch_stride / 4,
+                       (size_t)grh_batch_stride / 4);
     return camli_check_launch("camli_gru_gates_bwd");
+}
+
+extern "C" int camli_gru_gates_bwd(const float* gz, const float* grh, const float* z, const float* r, const float* h,
+                                   float* gpre_zr, float* gh, int B, int C, int P, void* stream) {
+    return camli_gru_gates_bwd_strided(gz, (int64_t)C * P, grh, (int64_t)C * P, z, r, h, gpre_zr, gh, B, C, P, stream);
 }
 
 extern "C" int camli_gru_blend_fwd(const float* pre_q, const float* ctx_q, const float* z, const float* h, float* q,

@@ -343,6 +343,11 @@ int camli_gru_gates_fwd(const float *pre_zr, const float *ctx_zr, const float *h
                         int B, int C, int P, void *stream);
 int camli_gru_gates_bwd(const float *gz, const float *grh, const float *z, const float *r, const float *h,
                         float *gpre_zr, float *gh, int B, int C, int P, void *stream);
+/* the same with gz / grh read in place from channel slices of wider gradients (what the adjoint of cat([r*h, x]) hands
+ * over): batch strides in floats, multiples of 4, >= C*P; pointers 16-byte aligned */
+int camli_gru_gates_bwd_strided(const float *gz, int64_t gz_batch_stride, const float *grh, int64_t grh_batch_stride,
+                                const float *z, const float *r, const float *h, float *gpre_zr, float *gh, int B, int C,
+                                int P, void *stream);
 /* nan_to_num = 1 (round 3): h_new = torch.nan_to_num(h_new), the last statement of the GRU (raft_core.py:138), folded
  * into the blend; its adjoint (zero gradient where the un-sanitised value was not finite) is folded into blend_bwd. */
 int camli_gru_blend_fwd(const float *pre_q, const float *ctx_q, const float *z, const float *h, float *q, float *h_new,
@@ -366,6 +371,10 @@ int64_t camli_bias_act_mask_bytes(int B, int C, int P);
 int camli_bias_act_fwd(float *x_inout, const float *bias, void *sign_mask, int B, int C, int P, int act, void *stream);
 int camli_bias_act_bwd(const float *gy, const float *y, const void *sign_mask, float *gx, float *gbias,
                        int B, int C, int P, int act, void *stream);
+/* gy read in place from a channel slice of a wider gradient: batch stride in floats (>= C*P; with P % 4 == 0 a multiple of 4
+ * and a 16-byte aligned pointer).  gx (dense [B,C,P]) and everything else as above. */
+int camli_bias_act_bwd_strided(const float *gy, int64_t gy_batch_stride, const float *y, const void *sign_mask, float *gx,
+                               float *gbias, int B, int C, int P, int act, void *stream);
 /* y = act(x + bias[c] + res) in place on x (round 3): the closing relu(bn3(conv3(.)) + shortcut) of a residual block in
  * one pass; act 0 or 1, res [B,C,P] like x.  The adjoint is camli_bias_act_bwd (the gradient of res equals that of x). */
 /* channels-last forms (round 3, the ResNet trunk): tensor [n_pix, C] with C fastest, C a power of two in [4, 1024], act 0 or

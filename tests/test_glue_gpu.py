@@ -133,3 +133,45 @@ def test_sequence_loss_l2_vs_oracle(case):
     assert abs(loss.item() - want) <= 1e-5 * abs(want)
     for got, g in zip(tp, glue.sequence_loss_l2_bwd(preds, target, c, cfgs.gamma)):
         assert np.allclose(host(got.grad), g, rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 68, 120), (3, 8, 5, 8), (1, 16, 2048)], ids=str)
+def test_gates_and_bias_adjoints_read_channel_slices_in_place(shape):
+    """The adjoint of cat([r*h, x]) hands the gates kernel a channel SLICE of a wider gradient, the adjoint of
+    cat([c, f]) hands one to the bias / activation kernel: camli_gru_gates_bwd_strided / camli_bias_act_bwd_strided read it
+    where it lies.  Same values as the oracle, and as the dense call (bit for bit)."""
+    from camliflow_amd.csrc import fused
+    b, c = shape[:2]
+    rng = np.random.default_rng(sum(shape) + 1)
+    zr_shape = (b, 2 * c) + shape[2:]
+    wide = (b, 2 * c + 4) + shape[2:]
+    pre_zr, ctx_zr = rng.standard_normal(zr_shape).astype(np.float32), rng.standard_normal(zr_shape).astype(np.float32)
+    h = rng.standard_normal(shape).astype(np.float32)
+    gz = rng.standard_normal(shape).astype(np.float32)
+    gwide = rng.standard_normal(wide).astype(np.float32)            # gradient of cat([rh, extra]) -> grh = gwide[:, :c]
+    extra = dev(rng.standard_normal((b, c + 4) + shape[2:]).astype(np.float32), True)
+    t_pre, t_ctx, t_h = dev(pre_zr, True), dev(ctx_zr, True), dev(h, True)
+    z, rh = fused.gru_gates(t_pre, t_ctx, t_h)
+    ((z * dev(gz)).sum() + (torch.cat([rh, extra], dim=1) * dev(gwide)).sum()).backward()
+    want_z, _, want_r = glue.gru_gates_fwd(pre_zr, ctx_zr, h)
+    gpre, gh = glue.gru_gates_bwd(gz, gwide[:, :c], want_z, want_r, h)
+    assert close(t_pre.grad, gpre) and close(t_h.grad, gh)
+    d_pre, d_h = dev(pre_zr, True), dev(h, True)
+    z2, rh2 = fused.gru_gates(d_pre, dev(ctx_zr), d_h)
+    ((z2 * dev(gz)).sum() + (rh2 * dev(np.ascontiguousarray(gwide[:, :c]))).sum()).backward()
+    assert torch.equal(d_pre.grad, t_pre.grad) and torch.equal(d_h.grad, t_h.grad)
+
+    # bias + activation: y = act(x + bias) sits in the middle of a cat
+    for act, fn in (('relu', lambda v: np.maximum(v, 0)), ('leaky_relu', lambda v: np.where(v > 0, v, 0.1 * v)), (None, lambda v: v)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        bias = rng.standard_normal(c).astype(np.float32)
+        left = dev(rng.standard_normal((b, 4) + shape[2:]).astype(np.float32), True)
+        t_x, t_b = dev(x, True), dev(bias, True)
+        y = fused.bias_act(t_x * 1.0, t_b, act)
+        gw = rng.standard_normal((b, c + 8) + shape[2:]).astype(np.float32)
+        (torch.cat([left, y, left], dim=1) * dev(gw)).sum().backward()
+        pre = x.astype(np.float64) + bias.reshape((1, c) + (1,) * (len(shape) - 2))
+        slope = np.ones_like(pre) if act is None else np.where(pre > 0, 1.0, 0.0 if act == 'relu' else 0.1)
+        want_gx = gw[:, 4:4 + c] * slope
+        assert close(y, fn(pre)) and close(t_x.grad, want_gx)
+        assert close(t_b.grad, want_gx.sum(axis=(0,) + tuple(range(2, len(shape)))), rtol=1e-4, atol=1e-4)
