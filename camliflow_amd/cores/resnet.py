@@ -44,8 +44,13 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, folded=None):
         if _foldable(self.bn1, x):
-            shortcut = x if self.downsample is None else _conv_bn(self.downsample[0], self.downsample[1], x, None, folded)
-            y = _conv_bn(self.conv1, self.bn1, x, 'relu', folded)
+            if (self.downsample is None and _FORK and _is_channels_last(x) and x.dtype == torch.float32
+                    and torch.is_grad_enabled() and x.requires_grad and not torch.is_autocast_enabled()):
+                # identity block: conv1 and the shortcut leave through one node whose adjoint accumulates in place
+                y, shortcut = _conv_bn(self.conv1, self.bn1, x, 'relu', folded, fork=True)
+            else:
+                shortcut = x if self.downsample is None else _conv_bn(self.downsample[0], self.downsample[1], x, None, folded)
+                y = _conv_bn(self.conv1, self.bn1, x, 'relu', folded)
             y = _conv_bn(self.conv2, self.bn2, y, 'relu', folded)
             # bn3's bias, the shortcut and the block's closing ReLU in ONE pass over conv3's output (camli_bias_act_res_fwd);
             # as bias pass + add + relu they were 7 tensor streams over the largest activations of the model
@@ -57,6 +62,49 @@ class Bottleneck(nn.Module):
         return self.relu(y + shortcut)
 
 
+class _PointwiseFork(torch.autograd.Function):
+    """``conv1`` of an identity bottleneck on a channels-last map, returned together with the block input it shares with the
+    shortcut: ``y, x = fork(x, w)``.  The point is the adjoint.  Autograd would compute the data gradient of the 1x1
+    convolution into a fresh tensor and then ADD the shortcut's gradient to it (three passes over the block's widest
+    tensor); here the data gradient is a GEMM with beta = 1 INTO the shortcut's gradient -- ``g_short += gy W`` on the
+    [pixels, C] matrices the channels-last tensors are -- one read-modify-write.  The shortcut gradient is the tensor the
+    closing epilogue's adjoint produced (``_BiasActNHWC.backward``); its other reader, conv3's adjoint, was enqueued on the
+    same stream before this node runs, so overwriting it here is ordered after that read."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        ctx.args = ([1, 1], [0, 0], [1, 1], False, [0, 0], 1)
+        y = torch.ops.aten.convolution(x, w, None, *ctx.args)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, g_short):
+        x, w = ctx.saved_tensors
+        need_x, need_w = ctx.needs_input_grad
+        gx = gw = None
+        fused_ok = (need_x and g_short is not None and g_short.dtype == torch.float32 and gy.dtype == torch.float32
+                    and _is_channels_last(g_short) and _is_channels_last(gy))
+        if need_w or (need_x and not fused_ok):
+            got = torch.ops.aten.convolution_backward(gy, x, w, None, *ctx.args, [need_x and not fused_ok, need_w, False])
+            gx, gw = got[0], got[1]
+        if need_x:
+            if fused_ok:
+                flat = g_short.permute(0, 2, 3, 1).reshape(-1, g_short.shape[1])            # [pixels, Cin]: a view
+                flat.addmm_(gy.permute(0, 2, 3, 1).reshape(-1, gy.shape[1]), w.flatten(1))
+                gx = g_short
+            elif g_short is not None:
+                gx = gx + g_short
+        return gx, gw
+
+
+def _is_channels_last(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+_FORK = os.environ.get('CAMLI_TRUNK_FORK', '1') != '0'
+
+
 def _foldable(bn, x):
     """Frozen-statistics BatchNorm (norm_eval) on the product path: it is an affine map per channel
     and can be folded into the preceding convolution."""
@@ -64,7 +112,7 @@ def _foldable(bn, x):
     return (not bn.training) and epilogue_ok(x)
 
 
-def _conv_bn(conv, bn, x, act, folded=None, residual=None):
+def _conv_bn(conv, bn, x, act, folded=None, residual=None, fork=False):
     """conv -> BatchNorm(eval) -> act as ONE convolution with folded weights plus the fused bias /
     activation epilogue:  y = conv(x, w * s) + (beta - mean * s),  s = gamma / sqrt(var + eps).
     gamma / beta stay trainable (the fold is differentiated by autograd on the small tensors); no
@@ -80,6 +128,9 @@ def _conv_bn(conv, bn, x, act, folded=None, residual=None):
     weight = conv.weight * scale.view(-1, 1, 1, 1)
     if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
         weight = weight.contiguous(memory_format=torch.channels_last)
+    if fork:        # 1x1, stride 1: (act(conv + bias), the input for the shortcut) -- see _PointwiseFork
+        y, shortcut = _PointwiseFork.apply(x, weight)
+        return fused.bias_act(y, bias, act), shortcut
     y = F.conv2d(x, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if residual is not None:
         return fused.bias_act_res(y, bias, residual, act)
