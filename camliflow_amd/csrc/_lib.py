@@ -27,6 +27,7 @@ PROTOTYPES = {
                                                ctypes.c_void_p, _int, _int, _int, ctypes.c_float, ctypes.c_void_p, _stream]),
     "camli_allpairs_lookup_bwd_marked": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                                 _c_float_p, _int, _int, _int, _int, ctypes.c_void_p, _stream]),
+    "camli_allpairs_clear_marked": (_int, [ctypes.c_void_p, ctypes.c_void_p, _int, ctypes.c_void_p, _int, _int, _stream]),
     "camli_allpairs_lookup_fwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                          _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_allpairs_lookup_bwd": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,

@@ -26,6 +26,16 @@ from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_slice
 _USE_MARKS = os.environ.get('CAMLI_ALLPAIRS_MARKS', '1') != '0'
 
 
+# CAMLI_ALLPAIRS_KEEP=0: allocate and zero-fill the gradient pyramid in every backward pass (the round-3 behaviour)
+_KEEP_GRAD_PYRAMID = os.environ.get('CAMLI_ALLPAIRS_KEEP', '1') != '0'
+# (device, level shapes) -> [grads, marks, event]: a gradient pyramid and its visit marks, ALL ZERO, kept between steps.  A pass
+# takes it (pop), its lookups dirty a band of blocks, the build adjoint reads it and then cleans exactly the marked blocks
+# (camli_allpairs_clear_marked) before putting it back; `event` orders that cleaning before the next pass's first write.
+# A pass that dies between the two never returns its buffers (the next one allocates fresh zeros), so what sits here is
+# always clean.  One entry per shape: a second pass alive at the same time allocates its own.
+_clean_grad_pyramids = {}
+
+
 class AllPairsPyramid:
     """The 4-level all-pairs volume of one forward pass plus the state its backward needs.
 
@@ -99,10 +109,11 @@ class _BuildPyramid(torch.autograd.Function):
         fmap1, *f2_levels = ctx.saved_tensors
         bs, dim, h, w = ctx.dims
         p = h * w
-        grads = marks = None
+        grads = marks = keep_key = None
         if pyr is not None:
             grads, pyr.grads = pyr.grads, None
             marks, pyr.marks = pyr.marks, None
+            keep_key = getattr(pyr, 'keep_key', None)
         if grads is None:
             return torch.zeros_like(fmap1), torch.zeros_like(fmap1), None, None
         sizes = ctx.sizes
@@ -121,6 +132,15 @@ class _BuildPyramid(torch.autograd.Function):
                 _lib.launch('camli_allpairs_build_bwd', lib.camli_allpairs_build_bwd, fmap1.data_ptr(), _ptr_array(f2_levels),
                             _ptr_array(grads), p_levels, len(sizes), g1.data_ptr(), _ptr_array(g2_levels), bs, dim, p,
                             1.0 / math.sqrt(dim), _stream_ptr(fmap1), **work)
+            if marks is not None and keep_key is not None and keep_key not in _clean_grad_pyramids:
+                # put the pyramid back to all-zero -- only the marked blocks were ever written -- and keep it for the next pass
+                _lib.launch('camli_allpairs_clear_marked', lib.camli_allpairs_clear_marked, _ptr_array(grads), p_levels, len(sizes),
+                            _ptr_array(marks), bs, p, _stream_ptr(fmap1), work=(0.2 * 4.0 * bs * p * total, 'B'))
+                cleaned = torch.cuda.Event()
+                cleaned.record(torch.cuda.current_stream(fmap1.device))
+                while len(_clean_grad_pyramids) >= 2:        # other shapes (another batch size): keep the two latest
+                    _clean_grad_pyramids.pop(next(iter(_clean_grad_pyramids)))
+                _clean_grad_pyramids[keep_key] = [grads, marks, cleaned]
         # adjoint of the avg_pool2d chain on the SMALL maps ([B,C,h_l,w_l]): fold the coarse levels into level 0
         g2 = g2_levels[-1]
         for lvl in range(len(g2_levels) - 2, -1, -1):
@@ -158,11 +178,20 @@ class _Lookup(torch.autograd.Function):
         pyr = ctx.pyr
         bs, h, w = pyr.shape
         if pyr.grads is None:
-            pyr.grads = [torch.zeros_like(lvl) for lvl in pyr.levels]
-            sb = (h * w + 31) // 32
-            if _USE_MARKS:
-                pyr.marks = [torch.zeros((bs, sb, (lvl.shape[-2] * lvl.shape[-1] + 31) // 32), dtype=torch.uint8, device=lvl.device)
-                             for lvl in pyr.levels]
+            kept = None
+            if _USE_MARKS and _KEEP_GRAD_PYRAMID and not torch.cuda.is_current_stream_capturing():
+                # (under graph capture the pass keeps the allocate-and-fill form: a captured replay owns its buffers)
+                pyr.keep_key = (coords.device, tuple(tuple(lvl.shape) for lvl in pyr.levels))
+                kept = _clean_grad_pyramids.pop(pyr.keep_key, None)
+            if kept is not None:        # all zero since the last pass cleaned up after itself
+                pyr.grads, pyr.marks, cleaned = kept
+                torch.cuda.current_stream(coords.device).wait_event(cleaned)
+            else:
+                pyr.grads = [torch.zeros_like(lvl) for lvl in pyr.levels]
+                sb = (h * w + 31) // 32
+                if _USE_MARKS:
+                    pyr.marks = [torch.zeros((bs, sb, (lvl.shape[-2] * lvl.shape[-1] + 31) // 32), dtype=torch.uint8,
+                                             device=lvl.device) for lvl in pyr.levels]
         gout = gout.contiguous().float()
         n, ptrs, hs, ws = pyr._level_args(pyr.grads)
         work = (4.0 * bs * h * w * (n * (2 * ctx.radius + 1) ** 2 + 2 * n * (2 * ctx.radius + 2) ** 2 + 2), 'B')

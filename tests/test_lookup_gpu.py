@@ -181,3 +181,42 @@ def test_pyramid_adjoint_following_visit_marks_equals_full_scan(shape):
         blocks = pad.reshape(b, sb, 32, tb, 32).any(dim=4).any(dim=2)
         assert not (blocks & (mark == 0)).any(), 'a non-zero gradient block is not marked'
         assert (mark != 0).float().mean() < 1.0 or pl <= 128
+
+
+def test_gradient_pyramid_kept_across_passes_is_clean_and_gives_the_same_gradients():
+    """The gradient pyramid survives the backward pass (camli_allpairs_clear_marked zeroes exactly the blocks the lookups
+    marked); three passes with different flow fields on the kept buffers == three passes on freshly zero-filled ones, bit
+    for bit, and what is kept between passes is all zero, marks included."""
+    from camliflow_amd.csrc import fused
+    b, c, h, w = 2, 64, 20, 28
+    g = torch.Generator().manual_seed(3)
+    f1 = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+    f2 = torch.randn(b, c, h, w, generator=g).cuda().requires_grad_(True)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    base = torch.stack([xs, ys])[None].repeat(b, 1, 1, 1)
+    passes = [[(base + torch.randn(b, 2, h, w, generator=g) * s).cuda() for s in scales] for scales in ((0.5, 3.0), (8.0,), (1.0, 1.5, 5.0))]
+    gouts = [[torch.randn(b, 4 * 81, h, w, generator=g).cuda() for _ in cs] for cs in passes]
+
+    def run(keep):
+        saved = fused._KEEP_GRAD_PYRAMID
+        fused._KEEP_GRAD_PYRAMID = keep
+        fused._clean_grad_pyramids.clear()
+        try:
+            results = []
+            for cs, gs in zip(passes, gouts):
+                pyr = fused.allpairs_pyramid(f1, f2, 4)
+                outs = [fused.allpairs_lookup(pyr, cc, 4) for cc in cs]
+                results.append(torch.autograd.grad(outs, [f1, f2], gs))
+                if keep:
+                    assert len(fused._clean_grad_pyramids) == 1
+                    grads, marks, _ = next(iter(fused._clean_grad_pyramids.values()))
+                    torch.cuda.synchronize()
+                    assert all(int(t.count_nonzero()) == 0 for t in grads) and all(int(m.count_nonzero()) == 0 for m in marks)
+            return results
+        finally:
+            fused._KEEP_GRAD_PYRAMID = saved
+            fused._clean_grad_pyramids.clear()
+
+    kept, fresh = run(True), run(False)
+    for a, c_ in zip(kept, fresh):
+        assert torch.equal(a[0], c_[0]) and torch.equal(a[1], c_[1])
