@@ -59,6 +59,18 @@ int camli_knn(const float *input, const float *query, int64_t *out_idx,
 int camli_knn_prefixes(const float *input, const float *query, int64_t *const *out_levels, const int *sizes,
                        int L, int B, int M, int Nq, int D, int k, void *stream);
 
+/*
+ * The same search, same results bit for bit, for LARGE candidate sets: the candidates are sorted along a Morton curve
+ * (once per call, in LDS), cut into chunks with bounding boxes, the queries are sorted the same way, and a query only
+ * visits the chunks whose box distance -- evaluated in the arithmetic of the point distance, hence a lower bound bit for
+ * bit -- is within its running bound of the k-th distance (csrc/hip/knn.hip, "spatially pruned search").
+ *   workspace: camli_knn_pruned_workspace_bytes(B, M, Nq) bytes of device memory; 0 = shape not served (M or Nq > 16384).
+ *   1 <= k <= 32, D in {2, 3}.  Replaces the same reference kernel as camli_knn.
+ */
+int64_t camli_knn_pruned_workspace_bytes(int B, int M, int Nq);
+int camli_knn_pruned(const float *input, const float *query, int64_t *out_idx, void *workspace, int B, int M, int Nq, int D,
+                     int k, void *stream);
+
 /* camli_fps tie rule: the LOWEST index among equal maxima (the reference's Python path, wrapper.py:83-96); the
  * reference's CUDA reduction tree keeps a different tied candidate (kernel.cu:5-10) -- see csrc/hip/fps.hip. */
 int camli_fps(const float *xyz, int64_t *out_idx, int B, int N, int n_samples, void *stream);

@@ -71,15 +71,46 @@ def test_knn_bit_exact(case, kind, ops, oracle_lib):
 
 @pytest.mark.parametrize('case', [(2, 2048, 1024, 3, 16), (1, 8192, 512, 3, 16), (2, 2048, 700, 3, 3), (2, 1000, 300, 2, 1),
                                   (1, 4096, 300, 3, 32)], ids=lambda c: 'B%d_M%d_N%d_D%d_k%d' % c)
-@pytest.mark.parametrize('mode', ['lane', 'xlane'])
+@pytest.mark.parametrize('mode', ['lane', 'xlane', 'pruned'])
 def test_knn_kernel_families_agree_with_the_oracle(case, mode, ops, oracle_lib, monkeypatch):
-    """Both kernel families behind camli_knn (lane-per-query, candidates-across-lanes) on a cloud with 25 % duplicates:
-    bit-exact vs the oracle whichever one the dispatcher is told to take."""
+    """The kernel families behind k_nearest_neighbor (lane-per-query, candidates-across-lanes, spatially pruned) on a cloud
+    with 25 % duplicates: bit-exact vs the oracle whichever one the dispatcher is told to take."""
     b, m, nq, d, k = case
     monkeypatch.setenv('CAMLI_KNN', mode)
     rng = np.random.default_rng(hash((case, 'fam')) % (2 ** 32))
     inp, qry = _cloud(rng, b, m, d, 'dup'), _cloud(rng, b, nq, d, 'dup')
     qry[:, :min(nq, m) // 2] = inp[:, :min(nq, m) // 2]
+    got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
+    assert np.array_equal(got, oracle_lib.knn(inp, qry, k))
+
+
+def _shaped_cloud(rng, kind, b, m, d):
+    if kind == 'uniform':
+        return (rng.random((b, m, d), dtype=np.float32) * 10).astype(np.float32)
+    if kind == 'clustered':       # twenty tight blobs: dense next to empty
+        centres = rng.random((b, 20, d)) * 10
+        pick = rng.integers(0, 20, size=(b, m))
+        return (np.take_along_axis(centres, pick[..., None].repeat(d, axis=2), axis=1) + rng.normal(0, 0.3, (b, m, d))).astype(np.float32)
+    if kind == 'lattice':         # integer grid: exact distance ties everywhere, many of them at the k-th distance
+        return rng.integers(0, 12, size=(b, m, d)).astype(np.float32)
+    ang, r = rng.random((b, m)) * 2 * np.pi, rng.exponential(8.0, (b, m)) + 2      # a disk with a dense centre, like a LiDAR sweep
+    cols = [r * np.cos(ang), r * np.sin(ang), rng.normal(0, 0.3, (b, m)) + 0.02 * r]
+    return np.stack(cols[:d], axis=2).astype(np.float32)
+
+
+@pytest.mark.parametrize('case', [(2, 8192, 1500, 3, 16), (1, 16384, 1100, 3, 16), (2, 5000, 1024, 3, 3), (2, 4099, 1031, 2, 1),
+                                  (1, 6000, 1200, 3, 32), (1, 300, 70, 3, 16)], ids=lambda c: 'B%d_M%d_N%d_D%d_k%d' % c)
+@pytest.mark.parametrize('kind', ['uniform', 'clustered', 'lattice', 'disk'])
+def test_knn_spatially_pruned_search_is_bit_exact(case, kind, ops, oracle_lib, monkeypatch):
+    """camli_knn_pruned (Morton-ordered chunks, exact box pruning) on clouds that stress it: empty space next to dense blobs,
+    lattices full of ties at the k-th distance (far more survivors than the list holds -> the rescue pass and the in-order
+    redo), ragged sizes, a partial last chunk, queries that coincide with candidates.  Bit-exact vs the oracle."""
+    b, m, nq, d, k = case
+    monkeypatch.setenv('CAMLI_KNN', 'pruned')
+    rng = np.random.default_rng(hash((case, kind)) % (2 ** 32))
+    inp = _shaped_cloud(rng, kind, b, m, d)
+    qry = _shaped_cloud(rng, kind, b, nq, d)
+    qry[:, :nq // 3] = inp[:, rng.permutation(m)[:nq // 3]]
     got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
     assert np.array_equal(got, oracle_lib.knn(inp, qry, k))
 
