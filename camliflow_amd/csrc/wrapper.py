@@ -214,3 +214,26 @@ def _pruned_workspace(lib, b, m, nq, k):
     if os.environ.get('CAMLI_KNN', '')[:1] != 'p' or not 1 <= k <= 32:
         return 0
     return int(lib.camli_knn_pruned_workspace_bytes(b, m, nq))
+
+
+def k_nearest_neighbor_prefixes(input_xyz: torch.Tensor, query_xyz: torch.Tensor, sizes, k: int):
+    """[k_nearest_neighbor(input_xyz[:, :m], query_xyz, k) for m in sizes] in one scan (sizes strictly descending,
+    sizes[0] = all inputs): the levels of the FPS pyramid are nested prefixes (models/utils.py:121-125), and the
+    sequential insertion semantics of the search make the k-list after the first m candidates the answer for that
+    prefix.  Channel-last [B,M,D] / [B,Nq,D] only (internal helper of the cores, not part of the reference boundary)."""
+    import ctypes
+    _require_cuda('k_nearest_neighbor_prefixes', input_xyz, query_xyz)
+    lib = _lib.load()
+    input_xyz = input_xyz.contiguous().float()
+    query_xyz = query_xyz.contiguous().float()
+    b, m, d = input_xyz.shape
+    nq = query_xyz.shape[1]
+    sizes = [int(v) for v in sizes]
+    assert sizes[0] == m and all(a > c for a, c in zip(sizes[:-1], sizes[1:])) and len(sizes) <= 4
+    outs = [torch.empty((b, nq, k), dtype=torch.int64, device=query_xyz.device) for _ in sizes]
+    ptrs = (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+    csizes = (ctypes.c_int * len(sizes))(*sizes)
+    with _on_device(input_xyz):
+        _lib.launch('camli_knn', lib.camli_knn_prefixes, input_xyz.data_ptr(), query_xyz.data_ptr(), ptrs, csizes, len(sizes),
+                    b, m, nq, d, k, _stream_ptr(input_xyz), work=(float(b) * m * nq, 'pairs'))
+    return outs

@@ -69,3 +69,15 @@ def test_composed_formulation_runs_anywhere():
     assert csrc.furthest_point_sampling(x, 8, cpp_impl=False).shape == (2, 8)
     out = csrc.correlation2d(torch.rand(1, 4, 5, 6, generator=g), torch.rand(1, 4, 5, 6, generator=g), 2, cpp_impl=False)
     assert out.shape == (1, 25, 5, 6)
+
+
+def test_python_boundary_keeps_every_operator_of_the_reference_wrapper():
+    """models/csrc/wrapper.py:18-127 exports correlation2d, furthest_point_sampling, k_nearest_neighbor and (utils) squared_distance;
+    the cores also rely on the nested-prefix search.  A lost definition must fail here, on the CPU."""
+    from camliflow_amd.csrc import wrapper
+    for name in ('correlation2d', 'furthest_point_sampling', 'k_nearest_neighbor', 'k_nearest_neighbor_prefixes', 'squared_distance',
+                 'CorrelationFunction'):
+        assert callable(getattr(wrapper, name, None)), name
+    import camliflow_amd.csrc as boundary
+    for name in ('correlation2d', 'furthest_point_sampling', 'k_nearest_neighbor'):
+        assert callable(getattr(boundary, name, None)), name
