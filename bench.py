@@ -809,6 +809,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model == 'camliraft':
             # free the bench model before the parity model is built
             del optimizer, graphed
+            from camliflow_amd.csrc import fused as _fused
+            _fused.release_cached_buffers()         # the clean gradient pyramid of the timed steps (2.8 GB)
             deadline = budget - 15.0
             got, why = run_with_deadline(lambda: cpu_baseline_and_reference(args, state_dict, deadline), deadline - _elapsed())
             if got is None:

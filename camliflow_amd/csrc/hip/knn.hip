@@ -1806,6 +1806,10 @@ extern "C" int camli_knn_pruned(const float* input, const float* query, int64_t*
         camli_set_error("camli_knn_pruned: bad shape B=%d M=%d Nq=%d D=%d k=%d", B, M, Nq, D, k);
         return CAMLI_EINVAL;
     }
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) {
+        camli_set_error("camli_knn_pruned: the workspace must be 16-byte aligned");
+        return CAMLI_EINVAL;
+    }
     if (!xl::k_supported(k) || camli_knn_pruned_workspace_bytes(B, M, Nq) == 0) {
         camli_set_error("camli_knn_pruned: shape not served (k=%d M=%d Nq=%d; needs k <= 32, M and Nq <= %d)", k, M, Nq, xl::PR_MAX_N);
         return CAMLI_ENOTSUP;

@@ -64,7 +64,8 @@ int camli_knn_prefixes(const float *input, const float *query, int64_t *const *o
  * (once per call, in LDS), cut into chunks with bounding boxes, the queries are sorted the same way, and a query only
  * visits the chunks whose box distance -- evaluated in the arithmetic of the point distance, hence a lower bound bit for
  * bit -- is within its running bound of the k-th distance (csrc/hip/knn.hip, "spatially pruned search").
- *   workspace: camli_knn_pruned_workspace_bytes(B, M, Nq) bytes of device memory; 0 = shape not served (M or Nq > 16384).
+ *   workspace: camli_knn_pruned_workspace_bytes(B, M, Nq) bytes of device memory, 16-byte aligned; 0 = shape not served
+ *   (M or Nq > 16384).
  *   1 <= k <= 32, D in {2, 3}.  Replaces the same reference kernel as camli_knn.
  */
 int64_t camli_knn_pruned_workspace_bytes(int B, int M, int Nq);
