@@ -40,6 +40,8 @@ PROTOTYPES = {
                                              _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _int, _stream]),
     "camli_pointconv_dw_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p,
                                       _int, _int, _int, _int, _stream]),
+    "camli_pointconv_dw_bwd_strided": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p,
+                                      _int, _int, _int, _int, _stream]),
     "camli_pointconv_dw_bwd_ordered": (_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p,
                                       _int, _int, _int, _int, _stream]),
     "camli_pointconv_dw_expand": (_int, [ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,

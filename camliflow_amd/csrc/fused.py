@@ -348,17 +348,25 @@ class _PointConvDW(torch.autograd.Function):
         shared = ctx.shared
         b, c, m = feat.shape
         n = wsel.shape[2]
-        gout = gout.contiguous().float()
+        gout = gout.float()
         gfeat = torch.empty_like(feat) if ctx.needs_input_grad[0] else None   # fully written by the kernel
         gwsel = torch.empty_like(wsel)
         # torch.use_deterministic_algorithms(True): the ordered form (no float atomics, fixed summation order; 1.7x the time)
         ordered = torch.are_deterministic_algorithms_enabled() and 12 * m <= 64 * 1024
+        # a channel slice of a wider gradient (the outputs are concatenated downstream) is read in place by the LDS row kernel
+        gout_bs = None if (ordered or 8 * m > 64 * 1024) else _batch_strided(gout)
+        work = dict(work=(16.0 * b * c * n + 8.0 * b * c * m, 'B'))
         with _on_device(feat):
-            _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd_ordered if ordered else lib.camli_pointconv_dw_bwd,
-                        gout.data_ptr(), feat.data_ptr(),
-                        wsel.data_ptr(), msel.data_ptr(), gfeat.data_ptr() if gfeat is not None else None,
-                        gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat),
-                        work=(16.0 * b * c * n + 8.0 * b * c * m, 'B'))
+            if gout_bs is not None and gout_bs != c * n:
+                _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd_strided, gout.data_ptr(), gout_bs, feat.data_ptr(),
+                            wsel.data_ptr(), msel.data_ptr(), gfeat.data_ptr() if gfeat is not None else None,
+                            gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat), **work)
+            else:
+                gout = gout.contiguous()
+                _lib.launch('camli_pointconv_dw_bwd', lib.camli_pointconv_dw_bwd_ordered if ordered else lib.camli_pointconv_dw_bwd,
+                            gout.data_ptr(), feat.data_ptr(),
+                            wsel.data_ptr(), msel.data_ptr(), gfeat.data_ptr() if gfeat is not None else None,
+                            gwsel.data_ptr(), b, c, m, n, _stream_ptr(feat), **work)
         shared.records.append((gwsel, arg))
         return gfeat, None, None, None, None
 

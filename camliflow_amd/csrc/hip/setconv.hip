@@ -433,11 +433,13 @@ __global__ __launch_bounds__(256) void pointconv_dw_bwd_row_kernel(const float* 
                                                                     const float* __restrict__ wsel,
                                                                     const int* __restrict__ msel,
                                                                     float* __restrict__ gfeat, float* __restrict__ gwsel,
-                                                                    int M, int N, int vec) {
+                                                                    int M, int N, int vec, int C, size_t gout_bs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sf = lds;        // feat row
     float* sg = lds + M;    // gradient row
     const size_t row = blockIdx.x;
+    // gout may be a channel slice of a wider gradient (batch stride gout_bs floats >= C * N): row (b, c) starts here
+    const float* __restrict__ grow = gout + (row / C) * gout_bs + (row % C) * (size_t)N;
     // 16-byte accesses whenever the rows allow it (r3: the scalar form kept one 4-byte load per lane in flight and ran
     // at 2.6 TB/s); `vec`: M and N multiples of 4 and every base pointer 16-byte aligned (checked by the launcher)
     if (vec) {
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(256) void pointconv_dw_bwd_row_kernel(const float* 
     }
     __syncthreads();
     if (vec) {
-        const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gout + row * N);
+        const float4* __restrict__ g4 = reinterpret_cast<const float4*>(grow);
         const int4* __restrict__ m4 = reinterpret_cast<const int4*>(msel + row * N);
         const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wsel + row * N);
         float4* __restrict__ o4 = reinterpret_cast<float4*>(gwsel + row * N);
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(256) void pointconv_dw_bwd_row_kernel(const float* 
     } else {
         for (int n = threadIdx.x; n < N; n += 256) {
             const size_t e = row * N + n;
-            const float g = gout[e];
+            const float g = grow[n];
             const int mm = msel[e];
             if (gwsel) gwsel[e] = g * sf[mm];
             if (gfeat) unsafeAtomicAdd(sg + mm, g * wsel[e]);
@@ -811,7 +813,9 @@ extern "C" int camli_pointconv_dw_fwd_kmajor(const float* feat, const float* wei
 }
 
 static int dw_bwd_impl(const float* gout, const float* feat, const float* wsel, const int* msel, float* gfeat, float* gwsel,
-                       int B, int C, int M, int N, bool ordered, void* stream) {
+                       int B, int C, int M, int N, bool ordered, void* stream, int64_t gout_bs = 0) {
+    if (gout_bs == 0) gout_bs = (int64_t)C * N;
+    const bool dense = gout_bs == (int64_t)C * N;
     if (B == 0) return CAMLI_OK;   // empty problem: nothing to launch (pointers may be null)
     if (!gout || !feat || !wsel || !msel || (!gfeat && !gwsel)) {
         camli_set_error("camli_pointconv_dw_bwd: null pointer");
@@ -826,6 +830,11 @@ static int dw_bwd_impl(const float* gout, const float* feat, const float* wsel, 
     const uintptr_t bits = (uintptr_t)gout | (uintptr_t)feat | (uintptr_t)wsel | (uintptr_t)msel | (uintptr_t)gfeat |
                            (uintptr_t)gwsel;      // a null pointer contributes no bits
     const int vec = ((M | N) & 3) == 0 && (bits & 15) == 0;
+    if (!dense && (ordered || row_lds > 64 * 1024 || gout_bs < (int64_t)C * N || (vec && (gout_bs & 3)))) {
+        camli_set_error("camli_pointconv_dw_bwd_strided: batch stride %lld is served by the LDS row kernel only (rows of <= 8192 floats, "
+                        "stride >= C*N and a multiple of 4)", (long long)gout_bs);
+        return CAMLI_ENOTSUP;
+    }
     if (ordered) {
         if ((size_t)3 * M * sizeof(float) > 64 * 1024) {
             camli_set_error("camli_pointconv_dw_bwd_ordered: a row of M=%d floats and its two side arrays exceed 64 KB of LDS", M);
@@ -837,7 +846,7 @@ static int dw_bwd_impl(const float* gout, const float* feat, const float* wsel, 
     }
     if (row_lds <= 64 * 1024) {
         hipLaunchKernelGGL(pointconv_dw_bwd_row_kernel, dim3((unsigned)((size_t)B * C)), dim3(256), row_lds, s, gout, feat,
-                           wsel, msel, gfeat, gwsel, M, N, vec);
+                           wsel, msel, gfeat, gwsel, M, N, vec, C, (size_t)gout_bs);
         return camli_check_launch("camli_pointconv_dw_bwd");
     }
     // rows too long for LDS: global float atomics into a zero-filled gradient
@@ -859,6 +868,15 @@ extern "C" int camli_pointconv_dw_bwd(const float* gout, const float* feat, cons
 
 // The same adjoint without float atomics: fixed summation order, bit-reproducible (1.7x the time of the LDS-atomic form at
 // C128 k16: 37.6 vs 21.7 us); what torch.use_deterministic_algorithms(True) selects.  M <= 5461.
+// gout read in place from a channel slice of a wider gradient: batch stride in floats (>= C*N, a multiple of 4 when M and N
+// are; rows of M <= 8192 floats -- the LDS row kernel); CAMLI_ENOTSUP otherwise (copy the slice and call camli_pointconv_dw_bwd)
+extern "C" int camli_pointconv_dw_bwd_strided(const float* gout, int64_t gout_batch_stride, const float* feat, const float* wsel,
+                                              const int* msel, float* gfeat, float* gwsel, int B, int C, int M, int N,
+                                              void* stream) {
+    if (gout_batch_stride < 1) { camli_set_error("camli_pointconv_dw_bwd_strided: bad stride"); return CAMLI_EINVAL; }
+    return dw_bwd_impl(gout, feat, wsel, msel, gfeat, gwsel, B, C, M, N, false, stream, gout_batch_stride);
+}
+
 extern "C" int camli_pointconv_dw_bwd_ordered(const float* gout, const float* feat, const float* wsel, const int* msel,
                                               float* gfeat, float* gwsel, int B, int C, int M, int N, void* stream) {
     return dw_bwd_impl(gout, feat, wsel, msel, gfeat, gwsel, B, C, M, N, true, stream);

@@ -170,6 +170,10 @@ int camli_pointconv_dw_bwd(const float *gout, const float *feat, const float *ws
                            float *gfeat, float *gwsel, int B, int C, int M, int N, void *stream);
 /* the same adjoint with a FIXED summation order (no float atomics: integer LDS tickets decide whose turn it is to add into a
  * target): bit-reproducible, ~1.7x the time; selected under torch.use_deterministic_algorithms(True).  M <= 5461. */
+/* gout read in place from a channel slice of a wider gradient (what the adjoint of a cat hands over): batch stride in floats,
+ * >= C*N; served by the LDS row kernel (M <= 8192), CAMLI_ENOTSUP otherwise */
+int camli_pointconv_dw_bwd_strided(const float *gout, int64_t gout_batch_stride, const float *feat, const float *wsel,
+                                   const int *msel, float *gfeat, float *gwsel, int B, int C, int M, int N, void *stream);
 int camli_pointconv_dw_bwd_ordered(const float *gout, const float *feat, const float *wsel, const int *msel,
                            float *gfeat, float *gwsel, int B, int C, int M, int N, void *stream);
 int camli_pointconv_dw_expand(const float *const *gwsel_list, const unsigned char *const *arg_list, int n_calls,

@@ -124,3 +124,28 @@ def test_k_major_layout_is_the_same_operator(case, oracle_lib):
         assert np.array_equal(res[k_major][0], want)
         assert np.allclose(res[k_major][1], gfeat, rtol=1e-5, atol=1e-5)
         assert np.array_equal(res[k_major][2], gweight)
+
+
+@pytest.mark.parametrize('case', [(2, 128, 2048, 2048, 16), (3, 32, 500, 300, 32), (1, 125, 2048, 2048, 4)],
+                         ids=lambda c: 'B%d_C%d_M%d_N%d_k%d' % c)
+def test_core_adjoint_reads_a_sliced_output_gradient_in_place(case, oracle_lib):
+    """The set-conv outputs are concatenated downstream (GRU3D, MotionEncoder3D): the adjoint of that cat hands
+    camli_pointconv_dw_bwd_strided a channel slice of a wider gradient.  Same gradients as the oracle (C = 125: the slice is not
+    16-byte aligned for every batch entry -> the wrapper copies it, the dense kernel runs)."""
+    from camliflow_amd.csrc import fused
+    b, c, m, n, k = case
+    rng = np.random.default_rng(sum(case) + 7)
+    feat = rng.standard_normal((b, c, m)).astype(np.float32)
+    weight = np.maximum(rng.standard_normal((b, c, n, k)), 0).astype(np.float32)
+    idx = rng.integers(0, m, size=(b, n, k)).astype(np.int64)
+    gwide = rng.standard_normal((b, c + 8, n)).astype(np.float32)
+    tf = torch.from_numpy(feat).cuda().requires_grad_(True)
+    tw = torch.from_numpy(weight).cuda().requires_grad_(True)
+    shared = fused.SharedSetConvWeights(tw)
+    out = fused.pointconv_dw(tf, shared, torch.from_numpy(idx).cuda(), k)
+    side = torch.zeros(b, 4, n, device='cuda', requires_grad=True)
+    (torch.cat([side, out, side], dim=1) * torch.from_numpy(gwide).cuda()).sum().backward()
+    _, arg = oracle_lib.pointconv_dw_fwd(feat, weight, idx, k)
+    gfeat, gweight = oracle_lib.pointconv_dw_bwd(np.ascontiguousarray(gwide[:, 4:4 + c]), feat, weight, idx, arg, k)
+    assert np.allclose(tf.grad.cpu().numpy(), gfeat, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(tw.grad.cpu().numpy(), gweight)
