@@ -5,6 +5,8 @@ Sub-module names (``core.branch_2d``, ``core.branch_3d``, ``clfm_*``) are a comp
 reference checkpoints key on them and its optimizer splits parameter groups on the prefix
 ``core.branch_3d`` (factory.py:50-58).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -45,11 +47,11 @@ class CamLiRAFT_Core(nn.Module):
     def _project_to_feature_grid(self, xyz, camera_info, feat_hw):
         return project_pc2image(xyz, camera_info, grid_hw=feat_hw)
 
-    def forward(self, image1, image2, pc1, pc2, camera_info):
+    def forward(self, image1, image2, pc1, pc2, camera_info, flow_rows=None):
         with pass_cache():   # iteration-invariant set-conv weights live for exactly one pass
-            return self._forward(image1, image2, pc1, pc2, camera_info)
+            return self._forward(image1, image2, pc1, pc2, camera_info, flow_rows)
 
-    def _forward(self, image1, image2, pc1, pc2, camera_info):
+    def _forward(self, image1, image2, pc1, pc2, camera_info, flow_rows=None):
         """Op order, detach points and module call sequence are those of camliraft_core.py:33-145.
         The image branch is issued on the current stream, the point branch inside ``lanes.side()``
         (a second HIP stream when ``runtime.overlap()`` is on, otherwise a no-op context); the two
@@ -151,7 +153,7 @@ class CamLiRAFT_Core(nn.Module):
                 flow_3d_preds.append(knn_interpolation(xyz1, flow_3d_pred, pc1, k=3, invariant_input=True, invariant_query=True))
             mask_branch = b2d.convex_upsampler.begin(h_2d) if runtime.fused() else None           # aux stream
             flow_2d_pred = flow_2d_pred + b2d.flow_head(h_2d)
-            flow_2d_preds.append(b2d.convex_upsampler.finish(mask_branch, h_2d, flow_2d_pred))
+            flow_2d_preds.append(b2d.convex_upsampler.finish(mask_branch, h_2d, flow_2d_pred, flow_rows))
 
         lanes.to_main(flow_3d_preds)
         return flow_2d_preds, flow_3d_preds
@@ -217,7 +219,10 @@ class CamLiRAFT(_FreezableBN, FlowModel):
         persp, paral = _camera_pair(image1.shape[-2], image1.shape[-1], inputs['intrinsics'])
         pc1, pc2 = persp2paral_both(inputs['pcs'], persp, paral)     # one launch for both clouds on the product path
 
-        flow_2d_preds, flow_3d_preds = self.core(image1, image2, pc1, pc2, paral)
+        # images padded at the bottom only (960x540 -> 544 rows): the up-sampler writes the 540 rows the un-padding would keep
+        rows = images.shape[2] if (padder.bottom_only() and runtime.fused() and images.is_cuda
+                                   and os.environ.get('CAMLI_UPSAMPLE_CROP', '1') == '1') else None
+        flow_2d_preds, flow_3d_preds = self.core(image1, image2, pc1, pc2, paral, flow_rows=rows)
         flow_2d_preds = [padder.unpad(f) for f in flow_2d_preds]
         flow_3d_preds = flows_paral2persp(pc1, flow_3d_preds, persp, paral)
 

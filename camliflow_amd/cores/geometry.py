@@ -21,8 +21,15 @@ class InputPadder:
     def pad(self, *inputs):
         return [pad(x, self._pad, mode='replicate').contiguous() for x in inputs]
 
+    def bottom_only(self):
+        """the padding is rows at the bottom only (always true for the height, true for the width when it is a multiple
+        of x already): the cores can then produce un-padded predictions directly (``flow_rows``)."""
+        return self._pad[0] == 0 and self._pad[1] == 0 and self._pad[2] == 0
+
     def unpad(self, x):
         ht, wd = x.shape[-2:]
+        if (ht, wd) == (self.ht, self.wd):      # already produced at the original size
+            return x
         left, right, top, bottom = self._pad
         return x[..., top:ht - bottom, left:wd - right]
 
@@ -186,7 +193,7 @@ def backwarp_2d(x, flow12, padding_mode):
     return grid_sample(x, norm.permute(0, 2, 3, 1), padding_mode=padding_mode, align_corners=True)
 
 
-def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0, mask_bias=None):
+def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0, mask_bias=None, out_rows=None):
     """RAFT convex upsampling: softmax over the 3x3 neighbourhood (utils.py:191-204).  ``mask_scale``
     is the factor the caller would otherwise multiply the mask by (RAFT: 0.25); ``mask_bias`` [9*S*S] is added to the
     mask first (a caller that leaves the bias of the mask head's last convolution to this op saves one pass over the
@@ -194,7 +201,7 @@ def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0, mask_bias=None):
     if runtime.fused() and flow.is_cuda and runtime.atomics_ok('convex_upsample'):
         if scale_factor in (4, 8):
             from ..csrc import fused
-            return fused.convex_upsample(flow, mask, scale_factor, mask_scale, mask_bias)
+            return fused.convex_upsample(flow, mask, scale_factor, mask_scale, mask_bias, out_rows)
         runtime.fallback('convex_upsample', 'scale factor %d (kernels exist for 4 and 8)' % scale_factor)
     if mask_bias is not None:
         mask = mask + mask_bias.view(1, -1, 1, 1)
@@ -204,7 +211,8 @@ def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0, mask_bias=None):
     mask = softmax(mask.float().view(batch_size, 1, 9, scale_factor, scale_factor, image_h, image_w), dim=2)
     patches = unfold(flow.float() * scale_factor, [3, 3], padding=1).view(batch_size, 2, 9, 1, 1, image_h, image_w)
     up = torch.sum(mask * patches, dim=2).permute(0, 1, 4, 2, 5, 3)
-    return up.reshape(batch_size, 2, image_h * scale_factor, image_w * scale_factor)
+    up = up.reshape(batch_size, 2, image_h * scale_factor, image_w * scale_factor)
+    return up if out_rows is None else up[:, :, :out_rows]
 
 
 def resize_flow2d(flow, target_h, target_w):

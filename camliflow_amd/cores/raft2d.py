@@ -269,23 +269,25 @@ class ConvexUpsampler2D(nn.Module):
             raw = conv_bias_act(self.mask[2], conv_bias_act(self.mask[0], h.float(), 'relu'), None, leave_bias=True)
         return branch, raw
 
-    def finish(self, handle, h, flow):
+    def finish(self, handle, h, flow, out_rows=None):
         if handle is None:
-            return self.forward(h, flow)
+            return self.forward(h, flow, out_rows)
         branch, raw = handle
         branch.join(raw)
-        return convex_upsample(flow, raw, mask_scale=0.25, mask_bias=self.mask[2].bias)
+        return convex_upsample(flow, raw, mask_scale=0.25, mask_bias=self.mask[2].bias, out_rows=out_rows)
 
-    def forward(self, h, flow):
+    def forward(self, h, flow, out_rows=None):
+        """``out_rows``: produce the first out_rows of the 8h fine rows only -- the caller's un-padding of a bottom-padded
+        image done by the up-sampling kernel (no slice + copy of every prediction, forward and backward)."""
         if epilogue_ok(h) and runtime.atomics_ok('convex_upsample'):
             # the last convolution's bias is added inside the up-sampling kernel: one pass less over [B,576,h,w]
             raw = conv_bias_act(self.mask[2], conv_bias_act(self.mask[0], h.float(), 'relu'), None, leave_bias=True)
-            return convex_upsample(flow, raw, mask_scale=0.25, mask_bias=self.mask[2].bias)
+            return convex_upsample(flow, raw, mask_scale=0.25, mask_bias=self.mask[2].bias, out_rows=out_rows)
         if epilogue_ok(h):
             mask = conv_bias_act(self.mask[2], conv_bias_act(self.mask[0], h.float(), 'relu'), None)
         else:
             mask = self.mask(h.float())
-        return convex_upsample(flow, mask, mask_scale=0.25)
+        return convex_upsample(flow, mask, mask_scale=0.25, out_rows=out_rows)
 
 
 class RAFTCore(nn.Module):

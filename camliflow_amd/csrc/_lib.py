@@ -91,6 +91,10 @@ PROTOTYPES = {
                                          ctypes.c_float, _stream]),
     "camli_convex_upsample_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                          _int, _int, _int, _int, ctypes.c_float, _stream]),
+    "camli_convex_upsample_rows_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int,
+                                              ctypes.c_float, _stream]),
+    "camli_convex_upsample_rows_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                              _int, _int, _int, _int, _int, ctypes.c_float, _stream]),
     "camli_gru_gates_fwd": (_int, [_c_float_p] * 6 + [_int, _int, _int, _stream]),
     "camli_gru_gates_bwd": (_int, [_c_float_p] * 7 + [_int, _int, _int, _stream]),
     "camli_gru_gates_bwd_strided": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int64] + [_c_float_p] * 5 + [_int, _int, _int, _stream]),

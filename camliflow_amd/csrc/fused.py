@@ -1513,14 +1513,17 @@ def pointconv_mix(feat_cl, wgt, knn_indices, k):
 class _ConvexUpsample(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, flow, mask, mask_bias, scale, mask_scale):
+    def forward(ctx, flow, mask, mask_bias, scale, mask_scale, out_rows=None):
         lib = _lib.load()
         b, _, h, w = flow.shape
-        out = torch.empty((b, 2, h * scale, w * scale), dtype=torch.float32, device=flow.device)
+        rows = h * scale if out_rows is None else int(out_rows)
+        assert 1 <= rows <= h * scale
+        ctx.rows = rows
+        out = torch.empty((b, 2, rows, w * scale), dtype=torch.float32, device=flow.device)
         with _on_device(flow):
-            _lib.launch('camli_convex_upsample_fwd', lib.camli_convex_upsample_fwd, flow.data_ptr(), mask.data_ptr(),
+            _lib.launch('camli_convex_upsample_fwd', lib.camli_convex_upsample_rows_fwd, flow.data_ptr(), mask.data_ptr(),
                         mask_bias.data_ptr() if mask_bias is not None else None,
-                        out.data_ptr(), b, h, w, scale, float(mask_scale), _stream_ptr(flow),
+                        out.data_ptr(), b, h, w, scale, rows, float(mask_scale), _stream_ptr(flow),
                         work=(4.0 * b * h * w * (9 * scale * scale + 2 * scale * scale + 2), 'B'))
         if mask_bias is None:
             ctx.save_for_backward(flow, mask)
@@ -1541,9 +1544,9 @@ class _ConvexUpsample(torch.autograd.Function):
         gflow = torch.zeros_like(flow)
         gmask = torch.empty_like(mask)
         with _on_device(flow):
-            _lib.launch('camli_convex_upsample_bwd', lib.camli_convex_upsample_bwd, gout.data_ptr(), flow.data_ptr(),
+            _lib.launch('camli_convex_upsample_bwd', lib.camli_convex_upsample_rows_bwd, gout.data_ptr(), flow.data_ptr(),
                         mask.data_ptr(), mask_bias.data_ptr() if mask_bias is not None else None, gflow.data_ptr(),
-                        gmask.data_ptr(), b, h, w, ctx.scale, float(ctx.mask_scale), _stream_ptr(flow),
+                        gmask.data_ptr(), b, h, w, ctx.scale, ctx.rows, float(ctx.mask_scale), _stream_ptr(flow),
                         work=(4.0 * b * h * w * (2 * 9 * ctx.scale ** 2 + 2 * ctx.scale ** 2 + 4), 'B'))
         gbias = None
         if mask_bias is not None and (ctx.bias_param is not None or ctx.needs_input_grad[2]):
@@ -1555,18 +1558,19 @@ class _ConvexUpsample(torch.autograd.Function):
                 _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd, gmask.data_ptr(), None, None, None, acc.data_ptr(),
                             b, c, h * w, 0, _stream_ptr(flow), work=(4.0 * b * c * h * w, 'B'))
             gbias = None if deferred else acc
-        return gflow, gmask, gbias, None, None
+        return gflow, gmask, gbias, None, None, None
 
 
-def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0, mask_bias=None):
+def convex_upsample(flow, mask, scale_factor=8, mask_scale=1.0, mask_bias=None, out_rows=None):
     """flow [B,2,h,w], raw mask [B,9*S*S,h,w] -> [B,2,h*S,w*S]; ``mask_scale`` multiplies the mask inside
     the kernel (RAFT passes 0.25, raft_core.py:195); ``mask_bias`` [9*S*S]: added to the mask first (the bias of the mask
-    head's last convolution, folded in)."""
+    head's last convolution, folded in); ``out_rows``: keep the first out_rows fine rows only (the un-padding of a
+    bottom-padded image, done by the kernel)."""
     _require_cuda('convex_upsample', flow, mask)
     assert flow.shape[1] == 2 and mask.shape[1] == 9 * scale_factor * scale_factor
     if mask_bias is not None:
         assert mask_bias.shape == (mask.shape[1],) and mask_bias.is_contiguous() and mask_bias.dtype == torch.float32
-    return _ConvexUpsample.apply(flow.float().contiguous(), mask.float().contiguous(), mask_bias, scale_factor, mask_scale)
+    return _ConvexUpsample.apply(flow.float().contiguous(), mask.float().contiguous(), mask_bias, scale_factor, mask_scale, out_rows)
 
 
 # ------------------------------------------------------------------------------------------------

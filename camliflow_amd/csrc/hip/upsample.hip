@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __rest
                                                               const float* __restrict__ mask,
                                                               const float* __restrict__ mask_bias,
                                                               float* __restrict__ out, int h, int w, float mask_scale,
-                                                              int IG) {
+                                                              int IG, int out_h) {
     __shared__ float tile[2][S][64 + 1];    // [channel][j][x_local]
     const int lane = threadIdx.x;
     const int x0 = blockIdx.x * 64, x = x0 + lane, y = blockIdx.y, b = blockIdx.z / IG;
@@ -52,8 +52,10 @@ __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __rest
             f[k][c] = in ? flow[((size_t)b * 2 + c) * plane + (size_t)yy * w + xx] * (float)S : 0.0f;
     }
     for (int i = i_beg; i < i_end; ++i) {
-        float* __restrict__ orow0 = out + (((size_t)b * 2 + 0) * h * S + (size_t)y * S + i) * W + (size_t)x0 * S;
-        float* __restrict__ orow1 = out + (((size_t)b * 2 + 1) * h * S + (size_t)y * S + i) * W + (size_t)x0 * S;
+        // out keeps the first out_h fine rows only (the caller's un-padding of a bottom-padded image, folded in): block-uniform
+        if (y * S + i >= out_h) break;
+        float* __restrict__ orow0 = out + (((size_t)b * 2 + 0) * out_h + (size_t)y * S + i) * W + (size_t)x0 * S;
+        float* __restrict__ orow1 = out + (((size_t)b * 2 + 1) * out_h + (size_t)y * S + i) * W + (size_t)x0 * S;
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             float p[9];
@@ -97,7 +99,8 @@ template <int S>
 __global__ __launch_bounds__(256) void convex_upsample_bwd_kernel(const float* __restrict__ flow, const float* __restrict__ mask,
                                                                   const float* __restrict__ mask_bias,
                                                                   const float* __restrict__ gout, float* __restrict__ gflow,
-                                                                  float* __restrict__ gmask, int h, int w, float mask_scale) {
+                                                                  float* __restrict__ gmask, int h, int w, float mask_scale,
+                                                                  int out_h) {
     constexpr int MAXG = 4;
     __shared__ float tile[MAXG][2][S][64 + 1];    // [row group][channel][j][x_local]
     __shared__ float gsum[MAXG][18][64];          // [row group][k*2 + c][x_local]
@@ -125,11 +128,12 @@ __global__ __launch_bounds__(256) void convex_upsample_bwd_kernel(const float* _
         }
     }
     for (int i = i_beg; i < i_end; ++i) {
-        const float* __restrict__ grow0 = gout + (((size_t)b * 2 + 0) * h * S + (size_t)y * S + i) * W + (size_t)x0 * S;
-        const float* __restrict__ grow1 = gout + (((size_t)b * 2 + 1) * h * S + (size_t)y * S + i) * W + (size_t)x0 * S;
+        const bool kept = y * S + i < out_h;        // a cropped fine row carries no gradient (its mask gradient is written as 0)
+        const float* __restrict__ grow0 = gout + (((size_t)b * 2 + 0) * out_h + (size_t)y * S + i) * W + (size_t)x0 * S;
+        const float* __restrict__ grow1 = gout + (((size_t)b * 2 + 1) * out_h + (size_t)y * S + i) * W + (size_t)x0 * S;
         for (int e = lane; e < ncols; e += 64) {     // fine gradient row segment in, coalesced, de-interleaved
-            tile[grp][0][e % S][e / S] = grow0[e];
-            tile[grp][1][e % S][e / S] = grow1[e];
+            tile[grp][0][e % S][e / S] = kept ? grow0[e] : 0.0f;
+            tile[grp][1][e % S][e / S] = kept ? grow1[e] : 0.0f;
         }
         __syncthreads();
 #pragma unroll 1      // 118 VGPRs (4 waves per SIMD, the whole launch resident) vs 222 fully unrolled: 99 vs 112 us
@@ -210,25 +214,46 @@ int upsample_row_groups(int B, int h, int w, int S, int cap) {
 
 }  // namespace
 
+extern "C" int camli_convex_upsample_rows_fwd(const float* flow, const float* mask, const float* mask_bias, float* out, int B,
+                                              int h, int w, int scale, int out_rows, float mask_scale, void* stream);
+extern "C" int camli_convex_upsample_rows_bwd(const float* gout, const float* flow, const float* mask, const float* mask_bias,
+                                              float* gflow, float* gmask, int B, int h, int w, int scale, int out_rows,
+                                              float mask_scale, void* stream);
+
 extern "C" int camli_convex_upsample_fwd(const float* flow, const float* mask, const float* mask_bias, float* out, int B,
                                          int h, int w, int scale, float mask_scale, void* stream) {
+    return camli_convex_upsample_rows_fwd(flow, mask, mask_bias, out, B, h, w, scale, h * scale, mask_scale, stream);
+}
+
+// out [B,2,out_rows,w*S]: the first out_rows of the h*S fine rows (an image padded at the bottom to a multiple of 8 is
+// un-padded by the up-sampling itself instead of a slice + copy each way)
+extern "C" int camli_convex_upsample_rows_fwd(const float* flow, const float* mask, const float* mask_bias, float* out, int B,
+                                              int h, int w, int scale, int out_rows, float mask_scale, void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!flow || !mask || !out) { camli_set_error("camli_convex_upsample_fwd: null pointer"); return CAMLI_EINVAL; }
     if (!upsample_shape_ok("camli_convex_upsample_fwd", B, h, w, scale)) return CAMLI_EINVAL;
+    if (out_rows < 1 || out_rows > h * scale) { camli_set_error("camli_convex_upsample_fwd: out_rows %d outside [1, %d]", out_rows, h * scale); return CAMLI_EINVAL; }
     const int ig = upsample_row_groups(B, h, w, scale, 8);
     const dim3 grid(camli_divup(w, 64), h, B * ig);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (scale == 8)
-        hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, dim3(64), 0, s, flow, mask, mask_bias, out, h, w, mask_scale, ig);
+        hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, dim3(64), 0, s, flow, mask, mask_bias, out, h, w, mask_scale, ig, out_rows);
     else
-        hipLaunchKernelGGL(convex_upsample_kernel<4>, grid, dim3(64), 0, s, flow, mask, mask_bias, out, h, w, mask_scale, ig);
+        hipLaunchKernelGGL(convex_upsample_kernel<4>, grid, dim3(64), 0, s, flow, mask, mask_bias, out, h, w, mask_scale, ig, out_rows);
     return camli_check_launch("camli_convex_upsample_fwd");
 }
 
 extern "C" int camli_convex_upsample_bwd(const float* gout, const float* flow, const float* mask, const float* mask_bias,
                                          float* gflow, float* gmask, int B, int h, int w, int scale, float mask_scale,
                                          void* stream) {
+    return camli_convex_upsample_rows_bwd(gout, flow, mask, mask_bias, gflow, gmask, B, h, w, scale, h * scale, mask_scale, stream);
+}
+
+extern "C" int camli_convex_upsample_rows_bwd(const float* gout, const float* flow, const float* mask, const float* mask_bias,
+                                              float* gflow, float* gmask, int B, int h, int w, int scale, int out_rows,
+                                              float mask_scale, void* stream) {
     if (B == 0) return CAMLI_OK;
+    if (out_rows < 1 || out_rows > h * scale) { camli_set_error("camli_convex_upsample_bwd: out_rows %d outside [1, %d]", out_rows, h * scale); return CAMLI_EINVAL; }
     if (!gout || !flow || !mask || !gflow || !gmask) {
         camli_set_error("camli_convex_upsample_bwd: null pointer");
         return CAMLI_EINVAL;
@@ -238,9 +263,9 @@ extern "C" int camli_convex_upsample_bwd(const float* gout, const float* flow, c
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (scale == 8)
         hipLaunchKernelGGL(convex_upsample_bwd_kernel<8>, grid, block, 0, s, flow, mask, mask_bias, gout, gflow, gmask, h, w,
-                           mask_scale);
+                           mask_scale, out_rows);
     else
         hipLaunchKernelGGL(convex_upsample_bwd_kernel<4>, grid, block, 0, s, flow, mask, mask_bias, gout, gflow, gmask, h, w,
-                           mask_scale);
+                           mask_scale, out_rows);
     return camli_check_launch("camli_convex_upsample_bwd");
 }

@@ -352,6 +352,13 @@ int camli_convex_upsample_fwd(const float *flow, const float *mask, const float 
                               int B, int h, int w, int scale, float mask_scale, void *stream);
 int camli_convex_upsample_bwd(const float *gout, const float *flow, const float *mask, const float *mask_bias, float *gflow,
                               float *gmask, int B, int h, int w, int scale, float mask_scale, void *stream);
+/* the same with the first out_rows of the h*S fine rows kept only: out / gout [B,2,out_rows,w*S] -- the un-padding of a
+ * bottom-padded image (models/utils.py:7-20 InputPadder) folded into the up-sampling; cropped rows carry no gradient */
+int camli_convex_upsample_rows_fwd(const float *flow, const float *mask, const float *mask_bias, float *out, int B, int h,
+                                   int w, int scale, int out_rows, float mask_scale, void *stream);
+int camli_convex_upsample_rows_bwd(const float *gout, const float *flow, const float *mask, const float *mask_bias,
+                                   float *gflow, float *gmask, int B, int h, int w, int scale, int out_rows, float mask_scale,
+                                   void *stream);
 
 /*
  * Elementwise halves of the convolutional GRU (models/raft_core.py:123-139 composes them from ~9 torch

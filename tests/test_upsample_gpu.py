@@ -146,3 +146,29 @@ def test_resnet_trunk_folded_batchnorm_vs_unfolded():
     # convolution algorithms chosen for the call (workspace-dependent).  Seen: 2e-5 typical, 6e-4 in about
     # one run in three of the whole suite.
     assert num / den < 5e-3, num / den
+
+
+@pytest.mark.parametrize('case', [(2, 68, 120, 8, 540), (1, 17, 30, 8, 131), (2, 36, 60, 4, 141), (1, 5, 70, 8, 33), (1, 3, 193, 4, 12)], ids=str)
+def test_convex_upsample_keeping_the_first_rows_only(case, oracle_lib):
+    """camli_convex_upsample_rows_fwd/bwd: the un-padding of a bottom-padded image (utils.py:7-20) done by the kernel -- the
+    first out_rows rows of the oracle's full up-sampling, and the gradients of the composition sliced the same way."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.geometry import convex_upsample
+    b, h, w, s, rows = case
+    g = torch.Generator(device='cpu').manual_seed(h * w + rows)
+    flow = torch.randn(b, 2, h, w, generator=g).cuda().requires_grad_(True)
+    mask = (torch.randn(b, 9 * s * s, h, w, generator=g) * 3).cuda().requires_grad_(True)
+    gout = torch.randn(b, 2, rows, w * s, generator=g).cuda()
+    res = {}
+    for backend in ('hip', 'composed'):
+        flow.grad = mask.grad = None
+        with runtime.use_backend(backend):
+            out = convex_upsample(flow, mask, scale_factor=s, mask_scale=0.25, out_rows=rows)
+        assert out.shape == (b, 2, rows, w * s)
+        out.backward(gout)
+        res[backend] = (out.detach(), flow.grad.clone(), mask.grad.clone())
+    assert res['hip'][0].is_contiguous()
+    want = oracle_lib.convex_upsample_fwd(flow.detach().cpu().numpy(), (mask.detach() * 0.25).cpu().numpy(), s)[:, :, :rows]
+    assert np.allclose(res['hip'][0].cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(res['hip'][1], res['composed'][1], rtol=1e-4, atol=1e-4)
+    assert torch.allclose(res['hip'][2], res['composed'][2], rtol=1e-4, atol=1e-5)
