@@ -1590,6 +1590,8 @@ class _GruGates(torch.autograd.Function):
                         z.data_ptr(), r.data_ptr(), rh.data_ptr(), b, c, p, _stream_ptr(h), work=(32.0 * b * c * p, 'B'))
         ctx.save_for_backward(z, r, h)
         ctx.mark_non_differentiable(r)
+        # no zero tensors for outputs without a gradient (r never has one: that was a 33 MB fill per call; backward takes None)
+        ctx.set_materialize_grads(False)
         return z, rh, r
 
     @staticmethod
