@@ -205,15 +205,38 @@ class MotionEncoder2D(nn.Module):
         if not epilogue_ok(flow):
             return None
         branch = runtime.Branch(flow, slot=0)
+        raw = self._cat_free(flow)
         with branch:
-            f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')
-        return branch, f
+            f = conv_bias_act(self.conv_f1, flow, 'relu')
+            # cat-free form: the second convolution leaves its bias + ReLU to the kernel that writes the concatenation
+            f = conv_bias_act(self.conv_f2, f, None, leave_bias=True) if raw else conv_bias_act(self.conv_f2, f, 'relu')
+        return branch, f, raw
+
+    @staticmethod
+    def _cat_free(t):
+        """bias + activation epilogues write straight into the concatenated tensors (fused.bias_act_cat): planes of 4k
+        elements, fp32 outside autocast; CAMLI_BIAS_CAT=0 restores epilogue + torch.cat."""
+        return (os.environ.get('CAMLI_BIAS_CAT', '1') == '1' and (t.shape[2] * t.shape[3]) % 4 == 0
+                and not torch.is_autocast_enabled())
 
     def forward(self, flow, corr, flow_branch=None):
+        if epilogue_ok(corr) and self._cat_free(flow) and (flow_branch is None or flow_branch[2]):
+            from ..csrc import fused
+            c_raw = conv_bias_act(self.conv_c2, conv_bias_act(self.conv_c1, corr, 'relu'), None, leave_bias=True)
+            if flow_branch is not None:
+                branch, f_raw, _ = flow_branch
+                branch.join(f_raw)
+            else:
+                f_raw = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), None, leave_bias=True)
+            x = fused.bias_act_cat([(c_raw, self.conv_c2.bias, 'relu'), (f_raw, self.conv_f2.bias, 'relu')])
+            joint_raw = conv_bias_act(self.conv, x, None, leave_bias=True)
+            # relu + nan_to_num (bias_act code 5) and the flow channels appended, in the pass that writes the motion features
+            return fused.bias_act_cat([(joint_raw, self.conv.bias, 'relu_nan_to_num')], tail=flow)
         if epilogue_ok(corr):
             c = conv_bias_act(self.conv_c2, conv_bias_act(self.conv_c1, corr, 'relu'), 'relu')
             if flow_branch is not None:
-                branch, f = flow_branch
+                branch, f = flow_branch[0], flow_branch[1]
+                assert not flow_branch[2]
                 branch.join(f)
             else:
                 f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')

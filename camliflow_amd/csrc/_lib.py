@@ -108,6 +108,7 @@ PROTOTYPES = {
     "camli_bias_act_nhwc_bwd": (_int, [_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_longlong, _int, _int, _stream]),
     "camli_bias_act_res_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p, _int, _int, _int, _int, _stream]),
     "camli_bias_act_bwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_bias_act_into_fwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, ctypes.c_int64, _int, _int, _int, _int, _stream]),
     "camli_bias_act_bwd_strided": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
     "camli_weightnet_fwd": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int] + [_c_float_p] * 7
                             + [_int, _int, _int, _int, _int, _int, _stream]),

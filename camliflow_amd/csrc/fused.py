@@ -1800,6 +1800,99 @@ class _BiasAct(torch.autograd.Function):
         return gx, (None if deferred else gbias), None
 
 
+class _BiasActCat(torch.autograd.Function):
+    """cat([act_i(x_i + bias_i) ...] (+ [tail])) along the channels, every part written by its epilogue kernel straight into its
+    slice of the result (camli_bias_act_into_fwd): the concatenation a following convolution reads exists without a cat pass.
+    args = (x_0, bias_0, x_1, bias_1, ..., [tail]); acts = activation code per part.  The adjoint reads the slices of the
+    incoming gradient in place (camli_bias_act_bwd_strided); the tail's gradient is its slice, as a view."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, acts, has_tail, *args):
+        lib = _lib.load()
+        n = len(acts)
+        xs = [args[2 * i].contiguous() for i in range(n)]
+        biases = [args[2 * i + 1] for i in range(n)]
+        tail = args[2 * n] if has_tail else None
+        b = xs[0].shape[0]
+        spatial = tuple(xs[0].shape[2:])
+        p = xs[0][0, 0].numel()
+        chans = [x.shape[1] for x in xs]
+        total = sum(chans) + (tail.shape[1] if tail is not None else 0)
+        out = torch.empty((b, total) + spatial, dtype=torch.float32, device=xs[0].device)
+        masks, c0 = [], 0
+        with _on_device(out):
+            for x, bias, act, c in zip(xs, biases, acts, chans):
+                mask = None
+                if act == 5 or (act in (1, 2) and p % 4 == 0):
+                    mask = torch.empty(lib.camli_bias_act_mask_bytes(b, c, p) // 8, dtype=torch.int64, device=x.device)
+                assert act in (0, 1, 2, 5) and (mask is not None or act == 0), 'bias_act_cat: relu-type parts on planes of 4k elements'
+                _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_into_fwd, x.data_ptr(), bias.data_ptr(),
+                            mask.data_ptr() if mask is not None else None, out.data_ptr() + 4 * c0 * p, total * p, b, c, p, act,
+                            _stream_ptr(x), work=(8.0 * b * c * p + (b * c * p / 8.0 if mask is not None else 0.0), 'B'))
+                masks.append(mask)
+                c0 += c
+            if tail is not None:
+                out[:, c0:].copy_(tail)
+        ctx.save_for_backward(*[m for m in masks if m is not None])
+        ctx.has_mask = [m is not None for m in masks]
+        ctx.acts, ctx.chans, ctx.dims, ctx.has_tail = list(acts), chans, (b, p, total), has_tail
+        ctx.bias_params = [_runtime.deferral_target(bias) for bias in biases]
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        lib = _lib.load()
+        b, p, total = ctx.dims
+        gout = gout.float()
+        if _batch_strided(gout) != total * p:
+            gout = gout.contiguous()
+        saved = list(ctx.saved_tensors)
+        grads, c0 = [], 0
+        spatial = tuple(gout.shape[2:])
+        with _on_device(gout):
+            for i, (act, c) in enumerate(zip(ctx.acts, ctx.chans)):
+                mask = saved.pop(0) if ctx.has_mask[i] else None
+                gslice = gout[:, c0:c0 + c]
+                identity = act == 0
+                deferred = ctx.bias_params[i] is not None
+                need_bias = deferred or ctx.needs_input_grad[2 + 2 * i + 1]
+                gx = gslice if identity else torch.empty((b, c) + spatial, dtype=torch.float32, device=gout.device)
+                gbias = None
+                if not identity or need_bias:
+                    gbias = (_runtime.PARAM_GRADS.slot(ctx.bias_params[i], lambda c=c: _zero_slice(c, gout), False) if deferred
+                             else _zero_slice(c, gout))
+                    _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd_strided, gout.data_ptr() + 4 * c0 * p, total * p, None,
+                                mask.data_ptr() if mask is not None else None, None if identity else gx.data_ptr(), gbias.data_ptr(),
+                                b, c, p, act, _stream_ptr(gout), work=((4.0 if identity else 8.125) * b * c * p, 'B'))
+                grads += [gx, None if (deferred or not need_bias) else gbias]
+                c0 += c
+        if ctx.has_tail:
+            grads.append(gout[:, c0:])
+        return (None, None, *grads)
+
+
+def bias_act_cat(parts, tail=None):
+    """parts: list of (x [B,C_i,...] fresh convolution output, bias [C_i], act name); tail: optional [B,C_t,...] appended
+    unchanged.  -> cat([act(x_i + bias_i)..., tail], dim=1) without the cat pass (and without touching the x_i)."""
+    _require_cuda('bias_act_cat', *[x for x, _, _ in parts])
+    acts = tuple(ACT_CODES[a] for _, _, a in parts)
+    flat = []
+    for x, bias, _ in parts:
+        flat += [x.float(), bias.float()]
+    if tail is not None:
+        flat.append(tail.float())
+    return _BiasActCat.apply(acts, tail is not None, *flat)
+
+
+def bias_act_cat_ok(parts, tail=None):
+    """the planes are multiples of 4 elements (16-byte stores into the slices, sign masks) and the activations are the
+    mask-backed ones"""
+    p = parts[0][0][0, 0].numel()
+    return p % 4 == 0 and all(ACT_CODES[a] in (0, 1, 2, 5) and x[0, 0].numel() == p and bias is not None for x, bias, a in parts)
+
+
 def _is_nhwc(t):
     return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
 

@@ -47,14 +47,19 @@ __host__ __device__ __forceinline__ int mask_words(int P) { return (P / 4 + 63) 
 template <int ACT, bool MASK, bool RES = false>
 __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x, const float* __restrict__ bias,
                                                             unsigned long long* __restrict__ mask, int C, int P,
-                                                            int chunk, const float* __restrict__ res = nullptr) {
+                                                            int chunk, const float* __restrict__ res = nullptr,
+                                                            float* out = nullptr, size_t out_bs = 0) {
+    // out == nullptr: in place.  Otherwise the result goes to out[b * out_bs + c * P + .] -- a channel slice of a wider
+    // tensor (the concatenation the next convolution reads: no cat pass), x is left untouched.
     const int c = blockIdx.y, b = blockIdx.z;
     const float bv = bias[c];
-    float* __restrict__ plane = x + ((size_t)b * C + c) * P;
+    float* plane = x + ((size_t)b * C + c) * P;
+    float* oplane = out ? out + (size_t)b * out_bs + (size_t)c * P : plane;
     const float* __restrict__ rplane = RES ? res + ((size_t)b * C + c) * P : nullptr;
     const int beg = blockIdx.x * chunk, end = min(P, beg + chunk);
     if ((P & 3) == 0 && (chunk & 3) == 0) {
-        float4* __restrict__ p4 = reinterpret_cast<float4*>(plane);
+        float4* p4 = reinterpret_cast<float4*>(plane);
+        float4* o4 = reinterpret_cast<float4*>(oplane);
         unsigned long long* __restrict__ mrow = MASK ? mask + ((size_t)b * C + c) * mask_words(P) * 4 : nullptr;
         const float4* __restrict__ r4 = reinterpret_cast<const float4*>(rplane);
         auto apply = [&](float4 v, int e) {
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x
                 raw.x += r.x; raw.y += r.y; raw.z += r.z; raw.w += r.w;
             }
             v.x = act_fwd<ACT>(raw.x); v.y = act_fwd<ACT>(raw.y); v.z = act_fwd<ACT>(raw.z); v.w = act_fwd<ACT>(raw.w);
-            p4[e] = v;
+            o4[e] = v;
             if (MASK) {
                 // ACT 5: the gradient passes where the pre-activation is positive AND finite (relu, then nan_to_num)
                 constexpr float top = 3.402823466e+38f;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void bias_act_fwd_kernel(float* __restrict__ x
         }
         for (; e < e4; e += 256) apply(p4[e], e);
     } else {
-        for (int e = beg + threadIdx.x; e < end; e += 256) plane[e] = act_fwd<ACT>(plane[e] + bv + (RES ? rplane[e] : 0.0f));
+        for (int e = beg + threadIdx.x; e < end; e += 256) oplane[e] = act_fwd<ACT>(plane[e] + bv + (RES ? rplane[e] : 0.0f));
     }
 }
 
@@ -372,6 +377,41 @@ extern "C" int camli_bias_act_fwd(float* x_inout, const float* bias, void* sign_
     }
 #undef L
     return camli_check_launch("camli_bias_act_fwd");
+}
+
+// act(x + bias[c]) written to a channel slice of a wider tensor: out[b * out_batch_stride + c * P + p]; x [B,C,P] is only read.
+// Sign mask as camli_bias_act_fwd (indexed by the dense (b, c, p)).  The adjoint is camli_bias_act_bwd_strided on the slice
+// of the wider gradient.
+extern "C" int camli_bias_act_into_fwd(const float* x, const float* bias, void* sign_mask, float* out, int64_t out_batch_stride,
+                                       int B, int C, int P, int act, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    if (!x || !bias || !out) { camli_set_error("camli_bias_act_into_fwd: null pointer"); return CAMLI_EINVAL; }
+    if (!shape_ok("camli_bias_act_into_fwd", B, C, P, act)) return CAMLI_EINVAL;
+    if ((sign_mask && !((act == 1 || act == 2 || act == 5) && (P & 3) == 0)) || (act == 5 && !sign_mask)) {
+        camli_set_error("camli_bias_act_into_fwd: a sign mask needs act 1, 2 or 5 and P %% 4 == 0, act 5 needs the mask (act=%d P=%d)", act, P);
+        return CAMLI_EINVAL;
+    }
+    if (out_batch_stride < (int64_t)C * P || ((P & 3) == 0 && ((out_batch_stride & 3) || (reinterpret_cast<uintptr_t>(out) & 15)))) {
+        camli_set_error("camli_bias_act_into_fwd: batch stride %lld (needs >= C*P, with P %% 4 == 0 a multiple of 4 and a 16-byte aligned out)",
+                        (long long)out_batch_stride);
+        return CAMLI_EINVAL;
+    }
+    const int chunk = pick_chunk(P);
+    dim3 grid(camli_divup(P, chunk), C, B);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned long long* m = static_cast<unsigned long long*>(sign_mask);
+    float* xin = const_cast<float*>(x);
+#define L(A, M) hipLaunchKernelGGL((bias_act_fwd_kernel<A, M>), grid, dim3(256), 0, s, xin, bias, m, C, P, chunk, nullptr, out, (size_t)out_batch_stride)
+    switch (act) {
+        case 0: L(0, false); break;
+        case 1: if (m) L(1, true); else L(1, false); break;
+        case 2: if (m) L(2, true); else L(2, false); break;
+        case 3: L(3, false); break;
+        case 5: L(5, true); break;
+        default: L(4, false); break;
+    }
+#undef L
+    return camli_check_launch("camli_bias_act_into_fwd");
 }
 
 extern "C" int camli_bias_act_res_fwd(float* x_inout, const float* bias, const float* res, void* sign_mask, int B, int C,

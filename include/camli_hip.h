@@ -401,6 +401,11 @@ int64_t camli_bias_act_mask_bytes(int B, int C, int P);
 int camli_bias_act_fwd(float *x_inout, const float *bias, void *sign_mask, int B, int C, int P, int act, void *stream);
 int camli_bias_act_bwd(const float *gy, const float *y, const void *sign_mask, float *gx, float *gbias,
                        int B, int C, int P, int act, void *stream);
+/* act(x + bias[c]) written to a channel slice of a wider tensor, out[b * out_batch_stride + c * P + p] (the concatenation the
+ * next convolution reads: no cat pass); x [B,C,P] is only read; sign mask as camli_bias_act_fwd; the adjoint is
+ * camli_bias_act_bwd_strided on the slice of the wider gradient */
+int camli_bias_act_into_fwd(const float *x, const float *bias, void *sign_mask, float *out, int64_t out_batch_stride, int B,
+                            int C, int P, int act, void *stream);
 /* gy read in place from a channel slice of a wider gradient: batch stride in floats (>= C*P; with P % 4 == 0 a multiple of 4
  * and a 16-byte aligned pointer).  gx (dense [B,C,P]) and everything else as above. */
 int camli_bias_act_bwd_strided(const float *gy, int64_t gy_batch_stride, const float *y, const void *sign_mask, float *gx,

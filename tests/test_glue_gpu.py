@@ -175,3 +175,46 @@ def test_gates_and_bias_adjoints_read_channel_slices_in_place(shape):
         want_gx = gw[:, 4:4 + c] * slope
         assert close(y, fn(pre)) and close(t_x.grad, want_gx)
         assert close(t_b.grad, want_gx.sum(axis=(0,) + tuple(range(2, len(shape)))), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('shape', [(2, 68, 120), (3, 5, 8), (1, 2048)], ids=str)
+def test_bias_act_cat_writes_the_concatenation_directly(shape):
+    """fused.bias_act_cat == cat([act_i(x_i + b_i)..., tail]) (camli_bias_act_into_fwd + camli_bias_act_bwd_strided): values,
+    every gradient, the inputs left untouched; relu_nan_to_num on a part that holds NaN / inf."""
+    from camliflow_amd.csrc import fused
+    b, spatial = shape[0], shape[1:]
+    rng = np.random.default_rng(sum(shape))
+    specs = [(7, 'relu'), (12, 'leaky_relu'), (3, None), (5, 'relu_nan_to_num')]
+    xs = [rng.standard_normal((b, c) + spatial).astype(np.float32) for c, _ in specs]
+    xs[3].reshape(-1)[::17] = np.inf
+    xs[3].reshape(-1)[5::23] = np.nan
+    xs[3].reshape(-1)[7::29] = -np.inf
+    bs = [rng.standard_normal(c).astype(np.float32) for c, _ in specs]
+    tail = rng.standard_normal((b, 2) + spatial).astype(np.float32)
+    txs, tbs, ttail = [dev(x, True) for x in xs], [dev(v, True) for v in bs], dev(tail, True)
+    keep = [t.detach().clone() for t in txs]
+    out = fused.bias_act_cat([(t * 1.0, bb, act) for t, bb, (_, act) in zip(txs, tbs, specs)], tail=ttail)
+    total = sum(c for c, _ in specs) + 2
+    assert out.shape == (b, total) + spatial and out.is_contiguous()
+    gout = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(gout))
+    c0 = 0
+    for x, bias, (c, act), tx, tb, k0 in zip(xs, bs, specs, txs, tbs, keep):
+        assert torch.equal(tx.detach().view(torch.int32), k0.view(torch.int32))      # bit patterns: the NaNs compare too
+        pre = x.astype(np.float64) + bias.reshape((1, c) + (1,) * len(spatial))
+        g = gout[:, c0:c0 + c].astype(np.float64)
+        with np.errstate(invalid='ignore'):
+            if act == 'relu':
+                want, slope = np.maximum(pre, 0), (pre > 0).astype(np.float64)
+            elif act == 'leaky_relu':
+                want, slope = np.where(pre > 0, pre, 0.1 * pre), np.where(pre > 0, 1.0, 0.1)
+            elif act is None:
+                want, slope = pre, np.ones_like(pre)
+            else:
+                want = np.nan_to_num(np.maximum(pre, 0).astype(np.float32), nan=0.0).astype(np.float64)
+                slope = ((pre > 0) & np.isfinite(pre)).astype(np.float64)
+        assert close(out[:, c0:c0 + c], want.astype(np.float32), rtol=1e-6, atol=1e-6), act
+        assert close(tx.grad, (g * slope).astype(np.float32)), act
+        assert close(tb.grad, (g * slope).sum(axis=(0,) + tuple(range(2, 2 + len(spatial)))).astype(np.float32), rtol=1e-4, atol=1e-3), act
+        c0 += c
+    assert torch.equal(out[:, c0:].detach(), dev(tail)) and close(ttail.grad, gout[:, c0:])
