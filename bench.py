@@ -653,6 +653,7 @@ def main():
     # parameter gradients of the iteration-shared 1x1 convolutions / biases accumulate inside their kernels and
     # reach .grad once per backward() (cores/runtime.py)
     runtime.set_deferred_param_grads(os.environ.get('CAMLI_DEFER_GRADS', '1') == '1')
+    tuned_gemms = runtime.use_tuned_gemms()      # TunableOp with the shipped table (no tuning at run time)
     torch.backends.cudnn.benchmark = os.environ.get('CAMLI_MIOPEN_FIND', '0') == '1'
 
     torch.manual_seed(0)
@@ -782,7 +783,7 @@ def main():
                                       ('%d GRU iters' % args.iters) if args.iters else 'coarse-to-fine pyramid',
                                       args.batch, stands_for),
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world,
-                       'lanes': 2 if two_lane else 1, 'hip_graph': bool(graphed),
+                       'lanes': 2 if two_lane else 1, 'hip_graph': bool(graphed), 'tuned_gemms': bool(tuned_gemms),
                        'loss': round(float(loss.detach()), 4),
                        'host_enqueue_ms_per_step': round(host_s / args.steps * 1e3, 1),
                        'hip_launches_per_step': round(sum(census['fused'].values()) / roofline_steps, 1)},

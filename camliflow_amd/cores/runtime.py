@@ -129,6 +129,39 @@ def fallback(op, reason):
 # ------------------------------------------------------------------------------------------------
 _DEFER_PARAM_GRADS = False
 
+GEMM_TUNING_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gemm_tuning_gfx950.csv')
+
+
+def use_tuned_gemms(path=None):
+    """Let PyTorch's TunableOp pick, per GEMM shape, the hipBLASLt / rocBLAS solution recorded in ``gemm_tuning_gfx950.csv``
+    (358 shapes: the GEMMs of the four bench configurations, tuned on an MI355X with this image by running bench.py once under
+    PYTORCH_TUNABLEOP_ENABLED=1).  The point MLPs, the 1x1 convolutions and their batched weight / data gradients go through
+    ``at::cuda::blas``; the library heuristics' first choice is not the fastest for a third of those shapes: -3.5 ... -4.7 ms
+    per training step (A/B on one box).  Tuning itself stays OFF (a shape that is not in the file runs the default solution),
+    the file's validators (PyTorch / HIP / hipBLASLt / rocBLAS versions, gfx950) must match or TunableOp ignores it.
+    Returns True when the table was installed.  CAMLI_TUNED_GEMMS=0 or an explicit PYTORCH_TUNABLEOP_ENABLED leave
+    TunableOp alone."""
+    import torch
+    if os.environ.get('CAMLI_TUNED_GEMMS', '1') == '0' or 'PYTORCH_TUNABLEOP_ENABLED' in os.environ:
+        return False
+    path = path or GEMM_TUNING_FILE
+    if not (torch.cuda.is_available() and os.path.exists(path)):
+        return False
+    try:
+        tunable = torch.cuda.tunable
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.set_filename(path, insert_device_ordinal=False)
+        return bool(tunable.read_file(path))
+    except Exception as exc:          # an older / differently built torch: run on the library defaults
+        import warnings
+        warnings.warn('camliflow_amd: tuned GEMM table not installed (%s)' % exc, RuntimeWarning)
+        try:
+            torch.cuda.tunable.enable(False)
+        except Exception:
+            pass
+        return False
+
 
 def set_deferred_param_grads(enabled):
     global _DEFER_PARAM_GRADS

@@ -61,3 +61,25 @@ def test_overlap_is_refused_when_cuda_was_live_before_the_package_import():
     assert out == 'False False' and 'multi-stream execution refused' in err
     out, err = _probe(code, '1')          # preset by the launcher: fine whatever ran before
     assert out == 'True True'
+
+
+def test_tuned_gemm_table_ships_and_is_not_installed_without_a_gpu():
+    """runtime.use_tuned_gemms: the table (TunableOp results of the bench configurations on the MI355X image) is in the package,
+    carries the validators TunableOp checks, and nothing is touched on a machine without a GPU or when the caller opted out."""
+    import os
+    import torch
+    from camliflow_amd.cores import runtime
+    assert os.path.exists(runtime.GEMM_TUNING_FILE)
+    lines = open(runtime.GEMM_TUNING_FILE).read().splitlines()
+    validators = [ln for ln in lines if ln.startswith('Validator,')]
+    assert {ln.split(',')[1] for ln in validators} >= {'PT_VERSION', 'HIPBLASLT_VERSION', 'ROCBLAS_VERSION', 'GCN_ARCH_NAME'}
+    assert any('gfx950' in ln for ln in validators)
+    rows = [ln for ln in lines if ln and not ln.startswith('Validator,')]
+    assert len(rows) > 50 and all(len(ln.split(',')) >= 3 for ln in rows)
+    if not torch.cuda.is_available():
+        assert runtime.use_tuned_gemms() is False
+    os.environ['CAMLI_TUNED_GEMMS'] = '0'
+    try:
+        assert runtime.use_tuned_gemms() is False
+    finally:
+        os.environ.pop('CAMLI_TUNED_GEMMS')
