@@ -24,6 +24,7 @@ from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_slice
 # ------------------------------------------------------------------------------------------------
 # CAMLI_ALLPAIRS_MARKS=0: the pyramid adjoint examines every gradient tile instead of following the lookups' visit marks
 _USE_MARKS = os.environ.get('CAMLI_ALLPAIRS_MARKS', '1') != '0'
+_ALLPAIRS_FWD_LIB = os.environ.get('CAMLI_ALLPAIRS_FWD', 'hip') == 'lib'
 
 
 # CAMLI_ALLPAIRS_KEEP=0: allocate and zero-fill the gradient pyramid in every backward pass (the round-3 behaviour)
@@ -93,10 +94,18 @@ class _BuildPyramid(torch.autograd.Function):
         p_levels = (ctypes.c_int * len(sizes))(*[a * b for a, b in sizes])
         levels = [torch.empty((bs * p, a, b), dtype=torch.float32, device=fmap1.device) for a, b in sizes]
         total = sum(a * b for a, b in sizes)
-        with _on_device(fmap1):
-            _lib.launch('camli_allpairs_build_fwd', lib.camli_allpairs_build_fwd, fmap1.data_ptr(), _ptr_array(f2_levels),
-                        _ptr_array(levels), p_levels, len(sizes), bs, dim, p, 1.0 / math.sqrt(dim), _stream_ptr(fmap1),
-                        work=(4.0 * bs * p * total + 4.0 * bs * dim * (p + total), 'B'), flop=2.0 * bs * p * total * dim)
+        if _ALLPAIRS_FWD_LIB:
+            # A/B switch (CAMLI_ALLPAIRS_FWD=lib): the same four GEMMs through the library (hipBLASLt reaches 0.81 of the fp32
+            # MFMA peak on the level-0 shape with 256-wide macro tiles, this repo's 128 x 128 kernel 0.58)
+            a = fmap1.flatten(2).transpose(1, 2)
+            for lvl, f2l in zip(levels, f2_levels):
+                out = lvl.view(bs, p, -1)
+                torch.baddbmm(out, a, f2l.flatten(2), beta=0.0, alpha=1.0 / math.sqrt(dim), out=out)
+        else:
+            with _on_device(fmap1):
+                _lib.launch('camli_allpairs_build_fwd', lib.camli_allpairs_build_fwd, fmap1.data_ptr(), _ptr_array(f2_levels),
+                            _ptr_array(levels), p_levels, len(sizes), bs, dim, p, 1.0 / math.sqrt(dim), _stream_ptr(fmap1),
+                            work=(4.0 * bs * p * total + 4.0 * bs * dim * (p + total), 'B'), flop=2.0 * bs * p * total * dim)
         pyr.levels = levels
         pyr.shape = (bs, h, w)
         ctx.save_for_backward(fmap1, *f2_levels)
