@@ -93,6 +93,7 @@ def epilogue_ok(x):
 
 
 _PW_DX_GEMM = os.environ.get('CAMLI_PW_DX', 'gemm') != 'lib'
+_PW_FWD_BMM = os.environ.get('CAMLI_PW_FWD', 'bmm') == 'bmm'
 
 
 def _is_nhwc(x):
@@ -120,6 +121,13 @@ class _PointwiseConv(torch.autograd.Function):
             w2 = w.flatten(1).unsqueeze(0).expand(x.shape[0], -1, -1)
             y = torch.empty((x.shape[0], w.shape[0]) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
             torch.bmm(w2, x.flatten(2), out=y.flatten(2))       # y itself is returned: the epilogue works in place on it
+            return y
+        if _PW_FWD_BMM and x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous():
+            # the forward as a strided-batched GEMM through at::cuda::blas (y_b = W x_b), where the shipped TunableOp table
+            # picks the solution -- the library's 1x1 convolution path calls rocBLAS itself, out of TunableOp's reach
+            w2 = w.flatten(1).unsqueeze(0).expand(x.shape[0], -1, -1)
+            y = torch.empty((x.shape[0], w.shape[0]) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+            torch.bmm(w2, x.flatten(2), out=y.flatten(2))
             return y
         return torch.ops.aten.convolution(x, w, None, *ctx.conv_args)
 

@@ -134,7 +134,7 @@ GEMM_TUNING_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 
 def use_tuned_gemms(path=None):
     """Let PyTorch's TunableOp pick, per GEMM shape, the hipBLASLt / rocBLAS solution recorded in ``gemm_tuning_gfx950.csv``
-    (358 shapes: the GEMMs of the four bench configurations, tuned on an MI355X with this image by running bench.py once under
+    (533 shapes: the GEMMs of the four bench configurations, tuned on an MI355X with this image by running bench.py once under
     PYTORCH_TUNABLEOP_ENABLED=1).  The point MLPs, the 1x1 convolutions and their batched weight / data gradients go through
     ``at::cuda::blas``; the library heuristics' first choice is not the fastest for a third of those shapes: -3.5 ... -4.7 ms
     per training step (A/B on one box).  Tuning itself stays OFF (a shape that is not in the file runs the default solution),
