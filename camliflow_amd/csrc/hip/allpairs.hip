@@ -20,6 +20,9 @@
 // floats, conflict-free); the next step's global loads are in flight in registers while the current one is on the
 // matrix cores.  Operands may be m-contiguous ([K][M], staged with 16-byte loads / ds_write_b128) or k-contiguous
 // ([M][K], transposed by the staging stores; row stride 130 floats keeps those stores on 32 distinct banks).
+// The forward build (both operands m-contiguous, K = C) takes its own loop instead: K steps of 16 loaded DIRECT TO LDS
+// (global_load_lds_dwordx4, no staging registers, two tiles in flight), see gemm_tile_loop_dma.  Edge tiles of aligned
+// operands run the same unchecked loops as interior ones (clamped addresses, tile_load_one).
 #include "camli_common.h"
 #include <stdlib.h>
 
@@ -53,8 +56,19 @@ __device__ __forceinline__ float4 tile_load_one(const float* __restrict__ base, 
                                                 bool vec, int f) {
     const int gk = k0 + TileGeom<KC, KS>::k_of(f), gm = m0 + TileGeom<KC, KS>::m_of(f);
     if (!CHECK) {
-        const float* p = KC ? base + (int64_t)gm * ld + gk : base + (int64_t)gk * ld + gm;
-        return *reinterpret_cast<const float4*>(p);
+        // Unconditional 16-byte loads for EVERY tile of an aligned operand, edge tiles included.  Rows / columns of the
+        // tile beyond M only feed outputs that are never stored, so their addresses are clamped into the operand and
+        // whatever they read is ignored; k beyond K must contribute zero: clamped address + a select, in the last step
+        // only (block-uniform test).  Needs M % 4 == 0 (m contiguous) resp. K % 4 == 0 (k contiguous): a float4 is
+        // inside or outside as a whole.
+        const int gmc = min(gm, KC ? M - 1 : M - 4);
+        int gkc = gk;
+        const bool tail = k0 + KS > K;
+        if (tail) gkc = min(gk, KC ? K - 4 : K - 1);
+        const float* p = KC ? base + (int64_t)gmc * ld + gkc : base + (int64_t)gkc * ld + gmc;
+        float4 v = *reinterpret_cast<const float4*>(p);
+        if (tail && gk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        return v;
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KC) {
@@ -186,6 +200,92 @@ __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, con
     }
 }
 
+// Fragment reads / MFMA batches of half a K step (NP k pairs) of the direct-to-LDS loop below.
+template <int NP, int LDA, int LDB>
+__device__ __forceinline__ void frag_read(const float* a, const float* b, float (&fa0)[NP], float (&fa1)[NP],
+                                          float (&fb0)[NP], float (&fb1)[NP]) {
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        fa0[t] = a[2 * t * LDA]; fa1[t] = a[2 * t * LDA + 32];
+        fb0[t] = b[2 * t * LDB]; fb1[t] = b[2 * t * LDB + 32];
+    }
+}
+template <int NP>
+__device__ __forceinline__ void frag_mfma(f32x16 (&acc)[2][2], const float (&fa0)[NP], const float (&fa1)[NP],
+                                          const float (&fb0)[NP], const float (&fb1)[NP]) {
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb0[t], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[t], fb1[t], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb0[t], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[t], fb1[t], acc[1][1], 0, 0, 0);
+    }
+}
+
+// The forward loop with DIRECT-TO-LDS operand loads (global_load_lds_dwordx4: 64 lanes x 16 bytes land at M0 + lane * 16,
+// i.e. one instruction fills two 128-float k rows of a tile).  No staging registers, no ds_write, no
+// "loads back -> LDS stores done" chain in front of the barrier; and since nothing is held in registers the loads of
+// tile t + 2 are issued as soon as the barrier of step t has freed the buffer tile t was read from -- a full step of
+// flight time out of two buffers.  LDS rows are unpadded (128 floats): the fragment reads take the two half-waves of a
+// ds_read in separate passes, so row k and row k + 1 on the same banks do not collide.  Both operands m-contiguous,
+// 16-byte aligned, K a multiple of 16 (nothing can zero-fill a k tail here); M / N edges by clamped addresses.
+__device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst_uniform) {
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
+}
+__device__ __forceinline__ void gemm_tile_loop_dma(const float* __restrict__ Ab, const float* __restrict__ Bb, float* lds,
+                                                   f32x16 (&acc)[2][2], int M, int N, int K, int64_t lda, int64_t ldb, int m0,
+                                                   int n0, int tid, int wm, int wn) {
+    constexpr int KS = 16, H = 8, NP = 4, LD = 128;
+    float* const sA = lds;                          // two buffers of [16][128]
+    float* const sB = lds + 2 * KS * LD;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fk = lane >> 5, fm = lane & 31;
+    // this lane's source column and first k row; instruction j of a step covers k rows 4 * wave + 2 * j + {0, 1}
+    const float* ga = Ab + (int64_t)(4 * wave + fk) * lda + min(m0 + 4 * fm, M - 4);
+    const float* gb = Bb + (int64_t)(4 * wave + fk) * ldb + min(n0 + 4 * fm, N - 4);
+    float* const da = sA + (4 * wave) * LD;         // wave-uniform LDS destinations (buffer 0)
+    float* const db = sB + (4 * wave) * LD;
+    auto issue = [&](int step, int buf) {
+        const float* pa = ga + (int64_t)step * KS * lda;
+        const float* pb = gb + (int64_t)step * KS * ldb;
+        lds_dma16(pa, da + buf * (KS * LD));
+        lds_dma16(pa + 2 * lda, da + buf * (KS * LD) + 2 * LD);
+        lds_dma16(pb, db + buf * (KS * LD));
+        lds_dma16(pb + 2 * ldb, db + buf * (KS * LD) + 2 * LD);
+    };
+    float pa0[NP], pa1[NP], pb0[NP], pb1[NP];
+    float qa0[NP], qa1[NP], qb0[NP], qb1[NP];
+    const int steps = K / KS;
+    issue(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+    __syncthreads();
+    if (steps > 1) issue(1, 1);
+    const float* a = sA + fk * LD + wm + fm;
+    const float* b = sB + fk * LD + wn + fm;
+    frag_read<NP, LD, LD>(a, b, pa0, pa1, pb0, pb1);
+    int buf = 0;
+    // all steps but the last: no conditions inside (a guarded fragment read makes the compiler wait for every LDS
+    // read in front of the next MFMA batch)
+    for (int t = 0; t + 1 < steps; ++t) {
+        frag_read<NP, LD, LD>(a + (buf * KS + H) * LD, b + (buf * KS + H) * LD, qa0, qa1, qb0, qb1);
+        __builtin_amdgcn_sched_barrier(0);
+        frag_mfma<NP>(acc, pa0, pa1, pb0, pb1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // tile t + 1 has landed (this wave's share; the barrier covers the rest)
+        __syncthreads();
+        if (t + 2 < steps) issue(t + 2, buf);       // the buffer every wave has just finished reading
+        buf ^= 1;
+        frag_read<NP, LD, LD>(a + buf * KS * LD, b + buf * KS * LD, pa0, pa1, pb0, pb1);
+        __builtin_amdgcn_sched_barrier(0);
+        frag_mfma<NP>(acc, qa0, qa1, qb0, qb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    frag_read<NP, LD, LD>(a + (buf * KS + H) * LD, b + (buf * KS + H) * LD, qa0, qa1, qb0, qb1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_mfma<NP>(acc, pa0, pa1, pb0, pb1);
+    frag_mfma<NP>(acc, qa0, qa1, qb0, qb1);
+}
+
 // The same K loop driven by visit marks instead of tests on loaded data.  The lookup adjoint records which 32x32
 // blocks (32 source pixels x 32 target pixels) of a gradient level it ever wrote (camli_allpairs_lookup_bwd_marked);
 // a K step whose B tile holds no marked block is never loaded, staged or multiplied.  ~80 % of the level-0 tiles are
@@ -282,7 +382,7 @@ __device__ __forceinline__ void gemm_tile_loop_marked(const float* __restrict__ 
 // C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
 // grid (ceil(N/128), ceil(M/128), batch), block 256
 // One 128x128 output tile (m0, n0) of one batch entry: Ab / Bb / Cb / mk already point at that entry.
-template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ, int KS = GB_K>
+template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ, int KS = GB_K, bool DMA = false>
 __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const float* __restrict__ Bb, float* __restrict__ Cb,
                                            int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, int vec_a,
                                            int vec_b, const unsigned char* __restrict__ mk, int mark_mode, int mark_tb,
@@ -298,7 +398,9 @@ __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const bool fast = vec_a && vec_b && (m0 + GB_T <= M) && (n0 + GB_T <= N) && (K % KS == 0);    // block-uniform
+    // block-uniform: aligned operands take the unchecked loops for every tile (see tile_load_one)
+    const bool fast = vec_a && vec_b && (A_KC ? (K % 4 == 0 && K >= 4) : (M % 4 == 0 && M >= 4)) &&
+                      (B_KC ? (K % 4 == 0 && K >= 4) : (N % 4 == 0 && N >= 4));
     if (SKIPZ && mk) {
         if (fast)
             gemm_tile_loop_marked<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn, mk,
@@ -306,13 +408,35 @@ __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const f
         else
             gemm_tile_loop_marked<A_KC, B_KC, true>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm,
                                                     wn, mk, mark_mode, mark_tb, mark_src_blocks);
-    } else if (fast)
-        gemm_tile_loop<A_KC, B_KC, false, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
-    else
+    } else if (fast) {
+        if constexpr (DMA && !SKIPZ && !A_KC && !B_KC)
+            gemm_tile_loop_dma(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, tid, wm, wn);      // launch_gemm checks K % 16 == 0
+        else
+            gemm_tile_loop<A_KC, B_KC, false, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
+    } else
         gemm_tile_loop<A_KC, B_KC, true, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn);
 
     const int fk = lane >> 5, fm = lane & 31;
     // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (m0 + GB_T <= M && n0 + GB_T <= N) {
+        // interior tile (block-uniform): every row address is a wave-uniform 64-bit pointer (scalar arithmetic) plus
+        // one per-lane 32-bit offset computed once -- no per-store 64-bit multiply, compare or exec masking as in the
+        // checked form below (fewer instructions; the kernel time did not move with it: the tail is bound by the
+        // writes themselves)
+        const int uwm = __builtin_amdgcn_readfirstlane(wm), uwn = __builtin_amdgcn_readfirstlane(wn);
+        const int lane_off = 4 * fk * (int)ldc + fm;            // ldc is a pixel count < 2^28 (build_args_ok)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* urow = Cb + (int64_t)(m0 + uwm + i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + (n0 + uwn + j * 32);
+                    const float v = alpha * acc[i][j][r];
+                    urow[lane_off] = ACC ? (urow[lane_off] + v) : v;
+                }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -342,6 +466,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
     gemm_block<A_KC, B_KC, ACC, SKIPZ, KS>(A + (int64_t)blockIdx.z * sa, Bm + (int64_t)blockIdx.z * sb, C + (int64_t)blockIdx.z * sc,
                                        M, N, K, lda, ldb, ldc, alpha, vec_a, vec_b, mk, mark_mode, mark_tb, mark_src_blocks,
                                        blockIdx.y * GB_T, blockIdx.x * GB_T, lds);
+}
+
+// The forward build's kernel: m-contiguous aligned operands, K % 16 == 0, direct-to-LDS loop (138 registers, 32 KB of
+// LDS: three workgroups per CU; aiming the allocation at four waves per SIMD was measured and is slower).
+template <bool ACC>
+__global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                            float* __restrict__ C, int M, int N, int K, int64_t lda, int64_t ldb,
+                                                            int64_t ldc, int64_t sa, int64_t sb, int64_t sc, float alpha) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 x 16 x (128 + 128) floats
+    gemm_block<false, false, ACC, false, 16, true>(A + (int64_t)blockIdx.z * sa, Bm + (int64_t)blockIdx.z * sb,
+                                                   C + (int64_t)blockIdx.z * sc, M, N, K, lda, ldb, ldc, alpha, 1, 1, nullptr, 0, 0,
+                                                   0, blockIdx.y * GB_T, blockIdx.x * GB_T, lds);
 }
 
 // The g_f2_l GEMMs of ALL pyramid levels in one launch.  Per level they are M = C (2 row tiles), N = P_l, K = P: the
@@ -384,9 +520,24 @@ void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K,
     const int vec_b = aligned16(Bm) && (ldb % 4 == 0) && (sb % 4 == 0);
     dim3 grid(camli_divup(N, GB_T), camli_divup(M, GB_T), batch);
     if constexpr (!SKIPZ) {
-        // unmarked loops (the forward build): K step 16 -- 33 KB of LDS and <= 168 registers, three workgroups per CU
-        // (CAMLI_GEMM_KS=32 restores the 67 KB / two-workgroup form for A/B runs)
+        // unmarked loops (the forward build).  Aligned m-contiguous operands with K % 16 == 0 (every level of the build)
+        // take the direct-to-LDS kernel; CAMLI_GEMM_DMA=0 keeps them on the register-staged two-phase loop for A/B runs.
+        // Otherwise: K step 16 -- 33 KB of LDS and <= 168 registers, three workgroups per CU (CAMLI_GEMM_KS=32 restores the
+        // 67 KB / two-workgroup form).
         static const bool ks32 = []() { const char* e = getenv("CAMLI_GEMM_KS"); return e && atoi(e) == 32; }();
+        static const bool dma = []() { const char* e = getenv("CAMLI_GEMM_DMA"); return !e || atoi(e) != 0; }();
+        if constexpr (!A_KC && !B_KC) {
+            constexpr size_t ldsd = (size_t)2 * 16 * (128 + 128) * sizeof(float);
+            if (dma && K % 16 == 0 && vec_a && vec_b && M % 4 == 0 && N % 4 == 0 && M >= 4 && N >= 4) {
+                if (accumulate)
+                    hipLaunchKernelGGL((gemm_fwd_dma_kernel<true>), grid, dim3(256), ldsd, stream, A, Bm, C, M, N, K, lda, ldb, ldc,
+                                       sa, sb, sc, alpha);
+                else
+                    hipLaunchKernelGGL((gemm_fwd_dma_kernel<false>), grid, dim3(256), ldsd, stream, A, Bm, C, M, N, K, lda, ldb,
+                                       ldc, sa, sb, sc, alpha);
+                return;
+            }
+        }
         if (!ks32 && K % 16 == 0) {
             constexpr size_t lds16 = (size_t)2 * 16 * (OperandTile<A_KC>::LD + OperandTile<B_KC>::LD) * sizeof(float);
             if (accumulate)
@@ -418,12 +569,12 @@ void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K,
 int build_args_ok(const char* what, const void* f1, const void* a, const void* b, const int* p_levels, int L, int B, int C,
                   int P) {
     if (!f1 || !a || !b || !p_levels) { camli_set_error("%s: null pointer", what); return 0; }
-    if (L < 1 || L > 8 || B < 0 || C < 1 || P < 1 || B > 65535) {
+    if (L < 1 || L > 8 || B < 0 || C < 1 || P < 1 || B > 65535 || P >= (1 << 28) || C >= (1 << 28)) {
         camli_set_error("%s: bad shape L=%d B=%d C=%d P=%d", what, L, B, C, P);
         return 0;
     }
     for (int l = 0; l < L; ++l)
-        if (p_levels[l] < 1) { camli_set_error("%s: level %d has %d target pixels", what, l, p_levels[l]); return 0; }
+        if (p_levels[l] < 1 || p_levels[l] >= (1 << 28)) { camli_set_error("%s: level %d has %d target pixels", what, l, p_levels[l]); return 0; }
     return 1;
 }
 
