@@ -27,6 +27,10 @@ PROTOTYPES = {
                                         ctypes.c_void_p, _int, _int, _int, ctypes.c_float, _stream]),
     "camli_allpairs_build_bwd_marked": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                                ctypes.c_void_p, _int, _int, _int, ctypes.c_float, ctypes.c_void_p, _stream]),
+    "camli_allpairs_build_bwd_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p, _int, _int, _int, _int]),
+    "camli_allpairs_build_bwd_splitk": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
+                                               ctypes.c_void_p, _int, _int, _int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_int64, _stream]),
     "camli_allpairs_lookup_bwd_marked": (_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                                 _c_float_p, _int, _int, _int, _int, ctypes.c_void_p, _stream]),
     "camli_allpairs_clear_marked": (_int, [ctypes.c_void_p, ctypes.c_void_p, _int, ctypes.c_void_p, _int, _int, _stream]),

@@ -22,6 +22,8 @@ from .wrapper import _on_device, _require_cuda, _stream_ptr, _zero_slice
 # ------------------------------------------------------------------------------------------------
 # all-pairs cost-volume pyramid (models/raft_core.py:52-107)
 # ------------------------------------------------------------------------------------------------
+# CAMLI_ALLPAIRS_SPLITK=0: the pyramid adjoint's g_f2 GEMMs unsplit (A/B switch; default: coarse levels split over K)
+_BUILD_SPLITK = os.environ.get('CAMLI_ALLPAIRS_SPLITK', '1') != '0'
 # CAMLI_ALLPAIRS_MARKS=0: the pyramid adjoint examines every gradient tile instead of following the lookups' visit marks
 _USE_MARKS = os.environ.get('CAMLI_ALLPAIRS_MARKS', '1') != '0'
 _ALLPAIRS_FWD_LIB = os.environ.get('CAMLI_ALLPAIRS_FWD', 'hip') == 'lib'
@@ -139,7 +141,14 @@ class _BuildPyramid(torch.autograd.Function):
         g2_levels = [torch.empty_like(t) for t in f2_levels]
         work = dict(work=(4.0 * bs * p * total + 4.0 * bs * dim * 2 * (p + total), 'B'), flop=4.0 * bs * p * total * dim)
         with _on_device(fmap1):
-            if marks is not None:
+            ws_bytes = int(lib.camli_allpairs_build_bwd_workspace_bytes(p_levels, len(sizes), bs, dim, p)) if _BUILD_SPLITK else 0
+            if marks is not None and ws_bytes > 0:
+                # ... and the coarse levels' g_f2 GEMMs (few tiles, the longest K loops) are split over K into a workspace
+                ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=fmap1.device)
+                _lib.launch('camli_allpairs_build_bwd', lib.camli_allpairs_build_bwd_splitk, fmap1.data_ptr(), _ptr_array(f2_levels),
+                            _ptr_array(grads), p_levels, len(sizes), g1.data_ptr(), _ptr_array(g2_levels), bs, dim, p,
+                            1.0 / math.sqrt(dim), _ptr_array(marks), ws.data_ptr(), ws_bytes, _stream_ptr(fmap1), **work)
+            elif marks is not None:
                 # the lookups marked the 32x32 blocks they wrote: the GEMMs never load the rest of the volume
                 _lib.launch('camli_allpairs_build_bwd', lib.camli_allpairs_build_bwd_marked, fmap1.data_ptr(), _ptr_array(f2_levels),
                             _ptr_array(grads), p_levels, len(sizes), g1.data_ptr(), _ptr_array(g2_levels), bs, dim, p,

@@ -144,15 +144,18 @@ __device__ __forceinline__ void tile_store_one(float* __restrict__ s, const floa
 template <bool A_KC, bool B_KC, bool CHECK, bool SKIPZ, int KS>
 __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, const float* __restrict__ Bb, float* lds,
                                                f32x16 (&acc)[2][2], int M, int N, int K, int64_t lda, int64_t ldb, int m0,
-                                               int n0, bool vec_a, bool vec_b, int tid, int wm, int wn) {
+                                               int n0, bool vec_a, bool vec_b, int tid, int wm, int wn, int k_begin = 0,
+                                               int k_end = 1 << 30) {
     constexpr int LDA = OperandTile<A_KC>::LD, LDB = OperandTile<B_KC>::LD;
+    k_end = min(k_end, K);                          // [k_begin, k_end): this workgroup's share of K (split-K adjoint)
+    if (k_begin >= k_end) return;
     float* const sA = lds;                          // two buffers of [GB_K][LDA]
     float* const sB = lds + 2 * KS * LDA;           // two buffers of [KS][LDB]
     const int lane = tid & 63;
     const int fk = lane >> 5, fm = lane & 31;
     float4 ra0, ra1, ra2 = make_float4(0.f, 0.f, 0.f, 0.f), ra3 = ra2, rb0, rb1, rb2 = ra2, rb3 = ra2;
-    GB_LOADK(A_KC, ra, Ab, lda, m0, 0, M, K, vec_a);
-    GB_LOADK(B_KC, rb, Bb, ldb, n0, 0, N, K, vec_b);
+    GB_LOADK(A_KC, ra, Ab, lda, m0, k_begin, M, K, vec_a);
+    GB_LOADK(B_KC, rb, Bb, ldb, n0, k_begin, N, K, vec_b);
     GB_STOREK(A_KC, ra, sA);
     GB_STOREK(B_KC, rb, sB);
 #define GB_NONZERO(R) (((R##0).x != 0.f) | ((R##0).y != 0.f) | ((R##0).z != 0.f) | ((R##0).w != 0.f) | ((R##1).x != 0.f) | ((R##1).y != 0.f) | \
@@ -162,8 +165,8 @@ __device__ __forceinline__ void gemm_tile_loop(const float* __restrict__ Ab, con
     if (SKIPZ) live = __syncthreads_or(GB_NONZERO(rb) ? 1 : 0);
     else __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += KS) {
-        const bool more = k0 + KS < K;
+    for (int k0 = k_begin; k0 < k_end; k0 += KS) {
+        const bool more = k0 + KS < k_end;
         if (more) {     // next step's operands: in flight while this step runs on the matrix cores
             GB_LOADK(A_KC, ra, Ab, lda, m0, k0 + KS, M, K, vec_a);
             GB_LOADK(B_KC, rb, Bb, ldb, n0, k0 + KS, N, K, vec_b);
@@ -297,7 +300,8 @@ template <bool A_KC, bool B_KC, bool CHECK>
 __device__ __forceinline__ void gemm_tile_loop_marked(const float* __restrict__ Ab, const float* __restrict__ Bb, float* lds,
                                                       f32x16 (&acc)[2][2], int M, int N, int K, int64_t lda, int64_t ldb,
                                                       int m0, int n0, bool vec_a, bool vec_b, int tid, int wm, int wn,
-                                                      const unsigned char* __restrict__ marks, int mode, int tb, int src_blocks) {
+                                                      const unsigned char* __restrict__ marks, int mode, int tb, int src_blocks,
+                                                      int ks_begin = 0, int ks_end = 1 << 24) {
     constexpr int LDA = OperandTile<A_KC>::LD, LDB = OperandTile<B_KC>::LD;
     __shared__ unsigned long long s_live[4];        // step s has a marked block (bit s & 63 of word s >> 6)
     float* const sA = lds;
@@ -308,7 +312,7 @@ __device__ __forceinline__ void gemm_tile_loop_marked(const float* __restrict__ 
         const int steps = (K + GB_K - 1) / GB_K;
         const int nb = n0 >> 5;
         bool live = false;
-        if (tid < steps) {
+        if (tid < steps && tid >= ks_begin && tid < ks_end) {      // [ks_begin, ks_end): this workgroup's share of the steps
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (mode == 1) { if (nb + i < src_blocks) live |= marks[(size_t)(nb + i) * tb + tid] != 0; }
@@ -386,7 +390,8 @@ template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ, int KS = GB_K, bool DMA = 
 __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const float* __restrict__ Bb, float* __restrict__ Cb,
                                            int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, int vec_a,
                                            int vec_b, const unsigned char* __restrict__ mk, int mark_mode, int mark_tb,
-                                           int mark_src_blocks, int m0, int n0, float* lds) {
+                                           int mark_src_blocks, int m0, int n0, float* lds, int ks_begin = 0,
+                                           int ks_end = 1 << 24) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
@@ -404,17 +409,19 @@ __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const f
     if (SKIPZ && mk) {
         if (fast)
             gemm_tile_loop_marked<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn, mk,
-                                                     mark_mode, mark_tb, mark_src_blocks);
+                                                     mark_mode, mark_tb, mark_src_blocks, ks_begin, ks_end);
         else
             gemm_tile_loop_marked<A_KC, B_KC, true>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm,
-                                                    wn, mk, mark_mode, mark_tb, mark_src_blocks);
+                                                    wn, mk, mark_mode, mark_tb, mark_src_blocks, ks_begin, ks_end);
     } else if (fast) {
         if constexpr (DMA && !SKIPZ && !A_KC && !B_KC)
             gemm_tile_loop_dma(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, tid, wm, wn);      // launch_gemm checks K % 16 == 0
         else
-            gemm_tile_loop<A_KC, B_KC, false, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn);
+            gemm_tile_loop<A_KC, B_KC, false, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn,
+                                                         ks_begin * GB_K, min(ks_end, 1 << 24) * GB_K);
     } else
-        gemm_tile_loop<A_KC, B_KC, true, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn);
+        gemm_tile_loop<A_KC, B_KC, true, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn,
+                                                    ks_begin * GB_K, min(ks_end, 1 << 24) * GB_K);
 
     const int fk = lane >> 5, fm = lane & 31;
     // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -484,12 +491,17 @@ __global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const float* __restri
 // coarse levels have 16 / 4 / 1 column tiles, i.e. 256 / 64 / 16 workgroups walking a 255-step K loop -- launched one
 // after the other they leave the chip mostly idle for ~1.5 ms.  grid.x enumerates the column tiles of the levels, coarse
 // levels FIRST (their long loops start at once, the level-0 tiles fill the remaining CUs).  A = f1 is shared.
-constexpr int GG_MAX = 8;
+// Split K: the coarse levels are few tiles with the longest and densest loops (measured on a training step: 40 live steps of
+// 255 per level-0 tile, 83 / 170 / 255 on levels 1 / 2 / 3), i.e. the launch lasted as long as ONE level-3 workgroup walking
+// 255 steps behind its barriers.  A group is therefore a (level, range of K steps) pair writing its own partial result;
+// reduce_parts_kernel adds the parts of a level in a fixed order (deterministic).
+constexpr int GG_MAX = 48;
 struct GemmGroup {
     const float* B[GG_MAX];
     float* C[GG_MAX];
     const unsigned char* marks[GG_MAX];
     int N[GG_MAX];
+    int ks_begin[GG_MAX], ks_end[GG_MAX];      // K steps (of 32) of this group
     int tile_begin[GG_MAX + 1];        // in launch order
     int groups;
 };
@@ -506,7 +518,35 @@ __global__ __launch_bounds__(256) void gemm_gf2_grouped_kernel(const float* __re
     const int vec_b = vec_ok && (N % 4 == 0);
     gemm_block<true, false, false, true>(A + (int64_t)blockIdx.z * sa, g.B[l] + (int64_t)blockIdx.z * K * N,
                                          g.C[l] + (int64_t)blockIdx.z * M * N, M, N, K, lda, N, N, alpha, vec_a, vec_b, mk, 2, tb,
-                                         mark_src_blocks, blockIdx.y * GB_T, n0, lds);
+                                         mark_src_blocks, blockIdx.y * GB_T, n0, lds, g.ks_begin[l], g.ks_end[l]);
+}
+
+// out[i] = part_0[i] + part_1[i] + ... (left to right) for every split level; grid (blocks, levels)
+constexpr int RG_MAX = 8;
+struct ReduceGroup {
+    float* out[RG_MAX];
+    const float* part[RG_MAX];         // parts of a level lie n floats apart
+    int parts[RG_MAX];
+    int64_t n[RG_MAX];
+};
+__global__ __launch_bounds__(256) void reduce_parts_kernel(ReduceGroup g) {
+    const int l = blockIdx.y;
+    const int64_t n = g.n[l];
+    const float* p = g.part[l];
+    float* out = g.out[l];
+    const int parts = g.parts[l];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float acc = p[i];
+        for (int s = 1; s < parts; ++s) acc += p[(int64_t)s * n + i];
+        out[i] = acc;
+    }
+}
+
+// parts of level l in the split-K adjoint: 1, 2, 4, 8, 8, ... with at least 16 K steps each
+int gf2_parts(int level, int steps) {
+    int parts = level >= 3 ? 8 : (1 << level);
+    while (parts > 1 && steps / parts < 16) parts >>= 1;
+    return parts;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -598,9 +638,20 @@ extern "C" int camli_allpairs_build_fwd(const float* f1, const float* const* f2_
 
 // g_f1[b, c, p]   = scale * sum_l sum_q gV_l[b, p, q] * f2_l[b, c, q]         (fully written)
 // g_f2_l[b, c, q] = scale * sum_p f1[b, c, p] * gV_l[b, p, q]                 (fully written, per level)
+static size_t gf2_workspace_floats(const int* p_levels, int L, int B, int C, int P) {
+    const int steps = camli_divup(P, GB_K);
+    size_t n = 0;
+    for (int l = 0; l < L; ++l) {
+        const int parts = gf2_parts(l, steps);
+        if (parts > 1) n += (size_t)parts * B * C * p_levels[l];
+    }
+    return n;
+}
+
 static int allpairs_build_bwd_impl(const float* f1, const float* const* f2_levels, const float* const* gvol_levels,
                                    const int* p_levels, int L, float* g_f1, float* const* g_f2_levels, int B, int C, int P,
-                                   float scale, const unsigned char* const* marks, void* stream, const char* what) {
+                                   float scale, const unsigned char* const* marks, void* stream, const char* what,
+                                   float* workspace = nullptr, size_t workspace_bytes = 0) {
     if (B == 0) return CAMLI_OK;
     if (!build_args_ok(what, f1, f2_levels, gvol_levels, p_levels, L, B, C, P)) return CAMLI_EINVAL;
     if (!g_f1 || !g_f2_levels) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
@@ -613,20 +664,39 @@ static int allpairs_build_bwd_impl(const float* f1, const float* const* f2_level
         }
     // g_f2_l for every level in one launch: M = C, N = P_l, K = P;  A = f1 [M][K] (k contiguous), B = gV_l [K][N] (n contiguous)
     {
+        const bool split = workspace && workspace_bytes >= gf2_workspace_floats(p_levels, L, B, C, P) * sizeof(float);
         GemmGroup g;
-        g.groups = L;
-        int tiles = 0, vec_ok = aligned16(f1) ? 1 : 0;
+        ReduceGroup rg;
+        int ng = 0, nr = 0, tiles = 0, vec_ok = aligned16(f1) ? 1 : 0;
+        float* ws = workspace;
+        int64_t max_n = 0;
         for (int i = 0; i < L; ++i) {
             const int l = L - 1 - i;            // coarse levels first
-            g.B[i] = gvol_levels[l];
-            g.C[i] = g_f2_levels[l];
-            g.marks[i] = (marks && P <= 256 * GB_K) ? marks[l] : nullptr;
-            g.N[i] = p_levels[l];
-            g.tile_begin[i] = tiles;
-            tiles += camli_divup(p_levels[l], GB_T);
+            const int parts = split ? gf2_parts(l, sb) : 1;
+            const int64_t n = (int64_t)B * C * p_levels[l];
+            if (parts > 1) {
+                rg.out[nr] = g_f2_levels[l];
+                rg.part[nr] = ws;
+                rg.parts[nr] = parts;
+                rg.n[nr] = n;
+                max_n = n > max_n ? n : max_n;
+                ++nr;
+            }
+            for (int part = 0; part < parts; ++part, ++ng) {
+                g.B[ng] = gvol_levels[l];
+                g.C[ng] = parts > 1 ? ws + (int64_t)part * n : g_f2_levels[l];
+                g.marks[ng] = (marks && P <= 256 * GB_K) ? marks[l] : nullptr;
+                g.N[ng] = p_levels[l];
+                g.ks_begin[ng] = (int)((int64_t)sb * part / parts);
+                g.ks_end[ng] = (int)((int64_t)sb * (part + 1) / parts);
+                g.tile_begin[ng] = tiles;
+                tiles += camli_divup(p_levels[l], GB_T);
+            }
+            if (parts > 1) ws += (int64_t)parts * n;
             vec_ok = vec_ok && aligned16(gvol_levels[l]);
         }
-        g.tile_begin[L] = tiles;
+        g.groups = ng;
+        g.tile_begin[ng] = tiles;
         const int vec_a = aligned16(f1) && (P % 4 == 0) && (((int64_t)C * P) % 4 == 0);
         constexpr size_t lds = (size_t)2 * GB_K * (OperandTile<true>::LD + OperandTile<false>::LD) * sizeof(float);
         static bool attr_set = false;
@@ -637,6 +707,10 @@ static int allpairs_build_bwd_impl(const float* f1, const float* const* f2_level
         }
         hipLaunchKernelGGL(gemm_gf2_grouped_kernel, dim3(tiles, camli_divup(C, GB_T), B), dim3(256), lds, s, f1, g, C, P,
                            (int64_t)P, (int64_t)C * P, scale, vec_a, vec_ok, sb);
+        if (nr > 0) {
+            const int blocks = (int)((max_n + 1023) / 1024 < 2048 ? (max_n + 1023) / 1024 : 2048);
+            hipLaunchKernelGGL(reduce_parts_kernel, dim3(blocks, nr), dim3(256), 0, s, rg);
+        }
     }
     for (int l = 0; l < L; ++l) {
         const int Pl = p_levels[l];
@@ -654,6 +728,28 @@ extern "C" int camli_allpairs_build_bwd(const float* f1, const float* const* f2_
                                         int P, float scale, void* stream) {
     return allpairs_build_bwd_impl(f1, f2_levels, gvol_levels, p_levels, L, g_f1, g_f2_levels, B, C, P, scale, nullptr, stream,
                                    "camli_allpairs_build_bwd");
+}
+
+// Workspace of the split-K form below (bytes; 0 when no level would be split).
+extern "C" int64_t camli_allpairs_build_bwd_workspace_bytes(const int* p_levels, int L, int B, int C, int P) {
+    if (!p_levels || L < 1 || L > 8 || B < 1 || C < 1 || P < 1) return 0;
+    return (int64_t)(gf2_workspace_floats(p_levels, L, B, C, P) * sizeof(float));
+}
+
+// camli_allpairs_build_bwd_marked (marks != NULL) or camli_allpairs_build_bwd (marks == NULL) with the g_f2 GEMMs of the
+// coarse levels split over K into 2 / 4 / 8 workgroups per tile; the parts of a level are written to the workspace and added
+// in a fixed order.  A NULL or too small workspace runs the unsplit form.
+extern "C" int camli_allpairs_build_bwd_splitk(const float* f1, const float* const* f2_levels, const float* const* gvol_levels,
+                                               const int* p_levels, int L, float* g_f1, float* const* g_f2_levels, int B, int C,
+                                               int P, float scale, const unsigned char* const* marks, void* workspace,
+                                               int64_t workspace_bytes, void* stream) {
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 15)) {
+        camli_set_error("camli_allpairs_build_bwd_splitk: workspace must be 16-byte aligned");
+        return CAMLI_EINVAL;
+    }
+    return allpairs_build_bwd_impl(f1, f2_levels, gvol_levels, p_levels, L, g_f1, g_f2_levels, B, C, P, scale, marks, stream,
+                                   "camli_allpairs_build_bwd_splitk", static_cast<float*>(workspace),
+                                   workspace_bytes > 0 ? (size_t)workspace_bytes : 0);
 }
 
 // Same adjoint, skipping every K step whose gradient tile was never written: marks[l] = [B][ceil(P/32)][ceil(P_l/32)]

@@ -126,6 +126,19 @@ int camli_allpairs_build_bwd_marked(const float *f1, const float *const *f2_leve
                                     const int *p_levels, int L, float *g_f1, float *const *g_f2_levels, int B, int C,
                                     int P, float scale, const unsigned char *const *marks, void *stream);
 
+/* The same adjoint with the g_f2 GEMMs of the coarse levels split over K.  Those levels are a few output tiles with the
+ * longest and densest K loops (8160 source pixels; level 3 of a 68x120 map is ONE 120-column tile per sample), so unsplit
+ * the launch lasts as long as one workgroup walking 255 K steps.  Level l is cut into min(2^l, 8) ranges of K steps (each at
+ * least 16 steps of 32 source pixels), every range writes its partial [B,C,P_l] into `workspace`, and the parts of a level are added left to
+ * right -- deterministic; equal to camli_allpairs_build_bwd(_marked) up to fp32 summation order on levels >= 1, bit for bit
+ * on level 0 and g_f1.  marks may be NULL (every gradient tile is examined).  workspace: 16-byte aligned device memory of
+ * camli_allpairs_build_bwd_workspace_bytes(...) bytes; NULL / too small runs the unsplit form. */
+int64_t camli_allpairs_build_bwd_workspace_bytes(const int *p_levels, int L, int B, int C, int P);
+int camli_allpairs_build_bwd_splitk(const float *f1, const float *const *f2_levels, const float *const *gvol_levels,
+                                    const int *p_levels, int L, float *g_f1, float *const *g_f2_levels, int B, int C,
+                                    int P, float scale, const unsigned char *const *marks, void *workspace,
+                                    int64_t workspace_bytes, void *stream);
+
 int camli_allpairs_lookup_fwd(const float *const *vols, const int *hs, const int *ws, int L,
                               const float *coords, float *out, int B, int h, int w, int r, void *stream);
 int camli_allpairs_lookup_bwd(float *const *gvols, const int *hs, const int *ws, int L,

@@ -151,9 +151,9 @@ def test_pyramid_adjoint_following_visit_marks_equals_full_scan(shape):
     coords = [(base + torch.randn(b, 2, h, w, generator=g) * s).cuda() for s in (0.5, 2.0, 6.0)]
     gouts = [torch.randn(b, 4 * 81, h, w, generator=g).cuda() for _ in coords]
 
-    def run(use_marks, keep=None):
-        saved = fused._USE_MARKS
-        fused._USE_MARKS = use_marks
+    def run(use_marks, keep=None, splitk=False):
+        saved = fused._USE_MARKS, fused._BUILD_SPLITK
+        fused._USE_MARKS, fused._BUILD_SPLITK = use_marks, splitk
         try:
             pyr = fused.allpairs_pyramid(f1, f2, 4)
             outs = [fused.allpairs_lookup(pyr, cc, 4) for cc in coords]
@@ -165,12 +165,19 @@ def test_pyramid_adjoint_following_visit_marks_equals_full_scan(shape):
                 hook.remove()
             return res
         finally:
-            fused._USE_MARKS = saved
+            fused._USE_MARKS, fused._BUILD_SPLITK = saved
 
     keep = {}
     got = run(True, keep)
     want = run(False)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the split-K form (camli_allpairs_build_bwd_splitk, the default of the product path): g_f1 bit for bit, g_f2 up to the
+    # fp32 summation order of the coarse levels' parts; and it is deterministic
+    split = run(True, splitk=True)
+    assert torch.equal(split[0], want[0])
+    assert (split[1] - want[1]).abs().max() <= 1e-5 * want[1].abs().max()
+    again = run(True, splitk=True)
+    assert torch.equal(again[1], split[1])
     p = h * w
     for grad, mark in zip(keep['grads'], keep['marks']):
         pl = grad.shape[-2] * grad.shape[-1]
@@ -220,3 +227,52 @@ def test_gradient_pyramid_kept_across_passes_is_clean_and_gives_the_same_gradien
     kept, fresh = run(True), run(False)
     for a, c_ in zip(kept, fresh):
         assert torch.equal(a[0], c_[0]) and torch.equal(a[1], c_[1])
+
+
+@pytest.mark.parametrize('shape', [(1, 128, 40, 64), (2, 40, 33, 50)], ids=str)
+def test_build_bwd_splitk_through_the_c_abi_matches_the_unsplit_adjoint(shape):
+    """camli_allpairs_build_bwd_splitk with marks == NULL on a DENSE gradient pyramid (every K step live) against
+    camli_allpairs_build_bwd: g_f1 and the level-0 g_f2 bit for bit, the split levels up to fp32 summation order; a NULL
+    workspace runs the unsplit form (bit for bit everywhere)."""
+    import ctypes
+    import math
+    from camliflow_amd.csrc import _lib
+    lib = _lib.load()
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(c + h)
+    p = h * w
+    sizes = [(h, w)]
+    for _ in range(3):
+        sizes.append((sizes[-1][0] // 2, sizes[-1][1] // 2))
+    f1 = torch.randn(b, c, p, generator=g).cuda()
+    f2 = [torch.randn(b, c, a * bb, generator=g).cuda() for a, bb in sizes]
+    gv = [torch.randn(b, p, a * bb, generator=g).cuda() for a, bb in sizes]
+    p_levels = (ctypes.c_int * 4)(*[a * bb for a, bb in sizes])
+    ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])      # noqa: E731
+    stream = torch.cuda.current_stream().cuda_stream
+    scale = 1.0 / math.sqrt(c)
+
+    def unsplit():
+        g1, g2 = torch.empty_like(f1), [torch.empty_like(t) for t in f2]
+        rc = lib.camli_allpairs_build_bwd(f1.data_ptr(), ptrs(f2), ptrs(gv), p_levels, 4, g1.data_ptr(), ptrs(g2), b, c, p, scale, stream)
+        assert rc == 0
+        return g1, g2
+
+    def splitk(with_ws):
+        g1, g2 = torch.empty_like(f1), [torch.empty_like(t) for t in f2]
+        nbytes = int(lib.camli_allpairs_build_bwd_workspace_bytes(p_levels, 4, b, c, p))
+        assert nbytes > 0
+        ws = torch.full((nbytes // 4,), float('nan'), device='cuda') if with_ws else None
+        rc = lib.camli_allpairs_build_bwd_splitk(f1.data_ptr(), ptrs(f2), ptrs(gv), p_levels, 4, g1.data_ptr(), ptrs(g2), b, c, p, scale,
+                                                 None, ws.data_ptr() if with_ws else None, nbytes if with_ws else 0, stream)
+        assert rc == 0
+        return g1, g2
+
+    want1, want2 = unsplit()
+    got1, got2 = splitk(True)
+    assert torch.equal(got1, want1) and torch.equal(got2[0], want2[0])
+    for a, bb in zip(got2[1:], want2[1:]):
+        assert (a - bb).abs().max() <= 1e-5 * bb.abs().max()          # K = h * w terms per sum, two summation orders
+    assert not any(torch.equal(a, bb) for a, bb in zip(got2[1:2], want2[1:2])) or p < 1024      # level 1 really was split
+    none1, none2 = splitk(False)
+    assert torch.equal(none1, want1) and all(torch.equal(a, bb) for a, bb in zip(none2, want2))
