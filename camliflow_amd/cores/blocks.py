@@ -197,6 +197,66 @@ def conv_bias_act(conv, x, act, leave_bias=False):
     return fused.bias_act(y, conv.bias, act)
 
 
+class _CatConvCL(torch.autograd.Function):
+    """``conv2d(cat(parts, 1), w, padding=padding)`` (stride 1, no bias) on explicitly channels-last operands.
+
+    The library runs these shapes (1x5 / 5x1 / 7x7, wide maps) on NHWC implicit-GEMM kernels and, given NCHW tensors,
+    wraps every call in layout transposes of its own: x and y in the forward, gy and gx in the data gradient, x AND gy
+    again in the weight gradient -- six volume-sized passes per layer and step.  Here the concatenation writes straight
+    into a channels-last buffer (it was a copy anyway), that buffer is kept for the weight gradient, and the output
+    gradient is transposed once for both adjoints: three passes less per layer."""
+
+    @staticmethod
+    def forward(ctx, w, padding, *parts):
+        b, _, hh, ww = parts[0].shape
+        widths = [p.shape[1] for p in parts]
+        hip = runtime.fused() and w.is_cuda
+        x_cl = torch.empty((b, sum(widths), hh, ww), dtype=w.dtype, device=w.device, memory_format=torch.channels_last)
+        c0 = 0
+        for p, c in zip(parts, widths):
+            if hip:
+                from ..csrc import fused
+                fused.nchw_into_channels_last(p, x_cl, c0)
+            else:
+                x_cl[:, c0:c0 + c].copy_(p)
+            c0 += c
+        w_cl = w.contiguous(memory_format=torch.channels_last)
+        ctx.conv_args = ([1, 1], list(padding), [1, 1], False, [0, 0], 1)
+        y_cl = torch.ops.aten.convolution(x_cl, w_cl, None, *ctx.conv_args)
+        ctx.save_for_backward(x_cl, w_cl)
+        ctx.widths, ctx.hip = widths, hip
+        if hip:
+            return fused.channels_last_to_nchw(y_cl, 0, y_cl.shape[1])
+        return y_cl.contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_cl, w_cl = ctx.saved_tensors
+        if ctx.hip:
+            from ..csrc import fused
+            gy_cl = torch.empty(gy.shape, dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
+            fused.nchw_into_channels_last(gy, gy_cl, 0)
+        else:
+            gy_cl = gy.contiguous(memory_format=torch.channels_last)
+        need_x = any(ctx.needs_input_grad[2:])
+        gx_cl, gw_cl, _ = torch.ops.aten.convolution_backward(gy_cl, x_cl, w_cl, None, *ctx.conv_args,
+                                                              [need_x, ctx.needs_input_grad[0], False])
+        gparts, c0 = [], 0
+        for i, c in enumerate(ctx.widths):
+            if not ctx.needs_input_grad[2 + i]:
+                gparts.append(None)
+            elif ctx.hip:
+                gparts.append(fused.channels_last_to_nchw(gx_cl, c0, c))
+            else:
+                gparts.append(gx_cl[:, c0:c0 + c].contiguous())
+            c0 += c
+        return (gw_cl.contiguous() if gw_cl is not None else None, None, *gparts)
+
+
+def cat_conv_cl(parts, w, padding):
+    return _CatConvCL.apply(w, tuple(padding), *parts)
+
+
 def flow_conv(conv, x):
     """A bare ``nn.Conv2d`` that ends a flow head (wide map -> 2 channels, pwc_core.py / raft_core.py:169-181): on the
     product path the two-channel 3x3 kernels of csrc/hip/smallconv.hip, otherwise the module itself."""

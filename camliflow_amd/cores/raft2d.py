@@ -9,7 +9,7 @@ import torch.nn as nn
 from torch.nn.functional import avg_pool2d, grid_sample
 
 from . import runtime
-from .blocks import Conv2dNormRelu, conv_bias_act, epilogue_ok
+from .blocks import Conv2dNormRelu, cat_conv_cl, conv_bias_act, epilogue_ok
 from .geometry import convex_upsample, mesh_grid
 from .resnet import ResNetTrunk
 
@@ -164,14 +164,18 @@ class GRU2D(nn.Module):
                 z, rh = fused.conv5_gru_gates(h, motion, packed[0], ctx_zr, vertical=(suffix == '2'))
                 h = fused.conv5_gru_blend(rh, motion, packed[1], ctx_q, z, h, vertical=(suffix == '2'), nan_to_num=(suffix == '2'))
                 continue
-            pre_zr = conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding)
+            # CAMLI_CONV_CL (default on): the two convolutions of a half step on explicitly channels-last operands
+            # (blocks._CatConvCL: the cat writes the channels-last input, kept for the weight gradient)
+            cl = os.environ.get('CAMLI_CONV_CL', '1') == '1' and fusable and runtime.fused() and h.dtype == torch.float32 and motion.dtype == torch.float32 \
+                and not torch.is_autocast_enabled()
+            pre_zr = cat_conv_cl([h, motion], w_zr, padding) if cl else conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding)
             if not fusable and h.is_cuda:
                 runtime.fallback('GRU2D', 'hidden plane is not a multiple of 4 elements')
             if fusable:
                 z, rh = fused.gru_gates(pre_zr, ctx_zr, h)
                 # the GRU's closing nan_to_num (raft_core.py:138) rides on the second half-step's blend kernel
-                h = fused.gru_blend(conv2d(torch.cat([rh, motion], dim=1), w_q, None, padding=padding), ctx_q, z, h,
-                                    nan_to_num=(suffix == '2'))
+                pre_q = cat_conv_cl([rh, motion], w_q, padding) if cl else conv2d(torch.cat([rh, motion], dim=1), w_q, None, padding=padding)
+                h = fused.gru_blend(pre_q, ctx_q, z, h, nan_to_num=(suffix == '2'))
             else:
                 zr = torch.sigmoid(pre_zr + ctx_zr)
                 z, r = zr[:, :hd], zr[:, hd:]

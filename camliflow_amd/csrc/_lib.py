@@ -27,6 +27,8 @@ PROTOTYPES = {
                                         ctypes.c_void_p, _int, _int, _int, ctypes.c_float, _stream]),
     "camli_allpairs_build_bwd_marked": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                                ctypes.c_void_p, _int, _int, _int, ctypes.c_float, ctypes.c_void_p, _stream]),
+    "camli_transpose_planes": (_int, [_c_float_p, ctypes.c_int64, ctypes.c_int64, _c_float_p, ctypes.c_int64, ctypes.c_int64, _int,
+                                      _int, _int, _stream]),
     "camli_allpairs_build_bwd_workspace_bytes": (ctypes.c_int64, [ctypes.c_void_p, _int, _int, _int, _int]),
     "camli_allpairs_build_bwd_splitk": (_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _c_float_p,
                                                ctypes.c_void_p, _int, _int, _int, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,

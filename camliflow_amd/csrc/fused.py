@@ -1763,6 +1763,39 @@ def _batch_strided(t):
     return bs
 
 
+# ------------------------------------------------------------------------------------------------
+# layout passes around the channels-last convolutions of the update block (cores/blocks.py:_CatConvCL)
+# ------------------------------------------------------------------------------------------------
+def _transpose_planes(src, src_off, src_bs, src_rs, dst, dst_off, dst_bs, dst_rs, b, rows, cols):
+    lib = _lib.load()
+    with _on_device(src):
+        _lib.launch('camli_transpose_planes', lib.camli_transpose_planes, src.data_ptr() + 4 * src_off, src_bs, src_rs,
+                    dst.data_ptr() + 4 * dst_off, dst_bs, dst_rs, b, rows, cols, _stream_ptr(src), work=(8.0 * b * rows * cols, 'B'))
+
+
+def nchw_into_channels_last(part, x_cl, c0):
+    """part [B,C,H,W] (contiguous, or a channel slice of a contiguous map) -> channels c0 .. c0+C of x_cl, a [B,Ct,H,W] tensor
+    in channels_last memory format (memory [B,H,W,Ct])."""
+    _require_cuda('nchw_into_channels_last', part, x_cl)
+    b, c, hh, ww = part.shape
+    ct, p = x_cl.shape[1], hh * ww
+    bs = _batch_strided(part)
+    if bs is None:
+        part = part.float().contiguous()
+        bs = c * p
+    _transpose_planes(part, 0, bs, p, x_cl, c0, p * ct, ct, b, c, p)
+
+
+def channels_last_to_nchw(x_cl, c0, c):
+    """channels c0 .. c0+c of x_cl ([B,Ct,H,W] in channels_last memory format) -> a contiguous [B,c,H,W] tensor."""
+    _require_cuda('channels_last_to_nchw', x_cl)
+    b, ct, hh, ww = x_cl.shape
+    p = hh * ww
+    out = torch.empty((b, c, hh, ww), dtype=torch.float32, device=x_cl.device)
+    _transpose_planes(x_cl, c0, p * ct, ct, out, 0, c * p, p, b, p, c)
+    return out
+
+
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)

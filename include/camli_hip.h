@@ -612,6 +612,17 @@ int camli_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *arg, int pla
 int camli_maxpool3x3s2_bwd(const float *gy, const unsigned char *arg, float *gx, int planes, int H, int W, int Ho, int Wo,
                            void *stream);
 
+/*
+ * Batched 2-D transpose between channel-first and channels-last maps (internal glue of the cores: the update block's wide
+ * convolutions run on channels-last operands, cores/blocks.py; the reference keeps everything NCHW and lets the library
+ * transpose around every call, raft_core.py:112-139).
+ *   dst[b*dst_batch_stride + j*dst_row_stride + i] = src[b*src_batch_stride + i*src_row_stride + j],  i < rows, j < cols
+ *   (strides in floats; a channel slice of a wider channels-last map is a row stride = the wide channel count).
+ *   16-byte accesses when rows, cols, all strides are multiples of 4 and both pointers 16-byte aligned, scalar otherwise.
+ */
+int camli_transpose_planes(const float *src, int64_t src_batch_stride, int64_t src_row_stride, float *dst,
+                           int64_t dst_batch_stride, int64_t dst_row_stride, int B, int rows, int cols, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
