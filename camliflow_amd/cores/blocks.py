@@ -175,6 +175,13 @@ def _is_pointwise(conv):
             and not isinstance(conv.padding, str))
 
 
+# CAMLI_CONV_CL=0: the GRU's half-step convolutions on NCHW tensors like every other one (the library transposes around its
+# NHWC kernels); default: on explicitly channels-last operands (_CatConvCL).  The same treatment of the 3x3 call sites that
+# gain in isolation (conv_c2 -123 us, flow-head / mask-head conv1 -9 .. -90 us fwd+bwd, tools/conv_cl_probe.py) was measured
+# in the step and LOSES there: 221.7 against 215.9 ms (alternating runs on one box), so those stay with the library.
+_CONV_CL = os.environ.get('CAMLI_CONV_CL', '1') != '0'
+
+
 def conv_bias_act(conv, x, act, leave_bias=False):
     """``act(conv(x))`` with the bias add, the activation and (backward) the bias-gradient reduction
     fused into one pass over the convolution output (camli_bias_act_fwd/bwd).  ``leave_bias`` (act None only): return

@@ -9,7 +9,7 @@ import torch.nn as nn
 from torch.nn.functional import avg_pool2d, grid_sample
 
 from . import runtime
-from .blocks import Conv2dNormRelu, cat_conv_cl, conv_bias_act, epilogue_ok
+from .blocks import _CONV_CL, Conv2dNormRelu, cat_conv_cl, conv_bias_act, epilogue_ok
 from .geometry import convex_upsample, mesh_grid
 from .resnet import ResNetTrunk
 
@@ -166,7 +166,7 @@ class GRU2D(nn.Module):
                 continue
             # CAMLI_CONV_CL (default on): the two convolutions of a half step on explicitly channels-last operands
             # (blocks._CatConvCL: the cat writes the channels-last input, kept for the weight gradient)
-            cl = os.environ.get('CAMLI_CONV_CL', '1') == '1' and fusable and runtime.fused() and h.dtype == torch.float32 and motion.dtype == torch.float32 \
+            cl = _CONV_CL and fusable and runtime.fused() and h.dtype == torch.float32 and motion.dtype == torch.float32 \
                 and not torch.is_autocast_enabled()
             pre_zr = cat_conv_cl([h, motion], w_zr, padding) if cl else conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding)
             if not fusable and h.is_cuda:
