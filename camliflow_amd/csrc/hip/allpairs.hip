@@ -70,29 +70,29 @@ __device__ __forceinline__ float4 tile_load_one(const float* __restrict__ base, 
         if (tail && gk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
         return v;
     }
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // CHECK = true: an operand whose rows are not 16-byte addressable (a level of 510 = 17 x 30 pixels, an odd channel
+    // count).  Still no branches: four 4-byte loads at clamped addresses (every address lies inside the operand), k beyond
+    // K reads as zero by a select, m beyond M feeds outputs that are never stored.  (The earlier form tested each element
+    // and branched around its load: the compiler then waits for every load in turn -- 279 us for the 510-pixel level of
+    // the forward build, 0.39 of the matrix rate where the aligned levels run at 0.67.)
+    float4 v;
     if (KC) {
-        if (gm < M) {
-            const float* p = base + (int64_t)gm * ld + gk;
-            if (vec && gk + 3 < K) v = *reinterpret_cast<const float4*>(p);
-            else {
-                if (gk < K) v.x = p[0];
-                if (gk + 1 < K) v.y = p[1];
-                if (gk + 2 < K) v.z = p[2];
-                if (gk + 3 < K) v.w = p[3];
-            }
-        }
+        const float* p = base + (int64_t)min(gm, M - 1) * ld;
+        v.x = p[min(gk, K - 1)];
+        v.y = p[min(gk + 1, K - 1)];
+        v.z = p[min(gk + 2, K - 1)];
+        v.w = p[min(gk + 3, K - 1)];
+        if (gk >= K) v.x = 0.f;
+        if (gk + 1 >= K) v.y = 0.f;
+        if (gk + 2 >= K) v.z = 0.f;
+        if (gk + 3 >= K) v.w = 0.f;
     } else {
-        if (gk < K) {
-            const float* p = base + (int64_t)gk * ld + gm;
-            if (vec && gm + 3 < M) v = *reinterpret_cast<const float4*>(p);
-            else {
-                if (gm < M) v.x = p[0];
-                if (gm + 1 < M) v.y = p[1];
-                if (gm + 2 < M) v.z = p[2];
-                if (gm + 3 < M) v.w = p[3];
-            }
-        }
+        const float* p = base + (int64_t)min(gk, K - 1) * ld;
+        v.x = p[min(gm, M - 1)];
+        v.y = p[min(gm + 1, M - 1)];
+        v.z = p[min(gm + 2, M - 1)];
+        v.w = p[min(gm + 3, M - 1)];
+        if (gk >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return v;
 }
@@ -235,12 +235,13 @@ __device__ __forceinline__ void frag_mfma(f32x16 (&acc)[2][2], const float (&fa0
 __device__ __forceinline__ void lds_dma16(const float* src, float* lds_dst_uniform) {
     __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)lds_dst_uniform, 16, 0, 0);
 }
+template <int NBUF>
 __device__ __forceinline__ void gemm_tile_loop_dma(const float* __restrict__ Ab, const float* __restrict__ Bb, float* lds,
                                                    f32x16 (&acc)[2][2], int M, int N, int K, int64_t lda, int64_t ldb, int m0,
                                                    int n0, int tid, int wm, int wn) {
     constexpr int KS = 16, H = 8, NP = 4, LD = 128;
-    float* const sA = lds;                          // two buffers of [16][128]
-    float* const sB = lds + 2 * KS * LD;
+    float* const sA = lds;                          // NBUF buffers of [16][128]
+    float* const sB = lds + NBUF * KS * LD;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fk = lane >> 5, fm = lane & 31;
     // this lane's source column and first k row; instruction j of a step covers k rows 4 * wave + 2 * j + {0, 1}
@@ -259,10 +260,15 @@ __device__ __forceinline__ void gemm_tile_loop_dma(const float* __restrict__ Ab,
     float pa0[NP], pa1[NP], pb0[NP], pb1[NP];
     float qa0[NP], qa1[NP], qb0[NP], qb1[NP];
     const int steps = K / KS;
+    // NBUF - 1 steps in flight beside the one on the matrix cores (the loads of a wave return in order: "all but the
+    // youngest 4 * (NBUF - 2)" = the next step has landed)
     issue(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+#pragma unroll
+    for (int i = 1; i < NBUF - 1; ++i)
+        if (i < steps) issue(i, i);
+    if (NBUF == 3 && steps > 1) __builtin_amdgcn_s_waitcnt(0x0F74); else __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (steps > 1) issue(1, 1);
+    if (NBUF - 1 < steps) issue(NBUF - 1, NBUF - 1);
     const float* a = sA + fk * LD + wm + fm;
     const float* b = sB + fk * LD + wn + fm;
     frag_read<NP, LD, LD>(a, b, pa0, pa1, pb0, pb1);
@@ -274,10 +280,12 @@ __device__ __forceinline__ void gemm_tile_loop_dma(const float* __restrict__ Ab,
         __builtin_amdgcn_sched_barrier(0);
         frag_mfma<NP>(acc, pa0, pa1, pb0, pb1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);         // tile t + 1 has landed (this wave's share; the barrier covers the rest)
+        // step t + 1 has landed (this wave's share; the barrier covers the rest)
+        if (NBUF == 3 && t + 2 < steps) __builtin_amdgcn_s_waitcnt(0x0F74);      // vmcnt(4): step t + 2 may still fly
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0)
         __syncthreads();
-        if (t + 2 < steps) issue(t + 2, buf);       // the buffer every wave has just finished reading
-        buf ^= 1;
+        if (t + NBUF < steps) issue(t + NBUF, buf);       // the buffer every wave has just finished reading
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
         frag_read<NP, LD, LD>(a + buf * KS * LD, b + buf * KS * LD, pa0, pa1, pb0, pb1);
         __builtin_amdgcn_sched_barrier(0);
         frag_mfma<NP>(acc, qa0, qa1, qb0, qb1);
@@ -383,46 +391,10 @@ __device__ __forceinline__ void gemm_tile_loop_marked(const float* __restrict__ 
     }
 }
 
-// C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
-// grid (ceil(N/128), ceil(M/128), batch), block 256
-// One 128x128 output tile (m0, n0) of one batch entry: Ab / Bb / Cb / mk already point at that entry.
-template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ, int KS = GB_K, bool DMA = false>
-__device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const float* __restrict__ Bb, float* __restrict__ Cb,
-                                           int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, int vec_a,
-                                           int vec_b, const unsigned char* __restrict__ mk, int mark_mode, int mark_tb,
-                                           int mark_src_blocks, int m0, int n0, float* lds, int ks_begin = 0,
-                                           int ks_end = 1 << 24) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // block-uniform: aligned operands take the unchecked loops for every tile (see tile_load_one)
-    const bool fast = vec_a && vec_b && (A_KC ? (K % 4 == 0 && K >= 4) : (M % 4 == 0 && M >= 4)) &&
-                      (B_KC ? (K % 4 == 0 && K >= 4) : (N % 4 == 0 && N >= 4));
-    if (SKIPZ && mk) {
-        if (fast)
-            gemm_tile_loop_marked<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn, mk,
-                                                     mark_mode, mark_tb, mark_src_blocks, ks_begin, ks_end);
-        else
-            gemm_tile_loop_marked<A_KC, B_KC, true>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm,
-                                                    wn, mk, mark_mode, mark_tb, mark_src_blocks, ks_begin, ks_end);
-    } else if (fast) {
-        if constexpr (DMA && !SKIPZ && !A_KC && !B_KC)
-            gemm_tile_loop_dma(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, tid, wm, wn);      // launch_gemm checks K % 16 == 0
-        else
-            gemm_tile_loop<A_KC, B_KC, false, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn,
-                                                         ks_begin * GB_K, min(ks_end, 1 << 24) * GB_K);
-    } else
-        gemm_tile_loop<A_KC, B_KC, true, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn,
-                                                    ks_begin * GB_K, min(ks_end, 1 << 24) * GB_K);
-
+// One wave's 64 x 64 share of a 128 x 128 output tile: C = alpha * acc (+ C when ACC).
+template <bool ACC>
+__device__ __forceinline__ void store_tile(f32x16 (&acc)[2][2], float* __restrict__ Cb, int M, int N, int64_t ldc, float alpha,
+                                           int m0, int n0, int wm, int wn, int lane) {
     const int fk = lane >> 5, fm = lane & 31;
     // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     if (m0 + GB_T <= M && n0 + GB_T <= N) {
@@ -461,6 +433,49 @@ __device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const f
         }
 }
 
+// C[b][m][n] (row-major, ldc)  =  alpha * sum_k A(b; m, k) * B(b; k, n)   (+ C when ACC)
+// grid (ceil(N/128), ceil(M/128), batch), block 256
+// One 128x128 output tile (m0, n0) of one batch entry: Ab / Bb / Cb / mk already point at that entry.
+template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ, int KS = GB_K, int DMA = 0>
+__device__ __forceinline__ void gemm_block(const float* __restrict__ Ab, const float* __restrict__ Bb, float* __restrict__ Cb,
+                                           int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, float alpha, int vec_a,
+                                           int vec_b, const unsigned char* __restrict__ mk, int mark_mode, int mark_tb,
+                                           int mark_src_blocks, int m0, int n0, float* lds, int ks_begin = 0,
+                                           int ks_end = 1 << 24) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // block-uniform: aligned operands take the unchecked loops for every tile (see tile_load_one)
+    const bool fast = vec_a && vec_b && (A_KC ? (K % 4 == 0 && K >= 4) : (M % 4 == 0 && M >= 4)) &&
+                      (B_KC ? (K % 4 == 0 && K >= 4) : (N % 4 == 0 && N >= 4));
+    if (SKIPZ && mk) {
+        if (fast)
+            gemm_tile_loop_marked<A_KC, B_KC, false>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn, mk,
+                                                     mark_mode, mark_tb, mark_src_blocks, ks_begin, ks_end);
+        else
+            gemm_tile_loop_marked<A_KC, B_KC, true>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm,
+                                                    wn, mk, mark_mode, mark_tb, mark_src_blocks, ks_begin, ks_end);
+    } else if (fast) {
+        if constexpr (DMA != 0 && !SKIPZ && !A_KC && !B_KC)
+            gemm_tile_loop_dma<DMA>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, tid, wm, wn);      // launch_gemm checks K % 16 == 0
+        else
+            gemm_tile_loop<A_KC, B_KC, false, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, true, true, tid, wm, wn,
+                                                         ks_begin * GB_K, min(ks_end, 1 << 24) * GB_K);
+    } else
+        gemm_tile_loop<A_KC, B_KC, true, SKIPZ, KS>(Ab, Bb, lds, acc, M, N, K, lda, ldb, m0, n0, vec_a != 0, vec_b != 0, tid, wm, wn,
+                                                    ks_begin * GB_K, min(ks_end, 1 << 24) * GB_K);
+
+    store_tile<ACC>(acc, Cb, M, N, ldc, alpha, m0, n0, wm, wn, lane);
+}
+
 template <bool A_KC, bool B_KC, bool ACC, bool SKIPZ, int KS = GB_K>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                              float* __restrict__ C, int M, int N, int K, int64_t lda,
@@ -475,14 +490,17 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                                        blockIdx.y * GB_T, blockIdx.x * GB_T, lds);
 }
 
-// The forward build's kernel: m-contiguous aligned operands, K % 16 == 0, direct-to-LDS loop (138 registers, 32 KB of
-// LDS: three workgroups per CU; aiming the allocation at four waves per SIMD was measured and is slower).
-template <bool ACC>
+// The forward build's kernel: m-contiguous aligned operands, K % 16 == 0, direct-to-LDS loop (32 KB of LDS, <= 168
+// registers: three workgroups per CU).  Measured on top of it and not kept, all within 0.5 % of it (0.67 of the fp32 MFMA
+// peak; profiles/r04_gemm_epilogue_experiments.txt): a fourth wave per SIMD, three LDS buffers (two steps in flight), a
+// 256 x 128 tile per workgroup (128 x 64 per wave: -25 % operand loads and fragment reads per MFMA), and a persistent form
+// (768 workgroups walking the tiles, K steps of consecutive tiles in one pipeline).
+template <bool ACC, int NBUF = 2>
 __global__ __launch_bounds__(256) void gemm_fwd_dma_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                             float* __restrict__ C, int M, int N, int K, int64_t lda, int64_t ldb,
                                                             int64_t ldc, int64_t sa, int64_t sb, int64_t sc, float alpha) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // 2 x 16 x (128 + 128) floats
-    gemm_block<false, false, ACC, false, 16, true>(A + (int64_t)blockIdx.z * sa, Bm + (int64_t)blockIdx.z * sb,
+    gemm_block<false, false, ACC, false, 16, NBUF>(A + (int64_t)blockIdx.z * sa, Bm + (int64_t)blockIdx.z * sb,
                                                    C + (int64_t)blockIdx.z * sc, M, N, K, lda, ldb, ldc, alpha, 1, 1, nullptr, 0, 0,
                                                    0, blockIdx.y * GB_T, blockIdx.x * GB_T, lds);
 }
