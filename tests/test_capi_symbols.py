@@ -81,3 +81,45 @@ def test_python_boundary_keeps_every_operator_of_the_reference_wrapper():
     import camliflow_amd.csrc as boundary
     for name in ('correlation2d', 'furthest_point_sampling', 'k_nearest_neighbor'):
         assert callable(getattr(boundary, name, None)), name
+
+
+def test_splitk_workspace_size_is_host_arithmetic():
+    """camli_allpairs_build_bwd_workspace_bytes launches nothing: level l of the pyramid adjoint is cut into min(2^l, 8) ranges of
+    K steps of at least 16 steps (32 source pixels each) and every range of a split level holds a [B,C,P_l] partial."""
+    from camliflow_amd.csrc import _lib
+    lib = _lib.load()
+
+    def want(p_levels, b, c, p):
+        steps = (p + 31) // 32
+        total = 0
+        for lvl, pl in enumerate(p_levels):
+            parts = 8 if lvl >= 3 else 1 << lvl
+            while parts > 1 and steps // parts < 16:
+                parts //= 2
+            if parts > 1:
+                total += parts * b * c * pl
+        return 4 * total
+
+    for p_levels, b, c, p in (((8160, 2040, 510, 120), 8, 256, 8160), ((2160, 540, 135, 28), 1, 256, 2160), ((480, 120, 30, 6), 2, 64, 480),
+                              ((100,), 3, 8, 100)):
+        arr = (ctypes.c_int * len(p_levels))(*p_levels)
+        assert int(lib.camli_allpairs_build_bwd_workspace_bytes(arr, len(p_levels), b, c, p)) == want(p_levels, b, c, p)
+    assert int(lib.camli_allpairs_build_bwd_workspace_bytes(None, 4, 8, 256, 8160)) == 0
+
+
+def test_cat_conv_channels_last_node_on_cpu():
+    """blocks._CatConvCL without a GPU (torch copies instead of camli_transpose_planes): conv2d(cat(parts)) and its three
+    gradients, for the GRU's two filter shapes and a part list of one."""
+    from camliflow_amd.cores.blocks import cat_conv_cl
+    g = torch.Generator().manual_seed(0)
+    for ksize, padding, widths in (((1, 5), (0, 2), (8, 6)), ((5, 1), (2, 0), (8, 6)), ((3, 3), (1, 1), (7,))):
+        parts = [torch.randn(2, c, 9, 11, generator=g, requires_grad=True) for c in widths]
+        w = torch.randn(5, sum(widths), *ksize, generator=g, requires_grad=True)
+        gy = torch.randn(2, 5, 9, 11, generator=g)
+        want = torch.nn.functional.conv2d(torch.cat(parts, 1), w, None, padding=padding)
+        want_g = torch.autograd.grad(want, parts + [w], gy)
+        got = cat_conv_cl(parts, w, padding)
+        got_g = torch.autograd.grad(got, parts + [w], gy)
+        assert got.is_contiguous() and torch.allclose(got, want, atol=1e-5)
+        for a, b in zip(got_g, want_g):
+            assert a.shape == b.shape and torch.allclose(a, b, atol=1e-4)
