@@ -19,6 +19,7 @@ so that
 import collections
 import contextlib
 import os
+import weakref
 
 _BACKEND = 'hip'
 
@@ -337,8 +338,9 @@ class Lanes:
             if signature not in _PRIMED:        # first pass of this shape: one lane (see set_overlap)
                 _PRIMED.add(signature)
                 self.enabled = False
-        global _LANES_LIVE
+        global _LANES_LIVE, _LANES_OWNER
         _LANES_LIVE = self.enabled and os.environ.get('CAMLI_BRANCHES', '1') == '1'
+        _LANES_OWNER = weakref.ref(self)    # the flag lives as long as the pass that set it (lanes_live)
         if self.enabled:
             self._torch = torch
             self.main = torch.cuda.current_stream(device)
@@ -365,6 +367,16 @@ class Lanes:
                 t.record_stream(self.main)
 
 _LANES_LIVE = False     # the Lanes of the pass that is being issued are enabled (set by Lanes.__init__)
+_LANES_OWNER = None     # weak reference to the Lanes object that set it
+
+
+def lanes_live():
+    """The auxiliary streams belong to the pass whose ``Lanes`` enabled them: once that object is gone (its forward has
+    returned), a model that builds no Lanes of its own (CamLiPWC, the image-only RAFT, CamLiRAFT-L) does not inherit the
+    flag of an earlier CamLiRAFT pass, even with the overlap left on."""
+    return bool(_LANES_LIVE and (_LANES_OWNER is None or _LANES_OWNER() is not None))
+
+
 _aux_streams = {}
 _BRANCH_MASK = int(os.environ.get('CAMLI_BRANCH_MASK', '15'))      # bit = slot: 1 motion encoder, 2 mask head, 4 CLFM, 8 context encoder
 _BRANCH_SHARE = os.environ.get('CAMLI_BRANCH_SHARE', '0') == '1'   # all slots on ONE auxiliary stream
@@ -397,7 +409,7 @@ class Branch:
         # with the CLFM direction forked in, hipStreamEndCapture itself crashes (SIGSEGV inside torch's capture_end where
         # an un-joinable fork should come back as hipErrorStreamCaptureUnjoined) -- profiles/r04_branch_capture_bisect.txt.
         # So the replayed configurations keep exactly their two lanes.
-        self.enabled = bool(_LANES_LIVE and _OVERLAP and _BACKEND == 'hip' and first is not None and first.is_cuda
+        self.enabled = bool(lanes_live() and _OVERLAP and _BACKEND == 'hip' and first is not None and first.is_cuda
                             and (_BRANCH_MASK >> slot) & 1
                             and (os.environ.get('CAMLI_BRANCH_IN_CAPTURE') == '1' or not torch.cuda.is_current_stream_capturing()))
         if self.enabled:

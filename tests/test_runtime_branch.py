@@ -43,6 +43,29 @@ def test_set_overlap_false_switches_the_auxiliary_streams_off():
         runtime._LANES_LIVE = False
 
 
+def test_auxiliary_streams_do_not_outlive_the_pass_that_enabled_them():
+    """With the overlap left on, the flag set by one pass's Lanes must not reach a later model that builds none: it is tied
+    to the lifetime of the Lanes object (runtime.lanes_live)."""
+    import weakref
+
+    class Pass:
+        pass
+
+    saved = runtime._LANES_LIVE, runtime._LANES_OWNER
+    try:
+        owner = Pass()
+        runtime._LANES_LIVE, runtime._LANES_OWNER = True, weakref.ref(owner)
+        assert runtime.lanes_live()
+        del owner
+        assert not runtime.lanes_live()
+        runtime._LANES_LIVE, runtime._LANES_OWNER = False, None
+        assert not runtime.lanes_live()
+        lanes = runtime.Lanes(torch.device('cpu'))      # a real Lanes registers itself (disabled off the GPU)
+        assert runtime._LANES_OWNER() is lanes and not runtime.lanes_live()
+    finally:
+        runtime._LANES_LIVE, runtime._LANES_OWNER = saved
+
+
 def test_upsampler_begin_finish_equal_forward_on_cpu():
     """begin() yields no handle off the fused path; finish(None, h, flow) is forward(h, flow)."""
     from camliflow_amd.cores.raft2d import ConvexUpsampler2D
