@@ -24,6 +24,7 @@
 // (global_load_lds_dwordx4, no staging registers, two tiles in flight), see gemm_tile_loop_dma.  Edge tiles of aligned
 // operands run the same unchecked loops as interior ones (clamped addresses, tile_load_one).
 #include "camli_common.h"
+#include "gemm_w128.h"
 #include <stdlib.h>
 
 namespace {
@@ -569,6 +570,43 @@ int gf2_parts(int level, int steps) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// The persistent 256 x 256-tile kernel of gemm_w128.h.  Returns false (nothing launched) when the shape is outside its range:
+// operands must be 16-byte addressable row by row (direct-to-LDS loads of 4 floats), K a multiple of 16 with at least three
+// steps (the pipeline's depth), the output slab of one batch entry below 2 GB (32-bit offsets behind a buffer descriptor), and
+// N wide enough that a 256-column tile is not mostly padding.  CAMLI_GEMM_W128=0 keeps every GEMM on the older kernels (A/B).
+bool launch_w128(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                 int64_t sa, int64_t sb, int64_t sc, int batch, float alpha, bool vec, hipStream_t stream) {
+    constexpr int KS = 16, NBUF = 3;
+    static const bool enabled = []() { const char* e = getenv("CAMLI_GEMM_W128"); return !e || atoi(e) != 0; }();
+    if (!enabled || !vec || M % 4 || N % 4 || M < 4 || N < 192 || K % KS || K < NBUF * KS) return false;
+    if (ldc % 4 || sc % 4 || !aligned16(C) || (int64_t)(M + 256) * ldc * 4 >= (int64_t)0x7FF00000) return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        cus = n >= 8 ? n / 8 * 8 : 8;
+    }
+    constexpr size_t lds = (size_t)NBUF * KS * 512 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&w128::gemm_w128_kernel<KS, NBUF, 0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return false;
+        attr_set = true;
+    }
+    w128::Problem p;
+    p.A = A; p.B = Bm; p.C = C; p.M = M; p.N = N; p.K = K;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.sa = sa; p.sb = sb; p.sc = sc;
+    p.alpha = alpha;
+    p.tiles_m = camli_divup(M, w128::MT);
+    p.tiles_n = camli_divup(N, w128::MT);
+    const int64_t tiles = (int64_t)batch * p.tiles_m * p.tiles_n;
+    if (tiles >= (int64_t)1 << 30) return false;
+    p.tiles = (int)tiles;
+    hipLaunchKernelGGL((w128::gemm_w128_kernel<KS, NBUF, 0>), dim3(cus), dim3(256), lds, stream, p);
+    return true;
+}
+
 template <bool A_KC, bool B_KC, bool SKIPZ>
 void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                  int64_t sa, int64_t sb, int64_t sc, int batch, float alpha, bool accumulate, hipStream_t stream,
@@ -585,6 +623,9 @@ void launch_gemm(const float* A, const float* Bm, float* C, int M, int N, int K,
         static const bool ks32 = []() { const char* e = getenv("CAMLI_GEMM_KS"); return e && atoi(e) == 32; }();
         static const bool dma = []() { const char* e = getenv("CAMLI_GEMM_DMA"); return !e || atoi(e) != 0; }();
         if constexpr (!A_KC && !B_KC) {
+            // r5: the 128 x 128-per-wave persistent kernel (gemm_w128.h; 0.85 of the fp32 MFMA peak on the level-0 build where
+            // the 128 x 128-per-workgroup kernel below reaches 0.67) for every level wide enough to fill its 256-column tiles
+            if (!accumulate && launch_w128(A, Bm, C, M, N, K, lda, ldb, ldc, sa, sb, sc, batch, alpha, vec_a && vec_b, stream)) return;
             constexpr size_t ldsd = (size_t)2 * 16 * (128 + 128) * sizeof(float);
             if (dma && K % 16 == 0 && vec_a && vec_b && M % 4 == 0 && N % 4 == 0 && M >= 4 && N >= 4) {
                 if (accumulate)
