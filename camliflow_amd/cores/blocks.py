@@ -180,6 +180,7 @@ def _is_pointwise(conv):
 # gain in isolation (conv_c2 -123 us, flow-head / mask-head conv1 -9 .. -90 us fwd+bwd, tools/conv_cl_probe.py) was measured
 # in the step and LOSES there: 221.7 against 215.9 ms (alternating runs on one box), so those stay with the library.
 _CONV_CL = os.environ.get('CAMLI_CONV_CL', '1') != '0'
+_CONVCL = os.environ.get('CAMLI_CONVCL', '1') != '0'
 
 
 def conv_bias_act(conv, x, act, leave_bias=False):
@@ -218,20 +219,31 @@ class _CatConvCL(torch.autograd.Function):
         b, _, hh, ww = parts[0].shape
         widths = [p.shape[1] for p in parts]
         hip = runtime.fused() and w.is_cuda
+        if hip:
+            from ..csrc import fused
         x_cl = torch.empty((b, sum(widths), hh, ww), dtype=w.dtype, device=w.device, memory_format=torch.channels_last)
         c0 = 0
         for p, c in zip(parts, widths):
             if hip:
-                from ..csrc import fused
                 fused.nchw_into_channels_last(p, x_cl, c0)
             else:
                 x_cl[:, c0:c0 + c].copy_(p)
             c0 += c
-        w_cl = w.contiguous(memory_format=torch.channels_last)
         ctx.conv_args = ([1, 1], list(padding), [1, 1], False, [0, 0], 1)
+        ctx.widths, ctx.hip = widths, hip
+        # r5: the contraction itself on this repo's channels-last kernels (csrc/hip/convcl.hip: forward 0.76-0.80 of the fp32
+        # MFMA peak where the library's NHWC implicit GEMM runs at 0.66-0.70; both adjoints); CAMLI_CONVCL=0 -> the library
+        ctx.own = (hip and _CONVCL and w.dtype == torch.float32 and fused.convcl_supported(w.shape[1], w.shape[0])
+                   and w.shape[2] * w.shape[3] <= 32)
+        if ctx.own:
+            wp, ctx.wpt = fused.convcl_pack(w)
+            ctx.taps = (w.shape[2], w.shape[3], padding[0], padding[1])
+            y = fused.convcl([x_cl.permute(0, 2, 3, 1)], wp, fused.convcl_taps(*ctx.taps))
+            ctx.save_for_backward(x_cl, w)
+            return fused.channels_last_to_nchw(y.permute(0, 3, 1, 2), 0, y.shape[3])
+        w_cl = w.contiguous(memory_format=torch.channels_last)
         y_cl = torch.ops.aten.convolution(x_cl, w_cl, None, *ctx.conv_args)
         ctx.save_for_backward(x_cl, w_cl)
-        ctx.widths, ctx.hip = widths, hip
         if hip:
             return fused.channels_last_to_nchw(y_cl, 0, y_cl.shape[1])
         return y_cl.contiguous()
@@ -246,8 +258,16 @@ class _CatConvCL(torch.autograd.Function):
         else:
             gy_cl = gy.contiguous(memory_format=torch.channels_last)
         need_x = any(ctx.needs_input_grad[2:])
-        gx_cl, gw_cl, _ = torch.ops.aten.convolution_backward(gy_cl, x_cl, w_cl, None, *ctx.conv_args,
-                                                              [need_x, ctx.needs_input_grad[0], False])
+        if ctx.own:
+            gy_n, x_n = gy_cl.permute(0, 2, 3, 1), x_cl.permute(0, 2, 3, 1)
+            gx_cl = gw_cl = None
+            if need_x:
+                gx_cl = fused.convcl([gy_n], ctx.wpt, fused.convcl_taps(*ctx.taps, negate=True)).permute(0, 3, 1, 2)
+            if ctx.needs_input_grad[0]:
+                gw_cl = fused.convcl_wrw([x_n], gy_n, fused.convcl_taps(*ctx.taps), ctx.taps[:2])
+        else:
+            gx_cl, gw_cl, _ = torch.ops.aten.convolution_backward(gy_cl, x_cl, w_cl, None, *ctx.conv_args,
+                                                                  [need_x, ctx.needs_input_grad[0], False])
         gparts, c0 = [], 0
         for i, c in enumerate(ctx.widths):
             if not ctx.needs_input_grad[2 + i]:

@@ -1790,10 +1790,124 @@ def channels_last_to_nchw(x_cl, c0, c):
     """channels c0 .. c0+c of x_cl ([B,Ct,H,W] in channels_last memory format) -> a contiguous [B,c,H,W] tensor."""
     _require_cuda('channels_last_to_nchw', x_cl)
     b, ct, hh, ww = x_cl.shape
+    if not (x_cl.stride(1) == 1 and x_cl.stride(3) == ct and x_cl.stride(2) == ww * ct and (b == 1 or x_cl.stride(0) == hh * ww * ct)):
+        # a library build that answered a channels-last convolution with an NCHW tensor (ADVICE r4): reading it as
+        # [B,H,W,C] memory would scramble it silently
+        x_cl = x_cl.contiguous(memory_format=torch.channels_last)
+        if x_cl.stride(1) != 1:         # (size-1 dimensions make the format ambiguous: force the physical layout)
+            x_cl = x_cl.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     p = hh * ww
     out = torch.empty((b, c, hh, ww), dtype=torch.float32, device=x_cl.device)
     _transpose_planes(x_cl, c0, p * ct, ct, out, 0, c * p, p, b, p, c)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# channels-last tap convolution on the fp32 matrix cores (csrc/hip/convcl.hip, round 5): forward, data gradient (the same
+# kernel on the negated taps and the transposed packing) and weight gradient of a stride-1 convolution whose operands are
+# NHWC tensors.  GRU2D's 1x5 / 5x1 convolutions (models/raft_core.py:110-140) run on it in training (cores/blocks._CatConvCL).
+# ------------------------------------------------------------------------------------------------
+def convcl_taps(kh, kw, ph, pw, negate=False):
+    """(T, dy bytes, dx bytes) of a kh x kw kernel with padding (ph, pw), taps in row-major order (the order of the weight
+    tensor's last two dimensions); ``negate``: the taps of the data gradient."""
+    import struct
+    sign = -1 if negate else 1
+    dy = [sign * (ky - ph) for ky in range(kh) for _ in range(kw)]
+    dx = [sign * (kx - pw) for _ in range(kh) for kx in range(kw)]
+    return kh * kw, struct.pack('%db' % len(dy), *dy), struct.pack('%db' % len(dx), *dx)
+
+
+def convcl_pack(w):
+    """[Cout, Cin, kh, kw] -> [Cout][T][Cin] (forward) and [Cin][T][Cout] (data gradient); cached on the tensor for as long
+    as its version stands (GRU2D's weight blocks are cut once per pass)."""
+    cached = getattr(w, '_camli_convcl_packs', None)
+    if cached is not None and cached[0] == w._version:
+        return cached[1], cached[2]
+    with torch.no_grad():
+        wd = w.detach().float()
+        co, ci, kh, kw = wd.shape
+        fwd = wd.permute(0, 2, 3, 1).reshape(co, kh * kw, ci).contiguous()
+        bwd = wd.permute(1, 2, 3, 0).reshape(ci, kh * kw, co).contiguous()
+    try:
+        w._camli_convcl_packs = (w._version, fwd, bwd)
+    except Exception:       # noqa: BLE001 -- a tensor subclass that refuses attributes: pack again next time
+        pass
+    return fwd, bwd
+
+
+def _nhwc_ld(t):
+    """floats per pixel of a [B,H,W,C] tensor whose pixels are rows of one dense [P, ld] matrix (channel slices allowed);
+    None when it is not one.  (The strides of size-1 dimensions carry no information and are not looked at.)"""
+    b, hh, ww, c = t.shape
+    ld = t.stride(2) if ww > 1 else (t.stride(1) if hh > 1 else (t.stride(0) if b > 1 else c))
+    ok = ((c == 1 or t.stride(3) == 1) and ld >= c and (hh == 1 or t.stride(1) == ww * ld)
+          and (b == 1 or t.stride(0) == hh * ww * ld))
+    return ld if ok and ld % 4 == 0 and t.data_ptr() % 16 == 0 else None
+
+
+def convcl_supported(cin, cout, parts=1):
+    return cin % 16 == 0 and cin % 256 == 0 and cout % 128 == 0 and cout >= 128 and parts <= 2
+
+
+def convcl(xs, wp, taps, split=None):
+    """y[p][n] = sum_t sum_c cat(xs)[p + tap_t][c] * wp[n][t][c].  xs: one or two fp32 NHWC tensors [B,H,W,Ci] (channel slices of
+    wider NHWC tensors allowed); wp [Cout][T][Cin]; taps from convcl_taps.  Returns [B,H,W,Cout], or with ``split`` = N0 the pair
+    ([B,H,W,N0], [B,H,W,Cout-N0])."""
+    _require_cuda('convcl', wp, *xs)
+    lib = _lib.load()
+    t, dy, dx = taps
+    x0 = xs[0]
+    x1 = xs[1] if len(xs) > 1 else None
+    b, hh, ww, c0 = x0.shape
+    c1 = x1.shape[3] if x1 is not None else 0
+    cout = wp.shape[0]
+    assert wp.shape == (cout, t, c0 + c1) and wp.is_contiguous() and wp.dtype == torch.float32
+    ld0, ld1 = _nhwc_ld(x0), (_nhwc_ld(x1) if x1 is not None else 0)
+    if ld0 is None or ld1 is None:
+        raise _lib.CamliHipError('convcl: inputs must be dense fp32 NHWC tensors (16-byte aligned, pixel stride a multiple of 4)')
+    n0 = cout if split is None else int(split)
+    y0 = torch.empty((b, hh, ww, n0), dtype=torch.float32, device=x0.device)
+    y1 = torch.empty((b, hh, ww, cout - n0), dtype=torch.float32, device=x0.device) if n0 < cout else None
+    with _on_device(x0):
+        _lib.launch('camli_convcl_fwd', lib.camli_convcl_fwd, x0.data_ptr(), ld0, c0, x1.data_ptr() if x1 is not None else 0, ld1, c1,
+                    wp.data_ptr(), y0.data_ptr(), n0, n0, y1.data_ptr() if y1 is not None else 0, cout - n0, b, hh, ww, cout, t, dy, dx,
+                    _stream_ptr(x0), work=(4.0 * b * hh * ww * (c0 + c1 + cout), 'B'), flop=2.0 * b * hh * ww * cout * (c0 + c1) * t)
+    return y0 if y1 is None else (y0, y1)
+
+
+_convcl_workspaces = {}
+
+
+def convcl_wrw(xs, gy, taps, kernel_hw, out=None):
+    """Weight gradient [Cout, Cin, kh, kw] of ``convcl(xs, pack(w), taps)`` for the output gradient gy [B,H,W,Cout] (NHWC);
+    ``out``: add into this tensor instead of creating one."""
+    _require_cuda('convcl_wrw', gy, *xs)
+    lib = _lib.load()
+    t, dy, dx = taps
+    x0 = xs[0]
+    x1 = xs[1] if len(xs) > 1 else None
+    b, hh, ww, c0 = x0.shape
+    c1 = x1.shape[3] if x1 is not None else 0
+    cout = gy.shape[3]
+    ld0, ld1, ldg = _nhwc_ld(x0), (_nhwc_ld(x1) if x1 is not None else 0), _nhwc_ld(gy)
+    if ld0 is None or ld1 is None or ldg is None:
+        raise _lib.CamliHipError('convcl_wrw: operands must be dense fp32 NHWC tensors (16-byte aligned, pixel stride a multiple of 4)')
+    need = lib.camli_convcl_wrw_workspace_bytes(b, hh, ww, c0 + c1, cout, t)
+    if need <= 0:
+        raise _lib.CamliHipError('convcl_wrw: unsupported shape Cin=%d Cout=%d' % (c0 + c1, cout))
+    # one workspace per (device, stream): the parts of a launch are consumed by the reduction of the same launch
+    key = (gy.device, torch.cuda.current_stream(gy.device).cuda_stream)
+    ws = _convcl_workspaces.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _convcl_workspaces[key] = torch.empty(need // 4, dtype=torch.float32, device=gy.device)
+    accumulate = out is not None
+    gw = out if accumulate else torch.empty((cout, c0 + c1) + tuple(kernel_hw), dtype=torch.float32, device=gy.device)
+    assert gw.is_contiguous() and gw.shape == (cout, c0 + c1) + tuple(kernel_hw) and kernel_hw[0] * kernel_hw[1] == t
+    with _on_device(gy):
+        _lib.launch('camli_convcl_wrw', lib.camli_convcl_wrw, x0.data_ptr(), ld0, c0, x1.data_ptr() if x1 is not None else 0, ld1, c1,
+                    gy.data_ptr(), ldg, ws.data_ptr(), ws.numel() * 4, gw.data_ptr(), int(accumulate), b, hh, ww, cout, t, dy, dx,
+                    _stream_ptr(gy), work=(4.0 * b * hh * ww * (c0 + c1 + cout), 'B'), flop=2.0 * b * hh * ww * cout * (c0 + c1) * t)
+    return gw
 
 
 class _BiasAct(torch.autograd.Function):

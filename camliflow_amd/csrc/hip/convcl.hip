@@ -1,0 +1,186 @@
+// C-ABI of the channels-last tap convolution on the fp32 matrix cores (convcl.h, wrwcl.h): forward / data gradient
+// (one kernel: the data gradient is the convolution with the negated taps on the transposed packing) and weight gradient.
+// Replaces, for GRU2D's 1x5 / 5x1 convolutions (models/raft_core.py:110-140), the library's NHWC implicit-GEMM kernels and
+// the layout transposes it wraps around them.
+#include "camli_common.h"
+#include "wrwcl.h"
+#include <stdlib.h>
+
+namespace {
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        cus = n > 0 ? n : 256;
+    }
+    return cus;
+}
+
+// 1 KB of zeros per device: the source of padded rows in the weight-gradient kernel
+const float* zero_page() {
+    static float* pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        float* q = nullptr;
+        if (hipMalloc(&q, 1024) != hipSuccess) return nullptr;
+        if (hipMemset(q, 0, 1024) != hipSuccess) { (void)hipFree(q); return nullptr; }
+        pages[dev] = q;
+    }
+    return pages[dev];
+}
+
+int taps_ok(const char* what, int T, const signed char* dy, const signed char* dx) {
+    if (T < 1 || T > ccl::MAX_TAPS || !dy || !dx) { camli_set_error("%s: 1 <= T <= %d taps with offset arrays", what, ccl::MAX_TAPS); return 0; }
+    return 1;
+}
+
+constexpr int NBUF = 3;
+
+template <int NTW>
+int launch_conv(const ccl::Problem& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)NBUF * (256 + 32 * NTW) * 16 * sizeof(float);
+    static bool set = false;
+    if (!set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl::convcl_kernel<NTW, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            camli_set_error("camli_convcl_fwd: cannot reserve %zu bytes of LDS", lds);
+            return CAMLI_ELAUNCH;
+        }
+        set = true;
+    }
+    const int tiles = p.tiles_p * p.tiles_n;
+    const int cus = cu_count();
+    hipLaunchKernelGGL((ccl::convcl_kernel<NTW, NBUF>), dim3(tiles < cus ? tiles : cus), dim3(256), lds, s, p);
+    return CAMLI_OK;
+}
+
+template <int TBN>
+int launch_wrw(const wrw::Problem& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)NBUF * 16 * (256 + 32 * TBN) * sizeof(float);
+    static bool set = false;
+    if (!set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw::wrw_kernel<TBN, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            camli_set_error("camli_convcl_wrw: cannot reserve %zu bytes of LDS", lds);
+            return CAMLI_ELAUNCH;
+        }
+        set = true;
+    }
+    hipLaunchKernelGGL((wrw::wrw_kernel<TBN, NBUF>), dim3(p.S * p.T * p.tiles_m * p.tiles_n), dim3(256), lds, s, p);
+    return CAMLI_OK;
+}
+
+// parts of the pixel range: one workgroup per (part, tap, tile), about one per CU; a part is a multiple of 16 pixels
+void wrw_split(int P, int T, int tiles, int& S, int& ksplit) {
+    int s = cu_count() / (T * tiles);
+    if (s < 1) s = 1;
+    ksplit = ((P + s - 1) / s + 15) / 16 * 16;
+    if (ksplit < 48) ksplit = 48;           // at least the pipeline's depth
+    S = (P + ksplit - 1) / ksplit;
+}
+
+}  // namespace
+
+extern "C" int camli_convcl_fwd(const float* x0, int ldx0, int C0, const float* x1, int ldx1, int C1, const float* wp, float* y0,
+                                int ldy0, int N0, float* y1, int ldy1, int B, int H, int W, int Cout, int T, const signed char* dy,
+                                const signed char* dx, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_convcl_fwd";
+    if (!x0 || !wp || !y0 || (C1 > 0 && !x1) || (N0 < Cout && !y1)) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    if (!taps_ok(what, T, dy, dx)) return CAMLI_EINVAL;
+    const int Cin = C0 + C1;
+    const int64_t P = (int64_t)B * H * W;
+    const int NT = Cout % 256 == 0 ? 256 : 128;
+    if (B < 0 || H < 1 || W < 1 || C0 < 16 || C0 % 16 || C1 < 0 || C1 % 16 || Cout < 128 || Cout % 128 || N0 < 1 || N0 > Cout ||
+        N0 % (NT / 2) || ldx0 < C0 || ldx0 % 4 || (C1 > 0 && (ldx1 < C1 || ldx1 % 4)) || ldy0 < N0 || ldy0 % 4 ||
+        (N0 < Cout && (ldy1 < Cout - N0 || ldy1 % 4))) {
+        camli_set_error("%s: unsupported shape B=%d %dx%d C0=%d C1=%d Cout=%d N0=%d ld %d %d %d %d (channels in multiples of 16 in, 128 out; "
+                        "an output split on a multiple of %d)", what, B, H, W, C0, C1, Cout, N0, ldx0, ldx1, ldy0, ldy1, NT / 2);
+        return CAMLI_ENOTSUP;
+    }
+    const int64_t lim = (int64_t)0x7FF00000;
+    if (P * ldx0 * 4 >= lim || P * (int64_t)(C1 > 0 ? ldx1 : 0) * 4 >= lim || P * ldy0 * 4 >= lim || P * (int64_t)(N0 < Cout ? ldy1 : 0) * 4 >= lim ||
+        (int64_t)Cout * T * Cin * 4 >= lim || (int64_t)Cin / 16 * T < NBUF - 1) {
+        camli_set_error("%s: tensor beyond 2 GB (32-bit offsets behind buffer descriptors) or fewer than %d K steps", what, NBUF - 1);
+        return CAMLI_ENOTSUP;
+    }
+    if (!aligned16(x0) || !aligned16(x1) || !aligned16(wp) || !aligned16(y0) || !aligned16(y1)) {
+        camli_set_error("%s: pointers must be 16-byte aligned", what);
+        return CAMLI_EINVAL;
+    }
+    ccl::Problem p;
+    p.x = x0; p.x1 = C1 > 0 ? x1 : x0; p.w = wp; p.y = y0; p.y1 = N0 < Cout ? y1 : y0;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.T = T; p.C0 = C0; p.N0 = N0;
+    p.ldx = ldx0; p.ldx1 = C1 > 0 ? ldx1 : ldx0; p.ldy = ldy0; p.ldy1 = N0 < Cout ? ldy1 : ldy0;
+    p.tiles_p = (int)((P + 255) / 256); p.tiles_n = Cout / NT;
+    for (int t = 0; t < T; ++t) {
+        if (dy[t] <= -H || dy[t] >= H || dx[t] <= -W || dx[t] >= W) { camli_set_error("%s: tap %d (%d, %d) beyond the image", what, t, dy[t], dx[t]); return CAMLI_EINVAL; }
+        p.dy[t] = dy[t]; p.dx[t] = dx[t];
+    }
+    for (int t = T; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rc = NT == 256 ? launch_conv<8>(p, s) : launch_conv<4>(p, s);
+    if (rc != CAMLI_OK) return rc;
+    return camli_check_launch(what);
+}
+
+extern "C" int64_t camli_convcl_wrw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int T) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 256 || Cin % 256 || Cout < 128 || Cout % 128 || T < 1 || T > ccl::MAX_TAPS) return 0;
+    const int NB = Cout % 256 == 0 ? 256 : 128;
+    int S, ksplit;
+    wrw_split(B * H * W, T, (Cin / 256) * (Cout / NB), S, ksplit);
+    return (int64_t)S * T * Cin * Cout * (int64_t)sizeof(float);
+}
+
+// gw [Cout][Cin][T] (the framework's [Cout, Cin, kh, kw] with the taps in row-major order) = or += the weight gradient
+extern "C" int camli_convcl_wrw(const float* x0, int ldx0, int C0, const float* x1, int ldx1, int C1, const float* gy, int ldg,
+                                float* workspace, int64_t workspace_bytes, float* gw, int accumulate, int B, int H, int W, int Cout,
+                                int T, const signed char* dy, const signed char* dx, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_convcl_wrw";
+    if (!x0 || !gy || !workspace || !gw || (C1 > 0 && !x1)) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    if (!taps_ok(what, T, dy, dx)) return CAMLI_EINVAL;
+    const int Cin = C0 + C1;
+    const int64_t P = (int64_t)B * H * W;
+    if (B < 0 || H < 1 || W < 1 || C0 < 4 || C0 % 4 || C1 < 0 || C1 % 4 || Cin % 256 || Cout < 128 || Cout % 128 || ldx0 < C0 || ldx0 % 4 ||
+        (C1 > 0 && (ldx1 < C1 || ldx1 % 4)) || ldg < Cout || ldg % 4 || P * (int64_t)ldg * 4 >= (int64_t)0x7FF00000 || P >= ((int64_t)1 << 30)) {
+        camli_set_error("%s: unsupported shape B=%d %dx%d C0=%d C1=%d Cout=%d ld %d %d %d (input channels in multiples of 256, output of 128)",
+                        what, B, H, W, C0, C1, Cout, ldx0, ldx1, ldg);
+        return CAMLI_ENOTSUP;
+    }
+    if (!aligned16(x0) || !aligned16(x1) || !aligned16(gy) || !aligned16(workspace) || !aligned16(gw)) {
+        camli_set_error("%s: pointers must be 16-byte aligned", what);
+        return CAMLI_EINVAL;
+    }
+    const int NB = Cout % 256 == 0 ? 256 : 128;
+    wrw::Problem p;
+    p.x = x0; p.x1 = C1 > 0 ? x1 : x0; p.gy = gy; p.part = workspace;
+    p.zero = zero_page();
+    if (!p.zero) { camli_set_error("%s: cannot allocate the zero page", what); return CAMLI_ELAUNCH; }
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.T = T; p.C0 = C0;
+    p.ldx = ldx0; p.ldx1 = C1 > 0 ? ldx1 : ldx0; p.ldg = ldg;
+    p.tiles_m = Cin / 256; p.tiles_n = Cout / NB;
+    wrw_split((int)P, T, p.tiles_m * p.tiles_n, p.S, p.ksplit);
+    if (workspace_bytes < (int64_t)p.S * T * Cin * Cout * (int64_t)sizeof(float)) {
+        camli_set_error("%s: workspace of %lld bytes, need %lld (camli_convcl_wrw_workspace_bytes)", what, (long long)workspace_bytes,
+                        (long long)((int64_t)p.S * T * Cin * Cout * 4));
+        return CAMLI_EINVAL;
+    }
+    for (int t = 0; t < T; ++t) {
+        if (dy[t] <= -H || dy[t] >= H || dx[t] <= -W || dx[t] >= W) { camli_set_error("%s: tap %d (%d, %d) beyond the image", what, t, dy[t], dx[t]); return CAMLI_EINVAL; }
+        p.dy[t] = dy[t]; p.dx[t] = dx[t];
+    }
+    for (int t = T; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rc = NB == 256 ? launch_wrw<8>(p, s) : launch_wrw<4>(p, s);
+    if (rc != CAMLI_OK) return rc;
+    const size_t n_el = (size_t)T * Cin * Cout;
+    hipLaunchKernelGGL(wrw::wrw_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, workspace, gw, p.S, T, Cin, Cout,
+                       accumulate ? 1 : 0);
+    return camli_check_launch(what);
+}

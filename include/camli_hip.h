@@ -596,6 +596,30 @@ int camli_conv3x3_co2_fwd(const float *x, const float *w, const float *bias, flo
 int camli_conv5_fwd(const float *in0, int C0, const float *in1, int C1, const float *wp, const float *bias,
                     const float *add, const float *h, const float *z, float *out, float *out2, float *out3, int B, int Cout,
                     int H, int W, int vertical, int epi, int nan_to_num, void *stream);
+/*
+ * Channels-last ("tap") convolution on the fp32 matrix cores (round 5, csrc/hip/convcl.h, wrwcl.h): GRU2D's 1x5 / 5x1
+ * convolutions (models/raft_core.py:110-140: nn.Conv2d(hidden + input, hidden, (1, 5) | (5, 1), padding (0, 2) | (2, 0))) with both
+ * adjoints, replacing the library's NHWC implicit-GEMM kernels and their layout transposes.  All tensors fp32 NHWC:
+ *     y[p][n] = sum_t sum_c x[p + (dy[t], dx[t])][c] * wp[n][t][c]          p = (b, y, x); zero outside the image; stride 1
+ * The input is cat[x0 (C0 channels, ldx0 floats per pixel), x1 (C1 channels; NULL / 0: none)], the output channels [0, N0) go to
+ * y0 (ldy0 floats per pixel) and [N0, Cout) to y1 (N0 = Cout: one output).  wp = the weights packed [Cout][T][C0 + C1]
+ * (from [Cout, Cin, kh, kw]: permute(0, 2, 3, 1), taps in row-major order, dy = ky - pad_h, dx = kx - pad_w).  The DATA GRADIENT
+ * is the same call on gy with the negated taps and wp' = [Cin][T][Cout] (permute(1, 2, 3, 0)).  C0, C1 multiples of 16, Cout of
+ * 128, every tensor below 2 GB.  dy / dx are HOST arrays of T <= 32 entries.
+ */
+int camli_convcl_fwd(const float *x0, int ldx0, int C0, const float *x1, int ldx1, int C1, const float *wp, float *y0, int ldy0,
+                     int N0, float *y1, int ldy1, int B, int H, int W, int Cout, int T, const signed char *dy, const signed char *dx,
+                     void *stream);
+/*
+ * Weight gradient of the same convolution: gw [Cout][C0 + C1][T] (= the [Cout, Cin, kh, kw] weight tensor) = or += (accumulate)
+ *     sum_p gy[p][n] * x[p + (dy[t], dx[t])][c]
+ * gy NHWC [P][ldg].  Split over the pixels into about one workgroup per CU, parts in `workspace`
+ * (camli_convcl_wrw_workspace_bytes), added in a fixed order: deterministic, no atomics.  C0 + C1 a multiple of 256, Cout of 128.
+ */
+int64_t camli_convcl_wrw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int T);
+int camli_convcl_wrw(const float *x0, int ldx0, int C0, const float *x1, int ldx1, int C1, const float *gy, int ldg, float *workspace,
+                     int64_t workspace_bytes, float *gw, int accumulate, int B, int H, int W, int Cout, int T, const signed char *dy,
+                     const signed char *dx, void *stream);
 int camli_conv3x3_co2_bwd_data(const float *gy, const float *w, float *gx, int B, int Cin, int H, int W, void *stream);
 long long camli_conv3x3_co2_bwd_weight_workspace_bytes(int B, int Cin, int W);
 int camli_conv3x3_co2_bwd_weight(const float *gy, const float *x, float *workspace, float *gw, float *gb, int accumulate,

@@ -106,6 +106,42 @@ def conv5_fwd(x, w, bias=None):
     return out.astype(np.float32)
 
 
+# ---- any stride-1 convolution with zero padding, as nn.Conv2d computes it (cross-correlation) -- models/raft_core.py:110-197 ----
+# (GRU2D's 1x5 / 5x1, MotionEncoder2D's 1x1 / 3x3 / 7x7, the flow and mask heads' 3x3): forward and both adjoints, the
+# oracle of camli_convcl_fwd / camli_convcl_wrw.  Pinned on torch's own conv2d in fp64 (tests/test_dense_oracle.py).
+
+def conv_taps_fwd(x, w, padding):
+    """x [B,Ci,H,W], w [Co,Ci,kh,kw], padding (ph, pw), stride 1 -> [B,Co,H+2ph-kh+1,W+2pw-kw+1]."""
+    x, w = _f64(x, w)
+    ph, pw = padding
+    kh, kw = w.shape[2:]
+    b, ci, hh, ww = x.shape
+    ho, wo = hh + 2 * ph - kh + 1, ww + 2 * pw - kw + 1
+    xp = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
+    out = np.zeros((b, w.shape[0], ho, wo))
+    for ky in range(kh):
+        for kx in range(kw):
+            out += np.einsum('oc,bchw->bohw', w[:, :, ky, kx], xp[:, :, ky:ky + ho, kx:kx + wo])
+    return out.astype(np.float32)
+
+
+def conv_taps_bwd(gy, x, w, padding):
+    """adjoint of conv_taps_fwd: (d/d x, d/d w)."""
+    gy, x, w = _f64(gy, x, w)
+    ph, pw = padding
+    kh, kw = w.shape[2:]
+    ho, wo = gy.shape[2:]
+    xp = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
+    gxp = np.zeros_like(xp)
+    gw = np.zeros_like(w)
+    for ky in range(kh):
+        for kx in range(kw):
+            gw[:, :, ky, kx] = np.einsum('bohw,bchw->oc', gy, xp[:, :, ky:ky + ho, kx:kx + wo])
+            gxp[:, :, ky:ky + ho, kx:kx + wo] += np.einsum('oc,bohw->bchw', w[:, :, ky, kx], gy)
+    hh, ww = x.shape[2:]
+    return gxp[:, :, ph:ph + hh, pw:pw + ww].astype(np.float32), gw.astype(np.float32)
+
+
 # ---- all-pairs volume pyramid, models/raft_core.py:52-68 (after fnet_aligner) -----------------------------------------
 # cost_volume = f1^T f2 / sqrt(C) as [B*P, 1, h, w]; then avg_pool2d(2, stride 2) over the TARGET dims, num_levels - 1
 # times (floor: an odd trailing row / column is dropped).

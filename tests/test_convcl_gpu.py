@@ -1,0 +1,121 @@
+"""Channels-last tap convolution on the fp32 matrix cores (csrc/hip/convcl.hip: camli_convcl_fwd / camli_convcl_wrw, round 5):
+forward, data gradient (the same kernel on the negated taps) and weight gradient against oracle/dense.conv_taps_fwd / _bwd
+(numpy, pinned on the reference's GRU2D convolutions and on torch's conv2d: tests/test_dense_oracle.py), the training path of
+GRU2D's half-step convolutions (cores/blocks._CatConvCL) against the library path it replaces, and this repo's GRU2D against
+the reference module's recorded output (tests/golden/dense_gru2d.npz, models/raft_core.py:110-140)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def nhwc(a):
+    return dev(np.transpose(a, (0, 2, 3, 1)))
+
+
+def _close(got, want, tol=2e-5, what=''):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    scale = max(1.0, float(np.abs(want).max()))
+    assert got.shape == want.shape and np.abs(got - want).max() <= tol * scale, (what, float(np.abs(got - want).max()), scale)
+
+
+# (B, C0, C1, Cout, H, W, kh, kw): partial pixel tiles, every pixel near a border, two inputs, 128 / 256 / 384 output channels,
+# GRU2D's own shapes at a small image, a 3 x 3 and a 5 x 5 kernel through the same code (at most 32 taps)
+FWD_CASES = [
+    (1, 32, 0, 256, 7, 9, 1, 5), (2, 64, 0, 128, 20, 30, 5, 1), (3, 16, 32, 256, 17, 33, 5, 1), (2, 16, 16, 128, 16, 40, 1, 5),
+    (1, 128, 128, 256, 17, 30, 1, 5), (1, 128, 128, 128, 17, 30, 5, 1), (2, 48, 0, 384, 5, 140, 3, 3), (1, 16, 0, 128, 9, 9, 5, 5),
+    (1, 16, 0, 128, 1, 1, 1, 5),
+]
+
+
+@pytest.mark.parametrize('case', FWD_CASES, ids=str)
+def test_convcl_forward_vs_oracle(case, oracle_dense):
+    from camliflow_amd.csrc import fused
+    b, c0, c1, cout, h, w, kh, kw = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((b, c0 + c1, h, w), dtype=np.float32)
+    wt = (rng.standard_normal((cout, c0 + c1, kh, kw)) * (kh * kw * (c0 + c1)) ** -0.5).astype(np.float32)
+    pad = (kh // 2, kw // 2)
+    wp, _ = fused.convcl_pack(dev(wt))
+    xs = [nhwc(x[:, :c0])] + ([nhwc(x[:, c0:])] if c1 else [])
+    got = fused.convcl(xs, wp, fused.convcl_taps(kh, kw, *pad))
+    _close(got.permute(0, 3, 1, 2), oracle_dense.conv_taps_fwd(x, wt, pad), what='forward')
+
+
+def test_convcl_reads_channel_slices_and_splits_its_output(oracle_dense):
+    """Inputs that are channel slices of wider NHWC tensors (pixel stride > channels) and an output split on a channel boundary:
+    how the data gradient hands the two parts of cat([h, motion]) back."""
+    from camliflow_amd.csrc import fused
+    rng = np.random.default_rng(11)
+    b, h, w = 2, 11, 23
+    wide = rng.standard_normal((b, 96, h, w), dtype=np.float32)
+    wt = (rng.standard_normal((256, 48, 1, 5)) * 0.1).astype(np.float32)
+    wide_d = nhwc(wide)
+    xs = [wide_d[..., 16:48], wide_d[..., 80:96]]
+    x = np.concatenate([wide[:, 16:48], wide[:, 80:96]], axis=1)
+    y0, y1 = fused.convcl(xs, fused.convcl_pack(dev(wt))[0], fused.convcl_taps(1, 5, 0, 2), split=128)
+    want = oracle_dense.conv_taps_fwd(x, wt, (0, 2))
+    _close(y0.permute(0, 3, 1, 2), want[:, :128], what='first output')
+    _close(y1.permute(0, 3, 1, 2), want[:, 128:], what='second output')
+
+
+BWD_CASES = [  # (B, C0, C1, Cout, H, W, kh, kw): Cin a multiple of 256
+    (1, 256, 0, 256, 7, 9, 1, 5), (2, 128, 128, 128, 20, 30, 5, 1), (3, 256, 0, 256, 17, 33, 5, 1), (2, 384, 128, 128, 6, 40, 1, 5),
+    (1, 128, 128, 256, 13, 21, 3, 3),
+]
+
+
+@pytest.mark.parametrize('case', BWD_CASES, ids=str)
+def test_convcl_adjoints_vs_oracle(case, oracle_dense):
+    from camliflow_amd.csrc import fused
+    b, c0, c1, cout, h, w, kh, kw = case
+    rng = np.random.default_rng(sum(case) + 1)
+    x = rng.standard_normal((b, c0 + c1, h, w), dtype=np.float32)
+    wt = (rng.standard_normal((cout, c0 + c1, kh, kw)) * (kh * kw * (c0 + c1)) ** -0.5).astype(np.float32)
+    gy = rng.standard_normal((b, cout, h, w), dtype=np.float32)
+    pad = (kh // 2, kw // 2)
+    want_gx, want_gw = oracle_dense.conv_taps_bwd(gy, x, wt, pad)
+    _, wpt = fused.convcl_pack(dev(wt))
+    gx = fused.convcl([nhwc(gy)], wpt, fused.convcl_taps(kh, kw, *pad, negate=True))
+    _close(gx.permute(0, 3, 1, 2), want_gx, what='data gradient')
+    xs = [nhwc(x[:, :c0])] + ([nhwc(x[:, c0:])] if c1 else [])
+    gw = fused.convcl_wrw(xs, nhwc(gy), fused.convcl_taps(kh, kw, *pad), (kh, kw))
+    _close(gw, want_gw, tol=5e-5, what='weight gradient')
+    # accumulate into an existing gradient; run-to-run bit-identical (split K with an ordered reduction, no atomics)
+    again = fused.convcl_wrw(xs, nhwc(gy), fused.convcl_taps(kh, kw, *pad), (kh, kw))
+    assert torch.equal(gw, again)
+    acc = gw.clone()
+    fused.convcl_wrw(xs, nhwc(gy), fused.convcl_taps(kh, kw, *pad), (kh, kw), out=acc)
+    _close(acc, 2 * want_gw, tol=5e-5, what='accumulated weight gradient')
+
+
+@pytest.mark.parametrize('vertical', [False, True])
+def test_gru_half_step_convolution_own_kernels_vs_library(vertical, monkeypatch):
+    """cores/blocks._CatConvCL (cat([h, motion]) -> 1x5 / 5x1 convolution, GRU2D's shapes): output, both input gradients and the
+    weight gradient on this repo's kernels against the library path (CAMLI_CONVCL=0) they replace."""
+    from camliflow_amd.cores import blocks, runtime
+    runtime.set_backend('hip')
+    torch.manual_seed(3)
+    b, hd, h, w = 2, 128, 21, 37
+    shape = (5, 1) if vertical else (1, 5)
+    pad = (2, 0) if vertical else (0, 2)
+    res = {}
+    for own in (True, False):
+        monkeypatch.setattr(blocks, '_CONVCL', own)
+        hh = torch.randn(b, hd, h, w, device='cuda', requires_grad=True)
+        x = torch.randn(b, hd, h, w, device='cuda', requires_grad=True)
+        wt = (torch.randn((2 * hd, 2 * hd) + shape, device='cuda') * 0.03).requires_grad_()
+        torch.manual_seed(4)
+        y = blocks.cat_conv_cl([hh, x], wt, pad)
+        g = torch.randn_like(y)
+        y.backward(g)
+        res[own] = (y.detach(), hh.grad, x.grad, wt.grad)
+        torch.manual_seed(3)
+    for a, bb, name in zip(res[True], res[False], ('output', 'gradient of h', 'gradient of motion', 'weight gradient')):
+        scale = max(1.0, float(bb.abs().max()))
+        assert float((a - bb).abs().max()) <= 3e-5 * scale, name

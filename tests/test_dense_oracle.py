@@ -99,3 +99,30 @@ def test_point_volume_pyramid_and_channel_last_gather_vs_reference(golden, oracl
     _close(oracle_lib.scatter_add_cl(g['cl_gout'].reshape(idx.shape + (-1,)), idx, g['cl_data'].shape[1]), g['cl_gdata'])
     assert np.array_equal(oracle_lib.gather_cl(g['cl2_data'], g['cl2_idx']), g['cl2_out'])
     _close(oracle_lib.scatter_add_cl(g['cl2_gout'], g['cl2_idx'], g['cl2_data'].shape[1]), g['cl2_gdata'])
+
+
+def test_conv_taps_forward_and_adjoints_vs_reference_gru2d_and_torch_conv2d(golden):
+    """oracle/dense.conv_taps_fwd / _bwd (the oracle of camli_convcl_fwd / _wrw): the forward against every 1x5 / 5x1 convolution
+    the reference's GRU2D ran (tests/golden/dense_gru2d.npz, models/raft_core.py:110-140), forward and both adjoints against
+    torch's own conv2d + autograd in fp64 -- what nn.Conv2d of the reference's modules computes -- for the kernel shapes of the
+    update block (1x5, 5x1, 3x3, 7x7, 1x1)."""
+    import torch
+    g = golden('dense_gru2d')
+    for name in ('convz1', 'convr1', 'convq1', 'convz2', 'convr2', 'convq2'):
+        w = g[name + '_w']
+        pad = (w.shape[2] // 2, w.shape[3] // 2)
+        _close(dense.conv_taps_fwd(g[name + '_in'], w, pad) + g[name + '_b'][None, :, None, None], g[name + '_out'], rtol=1e-5, atol=1e-6)
+    rng = np.random.default_rng(5)
+    for kh, kw in ((1, 5), (5, 1), (3, 3), (7, 7), (1, 1)):
+        x = rng.standard_normal((2, 6, 9, 11)).astype(np.float32)
+        w = rng.standard_normal((4, 6, kh, kw)).astype(np.float32)
+        gy = rng.standard_normal((2, 4, 9, 11)).astype(np.float32)
+        pad = (kh // 2, kw // 2)
+        xt = torch.from_numpy(x).double().requires_grad_()
+        wt = torch.from_numpy(w).double().requires_grad_()
+        yt = torch.nn.functional.conv2d(xt, wt, padding=pad)
+        yt.backward(torch.from_numpy(gy).double())
+        _close(dense.conv_taps_fwd(x, w, pad), yt.detach().numpy(), rtol=1e-5, atol=1e-6)
+        gx, gw = dense.conv_taps_bwd(gy, x, w, pad)
+        _close(gx, xt.grad.numpy(), rtol=1e-5, atol=1e-6)
+        _close(gw, wt.grad.numpy(), rtol=1e-5, atol=1e-6)
