@@ -137,6 +137,12 @@ class GRU2D(nn.Module):
             # contiguous once per pass: the gate kernels would otherwise copy these channel slices every iteration
             state[suffix] = (torch.cat(keep[:2], dim=0), keep[2], ctx[:, :2 * hd].contiguous(),
                              ctx[:, 2 * hd:].contiguous(), padding)
+            if (runtime.fused() and context.is_cuda and ctx.dtype == torch.float32 and not torch.is_autocast_enabled()
+                    and os.environ.get('CAMLI_GRU_CL', '1') != '0'):
+                # r5 (default): the whole update as ONE node on channels-last tensors, convolutions + gate arithmetic on this
+                # repo's matrix-core kernels (csrc/hip/convcl.hip, fused._GRU2DStepCL); the hoisted context terms are laid out
+                # NHWC once per pass
+                state['cl' + suffix] = (ctx[:, :2 * hd].permute(0, 2, 3, 1).contiguous(), ctx[:, 2 * hd:].permute(0, 2, 3, 1).contiguous())
             if runtime.fused() and context.is_cuda and not torch.is_grad_enabled() and os.environ.get('CAMLI_CONV5', '0') == '1':
                 # CAMLI_CONV5=1, inference only: the half-steps run on the implicit-GEMM kernels with the gate arithmetic
                 # in their epilogues (csrc/hip/conv5.hip; no adjoint, so not under autograd), weights packed once per
@@ -155,6 +161,10 @@ class GRU2D(nn.Module):
         from ..csrc import fused
         conv2d = torch.nn.functional.conv2d
         hd = h.shape[1]
+        if ('cl1' in state and 'cl2' in state and 'packed1' not in state and not torch.is_autocast_enabled()
+                and fused.gru2d_step_supported(h, motion, state['1'][0])):
+            return fused.gru2d_step_cl(h, motion, (state['1'][0], state['1'][1], state['2'][0], state['2'][1]),
+                                       (state['cl1'][0], state['cl1'][1], state['cl2'][0], state['cl2'][1]))
         fusable = h.is_cuda and (hd * h.shape[2] * h.shape[3]) % 4 == 0
         for suffix in ('1', '2'):
             w_zr, w_q, ctx_zr, ctx_q, padding = state[suffix]

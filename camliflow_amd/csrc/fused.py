@@ -1849,10 +1849,10 @@ def convcl_supported(cin, cout, parts=1):
     return cin % 16 == 0 and cin % 256 == 0 and cout % 128 == 0 and cout >= 128 and parts <= 2
 
 
-def convcl(xs, wp, taps, split=None):
+def convcl(xs, wp, taps, split=None, out=None, accumulate=(False, False)):
     """y[p][n] = sum_t sum_c cat(xs)[p + tap_t][c] * wp[n][t][c].  xs: one or two fp32 NHWC tensors [B,H,W,Ci] (channel slices of
     wider NHWC tensors allowed); wp [Cout][T][Cin]; taps from convcl_taps.  Returns [B,H,W,Cout], or with ``split`` = N0 the pair
-    ([B,H,W,N0], [B,H,W,Cout-N0])."""
+    ([B,H,W,N0], [B,H,W,Cout-N0]).  ``out``: existing output tensor(s); ``accumulate[i]``: add into out[i] instead of writing it."""
     _require_cuda('convcl', wp, *xs)
     lib = _lib.load()
     t, dy, dx = taps
@@ -1866,12 +1866,21 @@ def convcl(xs, wp, taps, split=None):
     if ld0 is None or ld1 is None:
         raise _lib.CamliHipError('convcl: inputs must be dense fp32 NHWC tensors (16-byte aligned, pixel stride a multiple of 4)')
     n0 = cout if split is None else int(split)
-    y0 = torch.empty((b, hh, ww, n0), dtype=torch.float32, device=x0.device)
-    y1 = torch.empty((b, hh, ww, cout - n0), dtype=torch.float32, device=x0.device) if n0 < cout else None
+    if out is None:
+        y0 = torch.empty((b, hh, ww, n0), dtype=torch.float32, device=x0.device)
+        y1 = torch.empty((b, hh, ww, cout - n0), dtype=torch.float32, device=x0.device) if n0 < cout else None
+        assert not any(accumulate)
+    else:
+        y0, y1 = (out, None) if torch.is_tensor(out) else out
+        assert y0.shape == (b, hh, ww, n0) and (y1 is None) == (n0 == cout) and (y1 is None or y1.shape == (b, hh, ww, cout - n0))
+    ldy0, ldy1 = _nhwc_ld(y0), (_nhwc_ld(y1) if y1 is not None else 0)
+    if ldy0 is None or ldy1 is None:
+        raise _lib.CamliHipError('convcl: outputs must be dense fp32 NHWC tensors')
     with _on_device(x0):
         _lib.launch('camli_convcl_fwd', lib.camli_convcl_fwd, x0.data_ptr(), ld0, c0, x1.data_ptr() if x1 is not None else 0, ld1, c1,
-                    wp.data_ptr(), y0.data_ptr(), n0, n0, y1.data_ptr() if y1 is not None else 0, cout - n0, b, hh, ww, cout, t, dy, dx,
-                    _stream_ptr(x0), work=(4.0 * b * hh * ww * (c0 + c1 + cout), 'B'), flop=2.0 * b * hh * ww * cout * (c0 + c1) * t)
+                    wp.data_ptr(), y0.data_ptr(), ldy0, n0, y1.data_ptr() if y1 is not None else 0, ldy1, b, hh, ww, cout, t, dy, dx,
+                    int(bool(accumulate[0])), int(bool(accumulate[1])), _stream_ptr(x0),
+                    work=(4.0 * b * hh * ww * (c0 + c1 + cout), 'B'), flop=2.0 * b * hh * ww * cout * (c0 + c1) * t)
     return y0 if y1 is None else (y0, y1)
 
 
@@ -1908,6 +1917,114 @@ def convcl_wrw(xs, gy, taps, kernel_hw, out=None):
                     gy.data_ptr(), ldg, ws.data_ptr(), ws.numel() * 4, gw.data_ptr(), int(accumulate), b, hh, ww, cout, t, dy, dx,
                     _stream_ptr(gy), work=(4.0 * b * hh * ww * (c0 + c1 + cout), 'B'), flop=2.0 * b * hh * ww * cout * (c0 + c1) * t)
     return gw
+
+
+# ------------------------------------------------------------------------------------------------
+# GRU2D, one whole update (both half-steps) as ONE autograd node on channels-last tensors (round 5).
+# models/raft_core.py:122-139 with the context term hoisted (cores/raft2d.GRU2D.prepare):
+#     half-step s:   z | r = sigmoid(conv_zr_s(cat[h, m]) + ctx_zr_s);   q = tanh(conv_q_s(cat[r h, m]) + ctx_q_s);   h <- (1 - z) h + z q
+# Forward: two layout passes in (h, m -> NHWC), four convolutions with the gate arithmetic in their epilogues
+# (camli_convcl_gru_gates / _blend), one layout pass out: 7 launches where the per-convolution nodes took 24 (six transposes
+# per convolution node, gate / blend kernels, the motion features transposed four times).  Backward: blend / gate adjoints on the
+# NHWC tensors (the stand-alone kernels of gru.hip read them as [P][128][1]), the data gradients as convolutions on the negated
+# taps that ADD into the hidden-state / motion gradients they complete, weight gradients by camli_convcl_wrw.
+# ------------------------------------------------------------------------------------------------
+def _to_nhwc(x):
+    """[B,C,H,W] fp32 -> a new dense [B,H,W,C] tensor (camli_transpose_planes)."""
+    b, c, hh, ww = x.shape
+    out = torch.empty((b, hh, ww, c), dtype=torch.float32, device=x.device)
+    nchw_into_channels_last(x, out.permute(0, 3, 1, 2), 0)
+    return out
+
+
+def _to_nchw(x_n):
+    return channels_last_to_nchw(x_n.permute(0, 3, 1, 2), 0, x_n.shape[3])
+
+
+class _GRU2DStepCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, m, w_zr1, w_q1, w_zr2, w_q2, c_zr1, c_q1, c_zr2, c_q2):
+        lib = _lib.load()
+        b, hd, hh, ww = h.shape
+        cx = m.shape[1]
+        h0, mn = _to_nhwc(h.float()), _to_nhwc(m.float())
+        ctx.geom = []
+        saved = [h0, mn]
+        hcur = h0
+        with _on_device(h):
+            for half, (w_zr, w_q, c_zr, c_q) in enumerate(((w_zr1, w_q1, c_zr1, c_q1), (w_zr2, w_q2, c_zr2, c_q2))):
+                kh, kw = w_zr.shape[2:]
+                geom = (kh, kw, kh // 2, kw // 2)
+                t, dy, dx = convcl_taps(*geom)
+                wp_zr, wpt_zr = convcl_pack(w_zr)
+                wp_q, wpt_q = convcl_pack(w_q)
+                z, rh, r, q, hn = (torch.empty_like(h0) for _ in range(5))
+                flop = 2.0 * b * hh * ww * (hd + cx) * t
+                _lib.launch('camli_convcl_gru_gates', lib.camli_convcl_gru_gates, hcur.data_ptr(), mn.data_ptr(), cx, wp_zr.data_ptr(),
+                            c_zr.data_ptr(), z.data_ptr(), rh.data_ptr(), r.data_ptr(), b, hh, ww, t, dy, dx, _stream_ptr(h),
+                            work=(4.0 * b * hh * ww * (6 * hd + cx), 'B'), flop=flop * 2 * hd)
+                _lib.launch('camli_convcl_gru_blend', lib.camli_convcl_gru_blend, rh.data_ptr(), mn.data_ptr(), cx, wp_q.data_ptr(),
+                            c_q.data_ptr(), z.data_ptr(), hcur.data_ptr(), hn.data_ptr(), q.data_ptr(), int(half == 1), b, hh, ww, t,
+                            dy, dx, _stream_ptr(h), work=(4.0 * b * hh * ww * (6 * hd + cx), 'B'), flop=flop * hd)
+                ctx.geom.append((geom, wpt_zr, wpt_q))
+                saved += [z, r, rh, q]
+                if half == 0:
+                    saved.append(hn)
+                hcur = hn
+        ctx.save_for_backward(*saved)
+        return _to_nchw(hcur)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        h0, mn, z1, r1, rh1, q1, h1, z2, r2, rh2, q2 = ctx.saved_tensors
+        b, hh, ww, hd = h0.shape
+        npix = b * hh * ww
+        need = ctx.needs_input_grad
+        gcur = _to_nhwc(g.float())             # gradient of the half-step's output
+        gm = torch.empty_like(mn)
+        gws, gcs = [None] * 4, [None] * 4
+        first_m = True
+        with _on_device(g):
+            for half, (hin, z, r, rh, q) in ((1, (h1, z2, r2, rh2, q2)), (0, (h0, z1, r1, rh1, q1))):
+                geom, wpt_zr, wpt_q = ctx.geom[half]
+                taps, ntaps = convcl_taps(*geom), convcl_taps(*geom, negate=True)
+                gpre_q, gz, gh = torch.empty_like(h0), torch.empty_like(h0), torch.empty_like(h0)
+                _lib.launch('camli_gru_blend_bwd', lib.camli_gru_blend_bwd, gcur.data_ptr(), z.data_ptr(), hin.data_ptr(), q.data_ptr(),
+                            gpre_q.data_ptr(), gz.data_ptr(), gh.data_ptr(), npix, hd, 1, int(half == 1), _stream_ptr(g),
+                            work=(28.0 * npix * hd, 'B'))
+                # q convolution: input gradient = (gradient of r h | + gradient of m), weight gradient
+                grh = torch.empty_like(h0)
+                convcl([gpre_q], wpt_q, ntaps, split=hd, out=(grh, gm), accumulate=(False, not first_m))
+                first_m = False
+                if need[3 + 2 * half]:
+                    gws[1 + 2 * half] = convcl_wrw([rh, mn], gpre_q, taps, geom[:2])
+                gcs[1 + 2 * half] = gpre_q
+                gpre_zr = torch.empty((b, hh, ww, 2 * hd), dtype=torch.float32, device=g.device)
+                _lib.launch('camli_gru_gates_bwd', lib.camli_gru_gates_bwd_into, gz.data_ptr(), hd, grh.data_ptr(), hd, z.data_ptr(),
+                            r.data_ptr(), hin.data_ptr(), gpre_zr.data_ptr(), gh.data_ptr(), npix, hd, 1, _stream_ptr(g),
+                            work=(36.0 * npix * hd, 'B'))
+                # z | r convolution: its input gradient completes the gradient of this half-step's hidden input and of m
+                convcl([gpre_zr], wpt_zr, ntaps, split=hd, out=(gh, gm), accumulate=(True, True))
+                if need[2 + 2 * half]:
+                    gws[2 * half] = convcl_wrw([hin, mn], gpre_zr, taps, geom[:2])
+                gcs[2 * half] = gpre_zr
+                gcur = gh
+        return (_to_nchw(gcur) if need[0] else None, _to_nchw(gm) if need[1] else None, gws[0], gws[1], gws[2], gws[3],
+                gcs[0], gcs[1], gcs[2], gcs[3])
+
+
+def gru2d_step_supported(h, m, w_zr):
+    return (h.is_cuda and h.dtype == torch.float32 and m.dtype == torch.float32 and h.shape[1] == 128 and m.shape[1] % 16 == 0
+            and (h.shape[1] + m.shape[1]) % 256 == 0 and w_zr.dtype == torch.float32 and w_zr.shape[0] == 256
+            and h.shape[0] * h.shape[2] * h.shape[3] * 256 * 4 < 0x7FF00000)
+
+
+def gru2d_step_cl(h, m, weights, contexts):
+    """One GRU2D update.  h [B,128,H,W], m [B,CX,H,W] (NCHW); weights = (w_zr1, w_q1, w_zr2, w_q2), the [h | m] blocks of the
+    1x5 / 5x1 gates; contexts = (ctx_zr1, ctx_q1, ctx_zr2, ctx_q2), the hoisted context terms as dense NHWC tensors."""
+    _require_cuda('gru2d_step_cl', h, m)
+    return _GRU2DStepCL.apply(h, m, *weights, *contexts)
 
 
 class _BiasAct(torch.autograd.Function):

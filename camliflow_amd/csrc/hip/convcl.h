@@ -44,8 +44,32 @@ struct Problem {
     int C0, N0;                   // multiples of 16 / of the wave's channel range
     int ldx, ldx1, ldy, ldy1;     // floats per pixel
     int tiles_p, tiles_n;         // pixel tiles (256) x channel tiles (NT)
+    // epilogue operands (see the EPI_* forms below)
+    const float* add;             // [P][ld_add]
+    const float* h;               // [P][ld_h]
+    const float* z;               // [P][ld_z]
+    float* y2;                    // [P][ldy2]
+    int ld_add, ld_h, ld_z, ldy2;
+    int acc0, acc1;               // EPI_PLAIN: add into y / y1 instead of overwriting
+    int sanitize;                 // EPI_BLEND: torch.nan_to_num on h'
     signed char dy[MAX_TAPS], dx[MAX_TAPS];
 };
+
+// Epilogues.  PLAIN: y / y1 (= or +=) the convolution.  The two GRU2D forms take the convolution as the pre-activation of a
+// half-step (models/raft_core.py:124-130 / 132-138, context term hoisted: cores/raft2d.GRU2D.prepare):
+//   GATES (Cout = 256 = z | r):  z = sigmoid(conv[:128] + add[:128]) -> y;   r = sigmoid(conv[128:] + add[128:]) -> y2,  r * h -> y1
+//   BLEND (Cout = 128):          q = tanh(conv + add) -> y1;   h' = (1 - z) h + z q (nan_to_num when `sanitize`) -> y
+// all operands NHWC; the arithmetic is that of gru.hip's stand-alone kernels.
+enum { EPI_PLAIN = 0, EPI_GATES = 1, EPI_BLEND = 2 };
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float nan_to_num_(float v) { return v != v ? 0.0f : fminf(fmaxf(v, -3.402823466e+38f), 3.402823466e+38f); }
+__device__ __forceinline__ f32x4 load4(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+__device__ __forceinline__ void store4(f32x4 v, __amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 0);
+}
 
 template <int V>
 __device__ __forceinline__ void wait_vm() {
@@ -83,7 +107,7 @@ __device__ __forceinline__ void mfma_x4(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& 
 // NTW: 16-channel tiles per wave along the output channels (8: 256-channel workgroup tile, 4: 128).  Workgroup tile =
 // 256 pixels x 32 NTW channels, waves 2 (pixels) x 2 (channels), 128 pixels x 16 NTW channels each.  NBUF LDS stages of
 // (256 + 32 NTW) rows x 64 bytes.
-template <int NTW, int NBUF>
+template <int NTW, int NBUF, int EPI = EPI_PLAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convcl_kernel(Problem p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(NBUF >= 3 && (NTW == 8 || NTW == 4), "");
@@ -231,24 +255,112 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- epilogue: y[pixel][channel], 4 channels per lane and accumulator quad ----------------------------------
         asm volatile("s_nop 15");
         __builtin_amdgcn_sched_barrier(0);
-        // the wave's channel range lies in one of the two outputs (N0 is a multiple of it)
-        const int nw0 = n0 + WROWS * wn;
-        const bool second_out = nw0 >= p.N0;
-        float* const ydst = second_out ? p.y1 : p.y;
-        const int ldy = second_out ? p.ldy1 : p.ldy;
-        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(ydst, 0, (int)((uint32_t)P * ldy * 4u), 0x00020000);
-        const uint32_t ybase = ((uint32_t)(p0 + 128 * wm + r) * ldy + (second_out ? nw0 - p.N0 : nw0) + 4 * q) * 4u;
+        const int nw0 = n0 + WROWS * wn;                  // the wave's first output channel
+        const uint32_t prow = (uint32_t)(p0 + 128 * wm + r);    // + 16 tpx
+        auto rsrc = [&](const float* ptr, int ld) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ptr), 0, (int)((uint32_t)P * ld * 4u), 0x00020000); };
+        // operands of one accumulator row (8 quads) are loaded one row ahead of the arithmetic that uses them
+        if constexpr (EPI == EPI_PLAIN) {
+            // the wave's channel range lies in one of the two outputs (N0 is a multiple of it)
+            const bool second_out = nw0 >= p.N0;
+            const int ldy = second_out ? p.ldy1 : p.ldy;
+            const bool accum = second_out ? p.acc1 != 0 : p.acc0 != 0;
+            const __amdgpu_buffer_rsrc_t rs_y = rsrc(second_out ? p.y1 : p.y, ldy);
+            const uint32_t ybase = (prow * ldy + (second_out ? nw0 - p.N0 : nw0) + 4 * q) * 4u;
+            f32x4 old[2][8];
+            auto fetch = [&](int tco, f32x4 (&o)[8]) {
 #pragma unroll
-        for (int tco = 0; tco < NTW; ++tco) {
-            // (the accumulators of this row become visible to hipcc only here: see gemm_w128.h)
-            asm volatile("" : "+a"(acc[tco][0]), "+a"(acc[tco][1]), "+a"(acc[tco][2]), "+a"(acc[tco][3]), "+a"(acc[tco][4]),
-                         "+a"(acc[tco][5]), "+a"(acc[tco][6]), "+a"(acc[tco][7]));
+                for (int tpx = 0; tpx < 8; ++tpx) o[tpx] = load4(rs_y, ybase + (uint32_t)(16 * tpx * ldy + 16 * tco) * 4u);
+            };
+            if (accum) fetch(0, old[0]);
 #pragma unroll
-            for (int tpx = 0; tpx < 8; ++tpx) {
-                const uint32_t off = ybase + (uint32_t)(16 * tpx * ldy + 16 * tco) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[tco][tpx]), rs_y, off, 0, 0);
+            for (int tco = 0; tco < NTW; ++tco) {
+                if (accum && tco + 1 < NTW) fetch(tco + 1, old[(tco + 1) & 1]);
+                // (the accumulators of this row become visible to hipcc only here: see gemm_w128.h)
+                asm volatile("" : "+a"(acc[tco][0]), "+a"(acc[tco][1]), "+a"(acc[tco][2]), "+a"(acc[tco][3]), "+a"(acc[tco][4]),
+                             "+a"(acc[tco][5]), "+a"(acc[tco][6]), "+a"(acc[tco][7]));
+#pragma unroll
+                for (int tpx = 0; tpx < 8; ++tpx) {
+                    f32x4 o = acc[tco][tpx];
+                    if (accum) o += old[tco & 1][tpx];
+                    store4(o, rs_y, ybase + (uint32_t)(16 * tpx * ldy + 16 * tco) * 4u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (EPI == EPI_GATES) {
+            static_assert(EPI != EPI_GATES || NTW == 8, "z | r = 256 output channels");
+            const bool rwave = wn != 0;                       // channels [128, 256) are r
+            const __amdgpu_buffer_rsrc_t rs_add = rsrc(p.add, p.ld_add), rs_h = rsrc(p.h, p.ld_h);
+            const __amdgpu_buffer_rsrc_t rs_o = rsrc(rwave ? p.y1 : p.y, rwave ? p.ldy1 : p.ldy), rs_r = rsrc(p.y2, p.ldy2);
+            const int ldo = rwave ? p.ldy1 : p.ldy;
+            const uint32_t c4 = 4 * q;                        // + 16 tco: channel inside the wave's 128
+            f32x4 av[2][8], hv[2][8];
+            auto fetch = [&](int tco, f32x4 (&a)[8], f32x4 (&hh)[8]) {
+#pragma unroll
+                for (int tpx = 0; tpx < 8; ++tpx) {
+                    const uint32_t row = prow + 16 * tpx;
+                    a[tpx] = load4(rs_add, (row * p.ld_add + nw0 + 16 * tco + c4) * 4u);
+                    if (rwave) hh[tpx] = load4(rs_h, (row * p.ld_h + 16 * tco + c4) * 4u);
+                }
+            };
+            fetch(0, av[0], hv[0]);
+#pragma unroll
+            for (int tco = 0; tco < NTW; ++tco) {
+                if (tco + 1 < NTW) fetch(tco + 1, av[(tco + 1) & 1], hv[(tco + 1) & 1]);
+                asm volatile("" : "+a"(acc[tco][0]), "+a"(acc[tco][1]), "+a"(acc[tco][2]), "+a"(acc[tco][3]), "+a"(acc[tco][4]),
+                             "+a"(acc[tco][5]), "+a"(acc[tco][6]), "+a"(acc[tco][7]));
+#pragma unroll
+                for (int tpx = 0; tpx < 8; ++tpx) {
+                    const uint32_t row = prow + 16 * tpx;
+                    const f32x4 pre = acc[tco][tpx] + av[tco & 1][tpx];
+                    f32x4 g;
+                    g[0] = sigmoid_(pre[0]); g[1] = sigmoid_(pre[1]); g[2] = sigmoid_(pre[2]); g[3] = sigmoid_(pre[3]);
+                    if (rwave) {
+                        store4(g, rs_r, (row * p.ldy2 + 16 * tco + c4) * 4u);
+                        store4(g * hv[tco & 1][tpx], rs_o, (row * ldo + 16 * tco + c4) * 4u);
+                    } else {
+                        store4(g, rs_o, (row * ldo + 16 * tco + c4) * 4u);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            static_assert(EPI != EPI_BLEND || NTW == 4, "q = 128 output channels");
+            const __amdgpu_buffer_rsrc_t rs_add = rsrc(p.add, p.ld_add), rs_h = rsrc(p.h, p.ld_h), rs_z = rsrc(p.z, p.ld_z);
+            const __amdgpu_buffer_rsrc_t rs_o = rsrc(p.y, p.ldy), rs_q = rsrc(p.y1, p.ldy1);
+            const uint32_t c4 = nw0 + 4 * q;                  // + 16 tco
+            f32x4 av[2][8], hv[2][8], zv[2][8];
+            auto fetch = [&](int tco, f32x4 (&a)[8], f32x4 (&hh)[8], f32x4 (&zz)[8]) {
+#pragma unroll
+                for (int tpx = 0; tpx < 8; ++tpx) {
+                    const uint32_t row = prow + 16 * tpx;
+                    a[tpx] = load4(rs_add, (row * p.ld_add + 16 * tco + c4) * 4u);
+                    hh[tpx] = load4(rs_h, (row * p.ld_h + 16 * tco + c4) * 4u);
+                    zz[tpx] = load4(rs_z, (row * p.ld_z + 16 * tco + c4) * 4u);
+                }
+            };
+            fetch(0, av[0], hv[0], zv[0]);
+#pragma unroll
+            for (int tco = 0; tco < NTW; ++tco) {
+                if (tco + 1 < NTW) fetch(tco + 1, av[(tco + 1) & 1], hv[(tco + 1) & 1], zv[(tco + 1) & 1]);
+                asm volatile("" : "+a"(acc[tco][0]), "+a"(acc[tco][1]), "+a"(acc[tco][2]), "+a"(acc[tco][3]), "+a"(acc[tco][4]),
+                             "+a"(acc[tco][5]), "+a"(acc[tco][6]), "+a"(acc[tco][7]));
+#pragma unroll
+                for (int tpx = 0; tpx < 8; ++tpx) {
+                    const uint32_t row = prow + 16 * tpx;
+                    const f32x4 pre = acc[tco][tpx] + av[tco & 1][tpx];
+                    const f32x4 zq = zv[tco & 1][tpx], hq = hv[tco & 1][tpx];
+                    f32x4 qv, hn;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        qv[e] = tanhf(pre[e]);
+                        hn[e] = (1.0f - zq[e]) * hq[e] + zq[e] * qv[e];
+                        if (p.sanitize) hn[e] = nan_to_num_(hn[e]);
+                    }
+                    store4(qv, rs_q, (row * p.ldy1 + 16 * tco + c4) * 4u);
+                    store4(hn, rs_o, (row * p.ldy + 16 * tco + c4) * 4u);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // before this workgroup's next tile reuses the LDS stages and the accumulators: everything has drained
         wait_vm<0>();

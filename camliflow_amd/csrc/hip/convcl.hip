@@ -41,12 +41,19 @@ int taps_ok(const char* what, int T, const signed char* dy, const signed char* d
 
 constexpr int NBUF = 3;
 
-template <int NTW>
+// a tap that reaches beyond the image only ever reads padding: legal, it contributes nothing
+template <class Problem>
+void set_taps(Problem& p, int T, const signed char* dy, const signed char* dx) {
+    for (int t = 0; t < T; ++t) { p.dy[t] = dy[t]; p.dx[t] = dx[t]; }
+    for (int t = T; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+}
+
+template <int NTW, int EPI = ccl::EPI_PLAIN>
 int launch_conv(const ccl::Problem& p, hipStream_t s) {
     constexpr size_t lds = (size_t)NBUF * (256 + 32 * NTW) * 16 * sizeof(float);
     static bool set = false;
     if (!set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl::convcl_kernel<NTW, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl::convcl_kernel<NTW, NBUF, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             camli_set_error("camli_convcl_fwd: cannot reserve %zu bytes of LDS", lds);
             return CAMLI_ELAUNCH;
@@ -55,7 +62,7 @@ int launch_conv(const ccl::Problem& p, hipStream_t s) {
     }
     const int tiles = p.tiles_p * p.tiles_n;
     const int cus = cu_count();
-    hipLaunchKernelGGL((ccl::convcl_kernel<NTW, NBUF>), dim3(tiles < cus ? tiles : cus), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((ccl::convcl_kernel<NTW, NBUF, EPI>), dim3(tiles < cus ? tiles : cus), dim3(256), lds, s, p);
     return CAMLI_OK;
 }
 
@@ -88,7 +95,7 @@ void wrw_split(int P, int T, int tiles, int& S, int& ksplit) {
 
 extern "C" int camli_convcl_fwd(const float* x0, int ldx0, int C0, const float* x1, int ldx1, int C1, const float* wp, float* y0,
                                 int ldy0, int N0, float* y1, int ldy1, int B, int H, int W, int Cout, int T, const signed char* dy,
-                                const signed char* dx, void* stream) {
+                                const signed char* dx, int accumulate0, int accumulate1, void* stream) {
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_convcl_fwd";
     if (!x0 || !wp || !y0 || (C1 > 0 && !x1) || (N0 < Cout && !y1)) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
@@ -118,11 +125,9 @@ extern "C" int camli_convcl_fwd(const float* x0, int ldx0, int C0, const float* 
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.T = T; p.C0 = C0; p.N0 = N0;
     p.ldx = ldx0; p.ldx1 = C1 > 0 ? ldx1 : ldx0; p.ldy = ldy0; p.ldy1 = N0 < Cout ? ldy1 : ldy0;
     p.tiles_p = (int)((P + 255) / 256); p.tiles_n = Cout / NT;
-    for (int t = 0; t < T; ++t) {
-        if (dy[t] <= -H || dy[t] >= H || dx[t] <= -W || dx[t] >= W) { camli_set_error("%s: tap %d (%d, %d) beyond the image", what, t, dy[t], dx[t]); return CAMLI_EINVAL; }
-        p.dy[t] = dy[t]; p.dx[t] = dx[t];
-    }
-    for (int t = T; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+    p.add = p.h = p.z = x0; p.y2 = y0; p.ld_add = p.ld_h = p.ld_z = p.ldy2 = 4;
+    p.acc0 = accumulate0 ? 1 : 0; p.acc1 = accumulate1 ? 1 : 0; p.sanitize = 0;
+    set_taps(p, T, dy, dx);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rc = NT == 256 ? launch_conv<8>(p, s) : launch_conv<4>(p, s);
     if (rc != CAMLI_OK) return rc;
@@ -171,16 +176,80 @@ extern "C" int camli_convcl_wrw(const float* x0, int ldx0, int C0, const float* 
                         (long long)((int64_t)p.S * T * Cin * Cout * 4));
         return CAMLI_EINVAL;
     }
-    for (int t = 0; t < T; ++t) {
-        if (dy[t] <= -H || dy[t] >= H || dx[t] <= -W || dx[t] >= W) { camli_set_error("%s: tap %d (%d, %d) beyond the image", what, t, dy[t], dx[t]); return CAMLI_EINVAL; }
-        p.dy[t] = dy[t]; p.dx[t] = dx[t];
-    }
-    for (int t = T; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+    set_taps(p, T, dy, dx);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rc = NB == 256 ? launch_wrw<8>(p, s) : launch_wrw<4>(p, s);
     if (rc != CAMLI_OK) return rc;
     const size_t n_el = (size_t)T * Cin * Cout;
     hipLaunchKernelGGL(wrw::wrw_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, workspace, gw, p.S, T, Cin, Cout,
                        accumulate ? 1 : 0);
+    return camli_check_launch(what);
+}
+
+// ---- GRU2D half-step: convolution + gate arithmetic in one launch (models/raft_core.py:124-130 / 132-138) -------------------
+// All tensors dense NHWC: h, z, r, rh, q, h_new [P][HD] with HD = 128, x [P][CX], ctx_zr [P][2 HD], ctx_q [P][HD].
+namespace {
+int gru_args_ok(const char* what, int B, int H, int W, int CX, int T, const signed char* dy, const signed char* dx) {
+    if (!taps_ok(what, T, dy, dx)) return 0;
+    const int64_t P = (int64_t)B * H * W;
+    if (B < 0 || H < 1 || W < 1 || CX < 16 || CX % 16 || P * (int64_t)(CX > 256 ? CX : 256) * 4 >= (int64_t)0x7FF00000 || (128 + CX) / 16 * T < NBUF - 1) {
+        camli_set_error("%s: unsupported shape B=%d %dx%d CX=%d", what, B, H, W, CX);
+        return 0;
+    }
+    return 1;
+}
+void gru_problem(ccl::Problem& p, const float* a0, const float* x, int CX, const float* wp, int Cout, int B, int H, int W, int T,
+                 const signed char* dy, const signed char* dx) {
+    const int64_t P = (int64_t)B * H * W;
+    p.x = a0; p.x1 = x; p.w = wp;
+    p.B = B; p.H = H; p.W = W; p.Cin = 128 + CX; p.Cout = Cout; p.T = T; p.C0 = 128; p.N0 = Cout;
+    p.ldx = 128; p.ldx1 = CX;
+    p.tiles_p = (int)((P + 255) / 256); p.tiles_n = 1;
+    p.acc0 = p.acc1 = p.sanitize = 0;
+    set_taps(p, T, dy, dx);
+}
+}  // namespace
+
+// z, r*h, r = gates(conv(cat[h, x]; wp_zr [256][T][128 + CX]) + ctx_zr, h)
+extern "C" int camli_convcl_gru_gates(const float* h, const float* x, int CX, const float* wp_zr, const float* ctx_zr, float* z,
+                                      float* rh, float* r, int B, int H, int W, int T, const signed char* dy, const signed char* dx,
+                                      void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_convcl_gru_gates";
+    if (!h || !x || !wp_zr || !ctx_zr || !z || !rh || !r) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    if (!gru_args_ok(what, B, H, W, CX, T, dy, dx)) return CAMLI_ENOTSUP;
+    if (!aligned16(h) || !aligned16(x) || !aligned16(wp_zr) || !aligned16(ctx_zr) || !aligned16(z) || !aligned16(rh) || !aligned16(r)) {
+        camli_set_error("%s: pointers must be 16-byte aligned", what);
+        return CAMLI_EINVAL;
+    }
+    ccl::Problem p;
+    gru_problem(p, h, x, CX, wp_zr, 256, B, H, W, T, dy, dx);
+    p.y = z; p.ldy = 128; p.y1 = rh; p.ldy1 = 128; p.y2 = r; p.ldy2 = 128;
+    p.add = ctx_zr; p.ld_add = 256; p.h = h; p.ld_h = 128; p.z = h; p.ld_z = 128;
+    const int rc = launch_conv<8, ccl::EPI_GATES>(p, reinterpret_cast<hipStream_t>(stream));
+    if (rc != CAMLI_OK) return rc;
+    return camli_check_launch(what);
+}
+
+// q = tanh(conv(cat[rh, x]; wp_q [128][T][128 + CX]) + ctx_q);  h_new = (1 - z) h + z q  (nan_to_num: followed by torch.nan_to_num)
+extern "C" int camli_convcl_gru_blend(const float* rh, const float* x, int CX, const float* wp_q, const float* ctx_q, const float* z,
+                                      const float* h, float* h_new, float* q, int nan_to_num, int B, int H, int W, int T,
+                                      const signed char* dy, const signed char* dx, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_convcl_gru_blend";
+    if (!rh || !x || !wp_q || !ctx_q || !z || !h || !h_new || !q) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    if (!gru_args_ok(what, B, H, W, CX, T, dy, dx)) return CAMLI_ENOTSUP;
+    if (!aligned16(rh) || !aligned16(x) || !aligned16(wp_q) || !aligned16(ctx_q) || !aligned16(z) || !aligned16(h) || !aligned16(h_new) ||
+        !aligned16(q)) {
+        camli_set_error("%s: pointers must be 16-byte aligned", what);
+        return CAMLI_EINVAL;
+    }
+    ccl::Problem p;
+    gru_problem(p, rh, x, CX, wp_q, 128, B, H, W, T, dy, dx);
+    p.y = h_new; p.ldy = 128; p.y1 = q; p.ldy1 = 128; p.y2 = q; p.ldy2 = 128;
+    p.add = ctx_q; p.ld_add = 128; p.h = h; p.ld_h = 128; p.z = z; p.ld_z = 128;
+    p.sanitize = nan_to_num ? 1 : 0;
+    const int rc = launch_conv<4, ccl::EPI_BLEND>(p, reinterpret_cast<hipStream_t>(stream));
+    if (rc != CAMLI_OK) return rc;
     return camli_check_launch(what);
 }

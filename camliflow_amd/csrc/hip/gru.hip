@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float4* __rest
                                                              const float4* __restrict__ z, const float4* __restrict__ r,
                                                              const float4* __restrict__ h, float4* __restrict__ gpre,
                                                              float4* __restrict__ gh, size_t n4, size_t cp4, size_t gz_bs4,
-                                                             size_t grh_bs4) {
+                                                             size_t grh_bs4, int into) {
     // gz / grh may be channel slices of wider gradients (what the adjoint of cat([rh, x]) hands over): batch strides in float4
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
         const size_t b = e / cp4, off = e - b * cp4;
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float4* __rest
         d.x = g2.x * rv.x; d.y = g2.y * rv.y; d.z = g2.z * rv.z; d.w = g2.w * rv.w;
         gpre[iz] = a;
         gpre[ir] = c;
+        if (into) { const float4 o = gh[e]; d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w; }
         gh[e] = d;
     }
 }
@@ -135,9 +136,8 @@ extern "C" int camli_gru_gates_fwd(const float* pre_zr, const float* ctx_zr, con
     return camli_check_launch("camli_gru_gates_fwd");
 }
 
-extern "C" int camli_gru_gates_bwd_strided(const float* gz, int64_t gz_batch_stride, const float* grh, int64_t grh_batch_stride,
-                                           const float* z, const float* r, const float* h, float* gpre_zr, float* gh, int B,
-                                           int C, int P, void* stream) {
+static int gates_bwd_impl(const float* gz, int64_t gz_batch_stride, const float* grh, int64_t grh_batch_stride, const float* z,
+                          const float* r, const float* h, float* gpre_zr, float* gh, int B, int C, int P, int into, void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!gz || !grh || !z || !r || !h || !gpre_zr || !gh) { camli_set_error("camli_gru_gates_bwd: null pointer"); return CAMLI_EINVAL; }
     if (!gru_shape_ok("camli_gru_gates_bwd", B, C, P)) return CAMLI_EINVAL;
@@ -151,8 +151,21 @@ extern "C" int camli_gru_gates_bwd_strided(const float* gz, int64_t gz_batch_str
     const size_t cp4 = (size_t)cp / 4, n4 = cp4 * B;
     hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        F4(gz), F4(grh), F4(z), F4(r), F4(h), F4W(gpre_zr), F4W(gh), n4, cp4, (size_t)gz_batch_stride / 4,
-                       (size_t)grh_batch_stride / 4);
+                       (size_t)grh_batch_stride / 4, into);
     return camli_check_launch("camli_gru_gates_bwd");
+}
+
+extern "C" int camli_gru_gates_bwd_strided(const float* gz, int64_t gz_batch_stride, const float* grh, int64_t grh_batch_stride,
+                                           const float* z, const float* r, const float* h, float* gpre_zr, float* gh, int B,
+                                           int C, int P, void* stream) {
+    return gates_bwd_impl(gz, gz_batch_stride, grh, grh_batch_stride, z, r, h, gpre_zr, gh, B, C, P, 0, stream);
+}
+
+// gh += (see include/camli_hip.h)
+extern "C" int camli_gru_gates_bwd_into(const float* gz, int64_t gz_batch_stride, const float* grh, int64_t grh_batch_stride,
+                                        const float* z, const float* r, const float* h, float* gpre_zr, float* gh, int B, int C,
+                                        int P, void* stream) {
+    return gates_bwd_impl(gz, gz_batch_stride, grh, grh_batch_stride, z, r, h, gpre_zr, gh, B, C, P, 1, stream);
 }
 
 extern "C" int camli_gru_gates_bwd(const float* gz, const float* grh, const float* z, const float* r, const float* h,

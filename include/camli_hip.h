@@ -386,6 +386,10 @@ int camli_gru_gates_fwd(const float *pre_zr, const float *ctx_zr, const float *h
                         int B, int C, int P, void *stream);
 int camli_gru_gates_bwd(const float *gz, const float *grh, const float *z, const float *r, const float *h,
                         float *gpre_zr, float *gh, int B, int C, int P, void *stream);
+/* camli_gru_gates_bwd_strided with gh += instead of gh = (the hidden state's gradient of a half-step has three producers:
+ * the blend adjoint writes it, this call and the data gradient of the z|r convolution add into it). */
+int camli_gru_gates_bwd_into(const float *gz, int64_t gz_batch_stride, const float *grh, int64_t grh_batch_stride, const float *z,
+                             const float *r, const float *h, float *gpre_zr, float *gh, int B, int C, int P, void *stream);
 /* the same with gz / grh read in place from channel slices of wider gradients (what the adjoint of cat([r*h, x]) hands
  * over): batch strides in floats, multiples of 4, >= C*P; pointers 16-byte aligned */
 int camli_gru_gates_bwd_strided(const float *gz, int64_t gz_batch_stride, const float *grh, int64_t grh_batch_stride,
@@ -609,7 +613,21 @@ int camli_conv5_fwd(const float *in0, int C0, const float *in1, int C1, const fl
  */
 int camli_convcl_fwd(const float *x0, int ldx0, int C0, const float *x1, int ldx1, int C1, const float *wp, float *y0, int ldy0,
                      int N0, float *y1, int ldy1, int B, int H, int W, int Cout, int T, const signed char *dy, const signed char *dx,
-                     void *stream);
+                     int accumulate0, int accumulate1, void *stream);
+/*
+ * One GRU2D half-step convolution with its gate arithmetic in the epilogue (models/raft_core.py:124-130, 132-138; the context
+ * term of the input hoisted out of the iteration: cores/raft2d.GRU2D.prepare).  Dense NHWC tensors, hidden width 128:
+ * h, z, r, rh, q, h_new [P][128], x [P][CX], ctx_zr [P][256], ctx_q [P][128]; wp_zr [256][T][128 + CX], wp_q [128][T][128 + CX].
+ *   gates:  z | r = sigmoid(conv(cat[h, x]; wp_zr) + ctx_zr);  outputs z, rh = r * h, r (kept for the adjoint)
+ *   blend:  q = tanh(conv(cat[rh, x]; wp_q) + ctx_q);  h_new = (1 - z) h + z q  (nan_to_num != 0: then torch.nan_to_num, :138)
+ * The adjoints are camli_gru_blend_bwd / camli_gru_gates_bwd_into on the same NHWC tensors (read as [P][128][1]) followed by
+ * camli_convcl_fwd on the negated taps and camli_convcl_wrw.
+ */
+int camli_convcl_gru_gates(const float *h, const float *x, int CX, const float *wp_zr, const float *ctx_zr, float *z, float *rh,
+                           float *r, int B, int H, int W, int T, const signed char *dy, const signed char *dx, void *stream);
+int camli_convcl_gru_blend(const float *rh, const float *x, int CX, const float *wp_q, const float *ctx_q, const float *z,
+                           const float *h, float *h_new, float *q, int nan_to_num, int B, int H, int W, int T, const signed char *dy,
+                           const signed char *dx, void *stream);
 /*
  * Weight gradient of the same convolution: gw [Cout][C0 + C1][T] (= the [Cout, Cin, kh, kw] weight tensor) = or += (accumulate)
  *     sum_p gy[p][n] * x[p + (dy[t], dx[t])][c]

@@ -10,6 +10,8 @@
                         models/utils.py batch_indexing(layout='channel_last') (:85-104), rank-3 and rank-2 data
   dense_gru2d           models/raft_core.py GRU2D (:110-140): weights, inputs (h, x = [context | motion]), the input and
                         output of each of its six 1x5 / 5x1 convolutions, the new hidden state
+  dense_gru2d_wide      the same module at the product's widths (hidden 128, x = 128 context + 128 motion channels), two updates
+                        with autograd: inputs, output, input gradients, fingerprints of the weight gradients (name-hashed weights)
   dense_resnet_glue     the stem max pooling and the bottleneck epilogue of the ResNet trunk the reference instantiates
                         through mmdet (README.md:78-79, models/raft_core.py:10-38; mmdet itself is not under
                         /root/reference -- SURVEY 8c): nn.MaxPool2d(3, 2, 1) and relu(bn-bias + conv + identity) from torch
@@ -184,6 +186,26 @@ def golden_gru2d():
     save('dense_gru2d', **arrays)
 
 
+def golden_gru2d_wide():
+    """The reference's GRU2D at the product's widths (hidden 128, x = [128 context | 128 motion]) with autograd: the shapes
+    camli_convcl_gru_gates / _blend take.  Weights are name-hashed (tests/modelutils.hashed_fill_: none are stored); the
+    weight gradients are recorded as fingerprints (L2 norm and the projection on a name-seeded random direction)."""
+    import zlib
+    from modelutils import hashed_fill_
+    g = torch.Generator().manual_seed(26)
+    gru = hashed_fill_(GRU2D(hidden_dim=128, input_dim=256))
+    h0 = torch.tanh(torch.randn(1, 128, 10, 14, generator=g)).requires_grad_()
+    x = torch.randn(1, 256, 10, 14, generator=g).requires_grad_()
+    out = gru(gru(h0, x), x)                     # two updates, as two GRU iterations share the weights
+    gout = torch.randn(out.shape, generator=g)
+    out.backward(gout)
+    arrays = {'h0': h0.detach(), 'x': x.detach(), 'out': out.detach(), 'gout': gout, 'gh0': h0.grad, 'gx': x.grad}
+    for name, p in gru.named_parameters():
+        d = torch.randn(p.shape, generator=torch.Generator().manual_seed(zlib.crc32(('dir.' + name).encode())))
+        arrays['fp_' + name] = torch.stack([p.grad.double().norm(), (p.grad.double() * d.double()).sum()])
+    save('dense_gru2d_wide', **arrays)
+
+
 def golden_resnet_glue():
     g = torch.Generator().manual_seed(24)
     x = torch.relu(torch.randn(2, 5, 13, 18, generator=g)).requires_grad_(True)     # post-ReLU stem output: zeros tie
@@ -209,5 +231,6 @@ if __name__ == '__main__':
     golden_allpairs('even', 8, 12)
     golden_allpairs('odd', 9, 15)
     golden_gru2d()
+    golden_gru2d_wide()
     golden_resnet_glue()
     golden_point_volume()

@@ -119,3 +119,67 @@ def test_gru_half_step_convolution_own_kernels_vs_library(vertical, monkeypatch)
     for a, bb, name in zip(res[True], res[False], ('output', 'gradient of h', 'gradient of motion', 'weight gradient')):
         scale = max(1.0, float(bb.abs().max()))
         assert float((a - bb).abs().max()) <= 3e-5 * scale, name
+
+
+def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden):
+    """cores/raft2d.GRU2D on the product path (fused._GRU2DStepCL: convolutions with the gate arithmetic in their epilogues, both
+    adjoints) against what the REFERENCE's GRU2D recorded at the product's widths -- two updates, the new hidden state, both
+    input gradients, fingerprints of all twelve parameter gradients (tests/golden/dense_gru2d_wide.npz from
+    tests/golden/make_dense_golden.py, models/raft_core.py:110-140; weights name-hashed on both sides)."""
+    import zlib
+    from modelutils import hashed_fill_
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.raft2d import GRU2D
+    runtime.set_backend('hip')
+    g = golden('dense_gru2d_wide')
+    gru = hashed_fill_(GRU2D(hidden_dim=128, input_dim=256)).cuda()
+    h0 = dev(g['h0']).requires_grad_()
+    x = dev(g['x']).requires_grad_()
+    context, motion = x[:, :128], x[:, 128:]       # GRU2D.prepare: the first channels of x are the per-pass context
+    state = gru.prepare(context)
+    assert 'cl1' in state and 'cl2' in state
+    out = gru.step(gru.step(h0, motion, state), motion, state)
+    _close(out, g['out'], tol=2e-5, what='new hidden state')
+    out.backward(dev(g['gout']))
+    _close(h0.grad, g['gh0'], tol=5e-5, what='gradient of h')
+    _close(x.grad, g['gx'], tol=5e-5, what='gradient of x')
+    for name, p_ in gru.named_parameters():
+        d = torch.randn(p_.shape, generator=torch.Generator().manual_seed(zlib.crc32(('dir.' + name).encode())))
+        fp = np.array([float(p_.grad.double().norm()), float((p_.grad.double().cpu() * d.double()).sum())])
+        want = g['fp_' + name]
+        assert abs(fp[0] - want[0]) <= 1e-4 * want[0] and abs(fp[1] - want[1]) <= 2e-4 * want[0], (name, fp, want)
+
+
+@pytest.mark.parametrize('shape', [(2, 19, 35), (1, 68, 120)], ids=str)
+def test_gru2d_update_one_node_vs_per_convolution_nodes(shape, monkeypatch):
+    """The one-node channels-last update (CAMLI_GRU_CL, default) against the per-convolution formulation it replaces
+    (cat -> library convolution -> gate kernels): new hidden state and every gradient (h, motion, context, the six weights and
+    biases)."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.raft2d import GRU2D
+    runtime.set_backend('hip')
+    b, hh, ww = shape
+    torch.manual_seed(7)
+    gru = GRU2D(hidden_dim=128, input_dim=256).cuda()
+    h0 = torch.tanh(torch.randn(b, 128, hh, ww, device='cuda'))
+    context = torch.randn(b, 128, hh, ww, device='cuda')
+    motion = torch.randn(b, 128, hh, ww, device='cuda')
+    gout = torch.randn(b, 128, hh, ww, device='cuda')
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('CAMLI_GRU_CL', mode)
+        monkeypatch.setenv('CAMLI_CONVCL', mode)
+        from camliflow_amd.cores import blocks
+        monkeypatch.setattr(blocks, '_CONVCL', mode == '1')
+        for p_ in gru.parameters():
+            p_.grad = None
+        h, c, m = (t.clone().requires_grad_() for t in (h0, context, motion))
+        state = gru.prepare(c)
+        assert ('cl1' in state) == (mode == '1')
+        out = gru.step(gru.step(h, m, state), m, state)         # two updates: gradients accumulate through the shared state
+        out.backward(gout)
+        res[mode] = [out.detach(), h.grad, c.grad, m.grad] + [p_.grad.clone() for p_ in gru.parameters()]
+    names = ['output', 'gradient of h', 'gradient of context', 'gradient of motion'] + [n for n, _ in gru.named_parameters()]
+    for a, bb, name in zip(res['1'], res['0'], names):
+        scale = max(1.0, float(bb.abs().max()))
+        assert float((a - bb).abs().max()) <= 1e-4 * scale, (name, float((a - bb).abs().max()), scale)
