@@ -92,6 +92,23 @@ def cases(batch):
                                                 'camli_allpairs_fold_bwd': 'hbm',
                                                 'camli_allpairs_lookup_fwd': 'hbm', 'camli_allpairs_lookup_bwd': 'hbm'}
 
+    # ---- (f)2 GRU2D: one update (both half-steps) on the channels-last matrix-core kernels, forward + backward (r5) ----
+    from camliflow_amd.cores.raft2d import GRU2D
+    gru = GRU2D(hidden_dim=128, input_dim=256).cuda()
+    gh0 = torch.tanh(_randn(g, b, 128, h, w)).requires_grad_(True)
+    gctx = _randn(g, b, 128, h, w)
+    gmot = _randn(g, b, 128, h, w).requires_grad_(True)
+    ggo = _randn(g, b, 128, h, w)
+    gstate = {}
+
+    def gru2d():
+        if not gstate:
+            gstate['s'] = gru.prepare(gctx)
+        out = gru.step(gh0, gmot, gstate['s'])
+        torch.autograd.grad(out, [gh0, gmot] + [p_ for p_ in gru.parameters() if p_.dim() == 4], ggo, retain_graph=True, allow_unused=True)
+    yield 'gru2d B%d 68x120' % b, gru2d, {'camli_convcl_gru_gates': 'mfma', 'camli_convcl_gru_blend': 'mfma', 'camli_convcl_fwd': 'mfma',
+                                         'camli_convcl_wrw': 'mfma'}
+
     # ---- A4 furthest point sampling ---------------------------------------------------------------------------
     xyz = _rand(g, 2 * b, 8192, 3, scale=10.0)
     yield 'fps B%d 8192->4096' % (2 * b), (lambda: csrc.furthest_point_sampling(xyz, 4096)), {'camli_fps': 'fps'}
