@@ -63,6 +63,7 @@ NORTH_STAR = {
     'camli_corr3d_gather_fwd': 'hbm', 'camli_corr3d_gather_bwd': 'hbm',
     'camli_corr3d_cost_levels_fwd': 'fma', 'camli_corr3d_cost_levels_bwd': 'fma',
     'camli_corr3d_mlp_fwd': 'fma', 'camli_corr3d_mlp_bwd': 'fma',      # plain fp32 FMA on the vector ALU (registers only)
+    'camli_convcl_gru_gates': 'mfma', 'camli_convcl_gru_blend': 'mfma', 'camli_convcl_fwd': 'mfma', 'camli_convcl_wrw': 'mfma',
     'camli_pwc3d_pair_fwd': 'hbm', 'camli_pwc3d_pair_bwd': 'hbm', 'camli_gather_wsum_fwd': 'hbm', 'camli_gather_wsum_bwd': 'hbm',
 }
 MFMA_F32_PEAK_TFLOPS = 157.3
@@ -352,6 +353,32 @@ def cpu_baseline_and_reference(args, state_dict, deadline=None):
     return base, batch, ref
 
 
+def cpu_all_cores_point(args, state_dict):
+    """SURVEY 8d also asks for the CPU path at all physical cores: one more batch-1 training step of the port with torch's
+    thread count = the physical core count (the 8-thread figure above is its best: round 2 measured 6.9 s at 8 threads,
+    50 s at 128).  Runs LAST, under its own deadline."""
+    from modelutils import oracle_boundary
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:      # noqa: BLE001
+        cores = os.cpu_count()
+    model = build_model(args).train()
+    model.load_state_dict(state_dict)
+    opt = make_optimizer(model)
+    batch = synthetic_batch(1, args.height, args.width, args.points, seed=1, kitti=args.config == 'kitti')
+    before = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        with oracle_boundary():
+            t0 = time.perf_counter()
+            train_step(model, opt, batch)
+            dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(before)
+    return {'value': round(1.0 / dt, 5), 'cores': cores, 'seconds_per_step': round(dt, 1), 'sample': 'one batch-1 training step, no warm-up'}
+
+
 def parity_check(args, state_dict, batch, ref, device):
     """The HIP path on the sample the CPU port just ran, with SHARED post-IDS core inputs (the IDS transform uses
     log / divide, which differ in the last ulp between CPU and GPU, and FPS -- 4096 chained arg-max decisions -- is
@@ -402,7 +429,10 @@ def parity_check(args, state_dict, batch, ref, device):
     return res
 
 
-SIDE_CONFIGS = ('camlipwc', 'kitti')       # BASELINE configs[1] and configs[4]: one short run each after the headline's legs
+SIDE_CONFIGS = ('camlipwc', 'kitti', 'ddp4')   # BASELINE configs[1], configs[4] and the per-rank cost of configs[3]
+# ddp4 = what ONE rank of configs[3] (batch 32 over 8 GPUs, train.py:99-101,307) runs: batch 4, SyncBatchNorm, broadcast,
+# the flat gradient all-reduce, on a 1-rank RCCL group (CAMLI_FORCE_DIST=1) -- the collectives cross no link here, so this is
+# the per-rank compute + launch cost of that configuration, not its scaling
 
 
 def side_configs(budget):
@@ -418,11 +448,18 @@ def side_configs(budget):
         cmd = [sys.executable, os.path.abspath(__file__), '--config', name, '--steps', '5', '--warmup', '2',
                '--no-cpu-baseline', '--no-isolated']
         env = dict(os.environ, CAMLI_BENCH_DETAIL='bench_detail_%s.json' % name)
+        if name == 'ddp4':
+            cmd = [sys.executable, os.path.abspath(__file__), '--config', 'camliraft', '--batch', '4', '--steps', '5', '--warmup', '2',
+                   '--no-cpu-baseline', '--no-isolated', '--no-side-configs']
+            env.update(CAMLI_FORCE_DIST='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+                       MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
         t0 = time.perf_counter()
         try:
             res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=left - 15)
             rec = json.loads(res.stdout.strip().splitlines()[-1])
             out[name] = {'ms_per_step': rec['ms_per_step'], 'value': rec['value'], 'dtype': rec['dtype'], 'steps': rec['steps']}
+            if name == 'ddp4':
+                out[name].update(batch=4, n_iters=12, sync_bn=True, ranks=1, collectives='1-rank RCCL group')
         except subprocess.TimeoutExpired:
             out[name] = {'skipped': 'did not finish in %.0f s' % (left - 15)}
         except Exception as exc:      # noqa: BLE001 -- an optional leg never costs the line
@@ -432,17 +469,18 @@ def side_configs(budget):
 
 
 def pmc_traffic(entry_point, args):
-    """HBM bytes per launch of `entry_point` from the committed PMC measurement of this same workload
-    (profiles/roofline_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
-    bench.py, corrected as MI355X_MICROARCH.md prescribes).  None when no matching record exists."""
+    """(HBM bytes per launch of `entry_point`, where the figure comes from): the committed PMC measurement of this same
+    workload (profiles/roofline_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py, corrected
+    as MI355X_MICROARCH.md prescribes) -- a STORED figure of an earlier pass, not a measurement of this run, and the line says
+    so.  (None, None) when no matching record exists."""
     path = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
     if not os.path.exists(path):
-        return None
+        return None, None
     want = {'batch': args.batch, 'iters': args.iters, 'height': args.height, 'width': args.width, 'points': args.points}
     for rec in json.load(open(path)):
         if rec.get('entry_point') == entry_point and rec.get('workload') == want:
-            return rec['traffic_bytes_per_launch']
-    return None
+            return rec['traffic_bytes_per_launch'], 'stored PMC pass %s (profiles/roofline_traffic.json), not this run' % rec.get('round', 'r03')
+    return None, None
 
 
 def roofline_report(summary, steps, args, step_ms):
@@ -501,8 +539,9 @@ def roofline_report(summary, steps, args, step_ms):
         achieved, peak, unit, per_launch = rec['work'] / secs / 1e9, VALU_PAIR_PEAK_G, 'Gpairs/s', rec['work'] / rec['launches']
     else:                    # fps: fraction of the register-resident ideal step time
         achieved, peak, unit, per_launch = table[name]['frac'] * 100.0, 100.0, '% of ideal step rate', rec['work'] / rec['launches']
+    traffic, traffic_source = pmc_traffic(name, args)
     roofline = {'kernel': name, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(kind, kind), 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
-                'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(name, args), 'launches': rec['launches'],
+                'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source, 'launches': rec['launches'],
                 'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
                 'algorithmic_work_per_launch': round(per_launch), 'measured': 'in situ: HIP events on the launch stream, timed region'}
     # the north-star entry point FURTHEST below its roofline among those that hold at least 1 % of the step
@@ -512,6 +551,38 @@ def roofline_report(summary, steps, args, step_ms):
         roofline['worst'] = {'kernel': worst, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(NORTH_STAR[worst], NORTH_STAR[worst]),
                              'frac': table[worst]['frac'], 'ms_per_step': table[worst]['ms_per_step']}
     return roofline, table
+
+
+def step_floor(step_fn, step_ms):
+    """Where the STEP stands against the hardware: one extra, instrumented step after the timed region.
+      mfma_flop  = floating-point work of every library convolution / GEMM of the step, forward and backward
+                   (torch.utils.flop_counter over the aten operators) + the flop the own matrix-core kernels declare
+      hbm_bytes  = the ALGORITHMIC bytes the own HBM-bound kernels declare (DESIGN section 5 formulas; the library's
+                   streamed bytes are not counted -- its kernels are priced by their flop alone)
+      floor_ms   = mfma_flop / 157.3 TFLOP/s + hbm_bytes / 8 TB/s       (no overlap of the two assumed)
+      frac       = floor_ms / ms_per_step"""
+    from torch.utils.flop_counter import FlopCounterMode
+    from camliflow_amd.csrc import _lib
+    _lib.TIMER.reset()
+    only = _lib.TIMER.only
+    _lib.TIMER.only = None
+    _lib.TIMER.enabled = True
+    counter = FlopCounterMode(display=False)
+    with counter:
+        step_fn()
+    torch.cuda.synchronize()
+    _lib.TIMER.enabled = False
+    _lib.TIMER.only = only
+    summary = _lib.TIMER.summary()
+    _lib.TIMER.reset()
+    lib_flop = float(counter.get_total_flops())
+    # (the pyramid adjoint executes only the K steps the lookups marked -- ~20 % of its dense product -- and is left out: the
+    # floor errs low, never high)
+    own_flop = sum(r['flop'] for n, r in summary.items() if NORTH_STAR.get(n) == 'mfma' and n != 'camli_allpairs_build_bwd')
+    own_bytes = sum(r['work'] for n, r in summary.items() if r['unit'] == 'B' and NORTH_STAR.get(n, 'hbm') == 'hbm')
+    floor_ms = (lib_flop + own_flop) / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3 + own_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
+    return {'mfma_flop': round(lib_flop + own_flop), 'library_flop': round(lib_flop), 'hbm_bytes': round(own_bytes),
+            'floor_ms': round(floor_ms, 1), 'frac': round(min(floor_ms / step_ms, 1.0), 4)}
 
 
 def write_detail(full, config='camliraft'):
@@ -541,8 +612,8 @@ def compact_line(full, detail_path=None):
     line = {k: full[k] for k in CONTRACT_KEYS if k in full}
     roof = full.get('roofline')
     if roof is not None:
-        keep = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_us', 'launches',
-                'algorithmic_work_per_launch', 'measured')
+        keep = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'frac_single_lane', 'avg_launch_us',
+                'launches', 'algorithmic_work_per_launch', 'measured', 'step')
         line['roofline'] = {k: roof[k] for k in keep if k in roof}
         if 'single_lane' in roof:
             line['roofline']['single_lane'] = {k: roof['single_lane'][k] for k in ('avg_launch_us', 'achieved', 'frac')}
@@ -551,7 +622,7 @@ def compact_line(full, detail_path=None):
         assert line['roofline']['frac'] <= 1.0, 'a roofline fraction above 1 is a mis-stated work figure'
     base = full.get('cpu_baseline')
     if base is not None:
-        line['cpu_baseline'] = {k: base[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model', 'os_cpu_count') if k in base}
+        line['cpu_baseline'] = {k: base[k] for k in ('value', 'unit', 'cores', 'kind', 'sample', 'cpu_model', 'os_cpu_count', 'all_cores') if k in base}
     par = full.get('parity')
     if par is not None:
         line['parity'] = {k: par[k] for k in ('epe2d_abs_diff', 'epe3d_abs_diff', 'fps_equal', 'knn_equal', 'tolerance', 'ok')}
@@ -769,6 +840,13 @@ def main():
                                            'achieved': round(rate, 2), 'frac': round(rate / roofline['peak'], 4),
                                            'launches': rec['launches'],
                                            'measured': '2 extra steps after the timed region with CAMLI_OVERLAP=0 semantics'}
+                # the same figure as a scalar (a parser that keeps scalars only dropped the object above in round 4)
+                roofline['frac_single_lane'] = roofline['single_lane']['frac']
+        if roofline is not None and graphed is None and not dist_on and os.environ.get('CAMLI_NO_STEP_FLOOR') != '1':
+            try:
+                roofline['step'] = step_floor(step, step_ms)
+            except Exception as exc:      # noqa: BLE001 -- an optional figure never costs the line
+                _log('step floor FAILED: %s: %s' % (type(exc).__name__, str(exc)[:200]))
         what = {'train': 'training step (fwd + losses + bwd + clip + AdamW)', 'eval': 'inference forward'}[args.mode]
         metric = 'frame-pairs/sec (fwd+bwd) 960x540 + 8192 pts, CamLiRAFT' if args.config == 'camliraft' else \
                  'frame-pairs/sec, %s %s, %dx%d + %d pts' % (args.model, args.mode, args.width, args.height, args.points)
@@ -783,7 +861,7 @@ def main():
                                       ('%d GRU iters' % args.iters) if args.iters else 'coarse-to-fine pyramid',
                                       args.batch, stands_for),
                        'global_batch': global_batch, 'parallelism': 'dp%d' % world,
-                       'lanes': 2 if two_lane else 1, 'hip_graph': bool(graphed), 'tuned_gemms': bool(tuned_gemms),
+                       'lanes': 2 if runtime.overlap() else 1, 'hip_graph': bool(graphed), 'tuned_gemms': bool(tuned_gemms),
                        'loss': round(float(loss.detach()), 4),
                        'host_enqueue_ms_per_step': round(host_s / args.steps * 1e3, 1),
                        'hip_launches_per_step': round(sum(census['fused'].values()) / roofline_steps, 1)},
@@ -828,6 +906,21 @@ def main():
                     _log('parity check done')
         if world == 1 and args.config == 'camliraft' and not args.no_side_configs:
             line['side_configs'] = side_configs(budget)
+        if (world == 1 and not args.no_cpu_baseline and args.model == 'camliraft' and not overrun and line.get('cpu_baseline', {}).get('value')
+                and os.environ.get('CAMLI_CPU_ALL_CORES', '1') == '1'):
+            # the all-physical-cores point of the CPU port, after everything else (it occupies every core): only when a
+            # generous margin is left -- 128 threads took 50 s per step in round 2
+            left = budget - 10.0 - _elapsed()
+            if left >= 90.0:
+                got, why = run_with_deadline(lambda: cpu_all_cores_point(args, state_dict), left)
+                if got is None:
+                    overrun = True
+                    line['cpu_baseline']['all_cores'] = {'skipped': why}
+                else:
+                    line['cpu_baseline']['all_cores'] = got
+                _log('CPU port at all physical cores: %s' % line['cpu_baseline']['all_cores'])
+            else:
+                line['cpu_baseline']['all_cores'] = {'skipped': 'time budget: %.0f s left' % left}
         detail_path = write_detail(line, args.config)
         # RCCL writes its version banner through C stdio when the communicator is created; flush it so that the JSON
         # line is the LAST line on stdout

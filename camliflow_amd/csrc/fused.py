@@ -2310,21 +2310,32 @@ class _BiasActRes(torch.autograd.Function):
         return gx, gbias, gx, None
 
 
+def _fresh_fp32(x, keep_layout=False):
+    """The tensor the in-place epilogues overwrite must be the very object handed to ``Function.apply`` (ctx.mark_dirty on
+    anything else -- a dtype cast made by custom_fwd under autocast, a ``.contiguous()`` copy made inside forward -- is what
+    torch warns it will stop tolerating): make those copies HERE, as ordinary differentiable operations."""
+    if x.dtype != torch.float32:
+        x = x.float()
+    if not keep_layout and not x.is_contiguous():
+        x = x.contiguous()
+    return x
+
+
 def bias_act_res(x, bias, res, act):
     """act(x + bias[c] + res) in place on the fresh convolution output x; act None or 'relu'; res shaped like x."""
     _require_cuda('bias_act_res', x, bias, res)
     assert act in (None, 'relu') and res.shape == x.shape
     if _nhwc_epilogue_ok(x, ACT_CODES[act]):
-        return _BiasActNHWC.apply(x, bias.float().contiguous(), res.float(), ACT_CODES[act])
-    return _BiasActRes.apply(x, bias.float(), res.float(), ACT_CODES[act])
+        return _BiasActNHWC.apply(_fresh_fp32(x, keep_layout=True), bias.float().contiguous(), res.float(), ACT_CODES[act])
+    return _BiasActRes.apply(_fresh_fp32(x), bias.float(), res.float(), ACT_CODES[act])
 
 
 def bias_act(x, bias, act):
     """act(x + bias[c]) in place on the (fresh) convolution output x [B,C,...]; ``act`` as in ACT_CODES."""
     _require_cuda('bias_act', x, bias)
     if _nhwc_epilogue_ok(x, ACT_CODES[act]):
-        return _BiasActNHWC.apply(x, bias.float().contiguous(), None, ACT_CODES[act])
-    return _BiasAct.apply(x, bias.float(), ACT_CODES[act])
+        return _BiasActNHWC.apply(_fresh_fp32(x, keep_layout=True), bias.float().contiguous(), None, ACT_CODES[act])
+    return _BiasAct.apply(_fresh_fp32(x), bias.float(), ACT_CODES[act])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -133,3 +133,37 @@ def test_roofline_report_lets_every_kind_compete():
     summary['camli_fps']['total_ms'] = 50.0
     roof, _ = bench.roofline_report(summary, 5, args, step_ms=233.0)
     assert roof['kernel'] == 'camli_fps' and roof['bound'] == 'latency' and roof['frac'] <= 1.0
+
+
+def test_compact_line_round5_fields():
+    """Round 5: the line says where the STEP stands (`roofline.step`: matrix-core flop, streamed bytes, floor,
+    fraction), carries the single-lane fraction as a SCALAR next to the object (a parser that keeps scalars dropped the object),
+    names where `traffic` comes from, prices configs[3]'s per-rank step (`side_configs.ddp4`) and keeps the all-physical-cores
+    CPU point -- all below the limit."""
+    import bench
+    full = _full_line()
+    full['roofline'].update(traffic_source='stored PMC pass r03 (profiles/roofline_traffic.json), not this run', frac_single_lane=0.5,
+                            step={'mfma_flop': 21800000000000, 'library_flop': 17000000000000, 'hbm_bytes': 13300000000,
+                                  'floor_ms': 140.3, 'frac': 0.6452})
+    full['side_configs'] = {'camlipwc': {'ms_per_step': 62.4, 'value': 16.0, 'dtype': 'f32', 'steps': 5},
+                            'kitti': {'ms_per_step': 124.9, 'value': 8.0, 'dtype': 'bf16', 'steps': 5},
+                            'ddp4': {'ms_per_step': 120.0, 'value': 33.3, 'dtype': 'f32', 'steps': 5, 'batch': 4, 'n_iters': 12,
+                                     'sync_bn': True, 'ranks': 1, 'collectives': '1-rank RCCL group'}}
+    full['cpu_baseline']['all_cores'] = {'value': 0.02, 'cores': 64, 'seconds_per_step': 50.0, 'sample': 'one batch-1 training step, no warm-up'}
+    line = bench.compact_line(full, 'gpurun_out/bench_detail.json')
+    assert len(json.dumps(line)) < bench.LINE_LIMIT_BYTES
+    roof = line['roofline']
+    assert set(roof['step']) == {'mfma_flop', 'library_flop', 'hbm_bytes', 'floor_ms', 'frac'} and 0 < roof['step']['frac'] <= 1
+    assert isinstance(roof['frac_single_lane'], float) and 'stored PMC pass' in roof['traffic_source']
+    assert set(line['side_configs']) == {'camlipwc', 'kitti', 'ddp4'} and line['side_configs']['ddp4']['batch'] == 4
+    assert line['cpu_baseline']['all_cores']['cores'] == 64
+    assert 'ddp4' in bench.SIDE_CONFIGS
+
+
+def test_pmc_traffic_names_its_source():
+    import types
+    import bench
+    args = types.SimpleNamespace(batch=8, iters=12, height=540, width=960, points=8192)
+    traffic, source = bench.pmc_traffic('camli_pointconv_dw_fwd', args)
+    assert traffic and 'stored PMC pass' in source and 'not this run' in source
+    assert bench.pmc_traffic('no_such_entry_point', args) == (None, None)
