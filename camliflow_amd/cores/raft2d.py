@@ -143,15 +143,6 @@ class GRU2D(nn.Module):
                 # repo's matrix-core kernels (csrc/hip/convcl.hip, fused._GRU2DStepCL); the hoisted context terms are laid out
                 # NHWC once per pass
                 state['cl' + suffix] = (ctx[:, :2 * hd].permute(0, 2, 3, 1).contiguous(), ctx[:, 2 * hd:].permute(0, 2, 3, 1).contiguous())
-            if runtime.fused() and context.is_cuda and not torch.is_grad_enabled() and os.environ.get('CAMLI_CONV5', '0') == '1':
-                # CAMLI_CONV5=1, inference only: the half-steps run on the implicit-GEMM kernels with the gate arithmetic
-                # in their epilogues (csrc/hip/conv5.hip; no adjoint, so not under autograd), weights packed once per
-                # pass.  OFF by default -- measured in the step (bench.py --config eval, alternating runs on one box):
-                # 121.3 / 121.7 ms with them against 117.8 / 117.8 ms with the library convolutions + gate kernels
-                # (profiles/r04_conv5_experiments.txt): the bare contraction is 0.9 x MIOpen's and what the epilogues
-                # save does not pay for it.
-                from ..csrc import fused
-                state['packed' + suffix] = (fused.pack_conv5_weight(state[suffix][0]), fused.pack_conv5_weight(state[suffix][1]))
         return state
 
     def step(self, h, motion, state):
@@ -161,19 +152,13 @@ class GRU2D(nn.Module):
         from ..csrc import fused
         conv2d = torch.nn.functional.conv2d
         hd = h.shape[1]
-        if ('cl1' in state and 'cl2' in state and 'packed1' not in state and not torch.is_autocast_enabled()
+        if ('cl1' in state and 'cl2' in state and not torch.is_autocast_enabled()
                 and fused.gru2d_step_supported(h, motion, state['1'][0])):
             return fused.gru2d_step_cl(h, motion, (state['1'][0], state['1'][1], state['2'][0], state['2'][1]),
                                        (state['cl1'][0], state['cl1'][1], state['cl2'][0], state['cl2'][1]))
         fusable = h.is_cuda and (hd * h.shape[2] * h.shape[3]) % 4 == 0
         for suffix in ('1', '2'):
             w_zr, w_q, ctx_zr, ctx_q, padding = state[suffix]
-            packed = state.get('packed' + suffix)
-            if packed is not None and not torch.is_grad_enabled() and h.dtype == torch.float32 and motion.dtype == torch.float32 \
-                    and not torch.is_autocast_enabled():
-                z, rh = fused.conv5_gru_gates(h, motion, packed[0], ctx_zr, vertical=(suffix == '2'))
-                h = fused.conv5_gru_blend(rh, motion, packed[1], ctx_q, z, h, vertical=(suffix == '2'), nan_to_num=(suffix == '2'))
-                continue
             # CAMLI_CONV_CL (default on): the two convolutions of a half step on explicitly channels-last operands
             # (blocks._CatConvCL: the cat writes the channels-last input, kept for the weight gradient)
             cl = _CONV_CL and fusable and runtime.fused() and h.dtype == torch.float32 and motion.dtype == torch.float32 \
@@ -191,7 +176,7 @@ class GRU2D(nn.Module):
                 z, r = zr[:, :hd], zr[:, hd:]
                 q = torch.tanh(conv2d(torch.cat([r * h, motion], dim=1), w_q, None, padding=padding) + ctx_q)
                 h = (1 - z) * h + z * q
-        return h if (fusable or state.get('packed2') is not None and not torch.is_grad_enabled()) else torch.nan_to_num(h)
+        return h if fusable else torch.nan_to_num(h)
 
 
 def _conv(cin, cout, ksize):

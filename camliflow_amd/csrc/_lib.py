@@ -126,8 +126,6 @@ PROTOTYPES = {
     "camli_ids_flow_bwd": (_int, [_c_float_p] * 7 + [ctypes.c_float] * 5 + [_int, _int, _stream]),
     "camli_persp2paral": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int] + [ctypes.c_float] * 5 + [_stream]),
     "camli_project_pc2image": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int] + [ctypes.c_float] * 4 + [_stream]),
-    "camli_conv5_fwd": (_int, [_c_float_p, _int, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                               _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _int, _int, _stream]),
     "camli_convcl_fwd": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _c_float_p, _int, _int, _c_float_p, _int,
                                 _int, _int, _int, _int, _int, ctypes.c_char_p, ctypes.c_char_p, _int, _int, _stream]),
     "camli_convcl_gru_gates": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,

@@ -1684,59 +1684,6 @@ def gru_blend(pre_q, ctx_q, z, h, nan_to_num=False):
 
 
 # ------------------------------------------------------------------------------------------------
-# GRU2D's separable convolutions as implicit GEMMs with the gate arithmetic in the epilogue (csrc/hip/conv5.hip, round 4).
-# INFERENCE only: the kernels have no adjoints (the training path keeps the library convolutions -- the contraction alone
-# runs at 0.9 x their rate, profiles/r04_conv5_experiments.txt -- followed by gru_gates / gru_blend above).
-# ------------------------------------------------------------------------------------------------
-def pack_conv5_weight(w):
-    """[Cout, Cin, 1, 5] or [Cout, Cin, 5, 1] -> the kernels' layout [Cin, 5 taps, Cout]; once per pass."""
-    assert w.dim() == 4 and sorted(w.shape[2:]) == [1, 5]
-    return w.detach().float().reshape(w.shape[0], w.shape[1], 5).permute(1, 2, 0).contiguous()
-
-
-def _conv5(in0, in1, wp, vertical, epi, bias=None, add=None, h=None, z=None, outs=1, out_channels=None, nan_to_num=False):
-    _require_cuda('conv5', in0, in1, wp)
-    assert not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in (in0, in1, add, h, z)), \
-        'camli_conv5_fwd has no adjoint: inference only'
-    lib = _lib.load()
-    in0, in1 = in0.float().contiguous(), in1.float().contiguous()
-    b, c0, hh, ww = in0.shape
-    c1 = in1.shape[1]
-    cout = wp.shape[2]
-    assert wp.shape[0] == c0 + c1 and wp.shape[1] == 5 and wp.is_contiguous()
-    res = [torch.empty((b, out_channels or cout, hh, ww), dtype=torch.float32, device=in0.device) for _ in range(outs)]
-    ptr = lambda t: t.data_ptr() if t is not None else 0        # noqa: E731
-    with _on_device(in0):
-        _lib.launch('camli_conv5_fwd', lib.camli_conv5_fwd, in0.data_ptr(), c0, in1.data_ptr(), c1, wp.data_ptr(), ptr(bias),
-                    ptr(add), ptr(h), ptr(z), res[0].data_ptr(), res[1].data_ptr() if outs > 1 else 0, 0, b, cout, hh, ww,
-                    int(bool(vertical)), epi, int(bool(nan_to_num)), _stream_ptr(in0),
-                    work=(4.0 * (in0.numel() + in1.numel() + sum(r.numel() for r in res)), 'B'),
-                    flop=2.0 * b * hh * ww * cout * (c0 + c1) * 5)
-    return res
-
-
-def conv5(in0, in1, wp, vertical, bias=None):
-    """conv2d(cat([in0, in1], 1), w, bias, padding 2 along the kernel) for a 1x5 (vertical=False) / 5x1 kernel."""
-    return _conv5(in0, in1, wp, vertical, 0, bias=bias)[0]
-
-
-def conv5_gru_gates(h, x, wp_zr, ctx_zr, vertical):
-    """(z, r*h) of one GRU half-step (raft_core.py:124-126 / 132-134) straight from h and x: the z|r convolution of
-    cat([h, x]) with the hoisted context term added and the sigmoid / product in the kernel's epilogue."""
-    ctx_zr, hc = ctx_zr.float().contiguous(), h.float().contiguous()
-    assert ctx_zr.shape[1] == wp_zr.shape[2] == 2 * h.shape[1]
-    z, rh = _conv5(hc, x, wp_zr, vertical, 1, add=ctx_zr, h=hc, outs=2, out_channels=h.shape[1])
-    return z, rh
-
-
-def conv5_gru_blend(rh, x, wp_q, ctx_q, z, h, vertical, nan_to_num=False):
-    """h' = (1 - z) h + z tanh(conv(cat([r*h, x])) + ctx_q) (raft_core.py:127-130 / 135-138), one kernel."""
-    ctx_q, z, hc = ctx_q.float().contiguous(), z.float().contiguous(), h.float().contiguous()
-    assert ctx_q.shape[1] == wp_q.shape[2] == h.shape[1]
-    return _conv5(rh, x, wp_q, vertical, 2, add=ctx_q, h=hc, z=z, nan_to_num=nan_to_num)[0]
-
-
-# ------------------------------------------------------------------------------------------------
 # bias + activation epilogue (models/mlp.py:41-128, models/raft_core.py:155-197)
 # ------------------------------------------------------------------------------------------------
 ACT_CODES = {None: 0, 'none': 0, 'relu': 1, 'leaky_relu': 2, 'sigmoid': 3, 'tanh': 4,

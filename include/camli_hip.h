@@ -586,20 +586,6 @@ int camli_project_pc2image(const float *pc, const float *intrinsics, float *uv, 
 int camli_conv3x3_co2_fwd(const float *x, const float *w, const float *bias, float *y, int B, int Cin, int H, int W,
                           void *stream);
 
-/* Separable 5-tap convolutions of the RAFT update block (models/raft_core.py:110-140, GRU2D: Conv2d(hidden + input,
- * hidden, (1,5) | (5,1), padding (0,2) | (2,0))) as implicit GEMMs on the fp32 matrix cores (round 4, csrc/hip/conv5.hip).
- * The input is cat[in0 (C0 channels), in1 (C1 channels)] read through two pointers, fp32 NCHW [B,C,H,W]; wp = the
- * weights packed as [C0 + C1][5 taps][Cout] (from the [Cout, Cin, 1, 5] / [Cout, Cin, 5, 1] tensor: fused.pack_conv5_weight);
- * vertical = 0: 1x5, 1: 5x1.  epi selects the epilogue:
- *   0  out [B,Cout,H,W] = conv (+ bias[Cout] or NULL)
- *   1  GRU gates (raft_core.py:124-126, 132-134): s = sigmoid(conv + add), add [B,Cout,H,W] = the per-pass context term;
- *      rows [0, Cout/2) are z, rows [Cout/2, Cout) are r:  out = z, out2 = r * h, out3 = r (NULL to skip), h [B,Cout/2,H,W]
- *   2  GRU blend (raft_core.py:127-130, 135-138): q = tanh(conv + add); out = (1 - z) h + z q (nan_to_num != 0: followed by
- *      torch.nan_to_num), out2 = q (NULL to skip); z, h [B,Cout,H,W]
- */
-int camli_conv5_fwd(const float *in0, int C0, const float *in1, int C1, const float *wp, const float *bias,
-                    const float *add, const float *h, const float *z, float *out, float *out2, float *out3, int B, int Cout,
-                    int H, int W, int vertical, int epi, int nan_to_num, void *stream);
 /*
  * Channels-last ("tap") convolution on the fp32 matrix cores (round 5, csrc/hip/convcl.h, wrwcl.h): GRU2D's 1x5 / 5x1
  * convolutions (models/raft_core.py:110-140: nn.Conv2d(hidden + input, hidden, (1, 5) | (5, 1), padding (0, 2) | (2, 0))) with both
