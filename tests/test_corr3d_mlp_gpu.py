@@ -1,5 +1,6 @@
 """Fused cost MLP + neighbour sum of the RAFT-style point cost-volume lookup (camli_corr3d_mlp_fwd/bwd,
-camliraft_l_core.py:96-100) against the torch composition of the same layers in fp32: values, the gradient of the
+camliraft_l_core.py:96-100) against oracle/dense.cost_mlp_fwd / _bwd (numpy in float64, pinned on the reference's own
+cost_mlp with autograd: tests/test_dense_oracle.py; round 4 compared with torch on the same GPU): values, the gradient of the
 cost-volume entry (channel 3 of the lookup input -- the only differentiable one on this path) and the four parameter
 gradients, returned to autograd or accumulated through the deferred-parameter sink."""
 import pytest
@@ -18,7 +19,7 @@ def _reference(lookup, w1, b1, w2, b2, levels):
 
 @pytest.mark.parametrize('shape', [(1, 8), (2, 64), (3, 200), (8, 2048)], ids=str)
 @pytest.mark.parametrize('deferred', [False, True])
-def test_cost_mlp_vs_torch(shape, deferred):
+def test_cost_mlp_vs_oracle(shape, deferred, oracle_dense):
     from camliflow_amd.cores import runtime
     from camliflow_amd.csrc import fused
     b, n = shape
@@ -32,13 +33,15 @@ def test_cost_mlp_vs_torch(shape, deferred):
     gout = torch.randn(b, 128, n, generator=g).cuda()
     assert fused.corr3d_cost_mlp_supported(lookup, [conv1, conv2], 4)
 
-    # reference in float64: the parameter gradients are sums over up to 1 M columns, where two fp32 summation orders
-    # differ by more than either differs from the exact value
-    params64 = [p.detach().double().requires_grad_(True) for p in (conv1.weight, conv1.bias, conv2.weight, conv2.bias)]
-    lookup64 = lookup.detach().double().requires_grad_(True)
-    want = _reference(lookup64, *params64, 4)
-    want.backward(gout.double())
-    ref = [want.detach(), lookup64.grad[:, 3]] + [p.grad for p in params64]
+    # reference in float64 (the oracle computes in float64): the parameter gradients are sums over up to 1 M columns, where
+    # two fp32 summation orders differ by more than either differs from the exact value
+    npar = [p.detach().cpu().numpy() for p in (conv1.weight, conv1.bias, conv2.weight, conv2.bias)]
+    w1n, b1n, w2n, b2n = npar[0].reshape(32, 4), npar[1], npar[2].reshape(32, 32), npar[3]
+    lookup_n, gout_n = lookup.detach().cpu().numpy(), gout.cpu().numpy()
+    want_n = oracle_dense.cost_mlp_fwd(lookup_n, w1n, b1n, w2n, b2n, 4)
+    gx_n, gw1_n, gb1_n, gw2_n, gb2_n = oracle_dense.cost_mlp_bwd(gout_n, lookup_n, w1n, b1n, w2n, b2n, 4)
+    ref = [torch.from_numpy(a).double().cuda() for a in (want_n, gx_n[:, 3], gw1_n.reshape(32, 4, 1, 1), gb1_n,
+                                                          gw2_n.reshape(32, 32, 1, 1), gb2_n)]
     # ... and the fp32 torch composition, to know what fp32 itself costs on this input: ReLU's derivative is discontinuous,
     # among 33 M (column, unit) pairs a few pre-activations sit within one rounding of zero, and a gradient term that
     # takes the other side there moves a parameter gradient by a whole term

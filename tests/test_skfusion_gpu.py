@@ -1,7 +1,13 @@
-"""camli_sk_* (selective-kernel fusion, full-size part) against the torch formulation of
-models/clfm.py:170-213: fp32, tolerances stated."""
+"""camli_sk_* (selective-kernel fusion, full-size part) against oracle/glue.py (numpy in float64, forward and hand-written
+adjoints, pinned on the reference's own SKFusion with autograd: tests/test_glue_oracle.py; models/clfm.py:170-213).  Round 4
+compared these kernels with torch on the same GPU."""
+import numpy as np
 import pytest
 import torch
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 pytestmark = pytest.mark.gpu
 
@@ -9,36 +15,33 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(8, 128, 68, 120), (2, 64, 2048), (3, 5, 7, 9), (1, 16, 1)],
                          ids=lambda s: 'x'.join(map(str, s)))
 @pytest.mark.parametrize('w_grad', [True, False], ids=['gate_differentiable', 'gate_constant'])
-def test_pool_and_mix_vs_torch(shape, w_grad):
+def test_pool_and_mix_vs_oracle(shape, w_grad):
     from camliflow_amd.csrc import fused
+    from oracle import glue
     torch.manual_seed(sum(shape))
     a0 = torch.randn(*shape, device='cuda')
     b0 = torch.randn(*shape, device='cuda')
     lin = torch.nn.Linear(shape[1], 2 * shape[1], bias=False).cuda().requires_grad_(w_grad)
     gout = torch.randn(*shape, device='cuda')
-    res = []
-    for impl in ('hip', 'torch'):
-        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
-        lin.zero_grad()
-        if impl == 'hip':
-            state = fused.SkState()
-            s = fused.sk_pool(a, b, state)
-            w = torch.softmax(lin(s).reshape(shape[0], -1, 2), dim=-1)
-            out = fused.sk_mix(a, b, w, state)
-        else:
-            s = (a + b).flatten(2).mean(-1)
-            w = torch.softmax(lin(s).reshape(shape[0], -1, 2), dim=-1)
-            bshape = [shape[0], -1] + [1] * (len(shape) - 2)
-            out = a * w[..., 0].reshape(bshape) + b * w[..., 1].reshape(bshape)
-        out.backward(gout)
-        res.append((s.detach(), out.detach(), a.grad, b.grad, lin.weight.grad.clone() if w_grad else None))
-    (s1, o1, ga1, gb1, gl1), (s2, o2, ga2, gb2, gl2) = res
-    assert torch.allclose(s1, s2, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(o1, o2, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(ga1, ga2, rtol=1e-4, atol=1e-5)
-    assert torch.allclose(gb1, gb2, rtol=1e-4, atol=1e-5)
-    if w_grad:
-        assert (gl1 - gl2).norm() <= 1e-4 * gl2.norm() + 1e-6
+    a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    state = fused.SkState()
+    s = fused.sk_pool(a, b, state)
+    w = torch.softmax(lin(s).reshape(shape[0], -1, 2), dim=-1)
+    w.retain_grad()
+    s.retain_grad()
+    out = fused.sk_mix(a, b, w, state)
+    out.backward(gout)
+    an, bn, gn = a0.cpu().numpy(), b0.cpu().numpy(), gout.cpu().numpy()
+    want_s = glue.sk_pool_fwd(an, bn)
+    want_out = glue.sk_mix_fwd(an, bn, w.detach().cpu().numpy())
+    # the gradient reaching s comes through the (torch) gate between the two kernels: taken from autograd
+    gs = s.grad.cpu().numpy() if (w_grad or s.grad is not None) and s.grad is not None else np.zeros_like(want_s)
+    want_ga, want_gb, want_gw = glue.sk_fuse_bwd(gn, an, bn, w.detach().cpu().numpy(), gs)
+    assert torch.allclose(s.detach(), _t(want_s), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out.detach(), _t(want_out), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(a.grad, _t(want_ga), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(b.grad, _t(want_gb), rtol=1e-4, atol=1e-5)
+    assert (w.grad - _t(want_gw)).norm() <= 1e-4 * _t(want_gw).norm() + 1e-6
 
 
 @pytest.mark.parametrize('fmt', ['nchw', 'ncm'])
@@ -67,23 +70,18 @@ def test_skfusion_module_hip_vs_composed(fmt):
 
 @pytest.mark.parametrize('dims', [(8, 128, 64), (3, 20, 7), (1, 256, 128), (8, 324, 162), (2, 512, 256), (1, 627, 313), (2, 1024, 512)],
                          ids=lambda d: 'B%d_C%d_R%d' % d)
-def test_gate_vs_torch(dims):
+def test_gate_vs_oracle(dims):
     from camliflow_amd.csrc import fused
+    from oracle import glue
     b, c, r = dims
     torch.manual_seed(sum(dims))
-    s0 = torch.randn(b, c, device='cuda')
+    s = torch.randn(b, c, device='cuda').requires_grad_(True)
     wmid = (torch.randn(r, c, device='cuda') * c ** -0.5).requires_grad_(True)
     wout = (torch.randn(2 * c, r, device='cuda') * r ** -0.5).requires_grad_(True)
     gw = torch.randn(b, c, 2, device='cuda')
-    res = []
-    for impl in ('hip', 'torch'):
-        s = s0.clone().requires_grad_(True)
-        wmid.grad = wout.grad = None
-        if impl == 'hip':
-            w = fused.sk_gate(s, wmid, wout)
-        else:
-            w = torch.softmax(torch.sigmoid(torch.relu(s @ wmid.t()) @ wout.t()).reshape(b, c, 2), dim=-1)
-        w.backward(gw)
-        res.append((w.detach(), s.grad, wmid.grad.clone(), wout.grad.clone()))
-    for x, y in zip(*res):
-        assert torch.allclose(x, y, rtol=1e-4, atol=1e-6), (x - y).abs().max()
+    w = fused.sk_gate(s, wmid, wout)
+    w.backward(gw)
+    sn, wm, wo = s.detach().cpu().numpy(), wmid.detach().cpu().numpy(), wout.detach().cpu().numpy()
+    want = [glue.sk_gate_fwd(sn, wm, wo)] + list(glue.sk_gate_bwd(gw.cpu().numpy(), sn, wm, wo))
+    for x, y in zip((w.detach(), s.grad, wmid.grad, wout.grad), want):
+        assert torch.allclose(x, _t(y), rtol=1e-4, atol=1e-6), (x - _t(y)).abs().max()

@@ -1,10 +1,10 @@
 """Two-channel 3x3 convolution heads (csrc/hip/smallconv.hip: FlowHead2D.conv2 of raft_core.py:169-181, PWC's
-conv_last) against torch's fp32 convolution on the same device -- forward, data gradient, weight and bias gradients;
+conv_last) against oracle/dense.conv3x3_fwd / _bwd (numpy in float64, pinned on the reference's FlowHead2D with autograd:
+tests/test_dense_oracle.py; round 4 compared with torch on the same GPU) -- forward, data gradient, weight and bias gradients;
 tolerances are those of a 2304-term fp32 dot product in a different summation order.  Weight gradients are
 bit-reproducible (no atomics)."""
 import pytest
 import torch
-import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -13,7 +13,8 @@ CASES = [(8, 256, 68, 120), (1, 256, 47, 156), (2, 529, 9, 15), (1, 7, 1, 1), (3
 
 @pytest.mark.parametrize('case', CASES, ids=lambda c: 'B%d_C%d_%dx%d' % c)
 @pytest.mark.parametrize('with_bias', [True, False])
-def test_conv3x3_co2_vs_torch(case, with_bias):
+def test_conv3x3_co2_vs_oracle(case, with_bias, oracle_dense):
+    import numpy as np
     from camliflow_amd.csrc import fused
     b, c, h, w = case
     g = torch.Generator().manual_seed(sum(case))
@@ -24,8 +25,10 @@ def test_conv3x3_co2_vs_torch(case, with_bias):
 
     y = fused.conv3x3_co2(x, wt, bias)
     grads = torch.autograd.grad(y, [x, wt] + ([bias] if with_bias else []), gy)
-    y_ref = F.conv2d(x, wt, bias, padding=1)
-    refs = torch.autograd.grad(y_ref, [x, wt] + ([bias] if with_bias else []), gy)
+    xn, wn, gn = x.detach().cpu().numpy(), wt.detach().cpu().numpy(), gy.cpu().numpy()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+    y_ref = dev(oracle_dense.conv3x3_fwd(xn, wn, bias.detach().cpu().numpy() if with_bias else None))
+    refs = [dev(a) for a in oracle_dense.conv3x3_bwd(gn, xn, wn)][:3 if with_bias else 2]
     assert torch.allclose(y, y_ref, rtol=1e-4, atol=1e-5), (y - y_ref).abs().max().item()
     for name, got, ref in zip(('gx', 'gw', 'gb'), grads, refs):
         err = (got - ref).norm().item() / max(ref.norm().item(), 1e-12)
