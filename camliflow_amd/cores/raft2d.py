@@ -143,6 +143,10 @@ class GRU2D(nn.Module):
                 # repo's matrix-core kernels (csrc/hip/convcl.hip, fused._GRU2DStepCL); the hoisted context terms are laid out
                 # NHWC once per pass
                 state['cl' + suffix] = (ctx[:, :2 * hd].permute(0, 2, 3, 1).contiguous(), ctx[:, 2 * hd:].permute(0, 2, 3, 1).contiguous())
+        if 'cl1' in state and 'cl2' in state:
+            from ..csrc import fused
+            state['hub'] = fused.GRU2DPass((state['1'][0], state['1'][1], state['2'][0], state['2'][1]),
+                                           (state['cl1'][0], state['cl1'][1], state['cl2'][0], state['cl2'][1]))
         return state
 
     def step(self, h, motion, state):
@@ -152,10 +156,8 @@ class GRU2D(nn.Module):
         from ..csrc import fused
         conv2d = torch.nn.functional.conv2d
         hd = h.shape[1]
-        if ('cl1' in state and 'cl2' in state and not torch.is_autocast_enabled()
-                and fused.gru2d_step_supported(h, motion, state['1'][0])):
-            return fused.gru2d_step_cl(h, motion, (state['1'][0], state['1'][1], state['2'][0], state['2'][1]),
-                                       (state['cl1'][0], state['cl1'][1], state['cl2'][0], state['cl2'][1]))
+        if 'hub' in state and not torch.is_autocast_enabled() and fused.gru2d_step_supported(h, motion, state['1'][0]):
+            return fused.gru2d_step_cl(h, motion, state['hub'])
         fusable = h.is_cuda and (hd * h.shape[2] * h.shape[3]) % 4 == 0
         for suffix in ('1', '2'):
             w_zr, w_q, ctx_zr, ctx_q, padding = state[suffix]

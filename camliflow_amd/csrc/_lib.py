@@ -133,7 +133,8 @@ PROTOTYPES = {
     "camli_convcl_gru_blend": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                       _c_float_p, _int, _int, _int, _int, _int, ctypes.c_char_p, ctypes.c_char_p, _stream]),
     "camli_gru_gates_bwd_into": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int64, _c_float_p, _c_float_p, _c_float_p,
-                                        _c_float_p, _c_float_p, _int, _int, _int, _stream]),
+                                        _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _stream]),
+    "camli_gru_blend_bwd_acc": (_int, [_c_float_p] * 8 + [_int, _int, _int, _int, _stream]),
     "camli_convcl_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 6),
     "camli_convcl_wrw": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _int, _c_float_p, ctypes.c_int64,
                                 _c_float_p, _int, _int, _int, _int, _int, _int, ctypes.c_char_p, ctypes.c_char_p, _stream]),

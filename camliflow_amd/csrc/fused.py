@@ -1888,14 +1888,53 @@ def _to_nchw(x_n):
     return channels_last_to_nchw(x_n.permute(0, 3, 1, 2), 0, x_n.shape[3])
 
 
+class GRU2DPass:
+    """What the GRU2D updates of one pass share: the four weight blocks and the four hoisted context terms (NHWC), and the
+    running totals of their gradients.  Every update's adjoint ADDS into the totals (the weight gradients through
+    camli_convcl_wrw's accumulate mode, the context gradients inside the gate / blend adjoint kernels); ``token`` makes the
+    hub node's backward run after the last update's, and it hands the totals to autograd once.  Without the hub each of the 12
+    updates returns 8 gradient tensors that autograd sums: 88 additions per step, 44 of them over [B,H,W,256] / [B,H,W,128]
+    maps."""
+
+    def __init__(self, weights, contexts):
+        self.weights = tuple(weights)
+        self.contexts = tuple(contexts)
+        self.gw = [None] * 4
+        self.gc = [None] * 4
+        self.token = _GRU2DHub.apply(self, *self.weights, *self.contexts)
+
+
+class _GRU2DHub(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hub, *tensors):
+        ctx.hub = weakref.ref(hub)          # hub.token is this node's output: no strong back-reference (cycle)
+        ctx.meta = [(tuple(t.shape), t.device) for t in tensors]
+        return tensors[0].new_zeros(1)
+
+    @staticmethod
+    def backward(ctx, _gtoken):
+        hub = ctx.hub()
+        totals = [None] * 8
+        if hub is not None:
+            totals = hub.gw + hub.gc
+            hub.gw, hub.gc = [None] * 4, [None] * 4
+        need = ctx.needs_input_grad[1:]
+        grads = [(t if t is not None else torch.zeros(shape, dtype=torch.float32, device=dev)) if n else None
+                 for t, (shape, dev), n in zip(totals, ctx.meta, need)]
+        return (None, *grads)
+
+
 class _GRU2DStepCL(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, m, w_zr1, w_q1, w_zr2, w_q2, c_zr1, c_q1, c_zr2, c_q2):
+    def forward(ctx, h, m, token, hub):
         lib = _lib.load()
         b, hd, hh, ww = h.shape
         cx = m.shape[1]
+        w_zr1, w_q1, w_zr2, w_q2 = hub.weights
+        c_zr1, c_q1, c_zr2, c_q2 = hub.contexts
         h0, mn = _to_nhwc(h.float()), _to_nhwc(m.float())
         ctx.geom = []
+        ctx.hub = hub
         saved = [h0, mn]
         hcur = h0
         with _on_device(h):
@@ -1925,40 +1964,53 @@ class _GRU2DStepCL(torch.autograd.Function):
     def backward(ctx, g):
         lib = _lib.load()
         h0, mn, z1, r1, rh1, q1, h1, z2, r2, rh2, q2 = ctx.saved_tensors
+        hub = ctx.hub
         b, hh, ww, hd = h0.shape
         npix = b * hh * ww
-        need = ctx.needs_input_grad
+        need_w = [w.requires_grad for w in hub.weights]
+        need_c = [c.requires_grad for c in hub.contexts]
         gcur = _to_nhwc(g.float())             # gradient of the half-step's output
         gm = torch.empty_like(mn)
-        gws, gcs = [None] * 4, [None] * 4
         first_m = True
+
+        def total(slot, shape, want):
+            """(running total to add into or NULL, tensor that becomes the total when there is none yet)"""
+            if not want:
+                return 0, None
+            return (hub.gc[slot].data_ptr(), None) if hub.gc[slot] is not None else (0, slot)
+
         with _on_device(g):
             for half, (hin, z, r, rh, q) in ((1, (h1, z2, r2, rh2, q2)), (0, (h0, z1, r1, rh1, q1))):
                 geom, wpt_zr, wpt_q = ctx.geom[half]
                 taps, ntaps = convcl_taps(*geom), convcl_taps(*geom, negate=True)
+                izr, iq = 2 * half, 2 * half + 1
                 gpre_q, gz, gh = torch.empty_like(h0), torch.empty_like(h0), torch.empty_like(h0)
-                _lib.launch('camli_gru_blend_bwd', lib.camli_gru_blend_bwd, gcur.data_ptr(), z.data_ptr(), hin.data_ptr(), q.data_ptr(),
-                            gpre_q.data_ptr(), gz.data_ptr(), gh.data_ptr(), npix, hd, 1, int(half == 1), _stream_ptr(g),
+                acc_ptr, becomes = total(iq, None, need_c[iq])
+                _lib.launch('camli_gru_blend_bwd', lib.camli_gru_blend_bwd_acc, gcur.data_ptr(), z.data_ptr(), hin.data_ptr(), q.data_ptr(),
+                            gpre_q.data_ptr(), gz.data_ptr(), gh.data_ptr(), acc_ptr, npix, hd, 1, int(half == 1), _stream_ptr(g),
                             work=(28.0 * npix * hd, 'B'))
                 # q convolution: input gradient = (gradient of r h | + gradient of m), weight gradient
                 grh = torch.empty_like(h0)
                 convcl([gpre_q], wpt_q, ntaps, split=hd, out=(grh, gm), accumulate=(False, not first_m))
                 first_m = False
-                if need[3 + 2 * half]:
-                    gws[1 + 2 * half] = convcl_wrw([rh, mn], gpre_q, taps, geom[:2])
-                gcs[1 + 2 * half] = gpre_q
+                if need_w[iq]:
+                    hub.gw[iq] = convcl_wrw([rh, mn], gpre_q, taps, geom[:2], out=hub.gw[iq])
+                if becomes is not None:      # the first contribution IS the total (after the convolutions above have read it:
+                    hub.gc[iq] = gpre_q      # later updates add into it in place, on this same stream)
                 gpre_zr = torch.empty((b, hh, ww, 2 * hd), dtype=torch.float32, device=g.device)
+                acc_ptr, becomes = total(izr, None, need_c[izr])
                 _lib.launch('camli_gru_gates_bwd', lib.camli_gru_gates_bwd_into, gz.data_ptr(), hd, grh.data_ptr(), hd, z.data_ptr(),
-                            r.data_ptr(), hin.data_ptr(), gpre_zr.data_ptr(), gh.data_ptr(), npix, hd, 1, _stream_ptr(g),
+                            r.data_ptr(), hin.data_ptr(), gpre_zr.data_ptr(), gh.data_ptr(), acc_ptr, npix, hd, 1, _stream_ptr(g),
                             work=(36.0 * npix * hd, 'B'))
                 # z | r convolution: its input gradient completes the gradient of this half-step's hidden input and of m
                 convcl([gpre_zr], wpt_zr, ntaps, split=hd, out=(gh, gm), accumulate=(True, True))
-                if need[2 + 2 * half]:
-                    gws[2 * half] = convcl_wrw([hin, mn], gpre_zr, taps, geom[:2])
-                gcs[2 * half] = gpre_zr
+                if need_w[izr]:
+                    hub.gw[izr] = convcl_wrw([hin, mn], gpre_zr, taps, geom[:2], out=hub.gw[izr])
+                if becomes is not None:
+                    hub.gc[izr] = gpre_zr
                 gcur = gh
-        return (_to_nchw(gcur) if need[0] else None, _to_nchw(gm) if need[1] else None, gws[0], gws[1], gws[2], gws[3],
-                gcs[0], gcs[1], gcs[2], gcs[3])
+        need = ctx.needs_input_grad
+        return (_to_nchw(gcur) if need[0] else None, _to_nchw(gm) if need[1] else None, None, None)
 
 
 def gru2d_step_supported(h, m, w_zr):
@@ -1967,11 +2019,11 @@ def gru2d_step_supported(h, m, w_zr):
             and h.shape[0] * h.shape[2] * h.shape[3] * 256 * 4 < 0x7FF00000)
 
 
-def gru2d_step_cl(h, m, weights, contexts):
-    """One GRU2D update.  h [B,128,H,W], m [B,CX,H,W] (NCHW); weights = (w_zr1, w_q1, w_zr2, w_q2), the [h | m] blocks of the
-    1x5 / 5x1 gates; contexts = (ctx_zr1, ctx_q1, ctx_zr2, ctx_q2), the hoisted context terms as dense NHWC tensors."""
+def gru2d_step_cl(h, m, hub):
+    """One GRU2D update.  h [B,128,H,W], m [B,CX,H,W] (NCHW); hub = the pass's GRU2DPass (weights = the [h | m] blocks of the
+    1x5 / 5x1 gates, contexts = the hoisted context terms as dense NHWC tensors)."""
     _require_cuda('gru2d_step_cl', h, m)
-    return _GRU2DStepCL.apply(h, m, *weights, *contexts)
+    return _GRU2DStepCL.apply(h, m, hub.token, hub)
 
 
 class _BiasAct(torch.autograd.Function):

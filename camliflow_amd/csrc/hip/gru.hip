@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float4* __rest
                                                              const float4* __restrict__ z, const float4* __restrict__ r,
                                                              const float4* __restrict__ h, float4* __restrict__ gpre,
                                                              float4* __restrict__ gh, size_t n4, size_t cp4, size_t gz_bs4,
-                                                             size_t grh_bs4, int into) {
+                                                             size_t grh_bs4, int into, float4* __restrict__ gacc) {
     // gz / grh may be channel slices of wider gradients (what the adjoint of cat([rh, x]) hands over): batch strides in float4
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
         const size_t b = e / cp4, off = e - b * cp4;
@@ -55,6 +55,13 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float4* __rest
         d.x = g2.x * rv.x; d.y = g2.y * rv.y; d.z = g2.z * rv.z; d.w = g2.w * rv.w;
         gpre[iz] = a;
         gpre[ir] = c;
+        if (gacc) {         // running total of gpre over the GRU iterations of a pass (= the gradient of the hoisted context term)
+            float4 t = gacc[iz], u = gacc[ir];
+            t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+            u.x += c.x; u.y += c.y; u.z += c.z; u.w += c.w;
+            gacc[iz] = t;
+            gacc[ir] = u;
+        }
         if (into) { const float4 o = gh[e]; d.x += o.x; d.y += o.y; d.z += o.z; d.w += o.w; }
         gh[e] = d;
     }
@@ -89,7 +96,7 @@ template <bool SANITIZE>
 __global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float4* __restrict__ g, const float4* __restrict__ z,
                                                              const float4* __restrict__ h, const float4* __restrict__ q,
                                                              float4* __restrict__ gpre, float4* __restrict__ gz,
-                                                             float4* __restrict__ gh, size_t n4) {
+                                                             float4* __restrict__ gh, size_t n4, float4* __restrict__ gacc) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
         float4 gv = g[e];
         const float4 zv = z[e], hv = h[e], qv = q[e];
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float4* __rest
         b.x = gv.x * (qv.x - hv.x); b.y = gv.y * (qv.y - hv.y); b.z = gv.z * (qv.z - hv.z); b.w = gv.w * (qv.w - hv.w);
         c.x = gv.x * (1.0f - zv.x); c.y = gv.y * (1.0f - zv.y); c.z = gv.z * (1.0f - zv.z); c.w = gv.w * (1.0f - zv.w);
         gpre[e] = a;
+        if (gacc) { float4 t = gacc[e]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; gacc[e] = t; }
         gz[e] = b;
         gh[e] = c;
     }
@@ -137,7 +145,8 @@ extern "C" int camli_gru_gates_fwd(const float* pre_zr, const float* ctx_zr, con
 }
 
 static int gates_bwd_impl(const float* gz, int64_t gz_batch_stride, const float* grh, int64_t grh_batch_stride, const float* z,
-                          const float* r, const float* h, float* gpre_zr, float* gh, int B, int C, int P, int into, void* stream) {
+                          const float* r, const float* h, float* gpre_zr, float* gh, int B, int C, int P, int into, float* gacc,
+                          void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!gz || !grh || !z || !r || !h || !gpre_zr || !gh) { camli_set_error("camli_gru_gates_bwd: null pointer"); return CAMLI_EINVAL; }
     if (!gru_shape_ok("camli_gru_gates_bwd", B, C, P)) return CAMLI_EINVAL;
@@ -151,21 +160,22 @@ static int gates_bwd_impl(const float* gz, int64_t gz_batch_stride, const float*
     const size_t cp4 = (size_t)cp / 4, n4 = cp4 * B;
     hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        F4(gz), F4(grh), F4(z), F4(r), F4(h), F4W(gpre_zr), F4W(gh), n4, cp4, (size_t)gz_batch_stride / 4,
-                       (size_t)grh_batch_stride / 4, into);
+                       (size_t)grh_batch_stride / 4, into, F4W(gacc));
     return camli_check_launch("camli_gru_gates_bwd");
 }
 
 extern "C" int camli_gru_gates_bwd_strided(const float* gz, int64_t gz_batch_stride, const float* grh, int64_t grh_batch_stride,
                                            const float* z, const float* r, const float* h, float* gpre_zr, float* gh, int B,
                                            int C, int P, void* stream) {
-    return gates_bwd_impl(gz, gz_batch_stride, grh, grh_batch_stride, z, r, h, gpre_zr, gh, B, C, P, 0, stream);
+    return gates_bwd_impl(gz, gz_batch_stride, grh, grh_batch_stride, z, r, h, gpre_zr, gh, B, C, P, 0, nullptr, stream);
 }
 
 // gh += (see include/camli_hip.h)
 extern "C" int camli_gru_gates_bwd_into(const float* gz, int64_t gz_batch_stride, const float* grh, int64_t grh_batch_stride,
-                                        const float* z, const float* r, const float* h, float* gpre_zr, float* gh, int B, int C,
-                                        int P, void* stream) {
-    return gates_bwd_impl(gz, gz_batch_stride, grh, grh_batch_stride, z, r, h, gpre_zr, gh, B, C, P, 1, stream);
+                                        const float* z, const float* r, const float* h, float* gpre_zr, float* gh, float* gpre_acc,
+                                        int B, int C, int P, void* stream) {
+    if (gpre_acc && (reinterpret_cast<uintptr_t>(gpre_acc) & 15)) { camli_set_error("camli_gru_gates_bwd_into: gpre_acc must be 16-byte aligned"); return CAMLI_EINVAL; }
+    return gates_bwd_impl(gz, gz_batch_stride, grh, grh_batch_stride, z, r, h, gpre_zr, gh, B, C, P, 1, gpre_acc, stream);
 }
 
 extern "C" int camli_gru_gates_bwd(const float* gz, const float* grh, const float* z, const float* r, const float* h,
@@ -188,17 +198,29 @@ extern "C" int camli_gru_blend_fwd(const float* pre_q, const float* ctx_q, const
     return camli_check_launch("camli_gru_blend_fwd");
 }
 
-extern "C" int camli_gru_blend_bwd(const float* g, const float* z, const float* h, const float* q, float* gpre_q, float* gz,
-                                   float* gh, int B, int C, int P, int nan_to_num, void* stream) {
+static int blend_bwd_impl(const float* g, const float* z, const float* h, const float* q, float* gpre_q, float* gz, float* gh,
+                          float* gacc, int B, int C, int P, int nan_to_num, void* stream) {
     if (B == 0) return CAMLI_OK;
     if (!g || !z || !h || !q || !gpre_q || !gz || !gh) { camli_set_error("camli_gru_blend_bwd: null pointer"); return CAMLI_EINVAL; }
     if (!gru_shape_ok("camli_gru_blend_bwd", B, C, P)) return CAMLI_EINVAL;
     const size_t n4 = (size_t)B * C * P / 4;
     if (nan_to_num)
         hipLaunchKernelGGL(gru_blend_bwd_kernel<true>, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           F4(g), F4(z), F4(h), F4(q), F4W(gpre_q), F4W(gz), F4W(gh), n4);
+                           F4(g), F4(z), F4(h), F4(q), F4W(gpre_q), F4W(gz), F4W(gh), n4, F4W(gacc));
     else
         hipLaunchKernelGGL(gru_blend_bwd_kernel<false>, dim3(gru_blocks(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                           F4(g), F4(z), F4(h), F4(q), F4W(gpre_q), F4W(gz), F4W(gh), n4);
+                           F4(g), F4(z), F4(h), F4(q), F4W(gpre_q), F4W(gz), F4W(gh), n4, F4W(gacc));
     return camli_check_launch("camli_gru_blend_bwd");
+}
+
+extern "C" int camli_gru_blend_bwd(const float* g, const float* z, const float* h, const float* q, float* gpre_q, float* gz,
+                                   float* gh, int B, int C, int P, int nan_to_num, void* stream) {
+    return blend_bwd_impl(g, z, h, q, gpre_q, gz, gh, nullptr, B, C, P, nan_to_num, stream);
+}
+
+// the same with gpre_acc += gpre_q (running total over the GRU iterations of a pass; see camli_gru_gates_bwd_into)
+extern "C" int camli_gru_blend_bwd_acc(const float* g, const float* z, const float* h, const float* q, float* gpre_q, float* gz,
+                                       float* gh, float* gpre_acc, int B, int C, int P, int nan_to_num, void* stream) {
+    if (gpre_acc && (reinterpret_cast<uintptr_t>(gpre_acc) & 15)) { camli_set_error("camli_gru_blend_bwd_acc: gpre_acc must be 16-byte aligned"); return CAMLI_EINVAL; }
+    return blend_bwd_impl(g, z, h, q, gpre_q, gz, gh, gpre_acc, B, C, P, nan_to_num, stream);
 }

@@ -389,7 +389,13 @@ int camli_gru_gates_bwd(const float *gz, const float *grh, const float *z, const
 /* camli_gru_gates_bwd_strided with gh += instead of gh = (the hidden state's gradient of a half-step has three producers:
  * the blend adjoint writes it, this call and the data gradient of the z|r convolution add into it). */
 int camli_gru_gates_bwd_into(const float *gz, int64_t gz_batch_stride, const float *grh, int64_t grh_batch_stride, const float *z,
-                             const float *r, const float *h, float *gpre_zr, float *gh, int B, int C, int P, void *stream);
+                             const float *r, const float *h, float *gpre_zr, float *gh, float *gpre_acc, int B, int C, int P,
+                             void *stream);
+/* camli_gru_blend_bwd / the call above with gpre_acc += gpre (NULL: none): the pre-activation gradient of a half-step is also
+ * the gradient of its hoisted context term, which is shared by every GRU iteration of a pass -- the running total is kept by
+ * the adjoint kernels themselves instead of one tensor addition per iteration. */
+int camli_gru_blend_bwd_acc(const float *g, const float *z, const float *h, const float *q, float *gpre_q, float *gz, float *gh,
+                            float *gpre_acc, int B, int C, int P, int nan_to_num, void *stream);
 /* the same with gz / grh read in place from channel slices of wider gradients (what the adjoint of cat([r*h, x]) hands
  * over): batch strides in floats, multiples of 4, >= C*P; pointers 16-byte aligned */
 int camli_gru_gates_bwd_strided(const float *gz, int64_t gz_batch_stride, const float *grh, int64_t grh_batch_stride,
