@@ -57,7 +57,7 @@ trace)
   ;;
 pmc)
   canary || continue
-  RX='fps_|knn_|conv3x3_co2|pointconv_dw_fwd|pointconv_mix|corr2d_fwd|corr2d_bwd|allpairs_lookup|gather_cf|gemm_f32_mfma|gemm_fwd_dma|gemm_gf2|segment_row_sum|knn_interp|corr3d_gather|weightnet|pointconv_dw_bwd|pointconv_dw_expand'
+  RX='fps_|knn_|conv3x3_co2|pointconv_dw_fwd|pointconv_mix|corr2d_fwd|corr2d_bwd|allpairs_lookup|gather_cf|gemm_f32_mfma|gemm_fwd_dma|gemm_gf2|gemm_w128|convcl_kernel|wrw_kernel|segment_row_sum|knn_interp|corr3d_gather|weightnet|pointconv_dw_bwd|pointconv_dw_expand'
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $OUT/pmc_$c -o p -- \
         python $ROOT/tools/kernel_bench.py --reps 2 > /dev/null 2>&1
@@ -65,8 +65,14 @@ pmc)
     rm -rf $OUT/pmc_$c
   done
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace \
-      --kernel-include-regex 'gemm_f32_mfma|gemm_fwd_dma|gemm_gf2|weightnet' --output-format csv -d $OUT/pmc_mfma -o p -- \
+      --kernel-include-regex 'gemm_f32_mfma|gemm_fwd_dma|gemm_gf2|gemm_w128|convcl_kernel|wrw_kernel|weightnet' --output-format csv -d $OUT/pmc_mfma -o p -- \
       python $ROOT/tools/kernel_bench.py --reps 2 --only 'a' > /dev/null 2>&1
+  # ('a' matches the allpairs case only; the GRU2D convolutions in a pass of their own)
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace \
+      --kernel-include-regex 'convcl_kernel|wrw_kernel' --output-format csv -d $OUT/pmc_mfma2 -o p -- \
+      python $ROOT/tools/kernel_bench.py --reps 2 --only 'gru2d' > /dev/null 2>&1
+  python $ROOT/tools/pmc_summary.py $OUT/pmc_mfma2/p_counter_collection.csv > $OUT/pmc_kernel_bench_mfma_gru2d.txt 2>&1
+  rm -rf $OUT/pmc_mfma2
   python $ROOT/tools/pmc_summary.py $OUT/pmc_mfma/p_counter_collection.csv > $OUT/pmc_kernel_bench_mfma.txt 2>&1
   rm -rf $OUT/pmc_mfma
   ;;
