@@ -1793,7 +1793,12 @@ def _nhwc_ld(t):
 
 
 def convcl_supported(cin, cout, parts=1):
-    return cin % 16 == 0 and cin % 256 == 0 and cout % 128 == 0 and cout >= 128 and parts <= 2
+    """forward + both adjoints: channels in multiples of 16 in / 128 out for the convolution itself; the weight gradient wants
+    256 | Cin and 128 | Cout, or (one input tensor) 128 | Cin and 256 | Cout (camli_convcl_wrw)."""
+    fwd = cin % 16 == 0 and cout % 128 == 0 and cout >= 128 and parts <= 2
+    dgrad = cout % 16 == 0 and cin % 128 == 0
+    wrw = (cin % 256 == 0 and cout % 128 == 0) or (parts == 1 and cin % 128 == 0 and cout % 256 == 0)
+    return fwd and dgrad and wrw
 
 
 def convcl(xs, wp, taps, split=None, out=None, accumulate=(False, False)):

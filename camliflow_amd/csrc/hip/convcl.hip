@@ -134,11 +134,26 @@ extern "C" int camli_convcl_fwd(const float* x0, int ldx0, int C0, const float* 
     return camli_check_launch(what);
 }
 
+namespace {
+// The kernel wants 256 channels on its M side and 128 / 256 on its N side.  Input channels on M when they come in multiples of
+// 256; otherwise (a 128-channel input, one tensor) the roles are exchanged: M = output channels (gy rows, shifted by the NEGATED
+// tap -- sum_p gy[p] x[p + d] = sum_q gy[q - d] x[q], the same border test), N = input channels.  0: unsupported.
+int wrw_mode(int C0, int C1, int Cout) {
+    const int Cin = C0 + C1;
+    if (Cin >= 256 && Cin % 256 == 0 && Cout >= 128 && Cout % 128 == 0) return 1;
+    if (C1 == 0 && Cout >= 256 && Cout % 256 == 0 && Cin >= 128 && Cin % 128 == 0) return 2;
+    return 0;
+}
+}  // namespace
+
 extern "C" int64_t camli_convcl_wrw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int T) {
-    if (B < 1 || H < 1 || W < 1 || Cin < 256 || Cin % 256 || Cout < 128 || Cout % 128 || T < 1 || T > ccl::MAX_TAPS) return 0;
-    const int NB = Cout % 256 == 0 ? 256 : 128;
+    if (B < 1 || H < 1 || W < 1 || T < 1 || T > ccl::MAX_TAPS) return 0;
+    const int mode = wrw_mode(Cin, 0, Cout);
+    if (!mode) return 0;
+    const int M = mode == 1 ? Cin : Cout, N = mode == 1 ? Cout : Cin;
+    const int NB = N % 256 == 0 ? 256 : 128;
     int S, ksplit;
-    wrw_split(B * H * W, T, (Cin / 256) * (Cout / NB), S, ksplit);
+    wrw_split(B * H * W, T, (M / 256) * (N / NB), S, ksplit);
     return (int64_t)S * T * Cin * Cout * (int64_t)sizeof(float);
 }
 
@@ -152,9 +167,11 @@ extern "C" int camli_convcl_wrw(const float* x0, int ldx0, int C0, const float* 
     if (!taps_ok(what, T, dy, dx)) return CAMLI_EINVAL;
     const int Cin = C0 + C1;
     const int64_t P = (int64_t)B * H * W;
-    if (B < 0 || H < 1 || W < 1 || C0 < 4 || C0 % 4 || C1 < 0 || C1 % 4 || Cin % 256 || Cout < 128 || Cout % 128 || ldx0 < C0 || ldx0 % 4 ||
-        (C1 > 0 && (ldx1 < C1 || ldx1 % 4)) || ldg < Cout || ldg % 4 || P * (int64_t)ldg * 4 >= (int64_t)0x7FF00000 || P >= ((int64_t)1 << 30)) {
-        camli_set_error("%s: unsupported shape B=%d %dx%d C0=%d C1=%d Cout=%d ld %d %d %d (input channels in multiples of 256, output of 128)",
+    const int mode = (B < 0 || H < 1 || W < 1 || C0 < 4 || C0 % 4 || C1 < 0 || C1 % 4) ? 0 : wrw_mode(C0, C1, Cout);
+    if (!mode || ldx0 < C0 || ldx0 % 4 || (C1 > 0 && (ldx1 < C1 || ldx1 % 4)) || ldg < Cout || ldg % 4 ||
+        P * (int64_t)ldg * 4 >= (int64_t)0x7FF00000 || P * (int64_t)ldx0 * 4 >= (int64_t)0x7FF00000 || P >= ((int64_t)1 << 30)) {
+        camli_set_error("%s: unsupported shape B=%d %dx%d C0=%d C1=%d Cout=%d ld %d %d %d (input channels in multiples of 256 and output "
+                        "of 128, or one input of a multiple of 128 channels and output channels in multiples of 256)",
                         what, B, H, W, C0, C1, Cout, ldx0, ldx1, ldg);
         return CAMLI_ENOTSUP;
     }
@@ -162,27 +179,38 @@ extern "C" int camli_convcl_wrw(const float* x0, int ldx0, int C0, const float* 
         camli_set_error("%s: pointers must be 16-byte aligned", what);
         return CAMLI_EINVAL;
     }
-    const int NB = Cout % 256 == 0 ? 256 : 128;
     wrw::Problem p;
-    p.x = x0; p.x1 = C1 > 0 ? x1 : x0; p.gy = gy; p.part = workspace;
     p.zero = zero_page();
     if (!p.zero) { camli_set_error("%s: cannot allocate the zero page", what); return CAMLI_ELAUNCH; }
-    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.T = T; p.C0 = C0;
-    p.ldx = ldx0; p.ldx1 = C1 > 0 ? ldx1 : ldx0; p.ldg = ldg;
-    p.tiles_m = Cin / 256; p.tiles_n = Cout / NB;
+    p.part = workspace;
+    p.B = B; p.H = H; p.W = W; p.T = T;
+    if (mode == 1) {
+        p.x = x0; p.x1 = C1 > 0 ? x1 : x0; p.gy = gy;
+        p.Cin = Cin; p.Cout = Cout; p.C0 = C0;
+        p.ldx = ldx0; p.ldx1 = C1 > 0 ? ldx1 : ldx0; p.ldg = ldg;
+        set_taps(p, T, dy, dx);
+    } else {        // roles exchanged: the kernel's "x" is gy, its "gy" is x
+        p.x = gy; p.x1 = gy; p.gy = x0;
+        p.Cin = Cout; p.Cout = Cin; p.C0 = Cout;
+        p.ldx = ldg; p.ldx1 = ldg; p.ldg = ldx0;
+        signed char ndy[ccl::MAX_TAPS], ndx[ccl::MAX_TAPS];
+        for (int t = 0; t < T; ++t) { ndy[t] = (signed char)-dy[t]; ndx[t] = (signed char)-dx[t]; }
+        set_taps(p, T, ndy, ndx);
+    }
+    const int NB = p.Cout % 256 == 0 ? 256 : 128;
+    p.tiles_m = p.Cin / 256; p.tiles_n = p.Cout / NB;
     wrw_split((int)P, T, p.tiles_m * p.tiles_n, p.S, p.ksplit);
     if (workspace_bytes < (int64_t)p.S * T * Cin * Cout * (int64_t)sizeof(float)) {
         camli_set_error("%s: workspace of %lld bytes, need %lld (camli_convcl_wrw_workspace_bytes)", what, (long long)workspace_bytes,
                         (long long)((int64_t)p.S * T * Cin * Cout * 4));
         return CAMLI_EINVAL;
     }
-    set_taps(p, T, dy, dx);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rc = NB == 256 ? launch_wrw<8>(p, s) : launch_wrw<4>(p, s);
     if (rc != CAMLI_OK) return rc;
     const size_t n_el = (size_t)T * Cin * Cout;
     hipLaunchKernelGGL(wrw::wrw_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, workspace, gw, p.S, T, Cin, Cout,
-                       accumulate ? 1 : 0);
+                       accumulate ? 1 : 0, mode == 2 ? 1 : 0);
     return camli_check_launch(what);
 }
 

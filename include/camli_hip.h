@@ -624,7 +624,9 @@ int camli_convcl_gru_blend(const float *rh, const float *x, int CX, const float 
  * Weight gradient of the same convolution: gw [Cout][C0 + C1][T] (= the [Cout, Cin, kh, kw] weight tensor) = or += (accumulate)
  *     sum_p gy[p][n] * x[p + (dy[t], dx[t])][c]
  * gy NHWC [P][ldg].  Split over the pixels into about one workgroup per CU, parts in `workspace`
- * (camli_convcl_wrw_workspace_bytes), added in a fixed order: deterministic, no atomics.  C0 + C1 a multiple of 256, Cout of 128.
+ * (camli_convcl_wrw_workspace_bytes), added in a fixed order: deterministic, no atomics.  C0 + C1 a multiple of 256 and Cout of 128;
+ * or ONE input (C1 = 0) of a multiple of 128 channels and Cout a multiple of 256 (the kernel then contracts with the operands' roles
+ * exchanged -- the flow / mask heads' 128 -> 512 convolution).
  */
 int64_t camli_convcl_wrw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int T);
 int camli_convcl_wrw(const float *x0, int ldx0, int C0, const float *x1, int ldx1, int C1, const float *gy, int ldg, float *workspace,

@@ -64,9 +64,9 @@ def test_convcl_reads_channel_slices_and_splits_its_output(oracle_dense):
     _close(y1.permute(0, 3, 1, 2), want[:, 128:], what='second output')
 
 
-BWD_CASES = [  # (B, C0, C1, Cout, H, W, kh, kw): Cin a multiple of 256
+BWD_CASES = [  # (B, C0, C1, Cout, H, W, kh, kw): Cin a multiple of 256, or ONE 128-multiple input with 256-multiple outputs
     (1, 256, 0, 256, 7, 9, 1, 5), (2, 128, 128, 128, 20, 30, 5, 1), (3, 256, 0, 256, 17, 33, 5, 1), (2, 384, 128, 128, 6, 40, 1, 5),
-    (1, 128, 128, 256, 13, 21, 3, 3),
+    (1, 128, 128, 256, 13, 21, 3, 3), (2, 128, 0, 512, 11, 19, 3, 3), (1, 128, 0, 256, 9, 40, 1, 5),
 ]
 
 

@@ -56,7 +56,7 @@ static void launch(const wrw::Problem& p, float* gw, hipStream_t s) {
     const int units = p.S * p.T * p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL((wrw::wrw_kernel<TBN, MB_NBUF>), dim3(units), dim3(256), lds, s, p);
     const size_t n_el = (size_t)p.T * p.Cin * p.Cout;
-    hipLaunchKernelGGL(wrw::wrw_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, p.part, gw, p.S, p.T, p.Cin, p.Cout, 0);
+    hipLaunchKernelGGL(wrw::wrw_reduce_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, p.part, gw, p.S, p.T, p.Cin, p.Cout, 0, 0);
 }
 
 static void run(int B, int H, int W, int Cin, int Cout, bool vertical, int S, bool check, int reps) {
