@@ -122,16 +122,6 @@ class Correlation3D(nn.Module):
             level0 = xyzs2[0]
             crosses = _ops.k_nearest_neighbor_prefixes(level0.detach().transpose(1, 2).contiguous(), _channel_last(xyz1, True),
                                                        pyr.sizes, self.k)
-            convs = [layer.conv_fn for layer in self.cost_mlp.convs]
-            if (os.environ.get('CAMLI_CORR3D_MLP', 'fused') == 'fused' and os.environ.get('CAMLI_CORR3D_GATHER', 'split') == 'fused'
-                    and all(layer._epilogue == 'relu' for layer in self.cost_mlp.convs)
-                    and fused.corr3d_cost_levels_supported(pyr, crosses, convs, n_src)):
-                # opt-in (CAMLI_CORR3D_GATHER=fused): gather, both layers, the ReLUs and the neighbour sum in one kernel
-                # each way -- not even the [B,4,N,64] lookup tensor exists.  Bit-identical to the two-launch form and 17 us
-                # faster forward, but its adjoint is 13 us slower (register pressure, csrc/hip/corr3dmlp.hip) and the
-                # training step measures 2-3 ms SLOWER with it on one box (237.5 / 238.1 vs 235.9 / 234.0 ms), so the
-                # two-launch form stays the default
-                return self.merge(fused.corr3d_cost_levels(pyr, xyz1, level0, crosses, convs[0], convs[1]))
             lookup = fused.corr3d_lookup_levels(pyr, xyz1, level0, crosses)
         else:
             columns = []

@@ -14,8 +14,6 @@ PROTOTYPES = {
     "camli_version": (_int, []),
     "camli_last_error_string": (ctypes.c_char_p, []),
     "camli_knn": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _int, _int, _int, _int, _stream]),
-    "camli_knn_pruned_workspace_bytes": (ctypes.c_int64, [_int, _int, _int]),
-    "camli_knn_pruned": (_int, [_c_float_p, _c_float_p, _c_i64_p, ctypes.c_void_p, _int, _int, _int, _int, _int, _stream]),
     "camli_knn_prefixes": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _int, _int, _int, _int, _int, _int, _stream]),
     "camli_fps": (_int, [_c_float_p, _c_i64_p, _int, _int, _int, _stream]),
     "camli_corr2d_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
@@ -89,10 +87,6 @@ PROTOTYPES = {
     "camli_corr3d_mlp_fwd": (_int, [_c_float_p] * 6 + [_int] * 5 + [_stream]),
     "camli_corr3d_mlp_bwd_workspace_bytes": (ctypes.c_int64, [_int, _int]),
     "camli_corr3d_mlp_bwd": (_int, [_c_float_p] * 12 + [_int] * 5 + [_stream]),
-    "camli_corr3d_cost_levels_fwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-                                     + [_c_float_p] * 5 + [_int] * 6 + [_stream]),
-    "camli_corr3d_cost_levels_bwd": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-                                     + [_c_float_p] * 5 + [ctypes.c_void_p] + [_c_float_p] * 5 + [_int] * 6 + [_stream]),
     "camli_convex_upsample_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int,
                                          ctypes.c_float, _stream]),
     "camli_convex_upsample_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,

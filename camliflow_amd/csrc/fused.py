@@ -1226,83 +1226,6 @@ class _Corr3DCostMLP(torch.autograd.Function):
         return (glookup,) + tuple(None if d else g for g, d in zip(grads, deferred)) + (None,)
 
 
-class _Corr3DCostLevels(torch.autograd.Function):
-    """_Corr3DLookupLevels + _Corr3DCostMLP as one kernel each way (camli_corr3d_cost_levels_fwd / _bwd): the [B,4,N,64]
-    lookup tensor and its gradient never exist; the adjoint adds straight into the pass's gradient volumes (pyr.grads)."""
-
-    @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, token, xyz1, xyz2, pyr, w1, b1, w2, b2, *knn_levels):
-        lib = _lib.load()
-        b, _, n = xyz1.shape
-        m0, k, nl, hidden = xyz2.shape[2], knn_levels[0].shape[2], len(knn_levels), w2.shape[0]
-        out = torch.empty((b, nl * hidden, n), dtype=torch.float32, device=xyz1.device)
-        cols = float(b) * n * nl * k
-        with _on_device(xyz1):
-            _lib.launch('camli_corr3d_cost_levels_fwd', lib.camli_corr3d_cost_levels_fwd, xyz1.data_ptr(), xyz2.data_ptr(),
-                        _ptr_array(pyr.levels), _ptr_array(knn_levels), (ctypes.c_int * nl)(*pyr.sizes), w1.data_ptr(),
-                        b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(), b, n, m0, nl, k, hidden, _stream_ptr(xyz1),
-                        work=(cols * (8.0 + 16.0 + 4.0) + 4.0 * out.numel(), 'B'), flop=2.0 * cols * (4 * hidden + hidden * hidden))
-        ctx.save_for_backward(xyz1, xyz2, w1, b1, w2, b2, *knn_levels)
-        ctx.params = [_runtime.deferral_target(t) for t in (w1, b1, w2, b2)]
-        ctx.pyr = pyr
-        return out
-
-    @staticmethod
-    @torch.amp.custom_bwd(device_type='cuda')
-    def backward(ctx, gout):
-        lib = _lib.load()
-        xyz1, xyz2, w1, b1, w2, b2, *knn_levels = ctx.saved_tensors
-        pyr = ctx.pyr
-        b, _, n = xyz1.shape
-        m0, k, nl, hidden = xyz2.shape[2], knn_levels[0].shape[2], len(knn_levels), w2.shape[0]
-        gout = gout.contiguous().float()
-        if pyr.grads is None:
-            pyr.grads = [torch.zeros_like(lvl) for lvl in pyr.levels]
-        grads, deferred = [], []
-        for param, like in zip(ctx.params, (w1, b1, w2, b2)):
-            if param is not None:
-                grads.append(_runtime.PARAM_GRADS.slot(param, lambda like=like: torch.zeros_like(like), False))
-            else:
-                grads.append(torch.zeros_like(like))
-            deferred.append(param is not None)
-        ws = torch.empty(lib.camli_corr3d_mlp_bwd_workspace_bytes(b, n) // 4, dtype=torch.float32, device=xyz1.device)
-        cols = float(b) * n * nl * k
-        with _on_device(xyz1):
-            _lib.launch('camli_corr3d_cost_levels_bwd', lib.camli_corr3d_cost_levels_bwd, xyz1.data_ptr(), xyz2.data_ptr(),
-                        _ptr_array(pyr.levels), _ptr_array(knn_levels), (ctypes.c_int * nl)(*pyr.sizes), gout.data_ptr(),
-                        w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), _ptr_array(pyr.grads), grads[0].data_ptr(),
-                        grads[1].data_ptr(), grads[2].data_ptr(), grads[3].data_ptr(), ws.data_ptr(), b, n, m0, nl, k, hidden,
-                        _stream_ptr(xyz1), work=(cols * (8.0 + 16.0 + 4.0 + 8.0) + 4.0 * gout.numel(), 'B'),
-                        flop=2.0 * cols * (2 * 4 * hidden + 3 * hidden * hidden))
-        return (None, None, None, None) + tuple(None if d else g for g, d in zip(grads, deferred)) + (None,) * nl
-
-
-def corr3d_cost_levels_supported(pyr, knn_levels, convs, n_points):
-    """4 nested levels x 16 neighbours, cost_mlp = two bias + ReLU layers 4 -> 32 -> 32 in fp32, N % 8 == 0."""
-    if len(convs) != 2 or len(knn_levels) != 4 or len(pyr.levels) != 4:
-        return False
-    c1, c2 = convs
-    if c1.bias is None or c2.bias is None or tuple(c1.weight.shape[:2]) != (c2.weight.shape[1], 4):
-        return False
-    if any(t.dtype != torch.float32 or not t.is_contiguous() for t in (c1.weight, c1.bias, c2.weight, c2.bias)):
-        return False
-    k = knn_levels[0].shape[2]
-    return bool(_lib.load().camli_corr3d_mlp_supported(4, k, c2.weight.shape[0], n_points)) \
-        and c2.weight.shape[0] == c2.weight.shape[1] and min(pyr.sizes) >= k
-
-
-def corr3d_cost_levels(pyr, xyz1, xyz2, knn_levels, conv1, conv2):
-    """``cost_mlp(lookup).sum(-1)`` of the four nested levels, [B, 4*hidden, N] (level-major channels), straight from the
-    volumes, the coordinates and the neighbour tables (camliraft_l_core.py:62-101); gradient to the cost volumes (through
-    pyr.token) and the MLP parameters."""
-    _require_cuda('corr3d_cost_levels', xyz1, xyz2, *knn_levels)
-    assert not xyz1.requires_grad and not xyz2.requires_grad
-    assert all(kn.is_contiguous() and kn.dtype == torch.int64 for kn in knn_levels)
-    return _Corr3DCostLevels.apply(pyr.token, xyz1.float().contiguous(), xyz2.float().contiguous(), pyr, conv1.weight, conv1.bias,
-                                   conv2.weight, conv2.bias, *knn_levels)
-
-
 def corr3d_cost_mlp_supported(lookup, convs, levels):
     """The fused cost MLP covers the reference's configuration: two bias + ReLU layers 4 -> 32 -> 32, 4 levels x 16
     neighbours, fp32 parameters, a point count that is a multiple of 8."""

@@ -475,40 +475,6 @@ extern "C" int camli_corr3d_mlp_fwd(const float* lookup, const float* w1, const 
     return camli_check_launch("camli_corr3d_mlp_fwd");
 }
 
-static int gather_pack(const char* what, CmGather& ga, const float* xyz1, const float* xyz2, const float* const* vols,
-                       const int64_t* const* knn_levels, const int* sizes, int M0) {
-    if (!xyz1 || !xyz2 || !vols || !knn_levels || !sizes) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
-    ga.xyz1 = xyz1;
-    ga.xyz2 = xyz2;
-    ga.m0 = M0;
-    for (int l = 0; l < 4; ++l) {
-        if (!vols[l] || !knn_levels[l] || sizes[l] < 1 || sizes[l] > M0) {
-            camli_set_error("%s: level %d: null pointer or size %d outside [1, %d]", what, l, sizes[l], M0);
-            return CAMLI_EINVAL;
-        }
-        ga.vol[l] = vols[l];
-        ga.knn[l] = knn_levels[l];
-        ga.size[l] = sizes[l];
-    }
-    return CAMLI_OK;
-}
-
-extern "C" int camli_corr3d_cost_levels_fwd(const float* xyz1, const float* xyz2, const float* const* cost_levels,
-                                            const int64_t* const* knn_levels, const int* sizes, const float* w1,
-                                            const float* b1, const float* w2, const float* b2, float* out, int B, int N,
-                                            int M0, int levels, int k, int hidden, void* stream) {
-    if (B == 0) return CAMLI_OK;
-    if (!w1 || !b1 || !w2 || !b2 || !out) { camli_set_error("camli_corr3d_cost_levels_fwd: null pointer"); return CAMLI_EINVAL; }
-    if (!mlp_shape_ok("camli_corr3d_cost_levels_fwd", B, N, levels, k, hidden) || M0 < 1) return CAMLI_EINVAL;
-    CmGather ga;
-    const int rc = gather_pack("camli_corr3d_cost_levels_fwd", ga, xyz1, xyz2, cost_levels, knn_levels, sizes, M0);
-    if (rc != CAMLI_OK) return rc;
-    const int blocks = camli_divup(B * (N / CM_CH), 4);
-    hipLaunchKernelGGL((corr3d_mlp_fwd_kernel<CM_CH, true>), dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       nullptr, ga, w1, b1, w2, b2, out, B, N);
-    return camli_check_launch("camli_corr3d_cost_levels_fwd");
-}
-
 extern "C" int64_t camli_corr3d_mlp_bwd_workspace_bytes(int B, int N) {
     if (B < 0 || N < CM_CH) return 0;
     return (int64_t)camli_divup(B * (N / CM_CH), CM_BW) * CM_PART * (int64_t)sizeof(float);
@@ -532,38 +498,3 @@ extern "C" int camli_corr3d_mlp_bwd(const float* lookup, const float* gout, cons
     return camli_check_launch("camli_corr3d_mlp_bwd");
 }
 
-// adjoint of camli_corr3d_cost_levels_fwd: gcost_levels[l] [B,N,sizes[l]] += d/d(volume entry) (caller zero-fills once per
-// pass, then calls once per GRU iteration); gw1 / gb1 / gw2 / gb2 += as camli_corr3d_mlp_bwd; same workspace.
-extern "C" int camli_corr3d_cost_levels_bwd(const float* xyz1, const float* xyz2, const float* const* cost_levels,
-                                            const int64_t* const* knn_levels, const int* sizes, const float* gout,
-                                            const float* w1, const float* b1, const float* w2, const float* b2,
-                                            float* const* gcost_levels, float* gw1, float* gb1, float* gw2, float* gb2,
-                                            float* workspace, int B, int N, int M0, int levels, int k, int hidden,
-                                            void* stream) {
-    if (B == 0) return CAMLI_OK;
-    if (!gout || !w1 || !b1 || !w2 || !b2 || !gw1 || !gb1 || !gw2 || !gb2 || !workspace || !cost_levels) {
-        camli_set_error("camli_corr3d_cost_levels_bwd: null pointer");
-        return CAMLI_EINVAL;
-    }
-    if (!mlp_shape_ok("camli_corr3d_cost_levels_bwd", B, N, levels, k, hidden) || M0 < 1) return CAMLI_EINVAL;
-    CmGather ga;
-    const int rc = gather_pack("camli_corr3d_cost_levels_bwd", ga, xyz1, xyz2, cost_levels, knn_levels, sizes, M0);
-    if (rc != CAMLI_OK) return rc;
-    if (!gcost_levels) { camli_set_error("camli_corr3d_cost_levels_bwd: null pointer"); return CAMLI_EINVAL; }
-    CmGradVols gv;
-    for (int l = 0; l < 4; ++l) {
-        if (!gcost_levels[l]) { camli_set_error("camli_corr3d_cost_levels_bwd: null gradient volume %d", l); return CAMLI_EINVAL; }
-        if (sizes[l] < 16) {      // fewer candidates than neighbours: the unfilled slots repeat index 0 and would race
-            camli_set_error("camli_corr3d_cost_levels_bwd: level %d has %d < 16 points", l, sizes[l]);
-            return CAMLI_ENOTSUP;
-        }
-        gv.vol[l] = gcost_levels[l];
-    }
-    const int blocks = camli_divup(B * (N / CM_CH), CM_BW);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL((corr3d_mlp_bwd_kernel<CM_CH, true>), dim3(blocks), dim3(64 * CM_BW), 0, s, nullptr, ga, gv, gout, w1, b1, w2, b2,
-                       nullptr, workspace, B, N);
-    hipLaunchKernelGGL(corr3d_mlp_reduce_kernel, dim3(camli_divup(CM_PART, 64)), dim3(64, 16), 0, s, workspace, blocks, gw1, gb1, gw2,
-                       gb2);
-    return camli_check_launch("camli_corr3d_cost_levels_bwd");
-}

@@ -1084,549 +1084,6 @@ __global__ __launch_bounds__(256) void knn_xlane_chain_kernel(const float* __res
     }
 }
 
-// ---- spatially pruned search (large candidate sets) --------------------------------------------------------------------
-// Above a few thousand candidates the brute-force scan is distance arithmetic on points that cannot matter.  Here the
-// candidates of a batch element are ordered in space once per call and cut into CHUNKS of at most 64 J points with a
-// bounding box each; the queries are ordered the same way, so the 4 x PR_QPW queries of a workgroup are neighbours.
-//   ordering (knn_order_kernel, one workgroup per cloud): every axis is histogram-equalised (256 bins -> the rank of a
-//     coordinate among the cloud's, so dense and sparse regions get the same resolution: LiDAR clouds are anything but
-//     uniform), 4 bits per axis are interleaved into a 12-bit Morton cell, the points are counting-sorted by cell (LDS
-//     atomics, one block-wide scan).  Any monotone map per axis and any order inside a cell will do: they decide which
-//     chunk a point lands in, never a result.  The 32 aligned Morton BLOCKS (top 5 bits) are cut into chunks of <= 64 J
-//     points -- chunk boundaries never straddle a block, so a chunk's box stays inside its block's region (a free-running
-//     cut every 64 J points gave boxes three times the volume).  Inside a chunk the points are dealt to the 64 lanes round
-//     robin (lane l holds points l, l + 64, ...): the lane minima below must be minima over unrelated points.
-//   search (knn_pruned_kernel): a query
-//     1. takes its bound T from the nearest chunks (box distance, one chunk per lane, wave arg-min) until they hold >= 512
-//        points, read straight from the sorted planes: T = the k-th smallest of the 64 lane minima -- k different lanes
-//        hold a real candidate within T, so T is an upper bound of the k-th distance;
-//     2. tests every chunk's box against T: gap = max(lo - q, q - hi, 0) per axis and the SAME unfused sum of squares as the
-//        point distance.  fp32 subtraction, squaring and addition are monotone, so that value is <= the computed distance
-//        of every point inside the box, bit for bit: a chunk with box distance > T holds no candidate within T.  The skip
-//        is exact, not approximate;
-//     3. the workgroup stages, one after the other, the chunks some query of it needs; a query visits the ones in its own
-//        mask and appends their candidates within T to its survivor list;
-//     4. ranks the list like the other kernels (finish_query: (distance, ORIGINAL index) ranks, boundary ties in closed
-//        form; overflow or a candidate at the initial distance -> the in-order redo on the unsorted cloud).
-// The list holds every candidate within T >= D_k, which is all finish_query needs: results are bit-identical to the
-// reference's sequential insertion.  Workspace (camli_knn_pruned_workspace_bytes): per batch element the chunk planes
-// X | Y | Z | index, the chunk table (box, count) and the order of the queries.
-constexpr int PR_MAX_N = 16384;                 // points per cloud (LDS of the ordering kernel)
-constexpr int PR_CELLS = 4096, PR_BLOCKS = 32, PR_MAXCH = 64;
-constexpr int PR_BOUND_PTS = 512;               // points behind a query's bound
-
-__device__ __forceinline__ float wave_fmin(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_fmax(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
-// exclusive scan of `vals[0 .. 4096)` in place by 1024 threads (4 per thread); scratch: 16 ints
-__device__ __forceinline__ void block_scan_4096(int* vals, int* wave_tot, int tid) {
-    const int lane = tid & 63, w = tid >> 6;
-    const int c0 = vals[4 * tid], c1 = vals[4 * tid + 1], c2 = vals[4 * tid + 2], c3 = vals[4 * tid + 3];
-    const int mine = (c0 + c1) + (c2 + c3);
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) wave_tot[w] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int v = 0; v < w; ++v) base += wave_tot[v];
-    int run = base + incl - mine;
-    vals[4 * tid] = run; run += c0;
-    vals[4 * tid + 1] = run; run += c1;
-    vals[4 * tid + 2] = run; run += c2;
-    vals[4 * tid + 3] = run;
-    __syncthreads();
-}
-
-// order-preserving map float -> uint32 (for LDS atomicMin / atomicMax on coordinates) and back
-__device__ __forceinline__ uint32_t f2ord(float f) {
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(uint32_t o) {
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-}
-
-// grid (2, B), block 1024: blockIdx.x = 0 orders the candidates of batch element b and writes chunk planes + table,
-// 1 orders the queries and writes their order.  Every thread keeps its (up to 16) points in registers from the first
-// read on: the phases below are LDS atomics and scans only, the sorted planes are SCATTERED from the registers (a first
-// form re-read the cloud from global memory in five barrier-separated phases: 40 us on 16 CUs).
-// dynamic LDS (ints): 4096 cell counters.   meta[b] = number of chunks of batch element b.
-// PR_PPT = points per thread (8 covers clouds up to 8192 points, 16 up to 16384)
-template <int D, int PR_PPT>
-__global__ __launch_bounds__(1024) void knn_order_kernel(const float* __restrict__ input, const float* __restrict__ query,
-                                                         float* __restrict__ ws_cand, float* __restrict__ ws_tab,
-                                                         uint32_t* __restrict__ ws_qperm, int* __restrict__ ws_meta, int M,
-                                                         int Nq, int CS) {
-    __shared__ int hist[PR_CELLS];
-    __shared__ float red[16][6];
-    __shared__ int wave_tot[16];
-    __shared__ int axis_hist[3][256];
-    __shared__ int blk_start[PR_BLOCKS + 1], blk_chunk[PR_BLOCKS + 1];
-    __shared__ uint32_t ch_box[PR_MAXCH][6];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int b = blockIdx.y;
-    const bool cands = blockIdx.x == 0;
-    const int n = cands ? M : Nq;
-    const float* __restrict__ pts = cands ? input + (size_t)b * M * D : query + (size_t)b * Nq * D;
-
-    // ---- the thread's points (index tid + 1024 e), bounding box ----
-    float px[PR_PPT], py[PR_PPT], pz[PR_PPT];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int e = 0; e < PR_PPT; ++e) {
-        const int i = tid + 1024 * e;
-        const bool in = i < n;
-        px[e] = in ? pts[(size_t)i * D] : 0.0f;
-        py[e] = in ? pts[(size_t)i * D + 1] : 0.0f;
-        pz[e] = (in && D == 3) ? pts[(size_t)i * D + 2] : 0.0f;
-        if (in) {
-            lo[0] = fminf(lo[0], px[e]); hi[0] = fmaxf(hi[0], px[e]);
-            lo[1] = fminf(lo[1], py[e]); hi[1] = fmaxf(hi[1], py[e]);
-            if (D == 3) { lo[2] = fminf(lo[2], pz[e]); hi[2] = fmaxf(hi[2], pz[e]); }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-        lo[a] = wave_fmin(lo[a]);
-        hi[a] = wave_fmax(hi[a]);
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            red[w][a] = lo[a];
-            red[w][3 + a] = hi[a];
-        }
-    }
-    for (int i = tid; i < PR_CELLS; i += 1024) hist[i] = 0;
-    if (tid < 768) (&axis_hist[0][0])[tid] = 0;
-    if (tid < PR_MAXCH * 6) (&ch_box[0][0])[tid] = (tid % 6) < 3 ? 0xffffffffu : 0u;      // min slots | max slots
-    __syncthreads();
-    float scale[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-        for (int v = 0; v < 16; ++v) {
-            lo[a] = fminf(lo[a], red[v][a]);
-            hi[a] = fmaxf(hi[a], red[v][3 + a]);
-        }
-        const float ext = hi[a] - lo[a];
-        scale[a] = (ext > 0.0f && ext < INFINITY) ? 255.999f / ext : 0.0f;
-    }
-    auto bin_of = [&](float v, int a) -> int {
-        const float q = (v - lo[a]) * scale[a];
-        return (int)fminf(fmaxf(q == q ? q : 0.0f, 0.0f), 255.0f);
-    };
-    // ---- per-axis histogram -> exclusive ranks ----
-#pragma unroll
-    for (int e = 0; e < PR_PPT; ++e) {
-        if (tid + 1024 * e < n) {
-            atomicAdd(&axis_hist[0][bin_of(px[e], 0)], 1);
-            atomicAdd(&axis_hist[1][bin_of(py[e], 1)], 1);
-            if (D == 3) atomicAdd(&axis_hist[2][bin_of(pz[e], 2)], 1);
-        }
-    }
-    __syncthreads();
-    if (w < D) {                                    // wave a scans axis a: 4 bins per lane
-        int* h = axis_hist[w];
-        const int c0 = h[4 * lane], c1 = h[4 * lane + 1], c2 = h[4 * lane + 2], c3 = h[4 * lane + 3];
-        const int mine = (c0 + c1) + (c2 + c3);
-        int incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        int run = incl - mine;
-        h[4 * lane] = run; run += c0;
-        h[4 * lane + 1] = run; run += c1;
-        h[4 * lane + 2] = run; run += c2;
-        h[4 * lane + 3] = run;
-    }
-    __syncthreads();
-    // ---- Morton cell of the equalised coordinates, cell histogram ----
-    constexpr int BITS = D == 3 ? 4 : 6;
-    const float rank_scale = (float)(1 << BITS) / (float)n;
-    unsigned short cell[PR_PPT];
-#pragma unroll
-    for (int e = 0; e < PR_PPT; ++e) {
-        unsigned code = 0;
-#pragma unroll
-        for (int a = 0; a < D; ++a) {
-            const float v = a == 0 ? px[e] : (a == 1 ? py[e] : pz[e]);
-            unsigned qi = (unsigned)((float)axis_hist[a][bin_of(v, a)] * rank_scale);          // rank -> BITS bits (monotone)
-            if (qi > (1u << BITS) - 1u) qi = (1u << BITS) - 1u;
-            unsigned sp = 0;
-#pragma unroll
-            for (int t = 0; t < BITS; ++t) sp |= ((qi >> t) & 1u) << (D * t);
-            code |= sp << a;
-        }
-        code &= PR_CELLS - 1;
-        cell[e] = (unsigned short)code;
-        if (tid + 1024 * e < n) atomicAdd(&hist[code], 1);
-    }
-    __syncthreads();
-    block_scan_4096(hist, wave_tot, tid);
-    if (tid <= PR_BLOCKS) blk_start[tid] = tid < PR_BLOCKS ? hist[tid * (PR_CELLS / PR_BLOCKS)] : n;
-    __syncthreads();
-    int pos[PR_PPT];                                // sorted position of the thread's points
-#pragma unroll
-    for (int e = 0; e < PR_PPT; ++e) pos[e] = tid + 1024 * e < n ? atomicAdd(&hist[cell[e]], 1) : -1;
-    if (!cands) {
-        uint32_t* __restrict__ qp = ws_qperm + (size_t)b * Nq;
-#pragma unroll
-        for (int e = 0; e < PR_PPT; ++e)
-            if (pos[e] >= 0) qp[pos[e]] = (uint32_t)(tid + 1024 * e);
-        return;
-    }
-    // ---- chunk numbering: block k owns chunks blk_chunk[k] .., each of <= CS points ----
-    if (tid == 0) {
-        int c = 0;
-        for (int k = 0; k < PR_BLOCKS; ++k) {
-            blk_chunk[k] = c;
-            c += (blk_start[k + 1] - blk_start[k] + CS - 1) / CS;
-        }
-        blk_chunk[PR_BLOCKS] = c;
-        ws_meta[b] = c;
-    }
-    __syncthreads();
-    const int nch = blk_chunk[PR_BLOCKS];
-    float* __restrict__ cb = ws_cand + (size_t)b * 4 * PR_MAXCH * CS;
-    const int plane = PR_MAXCH * CS;
-    // padding first (positions a chunk does not fill keep an infinite x: distance inf, never <= T), then the points
-    for (int p = tid; p < nch * CS; p += 1024) {
-        cb[p] = INFINITY;
-        reinterpret_cast<uint32_t*>(cb)[3 * plane + p] = 0xffffffffu;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < PR_PPT; ++e) {
-        if (pos[e] < 0) continue;
-        const int blk = cell[e] >> 7;                                  // PR_CELLS / PR_BLOCKS = 128 cells per block
-        const int within = pos[e] - blk_start[blk];
-        const int c = blk_chunk[blk] + within / CS, el = within % CS;    // element el of chunk c
-        // lane ln of the search holds elements ln, ln + 64, ... of a chunk: storage slot 256 g + 4 ln + t <-> element (4 g + t) 64 + ln
-        const int ln = el & 63, gt = el >> 6, g = gt >> 2, t = gt & 3;
-        const int p = c * CS + 256 * g + 4 * ln + t;
-        cb[p] = px[e];
-        cb[plane + p] = py[e];
-        cb[2 * plane + p] = pz[e];
-        reinterpret_cast<uint32_t*>(cb)[3 * plane + p] = (uint32_t)(tid + 1024 * e);
-        atomicMin(&ch_box[c][0], f2ord(px[e])); atomicMax(&ch_box[c][3], f2ord(px[e]));
-        atomicMin(&ch_box[c][1], f2ord(py[e])); atomicMax(&ch_box[c][4], f2ord(py[e]));
-        if (D == 3) { atomicMin(&ch_box[c][2], f2ord(pz[e])); atomicMax(&ch_box[c][5], f2ord(pz[e])); }
-    }
-    __syncthreads();
-    float* __restrict__ tb = ws_tab + (size_t)b * PR_MAXCH * 8;
-    if (tid < nch) {
-        // the chunk's point count: its block's remainder
-        int blk = 0;
-        for (int k = 0; k < PR_BLOCKS; ++k)
-            if (blk_chunk[k] <= tid) blk = k;
-        const int within = (tid - blk_chunk[blk]) * CS, left = blk_start[blk + 1] - blk_start[blk] - within;
-        for (int a = 0; a < 3; ++a) {
-            tb[tid * 8 + a] = a < D ? ord2f(ch_box[tid][a]) : 0.0f;
-            tb[tid * 8 + 3 + a] = a < D ? ord2f(ch_box[tid][3 + a]) : 0.0f;
-        }
-        tb[tid * 8 + 6] = __int_as_float(left < CS ? left : CS);
-        tb[tid * 8 + 7] = 0.0f;
-    }
-}
-
-// box distance in the arithmetic of dist_bits (see the header of this section)
-template <int D>
-__device__ __forceinline__ uint32_t box_bits(float ux, float uy, float uz, const float (&lo)[3], const float (&hi)[3]) {
-    const float gx = fmaxf(fmaxf(lo[0] - ux, ux - hi[0]), 0.0f);
-    const float gy = fmaxf(fmaxf(lo[1] - uy, uy - hi[1]), 0.0f);
-    float d = gx * gx + gy * gy;
-    if (D == 3) {
-        const float gz = fmaxf(fmaxf(lo[2] - uz, uz - hi[2]), 0.0f);
-        d = d + gz * gz;
-    }
-    return __float_as_uint(d);
-}
-
-// grid (ceil(Nq / (4 QPW)), B), block 256.  dynamic LDS (dwords): two staged chunks X | Y | Z | I (2 * 4 * 64 J) | per wave
-// QPW survivor lists | per wave QPW rows of 64 lane minima.
-// Every chunk a workgroup touches goes through LDS once per pass, loaded by all 256 threads (the next chunk's loads are in
-// flight while the current one is worked on); a first form read the bound chunks per query straight from global memory
-// and spent more time waiting for those dependent loads than the whole brute-force search takes.
-template <int D, int J, int QPW>
-__global__ __launch_bounds__(256) void knn_pruned_kernel(const float* __restrict__ input, const float* __restrict__ query,
-                                                         int64_t* __restrict__ out, const float* __restrict__ ws_cand,
-                                                         const float* __restrict__ ws_tab,
-                                                         const uint32_t* __restrict__ ws_qperm,
-                                                         const int* __restrict__ ws_meta, int M, int Nq, int k) {
-    constexpr int CS = 64 * J, PLANE = PR_MAXCH * CS, PER = CS / 256;      // PER elements of every plane per thread
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float s_q[4][QPW][4];
-    __shared__ uint32_t s_T[4][QPW];
-    __shared__ int s_cnt[4][QPW];
-    __shared__ int s_oq[4][QPW];
-    __shared__ unsigned long long s_mask[4][QPW];
-    __shared__ unsigned long long s_wmask[4];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    const LaneBits lb(lane);
-    float* cand = smem;                                                   // two buffers of 4 * CS
-    uint32_t* lists = reinterpret_cast<uint32_t*>(smem + 8 * CS) + w * (QPW * LIST_DW);
-    uint32_t* minima = reinterpret_cast<uint32_t*>(smem + 8 * CS) + 4 * (QPW * LIST_DW) + w * (QPW * 64);
-    const float* __restrict__ in_b = input + (size_t)b * M * D;
-    const float* __restrict__ query_b = query + (size_t)b * Nq * D;
-    int64_t* __restrict__ out_b = out + (size_t)b * Nq * k;
-    const float* __restrict__ cb = ws_cand + (size_t)b * 4 * PLANE;
-    const float* __restrict__ tb = ws_tab + (size_t)b * PR_MAXCH * 8;
-    const uint32_t* __restrict__ qp = ws_qperm + (size_t)b * Nq;
-    const int nchunks = __builtin_amdgcn_readfirstlane(ws_meta[b]);
-
-    const int qs0 = (blockIdx.x * 4 + w) * QPW;
-    const int nq = Nq - qs0 < 0 ? 0 : (Nq - qs0 < QPW ? Nq - qs0 : QPW);      // this wave's queries (sorted positions qs0 ..)
-    for (int i = lane; i < QPW * LIST_DW; i += 64) lists[i] = 0xffffffffu;
-    for (int i = lane; i < QPW * 64; i += 64) minima[i] = 0xffffffffu;
-    if (lane < QPW) {
-        const bool ok = lane < nq;
-        const int oq = ok ? (int)qp[qs0 + lane] : 0;
-        s_oq[w][lane] = oq;
-        s_q[w][lane][0] = query_b[(size_t)oq * D];
-        s_q[w][lane][1] = query_b[(size_t)oq * D + 1];
-        s_q[w][lane][2] = (D == 3) ? query_b[(size_t)oq * D + 2] : 0.0f;
-    }
-    // this lane's chunk (lane c < nchunks): box and point count
-    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {INFINITY, INFINITY, INFINITY};
-    int bcount = 0;
-    if (lane < nchunks) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            blo[a] = tb[lane * 8 + a];
-            bhi[a] = tb[lane * 8 + 3 + a];
-        }
-        bcount = __float_as_int(tb[lane * 8 + 6]);
-    }
-    __syncthreads();                                // s_q / s_oq of this wave are written
-
-    // One pass over the chunks in the union of the waves' masks: `work(u, X4, Y4, Z4, I)` runs for every query u of this
-    // wave whose own mask holds the staged chunk.  Double-buffered: the loads of the next chunk are issued before the
-    // current one is worked on, written to the other buffer afterwards; one barrier per chunk.
-    auto pass = [&](auto&& work) {
-        __syncthreads();
-        unsigned long long all = (s_wmask[0] | s_wmask[1]) | (s_wmask[2] | s_wmask[3]);
-        float r[4][PER];
-        auto fetch = [&](int ch) {
-            const float* __restrict__ src = cb + (size_t)ch * CS + threadIdx.x;
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                r[0][e] = src[256 * e];
-                r[1][e] = src[PLANE + 256 * e];
-                r[2][e] = src[2 * PLANE + 256 * e];
-                r[3][e] = src[3 * PLANE + 256 * e];
-            }
-        };
-        auto put = [&](int buf) {
-            float* dst = cand + buf * 4 * CS + threadIdx.x;
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                dst[256 * e] = r[0][e];
-                dst[CS + 256 * e] = r[1][e];
-                dst[2 * CS + 256 * e] = r[2][e];
-                dst[3 * CS + 256 * e] = r[3][e];
-            }
-        };
-        if (!all) return;
-        int cur = (int)__builtin_ctzll(all);
-        all &= all - 1;
-        fetch(cur);
-        put(0);
-        int buf = 0;
-        __syncthreads();
-        while (true) {
-            const int nxt = all ? (int)__builtin_ctzll(all) : -1;
-            all &= all - 1;
-            if (nxt >= 0) fetch(nxt);
-            const float* cbuf = cand + buf * 4 * CS;
-            const float4* X4 = reinterpret_cast<const float4*>(cbuf) + lane;
-            const float4* Y4 = reinterpret_cast<const float4*>(cbuf + CS) + lane;
-            const float4* Z4 = reinterpret_cast<const float4*>(cbuf + 2 * CS) + lane;
-            const uint32_t* I = reinterpret_cast<const uint32_t*>(cbuf + 3 * CS);
-            for (int u = 0; u < nq; ++u)
-                if ((s_mask[w][u] >> cur) & 1ull) work(u, X4, Y4, Z4, I);       // wave-uniform
-            if (nxt < 0) break;
-            put(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-            cur = nxt;
-        }
-    };
-
-    // ---- A: lane minima over the nearest chunks of every query (until they hold PR_BOUND_PTS points) ----
-    {
-        unsigned long long wmask = 0ull;
-        for (int u = 0; u < nq; ++u) {
-            const float ux = s_q[w][u][0], uy = s_q[w][u][1], uz = s_q[w][u][2];
-            const uint32_t db = lane < nchunks ? box_bits<D>(ux, uy, uz, blo, bhi) : 0xffffffffu;
-            const uint32_t dbc = (lane < nchunks && db > 0x7f800000u) ? 0x7f800000u : db;     // NaN coordinates: any chunk will do
-            unsigned long long taken = 0ull;
-            int got = 0;
-            while (got < PR_BOUND_PTS) {
-                const bool open = lane < nchunks && !((taken >> lane) & 1ull);
-                const uint32_t mn = wave_min_u32(open ? dbc : 0xffffffffu);
-                const uint64_t at = __ballot(open && dbc == mn);
-                if (!at) break;                     // every chunk is in
-                const int c = (int)__builtin_ctzll(at);
-                taken |= 1ull << c;
-                got += __builtin_amdgcn_readlane(bcount, c);
-            }
-            if (lane == 0) s_mask[w][u] = taken;
-            wmask |= taken;
-        }
-        if (lane == 0) s_wmask[w] = wmask;
-    }
-    pass([&](int u, const float4* X4, const float4* Y4, const float4* Z4, const uint32_t*) {
-        uint32_t d[J];
-        const uint32_t mc = distances<D, J, J / 4>(X4, Y4, Z4, s_q[w][u][0], s_q[w][u][1], s_q[w][u][2], d);
-        minima[u * 64 + lane] = min(minima[u * 64 + lane], mc);
-    });
-    // ---- B: bound, chunk masks, collection ----
-    {
-        unsigned long long wmask = 0ull;
-        for (int u = 0; u < nq; ++u) {
-            const float ux = s_q[w][u][0], uy = s_q[w][u][1], uz = s_q[w][u][2];
-            const uint32_t db = lane < nchunks ? box_bits<D>(ux, uy, uz, blo, bhi) : 0xffffffffu;
-            const uint32_t T = kth_bound(minima[u * 64 + lane], k, lb);
-            const unsigned long long need = __ballot(lane < nchunks && db <= T);
-            if (lane == 0) {
-                s_T[w][u] = T;
-                s_cnt[w][u] = 0;
-                s_mask[w][u] = need;
-            }
-            wmask |= need;
-        }
-        __syncthreads();                            // all waves are done reading the pass-A masks
-        if (lane == 0) s_wmask[w] = wmask;
-    }
-    auto collect_pass = [&]() {
-        pass([&](int u, const float4* X4, const float4* Y4, const float4* Z4, const uint32_t* I) {
-            uint32_t d[J];
-            (void)distances<D, J, 0>(X4, Y4, Z4, s_q[w][u][0], s_q[w][u][1], s_q[w][u][2], d);
-            const int cnt = collect<J, 0, J>(d, s_T[w][u], lists + u * LIST_DW, 1, 0, CAP,
-                                             [&](int slot) { return I[4 * lane + 256 * (slot >> 2) + (slot & 3)]; }, s_cnt[w][u]);
-            if (lane == 0) s_cnt[w][u] = cnt;
-        });
-    };
-    collect_pass();
-    __syncthreads();
-    // ---- C: a list that overflowed holds CAP REAL candidates: the k-th smallest of their distances is an upper bound of
-    // the k-th distance too, and a much tighter one -- collect again with it (dense clusters next to sparse regions) ----
-    {
-        unsigned long long wmask = 0ull;
-        for (int u = 0; u < nq; ++u) {
-            unsigned long long need = 0ull;
-            if (s_cnt[w][u] > CAP) {                // wave-uniform
-                uint32_t* list = lists + u * LIST_DW;
-                const uint32_t d0 = list[2 * lane + 1], d1 = list[2 * (64 + lane) + 1];
-                // k-th smallest of the 128 distances: the k-th smallest of the 64 pairwise minima is >= it, still a valid bound
-                const uint32_t T2 = kth_bound(min(d0, d1), k, lb);
-                list[2 * lane] = list[2 * lane + 1] = 0xffffffffu;
-                list[2 * (64 + lane)] = list[2 * (64 + lane) + 1] = 0xffffffffu;
-                const float ux = s_q[w][u][0], uy = s_q[w][u][1], uz = s_q[w][u][2];
-                const uint32_t db = lane < nchunks ? box_bits<D>(ux, uy, uz, blo, bhi) : 0xffffffffu;
-                need = __ballot(lane < nchunks && db <= T2);
-                if (lane == 0) {
-                    s_T[w][u] = T2;
-                    s_cnt[w][u] = 0;
-                }
-            }
-            if (lane == 0) s_mask[w][u] = need;
-            wmask |= need;
-        }
-        if (lane == 0) s_wmask[w] = wmask;
-    }
-    collect_pass();                                  // no chunk at all unless some list overflowed
-    __syncthreads();
-    for (int u = 0; u < nq; ++u) {
-        const int cnt = s_cnt[w][u];
-        const int n = cnt < CAP ? cnt : CAP;
-        int64_t* o = out_b + (size_t)s_oq[w][u] * k;
-        const bool init_tie = finish_query(lists + u * LIST_DW, n, n, n > 64, k, o, lane);
-        if (cnt > CAP || init_tie) redo_query<D>(in_b, M, s_q[w][u][0], s_q[w][u][1], s_q[w][u][2], k, o, lane);
-    }
-}
-
-struct PrunedPlan {
-    int J, CS;
-    size_t cand_off, tab_off, qperm_off, meta_off, bytes;     // per call (all batch elements)
-};
-static bool pruned_plan(int B, int M, int Nq, PrunedPlan* pl) {
-    if (M < 1 || Nq < 1 || M > PR_MAX_N || Nq > PR_MAX_N) return false;
-    // chunks: 32 blocks may each end in a partial chunk -> at most 32 + M / CS of them, one per lane
-    int J = 8;
-    if (const char* e = getenv("CAMLI_KNN_CHUNK")) J = atoi(e) / 64;
-    if (J != 4 && J != 8 && J != 16) J = 8;
-    while (J < 16 && PR_BLOCKS + M / (64 * J) > PR_MAXCH) J *= 2;
-    if (PR_BLOCKS + M / (64 * J) > PR_MAXCH) return false;
-    pl->J = J;
-    pl->CS = 64 * J;
-    pl->cand_off = 0;
-    pl->tab_off = (size_t)B * 4 * PR_MAXCH * pl->CS * 4;
-    pl->qperm_off = pl->tab_off + (size_t)B * PR_MAXCH * 8 * 4;
-    pl->meta_off = pl->qperm_off + (size_t)B * Nq * 4;
-    pl->bytes = pl->meta_off + (size_t)B * 4;
-    return true;
-}
-
-template <int D>
-int launch_pruned(const float* input, const float* query, int64_t* out, void* workspace, int B, int M, int Nq, int k,
-                  hipStream_t stream) {
-    PrunedPlan pl;
-    if (!pruned_plan(B, M, Nq, &pl)) return CAMLI_ENOTSUP;
-    char* ws = static_cast<char*>(workspace);
-    float* wc = reinterpret_cast<float*>(ws + pl.cand_off);
-    float* wt = reinterpret_cast<float*>(ws + pl.tab_off);
-    uint32_t* wq = reinterpret_cast<uint32_t*>(ws + pl.qperm_off);
-    int* wm = reinterpret_cast<int*>(ws + pl.meta_off);
-    const int nmax = M > Nq ? M : Nq;
-    if (nmax <= 4096)
-        hipLaunchKernelGGL((knn_order_kernel<D, 4>), dim3(2, B), dim3(1024), 0, stream, input, query, wc, wt, wq, wm, M, Nq, pl.CS);
-    else if (nmax <= 8192)
-        hipLaunchKernelGGL((knn_order_kernel<D, 8>), dim3(2, B), dim3(1024), 0, stream, input, query, wc, wt, wq, wm, M, Nq, pl.CS);
-    else
-        hipLaunchKernelGGL((knn_order_kernel<D, 16>), dim3(2, B), dim3(1024), 0, stream, input, query, wc, wt, wq, wm, M, Nq, pl.CS);
-    int qpw = 4;
-    if (const char* e = getenv("CAMLI_KNN_QPW")) qpw = atoi(e);
-    if (qpw != 4 && qpw != 8) qpw = 4;
-    dim3 grid(camli_divup(Nq, 4 * qpw), B);
-#define CAMLI_PRUNED(JJ, QQ)                                                                                              \
-    {                                                                                                                     \
-        const size_t lds = (size_t)(8 * 64 * JJ + 4 * QQ * LIST_DW + 4 * QQ * 64) * 4;                                    \
-        static bool set = false;                                                                                          \
-        if (!set) {                                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_pruned_kernel<D, JJ, QQ>),                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-            set = true;                                                                                                   \
-        }                                                                                                                 \
-        hipLaunchKernelGGL((knn_pruned_kernel<D, JJ, QQ>), grid, dim3(256), lds, stream, input, query, out, wc, wt, wq, wm, M, \
-                           Nq, k);                                                                                        \
-    }
-    if (pl.J == 4 && qpw == 4) CAMLI_PRUNED(4, 4)
-    else if (pl.J == 4) CAMLI_PRUNED(4, 8)
-    else if (pl.J == 8 && qpw == 4) CAMLI_PRUNED(8, 4)
-    else if (pl.J == 8) CAMLI_PRUNED(8, 8)
-    else if (qpw == 4) CAMLI_PRUNED(16, 4)
-    else CAMLI_PRUNED(16, 8)
-#undef CAMLI_PRUNED
-    return camli_check_launch("camli_knn_pruned");
-}
-
 static int mode() {   // CAMLI_KNN=lane forces the lane-per-query kernels, =xlane the cross-lane ones wherever they apply
     const char* e = getenv("CAMLI_KNN");      // read per call: tests and A/B tools flip it inside one process
     if (!e) return 0;
@@ -1787,36 +1244,6 @@ extern "C" int camli_knn(const float* input, const float* query, int64_t* out_id
     }
     return D == 2 ? dispatch_knn<2>(input, query, out_idx, B, M, Nq, k, s)
                   : dispatch_knn<3>(input, query, out_idx, B, M, Nq, k, s);
-}
-
-// Spatially pruned exact search for large candidate sets (see "spatially pruned search" above): same results as camli_knn,
-// bit for bit.  workspace: camli_knn_pruned_workspace_bytes(B, M, Nq) bytes of device memory (0 = shape not served:
-// M or Nq above 16384); 1 <= k <= 32.
-extern "C" int64_t camli_knn_pruned_workspace_bytes(int B, int M, int Nq) {
-    xl::PrunedPlan pl;
-    if (B < 1 || !xl::pruned_plan(B, M, Nq, &pl)) return 0;
-    return (int64_t)pl.bytes;
-}
-
-extern "C" int camli_knn_pruned(const float* input, const float* query, int64_t* out_idx, void* workspace, int B, int M,
-                                int Nq, int D, int k, void* stream) {
-    if (B == 0 || Nq == 0) return CAMLI_OK;
-    if (!input || !query || !out_idx || !workspace) { camli_set_error("camli_knn_pruned: null pointer"); return CAMLI_EINVAL; }
-    if (B < 0 || M < 1 || Nq < 0 || (D != 2 && D != 3) || k < 1 || B > 65535) {
-        camli_set_error("camli_knn_pruned: bad shape B=%d M=%d Nq=%d D=%d k=%d", B, M, Nq, D, k);
-        return CAMLI_EINVAL;
-    }
-    if (reinterpret_cast<uintptr_t>(workspace) & 15) {
-        camli_set_error("camli_knn_pruned: the workspace must be 16-byte aligned");
-        return CAMLI_EINVAL;
-    }
-    if (!xl::k_supported(k) || camli_knn_pruned_workspace_bytes(B, M, Nq) == 0) {
-        camli_set_error("camli_knn_pruned: shape not served (k=%d M=%d Nq=%d; needs k <= 32, M and Nq <= %d)", k, M, Nq, xl::PR_MAX_N);
-        return CAMLI_ENOTSUP;
-    }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return D == 2 ? xl::launch_pruned<2>(input, query, out_idx, workspace, B, M, Nq, k, s)
-                  : xl::launch_pruned<3>(input, query, out_idx, workspace, B, M, Nq, k, s);
 }
 
 // Nested prefixes: out_levels[l] [B,Nq,k] = the k nearest among the FIRST sizes[l] inputs (sizes strictly descending,

@@ -194,26 +194,9 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     assert query_xyz.shape[0] == b and query_xyz.shape[2] == d
     out = torch.empty((b, nq, k), dtype=torch.int64, device=query_xyz.device)
     with _on_device(input_xyz):
-        ws_bytes = _pruned_workspace(lib, b, m, nq, k)
-        if ws_bytes:
-            # large candidate sets: Morton-sorted chunks, exact box pruning (camli_knn_pruned; same indices bit for bit)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=query_xyz.device)
-            _lib.launch('camli_knn', lib.camli_knn_pruned, input_xyz.data_ptr(), query_xyz.data_ptr(), out.data_ptr(),
-                        ws.data_ptr(), b, m, nq, d, k, _stream_ptr(input_xyz), work=(float(b) * m * nq, 'pairs'))
-        else:
-            _lib.launch('camli_knn', lib.camli_knn, input_xyz.data_ptr(), query_xyz.data_ptr(), out.data_ptr(),
-                        b, m, nq, d, k, _stream_ptr(input_xyz), work=(float(b) * m * nq, 'pairs'))
+        _lib.launch('camli_knn', lib.camli_knn, input_xyz.data_ptr(), query_xyz.data_ptr(), out.data_ptr(),
+                    b, m, nq, d, k, _stream_ptr(input_xyz), work=(float(b) * m * nq, 'pairs'))
     return out
-
-
-def _pruned_workspace(lib, b, m, nq, k):
-    """bytes of workspace when the spatially pruned search is to serve this shape, else 0.  Opt-in (CAMLI_KNN=pruned): it is
-    exact everywhere, 1.4x (8192 candidates) to 1.6x (16384) faster than the brute-force kernels on uniform clouds, but even
-    or slower on strongly clustered ones (tools/knn_pruned_probe.py) -- not a default."""
-    import os
-    if os.environ.get('CAMLI_KNN', '')[:1] != 'p' or not 1 <= k <= 32:
-        return 0
-    return int(lib.camli_knn_pruned_workspace_bytes(b, m, nq))
 
 
 def k_nearest_neighbor_prefixes(input_xyz: torch.Tensor, query_xyz: torch.Tensor, sizes, k: int):

@@ -59,19 +59,6 @@ int camli_knn(const float *input, const float *query, int64_t *out_idx,
 int camli_knn_prefixes(const float *input, const float *query, int64_t *const *out_levels, const int *sizes,
                        int L, int B, int M, int Nq, int D, int k, void *stream);
 
-/*
- * The same search, same results bit for bit, for LARGE candidate sets: the candidates are sorted along a Morton curve
- * (once per call, in LDS), cut into chunks with bounding boxes, the queries are sorted the same way, and a query only
- * visits the chunks whose box distance -- evaluated in the arithmetic of the point distance, hence a lower bound bit for
- * bit -- is within its running bound of the k-th distance (csrc/hip/knn.hip, "spatially pruned search").
- *   workspace: camli_knn_pruned_workspace_bytes(B, M, Nq) bytes of device memory, 16-byte aligned; 0 = shape not served
- *   (M or Nq > 16384).
- *   1 <= k <= 32, D in {2, 3}.  Replaces the same reference kernel as camli_knn.
- */
-int64_t camli_knn_pruned_workspace_bytes(int B, int M, int Nq);
-int camli_knn_pruned(const float *input, const float *query, int64_t *out_idx, void *workspace, int B, int M, int Nq, int D,
-                     int k, void *stream);
-
 /* camli_fps tie rule: the LOWEST index among equal maxima (the reference's Python path, wrapper.py:83-96); the
  * reference's CUDA reduction tree keeps a different tied candidate (kernel.cu:5-10) -- see csrc/hip/fps.hip. */
 int camli_fps(const float *xyz, int64_t *out_idx, int B, int N, int n_samples, void *stream);
@@ -281,26 +268,6 @@ int64_t camli_corr3d_mlp_bwd_workspace_bytes(int B, int N);
 int camli_corr3d_mlp_bwd(const float *lookup, const float *gout, const float *w1, const float *b1, const float *w2,
                          const float *b2, float *glookup, float *gw1, float *gb1, float *gw2, float *gb2, float *workspace,
                          int B, int N, int levels, int k, int hidden, void *stream);
-
-/*
- * The same MLP with the lookup's gather folded in (camliraft_l_core.py:62-101 for the four NESTED target levels of a pass in
- * one launch each way): the column (level l, neighbour j) of point n is built in the kernel,
- *   x = (xyz2[:, m] - xyz1[:, n], cost_levels[l][b, n, m]),  m = knn_levels[l][b, n, j],
- * instead of being read from camli_corr3d_gather_levels_fwd's [B,4,N,L*k] tensor.
- *   xyz1 [B,3,N], xyz2 [B,3,M0] (level l = its first sizes[l] points), cost_levels[l] [B,N,sizes[l]], knn_levels[l] int64
- *   [B,N,k] (HOST arrays of DEVICE pointers); out as camli_corr3d_mlp_fwd.
- *   bwd: gcost_levels[l] [B,N,sizes[l]] += d/d(volume entry) (the caller zero-fills once per pass, then calls once per GRU
- *        iteration; needs sizes[l] >= k, else CAMLI_ENOTSUP); parameter gradients and workspace as camli_corr3d_mlp_bwd.
- */
-int camli_corr3d_cost_levels_fwd(const float *xyz1, const float *xyz2, const float *const *cost_levels,
-                                 const int64_t *const *knn_levels, const int *sizes, const float *w1, const float *b1,
-                                 const float *w2, const float *b2, float *out, int B, int N, int M0, int levels, int k,
-                                 int hidden, void *stream);
-int camli_corr3d_cost_levels_bwd(const float *xyz1, const float *xyz2, const float *const *cost_levels,
-                                 const int64_t *const *knn_levels, const int *sizes, const float *gout, const float *w1,
-                                 const float *b1, const float *w2, const float *b2, float *const *gcost_levels, float *gw1,
-                                 float *gb1, float *gw2, float *gb2, float *workspace, int B, int N, int M0, int levels,
-                                 int k, int hidden, void *stream);
 
 /*
  * PointPWC learnable cost volume, PWC-style Correlation3D (internal composite op; the reference materialises

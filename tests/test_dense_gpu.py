@@ -307,93 +307,3 @@ def test_channel_last_gather_vs_oracle(case, rank2, oracle_lib):
     assert np.array_equal(t.grad.cpu().numpy(), oracle_lib.scatter_add_cl(gout, flat, m))
 
 
-# ---- cost MLP with the lookup's gather folded in (camli_corr3d_cost_levels_fwd / _bwd, camliraft_l_core.py:62-101) ----
-def _cost_levels_case(b, n, sizes, seed):
-    rng = np.random.default_rng(seed)
-    xyz1 = rng.standard_normal((b, 3, n)).astype(np.float32)
-    xyz2 = rng.standard_normal((b, 3, sizes[0])).astype(np.float32)
-    vols = [rng.standard_normal((b, n, m)).astype(np.float32) for m in sizes]
-    # 16 DISTINCT neighbours per (point, level), as a KNN search returns them
-    knn = [np.stack([np.stack([rng.permutation(m)[:16] for _ in range(n)]) for _ in range(b)]).astype(np.int64) for m in sizes]
-    w1, b1 = (rng.standard_normal((32, 4)) * 0.5).astype(np.float32), (rng.standard_normal(32) * 0.2).astype(np.float32)
-    w2, b2 = (rng.standard_normal((32, 32)) * 0.2).astype(np.float32), (rng.standard_normal(32) * 0.2).astype(np.float32)
-    gout = rng.standard_normal((b, 128, n)).astype(np.float32)
-    return xyz1, xyz2, vols, knn, (w1, b1, w2, b2), gout
-
-
-@pytest.mark.parametrize('shape', [(2, 64, (96, 48, 24, 16)), (1, 8, (16, 16, 16, 16)), (3, 200, (257, 130, 65, 33))],
-                         ids=lambda s: 'b%dn%d' % s[:2])
-def test_cost_levels_kernel_vs_oracle_and_split_kernels(shape, oracle_lib, oracle_dense):
-    """one kernel each way == (gather kernel + MLP kernel) bit for bit, and both == the oracle's gather (bit-exact C) fed
-    to the numpy cost MLP; d/d(volume) accumulates over two calls like two GRU iterations."""
-    from camliflow_amd.csrc import fused
-    b, n, sizes = shape
-    xyz1, xyz2, vols, knn, params, gout = _cost_levels_case(b, n, sizes, n)
-
-    def run(fold):
-        levels = [dev(v).requires_grad_(True) for v in vols]
-        pyr = fused.Corr3DPyramid(levels)
-        c1, c2 = _cost_mlp_modules(*params)
-        tables = [dev(t) for t in knn]
-        outs = []
-        for _ in range(2):
-            if fold:
-                assert fused.corr3d_cost_levels_supported(pyr, tables, [c1, c2], n)
-                outs.append(fused.corr3d_cost_levels(pyr, dev(xyz1), dev(xyz2), tables, c1, c2))
-            else:
-                lookup = fused.corr3d_lookup_levels(pyr, dev(xyz1), dev(xyz2), tables)
-                outs.append(fused.corr3d_cost_mlp(lookup, c1, c2, 4))
-        (outs[0] * dev(gout)).sum().add((outs[1] * dev(gout) * 0.5).sum()).add(pyr.token.sum()).backward()
-        return outs[0].detach(), [lvl.grad for lvl in levels], [p.grad for p in (c1.weight, c1.bias, c2.weight, c2.bias)]
-
-    out_f, gv_f, gp_f = run(True)
-    out_s, gv_s, gp_s = run(False)
-    assert torch.equal(out_f, out_s)
-    for a, c in zip(gv_f, gv_s):
-        assert torch.equal(a, c)
-    for a, c in zip(gp_f, gp_s):
-        assert torch.equal(a, c)
-    # oracle: per-level gather (dxyz, entry) -> columns side by side -> numpy MLP
-    lookup = np.concatenate([oracle_lib.corr3d_gather_fwd(xyz1, np.ascontiguousarray(xyz2[:, :, :m]), v, t)
-                             for m, v, t in zip(sizes, vols, knn)], axis=3)
-    _close(out_f, oracle_dense.cost_mlp_fwd(lookup, *params, 4), what='out')
-    gx, gw1, gb1, gw2, gb2 = oracle_dense.cost_mlp_bwd(gout * 1.5, lookup, *params, 4)      # two lookups: 1 + 0.5
-    for lvl, (m, t) in enumerate(zip(sizes, knn)):
-        want = np.zeros((b, n, m), dtype=np.float64)
-        entry = gx[:, 3, :, lvl * 16:(lvl + 1) * 16]
-        for bi in range(b):
-            np.add.at(want[bi], (np.arange(n)[:, None], t[bi]), entry[bi])
-        _close(gv_f[lvl], want.astype(np.float32), what='gvol%d' % lvl)
-    for got, want, what in zip(gp_f, (gw1, gb1, gw2, gb2), ('gw1', 'gb1', 'gw2', 'gb2')):
-        _close(got.reshape(want.shape), want, rtol=2e-4, atol=2e-5, what=what)
-
-
-def test_correlation3d_module_with_and_without_the_folded_gather(monkeypatch):
-    """Correlation3D on nested levels: the default (gather launch + MLP launch) and CAMLI_CORR3D_GATHER=fused (one launch
-    each way) give identical costs and gradients."""
-    from camliflow_amd.cores import runtime
-    from camliflow_amd.cores.raft3d import Correlation3D
-    from camliflow_amd.cores.setconv import pass_cache
-    from modelutils import hashed_fill_
-    torch.manual_seed(1)
-    mod = hashed_fill_(Correlation3D(out_channels=128, k=16)).cuda()
-    b, n = 2, 512
-    xyz1 = torch.rand(b, 3, n, device='cuda') * 4
-    base2 = xyz1 + torch.randn(b, 3, n, device='cuda') * 0.2
-    xyzs2 = [base2[:, :, :m].contiguous() for m in (512, 256, 128, 64)]
-    f1 = torch.randn(b, 128, n, device='cuda', requires_grad=True)
-    f2 = torch.randn(b, 128, n, device='cuda', requires_grad=True)
-    g = torch.randn(b, 128, n, device='cuda')
-    res = {}
-    for mode in ('fused', 'split'):
-        monkeypatch.setenv('CAMLI_CORR3D_GATHER', mode)
-        with runtime.use_backend('hip'), pass_cache():
-            mod.zero_grad()
-            mod.build_cost_volume_pyramid(f1, f2, xyzs2, nested=True)
-            assert mod._nested is not None
-            out = mod(xyz1, xyzs2)
-            grads = torch.autograd.grad(out, [f1, f2] + list(mod.parameters()), g)
-        res[mode] = (out.detach(), grads)
-    assert torch.equal(res['fused'][0], res['split'][0])
-    for a, c in zip(res['fused'][1], res['split'][1]):
-        assert torch.equal(a, c)

@@ -71,9 +71,9 @@ def test_knn_bit_exact(case, kind, ops, oracle_lib):
 
 @pytest.mark.parametrize('case', [(2, 2048, 1024, 3, 16), (1, 8192, 512, 3, 16), (2, 2048, 700, 3, 3), (2, 1000, 300, 2, 1),
                                   (1, 4096, 300, 3, 32)], ids=lambda c: 'B%d_M%d_N%d_D%d_k%d' % c)
-@pytest.mark.parametrize('mode', ['lane', 'xlane', 'pruned'])
+@pytest.mark.parametrize('mode', ['lane', 'xlane'])
 def test_knn_kernel_families_agree_with_the_oracle(case, mode, ops, oracle_lib, monkeypatch):
-    """The kernel families behind k_nearest_neighbor (lane-per-query, candidates-across-lanes, spatially pruned) on a cloud
+    """The kernel families behind k_nearest_neighbor (lane-per-query, candidates-across-lanes) on a cloud
     with 25 % duplicates: bit-exact vs the oracle whichever one the dispatcher is told to take."""
     b, m, nq, d, k = case
     monkeypatch.setenv('CAMLI_KNN', mode)
@@ -96,23 +96,6 @@ def _shaped_cloud(rng, kind, b, m, d):
     ang, r = rng.random((b, m)) * 2 * np.pi, rng.exponential(8.0, (b, m)) + 2      # a disk with a dense centre, like a LiDAR sweep
     cols = [r * np.cos(ang), r * np.sin(ang), rng.normal(0, 0.3, (b, m)) + 0.02 * r]
     return np.stack(cols[:d], axis=2).astype(np.float32)
-
-
-@pytest.mark.parametrize('case', [(2, 8192, 1500, 3, 16), (1, 16384, 1100, 3, 16), (2, 5000, 1024, 3, 3), (2, 4099, 1031, 2, 1),
-                                  (1, 6000, 1200, 3, 32), (1, 300, 70, 3, 16)], ids=lambda c: 'B%d_M%d_N%d_D%d_k%d' % c)
-@pytest.mark.parametrize('kind', ['uniform', 'clustered', 'lattice', 'disk'])
-def test_knn_spatially_pruned_search_is_bit_exact(case, kind, ops, oracle_lib, monkeypatch):
-    """camli_knn_pruned (Morton-ordered chunks, exact box pruning) on clouds that stress it: empty space next to dense blobs,
-    lattices full of ties at the k-th distance (far more survivors than the list holds -> the rescue pass and the in-order
-    redo), ragged sizes, a partial last chunk, queries that coincide with candidates.  Bit-exact vs the oracle."""
-    b, m, nq, d, k = case
-    monkeypatch.setenv('CAMLI_KNN', 'pruned')
-    rng = np.random.default_rng(hash((case, kind)) % (2 ** 32))
-    inp = _shaped_cloud(rng, kind, b, m, d)
-    qry = _shaped_cloud(rng, kind, b, nq, d)
-    qry[:, :nq // 3] = inp[:, rng.permutation(m)[:nq // 3]]
-    got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
-    assert np.array_equal(got, oracle_lib.knn(inp, qry, k))
 
 
 @pytest.mark.parametrize('k', [1, 2, 5, 16, 20, 32])

@@ -16,7 +16,7 @@ VALU_PAIR_PEAK = 7865.0
 SHAPES = [(8192, 4096, 3, 16), (4096, 2048, 3, 16), (2048, 2048, 3, 32), (2048, 2048, 3, 16), (1024, 2048, 3, 16),
           (512, 2048, 3, 16), (256, 2048, 3, 16), (2048, 2048, 3, 3), (2048, 1024, 3, 3), (2048, 8192, 3, 3),
           (2048, 8160, 2, 1), (16384, 4096, 3, 16), (2048, 16384, 3, 3)]
-MODES = [('lane', {'CAMLI_KNN': 'lane'}), ('xlane', {'CAMLI_KNN': 'xlane'}), ('pruned', {'CAMLI_KNN': 'pruned'})]
+MODES = [('lane', {'CAMLI_KNN': 'lane'}), ('xlane', {'CAMLI_KNN': 'xlane'})]
 
 
 def timed(fn, reps, per_graph=20):
