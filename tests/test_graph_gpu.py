@@ -51,7 +51,7 @@ def _run(graphed, n_steps, warmup):
         finally:
             runtime.set_overlap(False)
             runtime.set_deferred_param_grads(False)
-    return float(loss), {n: p.detach().clone() for n, p in model.named_parameters()}
+    return float(loss.detach()), {n: p.detach().clone() for n, p in model.named_parameters()}
 
 
 def test_graph_replay_matches_eager_steps():
