@@ -445,5 +445,52 @@ class Branch:
                     t.record_stream(current)
 
 
+# ------------------------------------------------------------------------------------------------
+# weight gradients beside the data-gradient chain (round 5)
+# ------------------------------------------------------------------------------------------------
+# In a backward pass the DATA gradient of a convolution is on the critical chain (the next adjoint needs it); its WEIGHT gradient is
+# needed by nobody until the optimizer runs.  On one stream they run one after the other.  `wgrad_side(device)` hands out ONE
+# auxiliary stream per (device, current stream) for weight gradients: the node makes it wait for what the current stream holds
+# (`fork`), issues the weight gradient there -- accumulating into a per-pass total that only that stream touches -- and whoever
+# hands the totals to autograd (`GRU2DPass`'s hub node, the deferred-parameter sink's flush) joins it first.  Enabled with the
+# two-lane execution (never under graph capture); CAMLI_WGRAD_ASIDE=0 keeps everything on the current stream.
+_wgrad_streams = {}
+_WGRAD_ASIDE = os.environ.get('CAMLI_WGRAD_ASIDE', '1') != '0'
+
+
+class _WgradSide:
+    def __init__(self, main, side):
+        self.main, self.side = main, side
+
+    def fork(self, *tensors):
+        """the side stream waits for everything the current stream holds now; `tensors` will be read / written there"""
+        self.side.wait_stream(self.main)
+        for t in _flatten(tensors):
+            if t is not None:
+                t.record_stream(self.side)
+
+    def stream(self):
+        import torch
+        return torch.cuda.stream(self.side)
+
+    def join(self):
+        """the current stream waits for every weight gradient issued so far"""
+        import torch
+        torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+
+
+def wgrad_side(device):
+    """The weight-gradient side stream of the current stream on `device`, or None where it does not apply."""
+    import torch
+    if not (_WGRAD_ASIDE and _OVERLAP and _BACKEND == 'hip' and device.type == 'cuda') or torch.cuda.is_current_stream_capturing():
+        return None
+    main = torch.cuda.current_stream(device)
+    key = (device.index, main.cuda_stream)
+    side = _wgrad_streams.get(key)
+    if side is None:
+        side = _wgrad_streams[key] = torch.cuda.Stream(device)
+    return _WgradSide(main, side)
+
+
 if _CENSUS_ON:
     set_census(True)

@@ -1829,6 +1829,7 @@ class GRU2DPass:
         self.contexts = tuple(contexts)
         self.gw = [None] * 4
         self.gc = [None] * 4
+        self.side = None            # runtime._WgradSide once a weight gradient has been issued beside the main chain
         self.token = _GRU2DHub.apply(self, *self.weights, *self.contexts)
 
 
@@ -1844,6 +1845,12 @@ class _GRU2DHub(torch.autograd.Function):
         hub = ctx.hub()
         totals = [None] * 8
         if hub is not None:
+            if hub.side is not None:        # the weight gradients were accumulated on the side stream
+                hub.side.join()
+                for t in hub.gw:
+                    if t is not None:
+                        t.record_stream(torch.cuda.current_stream(t.device))
+                hub.side = None
             totals = hub.gw + hub.gc
             hub.gw, hub.gc = [None] * 4, [None] * 4
         need = ctx.needs_input_grad[1:]
@@ -1907,6 +1914,20 @@ class _GRU2DStepCL(torch.autograd.Function):
                 return 0, None
             return (hub.gc[slot].data_ptr(), None) if hub.gc[slot] is not None else (0, slot)
 
+        side = _runtime.wgrad_side(g.device)
+        if side is not None:
+            hub.side = side
+
+        def wgrad(slot, xs, gpre, taps, khw):
+            """the weight gradient of one convolution, added into the pass total -- beside the data-gradient chain when a side
+            stream is available (runtime.wgrad_side): nothing downstream needs it before the hub hands the totals over"""
+            if side is None:
+                hub.gw[slot] = convcl_wrw(xs, gpre, taps, khw, out=hub.gw[slot])
+                return
+            side.fork(gpre, *xs)
+            with side.stream():
+                hub.gw[slot] = convcl_wrw(xs, gpre, taps, khw, out=hub.gw[slot])
+
         with _on_device(g):
             for half, (hin, z, r, rh, q) in ((1, (h1, z2, r2, rh2, q2)), (0, (h0, z1, r1, rh1, q1))):
                 geom, wpt_zr, wpt_q = ctx.geom[half]
@@ -1922,9 +1943,9 @@ class _GRU2DStepCL(torch.autograd.Function):
                 convcl([gpre_q], wpt_q, ntaps, split=hd, out=(grh, gm), accumulate=(False, not first_m))
                 first_m = False
                 if need_w[iq]:
-                    hub.gw[iq] = convcl_wrw([rh, mn], gpre_q, taps, geom[:2], out=hub.gw[iq])
-                if becomes is not None:      # the first contribution IS the total (after the convolutions above have read it:
-                    hub.gc[iq] = gpre_q      # later updates add into it in place, on this same stream)
+                    wgrad(iq, [rh, mn], gpre_q, taps, geom[:2])
+                if becomes is not None:      # the first contribution starts the total (a copy: gpre_q itself may still be read
+                    hub.gc[iq] = gpre_q.clone()      # by the weight gradient on the side stream when later updates add into it)
                 gpre_zr = torch.empty((b, hh, ww, 2 * hd), dtype=torch.float32, device=g.device)
                 acc_ptr, becomes = total(izr, None, need_c[izr])
                 _lib.launch('camli_gru_gates_bwd', lib.camli_gru_gates_bwd_into, gz.data_ptr(), hd, grh.data_ptr(), hd, z.data_ptr(),
@@ -1933,9 +1954,9 @@ class _GRU2DStepCL(torch.autograd.Function):
                 # z | r convolution: its input gradient completes the gradient of this half-step's hidden input and of m
                 convcl([gpre_zr], wpt_zr, ntaps, split=hd, out=(gh, gm), accumulate=(True, True))
                 if need_w[izr]:
-                    hub.gw[izr] = convcl_wrw([hin, mn], gpre_zr, taps, geom[:2], out=hub.gw[izr])
+                    wgrad(izr, [hin, mn], gpre_zr, taps, geom[:2])
                 if becomes is not None:
-                    hub.gc[izr] = gpre_zr
+                    hub.gc[izr] = gpre_zr.clone()
                 gcur = gh
         need = ctx.needs_input_grad
         return (_to_nchw(gcur) if need[0] else None, _to_nchw(gm) if need[1] else None, None, None)
