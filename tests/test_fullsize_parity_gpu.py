@@ -178,8 +178,10 @@ def _train_step_vs_cpu_port(model_cls, cfg, inputs, monkeypatch):
     worst = max((abs(gg[n].norm().item() / gc[n].norm().item() - 1.0), n) for n in gc if gc[n].norm().item() > 1e-3 * den)
     print('loss %.6f vs %.6f; gradient relative L2 error %.2e over %d tensors; worst large-tensor norm ratio off by %.2e (%s)'
           % (loss_gpu.item(), loss_cpu.item(), num / den, len(gc), worst[0], worst[1]))
-    assert num / den < 2e-3, num / den
-    assert worst[0] < 1e-2, worst
+    # measured (round 5, gpurun_out/fullsize_grad_errors.txt -> profiles/r05e_fullsize_gradient_errors.txt): 7.1e-6 / 4.2e-7 /
+    # 3.2e-6 / 1.5e-6 over the four configurations, worst large-tensor norm ratio off by 3.1e-4; the bounds were 2e-3 / 1e-2
+    assert num / den < 1e-4, num / den
+    assert worst[0] < 2e-3, worst
 
 
 def test_config3_camliraft_960x540_training_step_gradients_vs_cpu_port(monkeypatch):
