@@ -263,6 +263,11 @@ def train_step(model, optimizer, batch, world=1, force_dist=False, autocast=None
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     model.clear_metrics()
+    # the step's autograd graph is spent: let go of it (the model keeps `loss`, base.py:28-31) before the next forward pass
+    # builds its own -- while it lives, the parameters' AccumulateGrad nodes of THIS step are reused by the next one with the
+    # streams they were created on (torch warns about exactly that: "AccumulateGrad node's stream does not match ...")
+    loss = loss.detach()
+    model.loss = loss
     return loss
 
 

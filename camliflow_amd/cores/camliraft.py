@@ -156,6 +156,8 @@ class CamLiRAFT_Core(nn.Module):
             flow_2d_preds.append(b2d.convex_upsampler.finish(mask_branch, h_2d, flow_2d_pred, flow_rows))
 
         lanes.to_main(flow_3d_preds)
+        b2d.correlation.release()
+        b3d.correlation.release()
         return flow_2d_preds, flow_3d_preds
 
 

@@ -66,6 +66,13 @@ class Correlation2D(nn.Module):
             volume = avg_pool2d(volume, 2, stride=2)
             self.cost_volume_pyramid.append(volume)
 
+    def release(self):
+        """Let go of the pass's pyramid once its last lookup is enqueued (the lookup nodes keep what their backward needs).
+        The reference leaves it in the module until the next build overwrites it; here that would keep the PREVIOUS step's
+        autograd graph -- through the pyramid's token, back to the encoders' parameters -- alive while the next forward
+        pass runs, and torch then reuses that step's AccumulateGrad nodes with the streams they were created on."""
+        self.cost_volume_pyramid = None
+
     def forward(self, coords):
         """coords [B,2,h,w] (x,y) at 1/8 resolution -> [B, levels*(2r+1)^2, h, w].
         Channel l*81 + i*9 + j samples level l at (x/2^l + d[i], y/2^l + d[j]) -- the transposed
@@ -353,4 +360,5 @@ class RAFTCore(nn.Module):
                 hidden = self.gru(hidden, torch.cat([context, motion], dim=1))
             flow = flow + self.flow_head(hidden)
             predictions.append(self.convex_upsampler(hidden, flow))
+        self.correlation.release()
         return predictions

@@ -86,6 +86,11 @@ class Correlation3D(nn.Module):
             from ..csrc import fused
             self._nested = fused.Corr3DPyramid(levels)
 
+    def release(self):
+        """Let go of the pass's volumes once the last lookup is enqueued (see raft2d.Correlation2D.release)."""
+        self.cost_volume_pyramid = None
+        self._nested = None
+
     def calc_matching_cost(self, xyz1, xyz2, cost_volume):
         bs, n_src, n_dst = cost_volume.shape
         cross = _ops.k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)       # [B,N,k]
@@ -260,4 +265,5 @@ class CamLiRAFT_L_Core(nn.Module):
             hidden = self.gru(xyz1, h=hidden, x=torch.cat([ctx, motion], dim=1), knn_indices=neighbours)
             flow = flow + self.flow_head(xyz1, hidden, neighbours).float()
             iterates.append(flow)
+        self.correlation.release()
         return [knn_interpolation(xyz1, f, pc1, k=3, invariant_input=True, invariant_query=True) for f in iterates]
