@@ -217,7 +217,10 @@ int launch_fps(const float* xyz, int64_t* out, int B, int N, int n_samples, hipS
 // Bucket-pruned form (round 3) -- same picks, a fraction of the arithmetic.
 //
 // dist[p] <- min(dist[p], d(p, c)) leaves every point untouched whose distance to the new centre c is at least its
-// current value.  The cloud is therefore sorted along a Morton curve once (bitonic sort of (code, index) in LDS), a
+// current value.  The cloud is therefore sorted along a space-filling curve once (bitonic sort of (code, index) in LDS;
+// round 5: a HILBERT curve -- consecutive cells of a Morton curve jump across the cloud at every octant boundary, the 64
+// points on either side of a jump share a bucket whose box then spans the cloud and is updated in up to 40 % of all steps;
+// on a Hilbert curve consecutive cells are always adjacent: 8.8 -> 5.6 bucket updates per step, 0.89 -> 0.77 us), a
 // BUCKET is the 64 consecutive sorted points one wave holds in one register slot, and each bucket keeps its bounding
 // box and the maximum of its running distances.  A step first evaluates, one bucket per lane,
 //      lb = ((ex*ex + ey*ey) + ez*ez),  e = max(lo - c, c - hi, 0) per axis        (same fp32 operation order as d)
@@ -274,12 +277,56 @@ __device__ __forceinline__ unsigned group_allmin_u32(unsigned v) {
     return v;
 }
 
-__device__ __forceinline__ unsigned morton_spread10(unsigned v) {      // 10 bits -> every third bit
+__device__ __forceinline__ unsigned morton_spread10(unsigned v) {      // 10 bits -> every third bit (bit interleave)
     v = (v | (v << 16)) & 0x030000FFu;
     v = (v | (v << 8)) & 0x0300F00Fu;
     v = (v | (v << 4)) & 0x030C30C3u;
     v = (v | (v << 2)) & 0x09249249u;
     return v;
+}
+
+// -DCAMLI_FPS_PROFILE (tools/microbench/fps_mb.hip only): shader-clock stamps around the phases of a step, summed per wave
+// of workgroup 0 into camli_fps_prof[wave][0..4] = box test / bucket updates / wave arg-max / slot + barrier / reduce of the
+// slots, [5] = buckets updated, [6] = steps with at least one bucket, [7] = steps.
+#ifdef CAMLI_FPS_PROFILE
+__device__ unsigned long long camli_fps_prof[16][8];
+__device__ unsigned camli_fps_touch[16][32];       // [wave][slot]: steps in which the bucket was updated
+#define FPS_STAMP(k)                                                          \
+    {                                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+        prof_[k] += now_ - t_;                                                \
+        t_ = now_;                                                            \
+    }
+#define FPS_COUNT(k, n) prof_[k] += (unsigned long long)(n);
+#else
+#define FPS_STAMP(k)
+#define FPS_COUNT(k, n)
+#endif
+
+// Hilbert curve index of a 10-bit lattice point, in place, "transposed" form (bit k of the index triple = bit k of
+// x[0], x[1], x[2], most significant first): Skilling's axes-to-transpose (AIP Conf. Proc. 707, 2004).
+__device__ __forceinline__ void hilbert_transpose10(unsigned (&x)[3]) {
+    for (unsigned q = 512u; q > 1u; q >>= 1) {
+        const unsigned p = q - 1u;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (x[a] & q) {
+                x[0] ^= p;
+            } else {
+                const unsigned t = (x[0] ^ x[a]) & p;
+                x[0] ^= t;
+                x[a] ^= t;
+            }
+        }
+    }
+    x[1] ^= x[0];
+    x[2] ^= x[1];
+    unsigned t = 0;
+    for (unsigned q = 512u; q > 1u; q >>= 1)
+        if (x[2] & q) t ^= q - 1u;
+    x[0] ^= t;
+    x[1] ^= t;
+    x[2] ^= t;
 }
 
 // P register slots per thread (16 or 32), T threads; sorted position of (wave w, slot j, lane l) = (j*NW + w)*64 + l:
@@ -336,17 +383,18 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
         scale[a] = ext > 0.0f ? 1023.0f / ext : 0.0f;       // any monotone quantisation does: only locality matters
     }
 
-    // ---- (Morton code, index) keys, bitonic sort in LDS ----
+    // ---- (Hilbert index, point index) keys, bitonic sort in LDS ----
     for (int i = tid; i < NP2; i += T) {
         unsigned long long key = ~0ull;
         if (i < N) {
-            unsigned code = 0;
+            unsigned qv[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const float q = (xyz[i * 3 + a] - lo[a]) * scale[a];
-                const unsigned qi = (unsigned)fminf(fmaxf(q, 0.0f), 1023.0f);
-                code |= morton_spread10(qi) << a;
+                qv[a] = (unsigned)fminf(fmaxf(q, 0.0f), 1023.0f);
             }
+            hilbert_transpose10(qv);
+            const unsigned code = morton_spread10(qv[0]) << 2 | morton_spread10(qv[1]) << 1 | morton_spread10(qv[2]);
             key = ((unsigned long long)code << 32) | (unsigned)i;
         }
         keys[i] = key;
@@ -375,7 +423,11 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
     const int myslot = lane & (P - 1);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-        const int pos = (j * NW + w) * 64 + lane;      // consecutive buckets go to different waves (see header)
+        // consecutive buckets go to different waves (see header), and the wave index is rotated by half the slot number:
+        // the buckets around the top-level splits of the curve sit at multiples of 16 buckets (1024 points of an 8192-point
+        // cloud) and are the ones updated most often -- unrotated they all landed in wave 0, which (Morton order) updated
+        // 2.5 buckets per step where the others updated 0.9 and held every step back (profiles/r05_experiments.txt 10)
+        const int pos = (j * NW + ((w - (j >> 1)) & (NW - 1))) * 64 + lane;
         const bool ok = pos < N;
         const unsigned o = ok ? (unsigned)(keys[pos] & 0xffffffffu) : 0u;
         orig[j] = ok ? o : FPS_NOIDX;
@@ -405,9 +457,14 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
     constexpr unsigned long long SLOT_LANES = (1ull << P) - 1ull;
     constexpr unsigned WAVE_LANES = (1u << NW) - 1u;
 
+#ifdef CAMLI_FPS_PROFILE
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int s = 0; s < n_samples; ++s) {
         if (tid == 0) picks[s] = cur;
         if (s == n_samples - 1) break;
+        FPS_STAMP(4)
 
         // ---- box test, one bucket per lane ----
         const float ex = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.0f);
@@ -415,10 +472,17 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
         const float ez = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.0f);
         const float lb = ex * ex + ey * ey + ez * ez;
         const unsigned todo = (unsigned)(__ballot(lb < bmax) & SLOT_LANES);
+        FPS_STAMP(0)
+        FPS_COUNT(5, __builtin_popcount(todo))
+        FPS_COUNT(6, todo != 0u ? 1 : 0)
+        FPS_COUNT(7, 1)
         if (todo != 0u) {
 #pragma unroll
             for (int j = 0; j < P; ++j) {
                 if ((todo >> j) & 1u) {     // wave-uniform
+#ifdef CAMLI_FPS_PROFILE
+                    if (blockIdx.x == 0 && lane == 0) camli_fps_touch[w][j] += 1;
+#endif
                     const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
                     const float d = dx * dx + dy * dy + dz * dz;
                     const float nd = fminf(dist[j], d);
@@ -445,6 +509,7 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
                     }
                 }
             }
+            FPS_STAMP(1)
             // ---- wave arg-max over the bucket maxima (group-local: every group of P lanes holds the same P buckets) ----
             const bool live = bmax >= 0.0f;
             const unsigned kb = live ? __float_as_uint(bmax) : 0u;
@@ -455,6 +520,7 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
                 top = __ballot(live && kb == wkey && bidx == low) & SLOT_LANES;
             }
             pub = top != 0ull ? (int)__builtin_ctzll(top) : -1;
+            FPS_STAMP(2)
         }
 
         // ---- one slot per wave, one barrier, every wave reduces the NW slots on its own ----
@@ -470,6 +536,7 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
             mine.idx = FPS_NOIDX;
         }
         __syncthreads();
+        FPS_STAMP(3)
         const FpsSlot* sp = &slots[s & 1][lane & (NW - 1)];
         const unsigned k2 = sp->key, i2 = sp->idx;
         const float x2 = sp->x, y2 = sp->y, z2 = sp->z;
@@ -485,6 +552,10 @@ __global__ __launch_bounds__(T) void fps_pruned_kernel(const float* __restrict__
         cy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(y2), src));
         cz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(z2), src));
     }
+#ifdef CAMLI_FPS_PROFILE
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 8; ++k) camli_fps_prof[w][k] = prof_[k];
+#endif
     __syncthreads();
     for (int s = tid; s < n_samples; s += T) out[s] = (int64_t)picks[s];
 }
