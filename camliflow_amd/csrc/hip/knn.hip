@@ -224,6 +224,34 @@ __device__ __forceinline__ void merge_topk(float (&dist)[K], int (&idx)[K], cons
     }
 }
 
+namespace xl {
+template <int D>
+__device__ void redo_query(const float* __restrict__ in_b, int M, float ux, float uy, float uz, int k,
+                           int64_t* __restrict__ o, int lane, float bound = 1e9f /* KNN_INIT: no bound */);
+}
+
+// The queries of a wave whose merged list may differ from the in-order result (`redo` lanes), one after the other, each by
+// the WHOLE wave (xl::redo_query: 64 candidates per trip, the reference's insertion rule; a few microseconds for 2048
+// candidates).  Round 5: until then the tied lanes re-ran the lane-per-query scan over the whole range with the other lanes
+// idle -- 130 us for ONE tied query of a 2048-candidate search, during which the kernel's other 255 workgroups had long
+// finished: a single tie among 16,384 queries took a 59 us launch to 190 us (profiles/r05_experiments.txt 11).
+// `o_wave` = the output row of the wave's lane 0 (query q0), rows are K entries apart; results are stored by redo_query.
+// `kth` = the lane's merged k-th distance: the true k-th smallest distance (a merge only errs in WHICH tied index it keeps),
+// so candidates beyond it never reach the final list and the redo only inserts the <= k + ties candidates within it.
+template <int D, int K>
+__device__ __forceinline__ void redo_tied_queries(uint64_t tied, const float* __restrict__ in_b, int M, float ux, float uy,
+                                                  float uz, float kth, int64_t* __restrict__ o_wave, int lane) {
+    while (tied) {
+        const int src = (int)__builtin_ctzll(tied);
+        tied &= tied - 1;
+        const float bound = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kth), src));
+        const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ux), src));
+        const float qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uy), src));
+        const float qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, uz), src));
+        xl::redo_query<D>(in_b, M, qx, qy, qz, K, o_wave + (size_t)src * K, lane, bound);
+    }
+}
+
 // grid (ceil(Nq/64), B); block 64*NW threads.  LDS (dynamic):
 //   queue region : 2 * QBUF * 64*NW dwords            (K >= 8 only)
 //   merge region : NW * K * 64 * 2 dwords + NW*64     (NW > 1 only)   -- the two regions alias
@@ -267,6 +295,7 @@ __global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_ke
     }
     scan_range<D, K>(in_b, lo, hi, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, NW);
 
+    uint64_t tied = 0;      // queries of wave 0 to be redone in order (below)
     if (NW > 1) {
         __syncthreads();  // queues are dead; the merge region aliases them
         float* md = smem;                                          // [NW][K][64]
@@ -330,30 +359,17 @@ __global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_ke
         }
         if (K > 1) {
             // a candidate tying the final k-th distance was dropped somewhere: the merged list
-            // may differ from the in-order result in WHICH tied index it keeps -> redo in order
-            bool redo = (ev_min == dist[K - 1]);
-            if (__ballot(redo)) {
-                if (redo) {
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        dist[j] = KNN_INIT;
-                        idx[j] = 0;
-                    }
-                    float ev2 = INFINITY;
-                    // wave 0's own queue slice: region [0, 2*QBUF*64) laid out with stride 64
-                    float* rqd = smem + 2 * NW * K * 64 + NW * 64 + lane;
-                    int* rqi = reinterpret_cast<int*>(rqd) + QBUF * 64;
-                    scan_range<D, K>(in_b, 0, M, ux, uy, uz, dist, idx, ev2, rqd, rqi, 64);
-                }
-            }
+            // may differ from the in-order result in WHICH tied index it keeps -> those queries are redone in order
+            tied = __ballot((ev_min == dist[K - 1]) && q_raw < Nq);
         }
     }
 
-    if (q_raw < Nq) {
+    if (q_raw < Nq && !((tied >> lane) & 1ull)) {
         int64_t* o = out + ((size_t)b * Nq + q_raw) * K;
 #pragma unroll
         for (int j = 0; j < K; ++j) o[j] = (int64_t)idx[j];
     }
+    if (tied) redo_tied_queries<D, K>(tied, in_b, M, ux, uy, uz, dist[K - 1], out + ((size_t)b * Nq + blockIdx.x * 64) * K, lane);
 }
 
 // Nested candidate prefixes in ONE scan.  The point-cloud pyramid is a chain of FPS prefixes (level l+1 = the first
@@ -368,6 +384,24 @@ struct KnnPrefixOut {
     int size[4];        // descending candidate counts, size[0] = M_0; unused entries 0
     int levels;
 };
+
+// -DCAMLI_KNN_PROFILE (tools/microbench/knn_prefix_mb.hip only): shader-clock stamps around the phases of the prefix search,
+// per wave of workgroup (0, 0): [0] set-up, [1] scan of the own chunk, [2] merge rounds (barriers included), [3] snapshots
+// (in-order rescans of tied queries + stores), [4] rescans started, [5] drains (scan_range), [6] insertions executed
+#ifdef CAMLI_KNN_PROFILE
+__device__ unsigned long long camli_knn_prof[16][8];
+__device__ unsigned camli_knn_wg_ticks[64][64][4];      // [blockIdx.y][blockIdx.x]: wave 0's scan / merge / snapshot ticks, rescans
+#define KNN_STAMP(k)                                                          \
+    {                                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();         \
+        prof_[k] += now_ - t_;                                                \
+        t_ = now_;                                                            \
+    }
+#define KNN_COUNT(k, n) prof_[k] += (unsigned long long)(n);
+#else
+#define KNN_STAMP(k)
+#define KNN_COUNT(k, n)
+#endif
 
 template <int D, int K>
 __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const float* __restrict__ input,
@@ -386,6 +420,10 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
     const float* qp = query + ((size_t)b * Nq + q) * D;
     const float ux = qp[0], uy = qp[1], uz = (D == 3) ? qp[2] : 0.0f;
 
+#ifdef CAMLI_KNN_PROFILE
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();
+#endif
     float dist[K];
     int idx[K];
 #pragma unroll
@@ -411,39 +449,28 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
         for (int g = 0; g < KNN_SLOT_ROWS; ++g) slots[(g * NW + w) * 64 + lane] = KNN_INIT;
         __syncthreads();
     }
+    KNN_STAMP(0)
     scan_range<D, K>(in_b, w * chunk, (w + 1) * chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
+    KNN_STAMP(1)
 
     __syncthreads();  // queues are dead; the merge region aliases them
     float* md = smem;                                          // [NW][K][64]
     int* mi = reinterpret_cast<int*>(smem) + NW * K * 64;      // [NW][K][64]
     float* mev = smem + 2 * NW * K * 64;                       // [NW][64]
-    float* rqd = smem + 2 * NW * K * 64 + NW * 64 + lane;      // wave 0's private queue for the redo scans
-    int* rqi = reinterpret_cast<int*>(rqd) + QBUF * 64;
     // snapshot of the merged prefix of `covered` candidates into every level of that size (wave 0 only)
     auto emit = [&](int covered, bool merged) {
         for (int l = 0; l < po.levels; ++l) {
             if (po.size[l] != covered) continue;            // wave-uniform
-            int oidx[K];
-#pragma unroll
-            for (int j = 0; j < K; ++j) oidx[j] = idx[j];
-            const bool redo = merged && (ev_min == dist[K - 1]);
-            if (__ballot(redo)) {
-                if (redo) {
-                    float rd[K];
-#pragma unroll
-                    for (int j = 0; j < K; ++j) {
-                        rd[j] = KNN_INIT;
-                        oidx[j] = 0;
-                    }
-                    float ev2 = INFINITY;
-                    scan_range<D, K>(in_b, 0, covered, ux, uy, uz, rd, oidx, ev2, rqd, rqi, 64);
-                }
-            }
-            if (q_raw < Nq) {
+            const uint64_t tied = __ballot(merged && (ev_min == dist[K - 1]) && q_raw < Nq);
+            KNN_COUNT(4, __builtin_popcountll(tied))
+            if (q_raw < Nq && !((tied >> lane) & 1ull)) {
                 int64_t* o = po.out[l] + ((size_t)b * Nq + q_raw) * K;
 #pragma unroll
-                for (int j = 0; j < K; ++j) o[j] = (int64_t)oidx[j];
+                for (int j = 0; j < K; ++j) o[j] = (int64_t)idx[j];
             }
+            // a merged list may differ from the in-order result in WHICH index it keeps at the k-th distance: those queries
+            // are redone in order over this prefix (the running lists go on unchanged: they only feed larger prefixes)
+            if (tied) redo_tied_queries<D, K>(tied, in_b, covered, ux, uy, uz, dist[K - 1], po.out[l] + ((size_t)b * Nq + blockIdx.x * 64) * K, lane);
         }
     };
     // binary tree when the wave count and every level size (in chunks) are powers of two -- the FPS pyramids are
@@ -453,8 +480,19 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
         const int sl = po.size[l] / chunk;
         tree = tree && (sl & (sl - 1)) == 0;
     }
+#ifdef CAMLI_KNN_PROFILE
+    auto flush = [&]() {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+            for (int k2 = 0; k2 < 8; ++k2) camli_knn_prof[w][k2] = prof_[k2];
+        if (w == 0 && lane == 0 && blockIdx.x < 64 && blockIdx.y < 64) {
+            unsigned* o = camli_knn_wg_ticks[blockIdx.y][blockIdx.x];
+            o[0] = (unsigned)prof_[1]; o[1] = (unsigned)prof_[2]; o[2] = (unsigned)prof_[3]; o[3] = (unsigned)prof_[4];
+        }
+    };
+#endif
     if (tree) {
         if (w == 0) emit(chunk, false);
+        KNN_STAMP(3)
         for (int step = 1; step < NW; step <<= 1) {
             if ((w & (2 * step - 1)) == step) {
 #pragma unroll
@@ -476,8 +514,13 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
                 ev_min = fminf(ev_min, mev[(w + step) * 64 + lane]);
                 merge_topk<K>(dist, idx, od, oi, ev_min);
             }
+            KNN_STAMP(2)
             if (w == 0) emit(2 * step * chunk, true);
+            KNN_STAMP(3)
         }
+#ifdef CAMLI_KNN_PROFILE
+        flush();
+#endif
         return;
     }
     if (w > 0) {
@@ -673,9 +716,11 @@ static_assert(LIST_DW % 4 == 0, "16-byte aligned LDS regions");
 // and the accepted ones are inserted one by one in index order with the reference's own rule
 // (k_nearest_neighbor_kernel.cu:80-90: start at slot min(idx, k-1), move left past entries with dist > d).  Slow (a
 // dozen instructions per accepted candidate) and rare; needs no LDS and ~10 registers.
+// `bound`: an upper bound of the final k-th distance when the caller has one (KNN_INIT otherwise): candidates beyond it are
+// inserted and pushed out again by the reference without a trace in the final list, so they are skipped.
 template <int D>
 __device__ __noinline__ void redo_query(const float* __restrict__ in_b, int M, float ux, float uy, float uz, int k,
-                                        int64_t* __restrict__ o, int lane) {
+                                        int64_t* __restrict__ o, int lane, float bound) {
     float ld = KNN_INIT;
     int li = 0;
     for (int c0 = 0; c0 < M; c0 += 64) {
@@ -685,7 +730,7 @@ __device__ __noinline__ void redo_query(const float* __restrict__ in_b, int M, f
         float d = (ux - p[0]) * (ux - p[0]) + (uy - p[1]) * (uy - p[1]);
         if (D == 3) d = d + (uz - p[2]) * (uz - p[2]);
         float kth = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ld), k - 1));
-        uint64_t acc = __ballot(in && !(d > kth));
+        uint64_t acc = __ballot(in && !(d > kth) && !(d > bound));
         while (acc) {
             const int src = (int)__builtin_ctzll(acc);
             acc &= acc - 1;
@@ -1191,7 +1236,7 @@ int launch_knn(const float* input, const float* query, int64_t* out, int B, int 
     while (nw < lds_cap_nw && base_waves * nw < target_waves && M / (nw * 2) >= 128) nw *= 2;
     size_t q_bytes = (K >= 8) ? (size_t)2 * QBUF * 64 * nw * 4 : 0;
     if (K >= 8 && nw > 1) q_bytes += (size_t)KNN_SLOT_ROWS * nw * 64 * 4;      // published bounds
-    size_t m_bytes = (nw > 1) ? ((size_t)2 * nw * K * 64 + (size_t)nw * 64 + (size_t)2 * QBUF * 64) * 4 : 0;
+    size_t m_bytes = (nw > 1) ? ((size_t)2 * nw * K * 64 + (size_t)nw * 64) * 4 : 0;
     size_t lds = q_bytes > m_bytes ? q_bytes : m_bytes;
     dim3 grid(qblocks, B);
     hipLaunchKernelGGL((knn_kernel<D, K>), grid, dim3(64 * nw), lds, stream, input, query, out, M, Nq, knn_share());
@@ -1295,7 +1340,7 @@ extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_
         po.size[l] = l < L ? sizes[l] : 0;
     }
     const size_t q_bytes = (size_t)2 * QBUF * 64 * nw * 4 + (size_t)KNN_SLOT_ROWS * nw * 64 * 4;
-    const size_t m_bytes = ((size_t)2 * nw * k * 64 + (size_t)nw * 64 + (size_t)2 * QBUF * 64) * 4;
+    const size_t m_bytes = ((size_t)2 * nw * k * 64 + (size_t)nw * 64) * 4;
     const size_t lds = q_bytes > m_bytes ? q_bytes : m_bytes;
     dim3 grid(camli_divup(Nq, 64), B);
     if (k == 16)
