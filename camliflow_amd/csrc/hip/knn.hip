@@ -450,13 +450,6 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
         __syncthreads();
     }
     KNN_STAMP(0)
-    scan_range<D, K>(in_b, w * chunk, (w + 1) * chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
-    KNN_STAMP(1)
-
-    __syncthreads();  // queues are dead; the merge region aliases them
-    float* md = smem;                                          // [NW][K][64]
-    int* mi = reinterpret_cast<int*>(smem) + NW * K * 64;      // [NW][K][64]
-    float* mev = smem + 2 * NW * K * 64;                       // [NW][64]
     // snapshot of the merged prefix of `covered` candidates into every level of that size (wave 0 only)
     auto emit = [&](int covered, bool merged) {
         for (int l = 0; l < po.levels; ++l) {
@@ -473,6 +466,28 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
             if (tied) redo_tied_queries<D, K>(tied, in_b, covered, ux, uy, uz, dist[K - 1], po.out[l] + ((size_t)b * Nq + blockIdx.x * 64) * K, lane);
         }
     };
+    // Levels smaller than a chunk lie inside wave 0's range: its in-order list after the first size[l] candidates IS that
+    // level's answer (no merge, no tie question), so wave 0 scans its chunk in pieces and takes a snapshot between them.
+    // (Round 5: lets k = 32 take the one-launch path on an 8-chunk pyramid -- 4 waves of 2 chunks -- and fewer, larger chunks
+    // be measured: profiles/r05_experiments.txt 12.)
+    if (w == 0) {
+        int lo = 0;
+        for (int l = po.levels - 1; l >= 0; --l) {
+            if (po.size[l] >= chunk) break;
+            scan_range<D, K>(in_b, lo, po.size[l], ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
+            emit(po.size[l], false);
+            lo = po.size[l];
+        }
+        scan_range<D, K>(in_b, lo, chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
+    } else {
+        scan_range<D, K>(in_b, w * chunk, (w + 1) * chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
+    }
+    KNN_STAMP(1)
+
+    __syncthreads();  // queues are dead; the merge region aliases them
+    float* md = smem;                                          // [NW][K][64]
+    int* mi = reinterpret_cast<int*>(smem) + NW * K * 64;      // [NW][K][64]
+    float* mev = smem + 2 * NW * K * 64;                       // [NW][64]
     // binary tree when the wave count and every level size (in chunks) are powers of two -- the FPS pyramids are
     // (2048, 1024, 512, 256): the merged prefix after round r covers 2^(r+1) chunks, which is where the snapshots fall
     bool tree = (NW & (NW - 1)) == 0;
@@ -1317,11 +1332,19 @@ extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_
         int rc = CAMLI_OK;
         if (xl::dispatch_prefix(input, query, xpo, B, M, Nq, D, k, reinterpret_cast<hipStream_t>(stream), &rc) == 0) return rc;
     }
-    const int chunk = sizes[L - 1];
+    // one wave per chunk of the candidate range; a chunk is a level size (levels below it are snapshots inside wave 0's scan):
+    // the smallest level that leaves at most max_nw waves.  CAMLI_KNN_PREFIX_NW=4 asks for fewer, larger chunks (measured on the
+    // 2048/1024/512/256 pyramid: 84 us against 58 us with 8 -- a wave's scan is a chain, two waves per SIMD overlap theirs)
+    const char* nw_env = getenv("CAMLI_KNN_PREFIX_NW");
+    const int want_nw = nw_env ? atoi(nw_env) : 8;
+    const int max_nw = k >= 32 ? 4 : 8;
+    int chunk = sizes[L - 1];
+    for (int l = L - 1; l >= 0; --l)
+        if (M % sizes[l] == 0 && M / sizes[l] <= max_nw && (M / sizes[l] >= want_nw || l == L - 1)) chunk = sizes[l];
     bool one_launch = (D == 3) && (k == 16 || k == 32) && chunk >= 64;
-    for (int l = 0; l < L; ++l) one_launch = one_launch && (sizes[l] % chunk == 0);
+    for (int l = 0; l < L; ++l) one_launch = one_launch && (sizes[l] % chunk == 0 || sizes[l] < chunk);
     const int nw = M / chunk;
-    one_launch = one_launch && nw >= 1 && nw <= (k >= 32 ? 4 : 8);
+    one_launch = one_launch && nw >= 1 && nw <= max_nw && nw * chunk == M;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (!one_launch) {
         // general shapes: one plain search per (level, sample) -- a prefix of sample b starts at b * M * D

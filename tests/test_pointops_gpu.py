@@ -286,13 +286,16 @@ def test_gather_scale_vs_torch(case):
                                   (2, 2048, 700, 3, (2048, 1024)), (1, 2048, 64, 16, (2048, 1024, 512)), (2, 512, 300, 8, (512, 256)),
                                   (2, 2048, 500, 16, (2048, 1536, 512)), (3, 900, 200, 16, (900, 450)), (2, 512, 128, 3, (512, 256))],
                          ids=str)
-@pytest.mark.parametrize('mode', ['lane', 'xlane'])
+@pytest.mark.parametrize('mode', ['lane', 'xlane', 'lane4'])
 def test_knn_prefixes_equal_separate_searches(case, mode, oracle_lib, monkeypatch):
     """camli_knn_prefixes: the neighbours among the first m inputs for every nested prefix size, from one scan --
     bit-identical to one search per prefix (oracle), on a cloud with 25 % exact duplicates (ties at the k-th distance
     exercise the per-snapshot redo) and for shapes that take the one-launch kernel as well as the per-level fallback."""
     from camliflow_amd.csrc import wrapper
     b, m, nq, k, sizes = case
+    if mode == 'lane4':     # round 5: at most four waves per query group -- levels below a chunk are snapshots inside wave 0's scan
+        mode = 'lane'
+        monkeypatch.setenv('CAMLI_KNN_PREFIX_NW', '4')
     monkeypatch.setenv('CAMLI_KNN', mode)        # lane-per-query prefix kernel / cross-lane chain kernel (round 4)
     rng = np.random.default_rng(m + k)
     inp = (rng.random((b, m, 3), dtype=np.float32) * 4).astype(np.float32)
