@@ -82,6 +82,7 @@ class Correlation3D(nn.Module):
         dense = levels[0]
         self.cost_volume_pyramid = levels
         self._nested = None
+        self._prior_crosses = None        # a new pass: other clouds
         if nested and runtime.fused() and dense.is_cuda and len(levels) <= 4 and min(lvl.shape[2] for lvl in levels) >= self.k:
             from ..csrc import fused
             self._nested = fused.Corr3DPyramid(levels)
@@ -90,6 +91,7 @@ class Correlation3D(nn.Module):
         """Let go of the pass's volumes once the last lookup is enqueued (see raft2d.Correlation2D.release)."""
         self.cost_volume_pyramid = None
         self._nested = None
+        self._prior_crosses = None
 
     def calc_matching_cost(self, xyz1, xyz2, cost_volume):
         bs, n_src, n_dst = cost_volume.shape
@@ -125,8 +127,15 @@ class Correlation3D(nn.Module):
             # writes the concatenated columns, and the adjoint accumulates into per-pass gradient volumes
             from .geometry import _channel_last
             level0 = xyzs2[0]
-            crosses = _ops.k_nearest_neighbor_prefixes(level0.detach().transpose(1, 2).contiguous(), _channel_last(xyz1, True),
-                                                       pyr.sizes, self.k)
+            # round 5: the previous iteration's neighbours bound this iteration's k-th distances (the target cloud is the same
+            # one back-warped a little further): same indices, the scan queues a fraction of the candidates
+            prior = getattr(self, '_prior_crosses', None)
+            queries = _channel_last(xyz1, True)
+            if prior is not None and (len(prior) != len(pyr.sizes) or prior[0].shape[:2] != queries.shape[:2]):
+                prior = None
+            crosses = _ops.k_nearest_neighbor_prefixes(level0.detach().transpose(1, 2).contiguous(), queries, pyr.sizes, self.k,
+                                                       prior=prior)
+            self._prior_crosses = crosses
             lookup = fused.corr3d_lookup_levels(pyr, xyz1, level0, crosses)
         else:
             columns = []

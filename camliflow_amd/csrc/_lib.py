@@ -15,6 +15,8 @@ PROTOTYPES = {
     "camli_last_error_string": (ctypes.c_char_p, []),
     "camli_knn": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _int, _int, _int, _int, _stream]),
     "camli_knn_prefixes": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _int, _int, _int, _int, _int, _int, _stream]),
+    "camli_knn_prefixes_prior": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _int, _int, _int, _int,
+                                        _int, _int, _stream]),
     "camli_fps": (_int, [_c_float_p, _c_i64_p, _int, _int, _int, _stream]),
     "camli_corr2d_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _int, _int, _stream]),
     "camli_corr2d_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,

@@ -130,7 +130,10 @@ template <int D, int K>
 __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int lo, int hi, float ux, float uy,
                                            float uz, float (&dist)[K], int (&idx)[K], float& ev_min,
                                            float* __restrict__ qd, int* __restrict__ qi, int qstride,
-                                           volatile float* slots = nullptr, int nw = 1, int w = 0, int group = 1) {
+                                           volatile float* slots = nullptr, int nw = 1, int w = 0, int group = 1,
+                                           float cap = INFINITY) {
+    // `cap` (K >= 8 path only): an upper bound of the k-th distance of every result this list feeds, known to the caller
+    // (camli_knn_prefixes_prior); candidates beyond it never reach those results and are not even queued.
     constexpr int U = KNN_UNROLL;
     if (K == 1) {
         float best = dist[0];
@@ -148,7 +151,7 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int l
                               [&](float d, int c) { if (!(d > dist[K - 1])) list_insert<K>(dist, idx, d, c, ev_min); }, [] {});
     } else {
         int cnt = 0;
-        float thr = dist[K - 1];
+        float thr = fminf(dist[K - 1], cap);
         auto drain = [&]() {
 #pragma nounroll
             for (int t = 0; t < QBUF; ++t) {
@@ -161,7 +164,7 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ in_b, int l
                 }
             }
             cnt = 0;
-            thr = dist[K - 1];
+            thr = fminf(dist[K - 1], cap);
             if (slots) {
                 const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(K >= 32 ? 256 : (K >= 16 ? 512 : 1024)) void knn_ke
 // detected per snapshot exactly as in knn_kernel and those queries are redone by an in-order scan of that prefix.
 struct KnnPrefixOut {
     int64_t* out[4];
+    const int64_t* prior[4];    // optional (all or none): an earlier result of the same search, queries and / or candidates moved since
     int size[4];        // descending candidate counts, size[0] = M_0; unused entries 0
     int levels;
 };
@@ -447,7 +451,48 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
         slots = smem + 2 * QBUF * nthreads;
 #pragma unroll
         for (int g = 0; g < KNN_SLOT_ROWS; ++g) slots[(g * NW + w) * 64 + lane] = KNN_INIT;
-        __syncthreads();
+    }
+    // An earlier result of the same search (the GRU iterations search the same clouds, moved a little, twelve times): its
+    // K candidates of level l are K different candidates of that prefix, so the largest of their distances NOW is an upper
+    // bound of the level's k-th distance now -- and the largest such bound over the levels this wave's chunk belongs to caps
+    // what the wave ever needs to queue.  With it the scan keeps ~K / NW + a few candidates per lane instead of
+    // ~K (1 + ln(chunk / K)).  Same arithmetic as the scan (sqdist), so the prior candidates themselves pass the cap; an
+    // index outside the level switches the cap off.  Wave l evaluates level l for the 64 queries (2 K scattered reads per
+    // lane: with every wave doing its own levels the CU's address unit took 15 kiloticks over it) and leaves it in LDS.
+    float cap = INFINITY;
+    float* level_cap = smem + 2 * QBUF * nthreads + KNN_SLOT_ROWS * NW * 64;       // [levels][64], behind the slots
+    const bool bounded = po.prior[0] != nullptr && NW >= po.levels;
+    if (bounded && w < po.levels) {
+        const int l = w;
+        const int64_t* __restrict__ pr = po.prior[l] + ((size_t)b * Nq + q) * K;
+        long long c[K];
+        float px[K], py[K], pz[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) c[j] = pr[j];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool in = c[j] >= 0 && c[j] < po.size[l];
+            ok = ok && in;
+            const float* __restrict__ pt = in_b + (size_t)(in ? c[j] : 0) * D;
+            px[j] = pt[0];
+            py[j] = pt[1];
+            pz[j] = D == 3 ? pt[2] : 0.0f;
+        }
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float d = (ux - px[j]) * (ux - px[j]) + (uy - py[j]) * (uy - py[j]);       // sqdist's arithmetic
+            if (D == 3) d = d + (uz - pz[j]) * (uz - pz[j]);
+            t = fmaxf(t, d);
+        }
+        level_cap[l * 64 + lane] = ok ? t : INFINITY;
+    }
+    if (slots || bounded) __syncthreads();
+    if (bounded) {
+        cap = 0.0f;
+        for (int l = 0; l < po.levels; ++l)
+            if (po.size[l] > w * chunk) cap = fmaxf(cap, level_cap[l * 64 + lane]);      // wave-uniform: levels holding this chunk
     }
     KNN_STAMP(0)
     // snapshot of the merged prefix of `covered` candidates into every level of that size (wave 0 only)
@@ -474,13 +519,13 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
         int lo = 0;
         for (int l = po.levels - 1; l >= 0; --l) {
             if (po.size[l] >= chunk) break;
-            scan_range<D, K>(in_b, lo, po.size[l], ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
+            scan_range<D, K>(in_b, lo, po.size[l], ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group, cap);
             emit(po.size[l], false);
             lo = po.size[l];
         }
-        scan_range<D, K>(in_b, lo, chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
+        scan_range<D, K>(in_b, lo, chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group, cap);
     } else {
-        scan_range<D, K>(in_b, w * chunk, (w + 1) * chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group);
+        scan_range<D, K>(in_b, w * chunk, (w + 1) * chunk, ux, uy, uz, dist, idx, ev_min, qd, qi, nthreads, slots, NW, w, group, cap);
     }
     KNN_STAMP(1)
 
@@ -1309,8 +1354,13 @@ extern "C" int camli_knn(const float* input, const float* query, int64_t* out_id
 // Nested prefixes: out_levels[l] [B,Nq,k] = the k nearest among the FIRST sizes[l] inputs (sizes strictly descending,
 // sizes[0] = M).  One launch when every size is a multiple of the smallest one and M / smallest <= 8 (k = 16; 4 for
 // k = 32); otherwise one camli_knn per level.
-extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_t* const* out_levels, const int* sizes,
-                                  int L, int B, int M, int Nq, int D, int k, void* stream) {
+// `prior_levels` (may be null; then this is camli_knn_prefixes): out_levels of an EARLIER call with the same sizes and k on the
+// same clouds moved a little (a GRU iteration later) -- an upper bound of every level's k-th distance comes out of its K
+// candidates, and the scan queues nothing beyond it.  The results do not depend on the prior (any K different in-range
+// candidates per query and level bound the k-th distance); a prior from different clouds only costs the speed-up.
+extern "C" int camli_knn_prefixes_prior(const float* input, const float* query, int64_t* const* out_levels,
+                                        const int64_t* const* prior_levels, const int* sizes, int L, int B, int M, int Nq, int D,
+                                        int k, void* stream) {
     if (B == 0 || Nq == 0) return CAMLI_OK;
     if (!input || !query || !out_levels || !sizes) { camli_set_error("camli_knn_prefixes: null pointer"); return CAMLI_EINVAL; }
     if (L < 1 || L > 4 || B < 0 || M < 1 || (D != 2 && D != 3) || k < 1 || k > 64 || sizes[0] != M || B > 65535) {
@@ -1322,11 +1372,12 @@ extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_
             camli_set_error("camli_knn_prefixes: level sizes must be strictly descending and positive");
             return CAMLI_EINVAL;
         }
-    if (xl::mode() != 1) {
+    if (xl::mode() != 1 && !prior_levels) {
         KnnPrefixOut xpo;
         xpo.levels = L;
         for (int l = 0; l < 4; ++l) {
             xpo.out[l] = l < L ? out_levels[l] : nullptr;
+            xpo.prior[l] = nullptr;
             xpo.size[l] = l < L ? sizes[l] : 0;
         }
         int rc = CAMLI_OK;
@@ -1360,9 +1411,13 @@ extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_
     po.levels = L;
     for (int l = 0; l < 4; ++l) {
         po.out[l] = l < L ? out_levels[l] : nullptr;
+        po.prior[l] = (prior_levels && l < L) ? prior_levels[l] : nullptr;
         po.size[l] = l < L ? sizes[l] : 0;
     }
-    const size_t q_bytes = (size_t)2 * QBUF * 64 * nw * 4 + (size_t)KNN_SLOT_ROWS * nw * 64 * 4;
+    if (prior_levels)
+        for (int l = 0; l < L; ++l)
+            if (!prior_levels[l]) { camli_set_error("camli_knn_prefixes_prior: prior level %d is null", l); return CAMLI_EINVAL; }
+    const size_t q_bytes = (size_t)2 * QBUF * 64 * nw * 4 + (size_t)KNN_SLOT_ROWS * nw * 64 * 4 + (size_t)4 * 64 * 4;   // queues, slots, level caps
     const size_t m_bytes = ((size_t)2 * nw * k * 64 + (size_t)nw * 64) * 4;
     const size_t lds = q_bytes > m_bytes ? q_bytes : m_bytes;
     dim3 grid(camli_divup(Nq, 64), B);
@@ -1371,4 +1426,9 @@ extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_
     else
         hipLaunchKernelGGL((knn_prefix_kernel<3, 32>), grid, dim3(64 * nw), lds, s, input, query, po, M, Nq, chunk, knn_share());
     return camli_check_launch("camli_knn_prefixes");
+}
+
+extern "C" int camli_knn_prefixes(const float* input, const float* query, int64_t* const* out_levels, const int* sizes,
+                                  int L, int B, int M, int Nq, int D, int k, void* stream) {
+    return camli_knn_prefixes_prior(input, query, out_levels, nullptr, sizes, L, B, M, Nq, D, k, stream);
 }

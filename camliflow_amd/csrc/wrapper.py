@@ -199,11 +199,13 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     return out
 
 
-def k_nearest_neighbor_prefixes(input_xyz: torch.Tensor, query_xyz: torch.Tensor, sizes, k: int):
+def k_nearest_neighbor_prefixes(input_xyz: torch.Tensor, query_xyz: torch.Tensor, sizes, k: int, prior=None):
     """[k_nearest_neighbor(input_xyz[:, :m], query_xyz, k) for m in sizes] in one scan (sizes strictly descending,
     sizes[0] = all inputs): the levels of the FPS pyramid are nested prefixes (models/utils.py:121-125), and the
     sequential insertion semantics of the search make the k-list after the first m candidates the answer for that
-    prefix.  Channel-last [B,M,D] / [B,Nq,D] only (internal helper of the cores, not part of the reference boundary)."""
+    prefix.  Channel-last [B,M,D] / [B,Nq,D] only (internal helper of the cores, not part of the reference boundary).
+    ``prior``: the list this function returned for the same clouds a GRU iteration earlier (camli_knn_prefixes_prior: a bound
+    on every k-th distance, same results, a fraction of the sorted insertions)."""
     import ctypes
     _require_cuda('k_nearest_neighbor_prefixes', input_xyz, query_xyz)
     lib = _lib.load()
@@ -216,6 +218,14 @@ def k_nearest_neighbor_prefixes(input_xyz: torch.Tensor, query_xyz: torch.Tensor
     outs = [torch.empty((b, nq, k), dtype=torch.int64, device=query_xyz.device) for _ in sizes]
     ptrs = (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
     csizes = (ctypes.c_int * len(sizes))(*sizes)
+    if prior is not None:
+        assert len(prior) == len(sizes) and all(p.shape == (b, nq, k) and p.dtype == torch.int64 and p.is_contiguous() and
+                                                p.device == query_xyz.device for p in prior)
+        pptrs = (ctypes.c_void_p * len(prior))(*[p.data_ptr() for p in prior])
+        with _on_device(input_xyz):
+            _lib.launch('camli_knn', lib.camli_knn_prefixes_prior, input_xyz.data_ptr(), query_xyz.data_ptr(), ptrs, pptrs, csizes,
+                        len(sizes), b, m, nq, d, k, _stream_ptr(input_xyz), work=(float(b) * m * nq, 'pairs'))
+        return outs
     with _on_device(input_xyz):
         _lib.launch('camli_knn', lib.camli_knn_prefixes, input_xyz.data_ptr(), query_xyz.data_ptr(), ptrs, csizes, len(sizes),
                     b, m, nq, d, k, _stream_ptr(input_xyz), work=(float(b) * m * nq, 'pairs'))

@@ -309,6 +309,38 @@ def test_knn_prefixes_equal_separate_searches(case, mode, oracle_lib, monkeypatc
         assert np.array_equal(idx.cpu().numpy(), want), size
 
 
+@pytest.mark.parametrize('case', [(8, 2048, 2048, 16, (2048, 1024, 512, 256)), (2, 1024, 300, 32, (1024, 512, 256)),
+                                  (2, 2048, 500, 16, (2048, 1536, 512)), (1, 2048, 64, 16, (2048, 1024, 512))], ids=str)
+@pytest.mark.parametrize('prior_kind', ['same', 'moved', 'permuted', 'out_of_range'])
+def test_knn_prefixes_with_prior_are_unchanged(case, prior_kind, oracle_lib):
+    """camli_knn_prefixes_prior: an earlier result bounds every level's k-th distance and the scan queues nothing beyond the
+    bound -- the indices must be those of the plain search (oracle) whatever the prior holds: the result of the same search,
+    of the search on clouds moved since (the GRU loop's case), arbitrary different in-range candidates, or indices outside the
+    level (bound switched off).  25 % exact duplicates in the cloud, so ties at the k-th distance meet the bound."""
+    from camliflow_amd.csrc import wrapper
+    b, m, nq, k, sizes = case
+    rng = np.random.default_rng(m + k + len(prior_kind))
+    inp = (rng.random((b, m, 3), dtype=np.float32) * 4).astype(np.float32)
+    inp[:, rng.integers(0, m, size=m // 4)] = inp[:, rng.integers(0, m, size=m // 4)]
+    qry = (rng.random((b, nq, 3), dtype=np.float32) * 4).astype(np.float32)
+    qry[:, :8] = inp[:, :8]
+    if prior_kind == 'same':
+        prior = wrapper.k_nearest_neighbor_prefixes(dev(inp), dev(qry), sizes, k)
+    elif prior_kind == 'moved':
+        earlier = (inp + rng.normal(0, 0.05, inp.shape)).astype(np.float32)
+        prior = wrapper.k_nearest_neighbor_prefixes(dev(earlier), dev(qry), sizes, k)
+    elif prior_kind == 'permuted':
+        prior = [dev(np.stack([np.stack([rng.permutation(size)[:k] for _ in range(nq)]) for _ in range(b)]).astype(np.int64))
+                 for size in sizes]
+    else:
+        prior = [dev(np.full((b, nq, k), size + 5, dtype=np.int64)) for size in sizes]
+    prior = [p.contiguous() for p in prior]
+    got = wrapper.k_nearest_neighbor_prefixes(dev(inp), dev(qry), sizes, k, prior=prior)
+    for size, idx in zip(sizes, got):
+        want = oracle_lib.knn(np.ascontiguousarray(inp[:, :size]), qry, k)
+        assert np.array_equal(idx.cpu().numpy(), want), (prior_kind, size)
+
+
 def test_nested_pyramid_paths_match_per_level_paths():
     """Correlation3D with nested target levels (one prefix search, one multi-level gather, persistent gradient volumes)
     and the single back-warp against the per-level forms: identical forward values, gradients to float noise."""

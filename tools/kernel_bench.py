@@ -126,6 +126,13 @@ def cases(batch):
     yield ('knn prefixes B%d 2048/1024/512/256 Nq2048 k16' % b,
            (lambda: wrapper.k_nearest_neighbor_prefixes(inp_p, qry_p, (2048, 1024, 512, 256), 16)), {'camli_knn': 'valu'})
 
+    # the same search one GRU iteration later (11 of the 12 per step): the target cloud moved by ~1 % of its extent, the previous
+    # result passed as prior (camli_knn_prefixes_prior: a bound on every k-th distance, identical indices)
+    inp_m = (inp_p + _rand(g, b, 2048, 3, scale=0.2) - 0.1).contiguous()
+    prior_p = wrapper.k_nearest_neighbor_prefixes(inp_p, qry_p, (2048, 1024, 512, 256), 16)
+    yield ('knn prefixes B%d 2048/1024/512/256 Nq2048 k16, prior = the result one iteration earlier' % b,
+           (lambda: wrapper.k_nearest_neighbor_prefixes(inp_m, qry_p, (2048, 1024, 512, 256), 16, prior=prior_p)), {'camli_knn': 'valu'})
+
     # the dense-query interpolation of kitti_submission.py:89-93 (every pixel of a 375x1242 map)
     inp1, qry1 = _rand(g, 1, 8192, 3, scale=10.0), _rand(g, 1, 465750, 3, scale=10.0)
     yield 'knn B1 M8192 Nq465750 D3 k3', (lambda: csrc.k_nearest_neighbor(inp1, qry1, 3)), {'camli_knn': 'valu'}

@@ -55,6 +55,33 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < ho.size(); ++i) sum = sum * 1000003ull + (unsigned long long)ho[i];
     }
     printf("checksum of the indices %llu\n", sum);
+    // the same search one GRU iteration later: targets displaced by up to 2 % of the cloud's extent, the first call's results as prior
+    {
+        std::vector<float> hm(hi);
+        for (size_t i = 0; i < hm.size(); ++i) hm[i] += (rnd() - 0.5f) * (cube ? 0.2f : 0.6f);
+        float* in2; int64_t* out2[4]; int64_t* out3[4];
+        CK(hipMalloc(&in2, hm.size() * 4));
+        CK(hipMemcpy(in2, hm.data(), hm.size() * 4, hipMemcpyHostToDevice));
+        for (int l = 0; l < L; ++l) { CK(hipMalloc(&out2[l], (size_t)B * Nq * K * 8)); CK(hipMalloc(&out3[l], (size_t)B * Nq * K * 8)); }
+        auto train = [&](bool with_prior, int64_t** o) {
+            for (int r = 0; r < 50; ++r)
+                if (camli_knn_prefixes_prior(in2, q, o, with_prior ? out : nullptr, sizes, L, B, M, Nq, 3, K, nullptr) != CAMLI_OK) exit(1);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 100; ++i)
+                if (camli_knn_prefixes_prior(in2, q, o, with_prior ? out : nullptr, sizes, L, B, M, Nq, 3, K, nullptr) != CAMLI_OK) exit(1);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long cs = 0;
+            for (int l = 0; l < L; ++l) {
+                std::vector<int64_t> ho((size_t)B * Nq * K);
+                CK(hipMemcpy(ho.data(), o[l], ho.size() * 8, hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < ho.size(); ++i) cs = cs * 1000003ull + (unsigned long long)ho[i];
+            }
+            printf("moved targets, %s: %.1f us per launch, checksum %llu\n", with_prior ? "with the earlier result as prior" : "no prior", ms * 10, cs);
+        };
+        train(false, out2);
+        train(true, out3);
+    }
 #ifdef CAMLI_KNN_PROFILE
     unsigned long long prof[16][8];
     CK(hipMemcpyFromSymbol(prof, HIP_SYMBOL(camli_knn_prof), sizeof(prof)));
