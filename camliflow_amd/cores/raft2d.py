@@ -170,8 +170,11 @@ class GRU2D(nn.Module):
             w_zr, w_q, ctx_zr, ctx_q, padding = state[suffix]
             # CAMLI_CONV_CL (default on): the two convolutions of a half step on explicitly channels-last operands
             # (blocks._CatConvCL: the cat writes the channels-last input, kept for the weight gradient)
+            # (channel counts in multiples of 16 only: on an 8 + 16-channel NHWC input the library's kernels read past the end
+            # of the tensor -- "Memory access fault by GPU" whenever the allocation ends a segment, 2 of 3 full test runs late
+            # in round 5; the models' GRUs carry 128-channel maps)
             cl = _CONV_CL and fusable and runtime.fused() and h.dtype == torch.float32 and motion.dtype == torch.float32 \
-                and not torch.is_autocast_enabled()
+                and not torch.is_autocast_enabled() and hd % 16 == 0 and motion.shape[1] % 16 == 0
             pre_zr = cat_conv_cl([h, motion], w_zr, padding) if cl else conv2d(torch.cat([h, motion], dim=1), w_zr, None, padding=padding)
             if not fusable and h.is_cuda:
                 runtime.fallback('GRU2D', 'hidden plane is not a multiple of 4 elements')
