@@ -247,8 +247,9 @@ class MotionEncoder2D(nn.Module):
             c = conv_bias_act(self.conv_c2, conv_bias_act(self.conv_c1, corr, 'relu'), 'relu')
             if flow_branch is not None:
                 branch, f = flow_branch[0], flow_branch[1]
-                assert not flow_branch[2]
                 branch.join(f)
+                if flow_branch[2]:           # a raw handle (bias and ReLU left to the caller) after the state changed in between
+                    f = self.relu(f + self.conv_f2.bias.view(1, -1, 1, 1))
             else:
                 f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')
             x = torch.cat([c, f], dim=1)
@@ -262,6 +263,8 @@ class MotionEncoder2D(nn.Module):
         if flow_branch is not None:          # issued by begin(): same values, join before use
             flow_branch[0].join(flow_branch[1])
             f = flow_branch[1]
+            if flow_branch[2]:               # begin() left conv_f2's bias + ReLU to the epilogue branch above: finish it here
+                f = self.relu(f + self.conv_f2.bias.view(1, -1, 1, 1))
         else:
             f = self.relu(self.conv_f1(flow))
             f = self.relu(self.conv_f2(f))
