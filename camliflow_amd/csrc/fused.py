@@ -235,6 +235,11 @@ class _Lookup(torch.autograd.Function):
 def allpairs_pyramid(fmap1, fmap2, num_levels=4):
     """fmap1/fmap2 [B,C,h,w] (already through ``fnet_aligner``) -> AllPairsPyramid."""
     _require_cuda('allpairs_pyramid', fmap1, fmap2)
+    if not (torch.is_grad_enabled() and (fmap1.requires_grad or fmap2.requires_grad)) and _clean_grad_pyramids:
+        # a pass that will not run backward (validation between training steps, another model's inference): the gradient
+        # pyramid kept clean for the NEXT backward (2.8 GB at batch 8) would sit outside the allocator's reach for its whole
+        # duration -- let it go, the next training step zero-fills a fresh one (ADVICE r4)
+        _clean_grad_pyramids.clear()
     pyr = AllPairsPyramid()
     pyr.token = _BuildPyramid.apply(fmap1.float().contiguous(), fmap2.float().contiguous(), num_levels, pyr)
     return pyr
