@@ -197,9 +197,11 @@ class KernelTimer:
         self.enabled = False
         self.only = None        # optional set of entry-point names to restrict timing to
         self.records = {}
+        self.order = []         # entry-point names in launch order (tools/kernel_bench.py pairs them with a kineto trace)
         self._pool = []         # recycled events: creating one costs as much as recording it
 
     def reset(self):
+        self.order = []
         for recs in self.records.values():
             for r in recs:
                 self._pool.append(r[0])
@@ -241,6 +243,7 @@ def launch(name, fn, *args, work=None, flop=0.0):
         end.record()
         amount, unit = work if work is not None else (0.0, 'B')
         TIMER.records.setdefault(name, []).append((start, end, amount, unit, flop))
+        TIMER.order.append(name)
     else:
         code = fn(*args)
     check(code, name)

@@ -264,6 +264,9 @@ def run(batch=8, reps=10, only=None):
         runtime.set_deferred_param_grads(deferred)
 
 
+KINETO = os.environ.get('CAMLI_KB_KINETO', '1') == '1'      # kernel_us / frac_kernel from a kineto trace of every case
+
+
 def _train_us(fn, per_graph=20, replays=7):
     """Device time of one call inside a train: `per_graph` back-to-back calls captured in a HIP graph and replayed (median of
     `replays`).  An event pair around ONE launch has a floor of 17-19 us on this stack (marker packets on either side), more than
@@ -294,6 +297,57 @@ def _train_us(fn, per_graph=20, replays=7):
     except Exception:       # noqa: BLE001 -- a case that allocates / synchronises under capture just keeps its event figure
         torch.cuda.synchronize()
         return None
+
+
+def _kernel_us(fn, reps):
+    """entry point -> mean DEVICE time of the kernels one call of it launches, from a kineto trace of `reps` calls of the case:
+    the timer's event pair brackets every entry point on the CPU timeline (hipEventRecord ... hipLaunchKernel ... hipEventRecord),
+    the launches in between carry correlation ids, the GPU activities with those ids carry the kernels' own begin / end
+    timestamps -- what rocprofv3 reports, without the 14-19 us floor of an event pair.  None when the trace does not pair up
+    (some other hipEventRecord in between)."""
+    from camliflow_amd.csrc import _lib
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        _lib.TIMER.reset()
+        _lib.TIMER.enabled = True
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+        _lib.TIMER.enabled = False
+        order = list(_lib.TIMER.order)
+        events = prof.profiler.kineto_results.events()
+        gpu = {}
+        for e in events:
+            if 'CUDA' in str(e.device_type()) or 'PrivateUse' in str(e.device_type()):
+                gpu[e.correlation_id()] = gpu.get(e.correlation_id(), 0.0) + e.duration_ns() * 1e-3
+        cpu = sorted((e for e in events if 'CPU' in str(e.device_type()) and
+                      (e.name() == 'hipEventRecord' or 'Launch' in e.name())), key=lambda e: e.start_ns())
+        if sum(e.name() == 'hipEventRecord' for e in cpu) != 2 * len(order):
+            return None
+        out, inside, acc, i = {}, False, 0.0, 0
+        for e in cpu:
+            if e.name() == 'hipEventRecord':
+                if inside:
+                    out.setdefault(order[i], []).append(acc)
+                    i += 1
+                inside, acc = not inside, 0.0
+            elif inside:
+                acc += gpu.get(e.correlation_id(), 0.0)
+        return {name: sum(v) / len(v) for name, v in out.items() if v}
+    except Exception:       # noqa: BLE001 -- no profiler, no figure
+        _lib.TIMER.enabled = False
+        return None
+
+
+def _with_kernel(row, kernel_us):
+    """the row's rate on the kernels' own duration, next to the event figure"""
+    if kernel_us is None or kernel_us <= 0:
+        return row
+    scale = row['avg_launch_us'] / kernel_us
+    row['kernel_us'] = round(kernel_us, 2)
+    row['frac_kernel'] = round(min(row['frac'] * scale, 1.0) if row.get('bound') == 'latency' else row['frac'] * scale, 4)
+    return row
 
 
 def _with_train(row, train_us):
@@ -328,6 +382,7 @@ def _run(batch, reps, only):
         summary = _lib.TIMER.summary()
         # short single-kernel rows: the event pair's floor is most of the figure -> add the replayed-train time
         timed_names = [n for n in summary if n in kinds]
+        kernel_us = _kernel_us(fn, min(reps, 3)) if KINETO else None
         train = None
         if len(timed_names) == 1 and summary[timed_names[0]]['launches'] == reps and \
                 summary[timed_names[0]]['total_ms'] / reps < 0.06 and not getattr(fn, 'flop_override', None):
@@ -343,9 +398,9 @@ def _run(batch, reps, only):
                     row = _row(case, name, kinds[name], rec)
                     row['dense_flop_per_launch'] = dense
                     row['dense_equivalent_tflops'] = round(dense / row['avg_launch_us'] / 1e6, 2)
-                    rows.append(row)
+                    rows.append(_with_kernel(row, (kernel_us or {}).get(name)))
                     continue
-                rows.append(_with_train(_row(case, name, kinds[name], rec), train))
+                rows.append(_with_kernel(_with_train(_row(case, name, kinds[name], rec), train), (kernel_us or {}).get(name)))
     _lib.TIMER.reset()
     return rows
 
