@@ -29,6 +29,9 @@ bool camli_corr2d_use_tile() {
 constexpr int CT_PX = 64;     // pixels per workgroup (one wave-width)
 constexpr int CT_CMAX = 256;  // in1 channels resident in LDS per pass
 constexpr int CT_CH = 64;     // in2 channels staged per chunk
+#ifndef CAMLI_CORR2D_SPLIT_BELOW
+#define CAMLI_CORR2D_SPLIT_BELOW 2048
+#endif
 
 // grid (ceil(W/64), H, B), block 256.  VEC: C % 4 == 0 -> 16-byte global loads, ds_read_b128 in the
 // inner loop (row stride = channels + 4 dwords keeps the 16-lane b128 phases conflict-free).
@@ -37,7 +40,7 @@ constexpr int CT_CH = 64;     // in2 channels staged per chunk
 template <int MD, bool VEC>
 __global__ __launch_bounds__(256) void corr2d_fwd_kernel(const float* __restrict__ in1,
                                                           const float* __restrict__ in2,
-                                                          float* __restrict__ out, int C, int H, int W) {
+                                                          float* __restrict__ out, int C, int H, int W, int zsplit) {
     constexpr int DD = 2 * MD + 1;
     constexpr int HALO = CT_PX + 2 * MD;
     constexpr int PAD = VEC ? 4 : 1;
@@ -46,7 +49,10 @@ __global__ __launch_bounds__(256) void corr2d_fwd_kernel(const float* __restrict
     const int tid = threadIdx.x;
     const int px = tid & 63;
     const int cq = tid >> 6;
-    const int x0 = blockIdx.x * CT_PX, y = blockIdx.y, n = blockIdx.z;
+    // zsplit > 1 (small pyramid levels, round 5): the displacement rows dy are dealt to zsplit workgroups per (row, image) --
+    // a 9 x 15 level is 9 workgroups walking 9 dy x 3 channel chunks of stage -> barrier -> accumulate one after the other
+    // (55 us for 2 MFLOP); the per-element arithmetic and its order are unchanged
+    const int x0 = blockIdx.x * CT_PX, y = blockIdx.y, n = blockIdx.z / zsplit, part = blockIdx.z - n * zsplit;
     const float inv_c = 1.0f / (float)C;
     const int cs_max = min(C, CT_CMAX);
     const int ld1 = cs_max + PAD;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void corr2d_fwd_kernel(const float* __restrict
             }
         }
 
-        for (int dyi = 0; dyi < DD; ++dyi) {
+        for (int dyi = part; dyi < DD; dyi += zsplit) {
             const int y2 = y + dyi - MD;
             if (y2 < 0 || y2 >= H) {   // whole displacement row is outside: zeros (block-uniform branch)
                 if (c0 == 0)
@@ -473,11 +479,14 @@ int launch_fwd(const float* in1, const float* in2, float* out, int B, int C, int
     const int pad = vec ? 4 : 1;
     const int cs = C < CT_CMAX ? C : CT_CMAX;
     const size_t lds = ((size_t)CT_PX * (cs + pad) + (size_t)(CT_PX + 2 * MD) * (CT_CH + pad) + 4 * DD * CT_PX) * sizeof(float);
-    dim3 grid(camli_divup(W, CT_PX), H, B);
+    // few workgroups (the coarse levels of the PWC pyramid): one workgroup per displacement row as well
+    const long long wgs = (long long)camli_divup(W, CT_PX) * H * B;
+    const int zsplit = (wgs < CAMLI_CORR2D_SPLIT_BELOW && (long long)B * DD <= 65535) ? DD : 1;
+    dim3 grid(camli_divup(W, CT_PX), H, B * zsplit);
     if (vec)
-        hipLaunchKernelGGL((corr2d_fwd_kernel<MD, true>), grid, dim3(256), lds, stream, in1, in2, out, C, H, W);
+        hipLaunchKernelGGL((corr2d_fwd_kernel<MD, true>), grid, dim3(256), lds, stream, in1, in2, out, C, H, W, zsplit);
     else
-        hipLaunchKernelGGL((corr2d_fwd_kernel<MD, false>), grid, dim3(256), lds, stream, in1, in2, out, C, H, W);
+        hipLaunchKernelGGL((corr2d_fwd_kernel<MD, false>), grid, dim3(256), lds, stream, in1, in2, out, C, H, W, zsplit);
     return camli_check_launch("camli_corr2d_fwd");
 }
 
