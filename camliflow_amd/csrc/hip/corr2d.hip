@@ -236,16 +236,14 @@ __global__ __launch_bounds__(256) void corr2d_bwd_kernel(const float* __restrict
 constexpr int CB_TW = 16;    // pixels per workgroup
 
 template <int MD, int WHICH>
-__global__ __launch_bounds__(256) void corr2d_bwd_tiled_kernel(const float* __restrict__ gout,
-                                                                const float* __restrict__ other,
-                                                                float* __restrict__ gdst, int C, int H, int W) {
+__device__ __forceinline__ void corr2d_bwd_tiled_body(const float* __restrict__ gout, const float* __restrict__ other,
+                                                      float* __restrict__ gdst, int C, int H, int W, int n, float* gw) {
     constexpr int DD = 2 * MD + 1;
     constexpr int HW = CB_TW + 2 * MD;
-    __shared__ __attribute__((aligned(16))) float gw[DD * DD * CB_TW];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6, nw = blockDim.x >> 6;
-    const int x0 = blockIdx.x * CB_TW, y = blockIdx.y, n = blockIdx.z;
+    const int x0 = blockIdx.x * CB_TW, y = blockIdx.y;
     const float inv_c = 1.0f / (float)C;
     const size_t plane = (size_t)H * W;
     const float* __restrict__ gn = gout + (size_t)n * DD * DD * plane;
@@ -297,6 +295,20 @@ __global__ __launch_bounds__(256) void corr2d_bwd_tiled_kernel(const float* __re
             }
         }
     }
+}
+
+// Both gradients in ONE launch (round 5): blockIdx.z = 2 n + which.  They were two launches in a row, each a chain of
+// 9 window rows x 24 loads per wave -- on the coarse PWC levels (9 to 600 workgroups) the second only started when the first
+// had drained: 30-57 us of kernel time for a few MFLOP.  Same arithmetic per element.
+template <int MD>
+__global__ __launch_bounds__(256) void corr2d_bwd_tiled_kernel(const float* __restrict__ gout, const float* __restrict__ in1,
+                                                                const float* __restrict__ in2, float* __restrict__ g1,
+                                                                float* __restrict__ g2, int C, int H, int W) {
+    constexpr int DD = 2 * MD + 1;
+    __shared__ __attribute__((aligned(16))) float gw[DD * DD * CB_TW];
+    const int n = blockIdx.z >> 1;
+    if (blockIdx.z & 1) corr2d_bwd_tiled_body<MD, 1>(gout, in1, g2, C, H, W, n, gw);
+    else corr2d_bwd_tiled_body<MD, 0>(gout, in2, g1, C, H, W, n, gw);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -465,10 +477,9 @@ int launch_fwd_tile(const float* in1, const float* in2, float* out, int B, int C
 template <int MD>
 int launch_bwd(const float* gout, const float* in1, const float* in2, float* g1, float* g2, int B, int C, int H, int W,
                hipStream_t stream) {
-    dim3 grid(camli_divup(W, CB_TW), H, B);
+    dim3 grid(camli_divup(W, CB_TW), H, 2 * B);
     const int nw = camli_divup(C, 64) < 4 ? camli_divup(C, 64) : 4;
-    hipLaunchKernelGGL((corr2d_bwd_tiled_kernel<MD, 0>), grid, dim3(64 * nw), 0, stream, gout, in2, g1, C, H, W);
-    hipLaunchKernelGGL((corr2d_bwd_tiled_kernel<MD, 1>), grid, dim3(64 * nw), 0, stream, gout, in1, g2, C, H, W);
+    hipLaunchKernelGGL((corr2d_bwd_tiled_kernel<MD>), grid, dim3(64 * nw), 0, stream, gout, in1, in2, g1, g2, C, H, W);
     return camli_check_launch("camli_corr2d_bwd");
 }
 
@@ -538,7 +549,7 @@ extern "C" int camli_corr2d_bwd(const float* gout_nchw, const float* in1_nhwc, c
     }
     if (B == 0) return CAMLI_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (B > 65535 || H > 65535) {
+    if (B > 32767 || H > 65535) {       // grid z = 2 B (both gradients in one launch)
         camli_set_error("camli_corr2d_bwd: bad shape B=%d H=%d", B, H);
         return CAMLI_EINVAL;
     }
