@@ -124,7 +124,8 @@ def knn_interpolation(input_xyz, input_features, query_xyz, k=3, invariant_input
     if runtime.fused() and input_xyz.is_cuda and runtime.atomics_ok('knn_interpolation'):
         if k <= 8:
             from ..csrc import fused
-            return fused.knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
+            return fused.knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k,
+                                         invariant=invariant_input and invariant_query)
         runtime.fallback('knn_interpolation', 'k = %d > 8' % k)
     knn_xyz = batch_indexing(input_xyz, knn_indices)
     knn_dists = torch.linalg.norm(knn_xyz - query_xyz[..., None], dim=1).clamp(1e-8)

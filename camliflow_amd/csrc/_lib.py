@@ -64,6 +64,9 @@ PROTOTYPES = {
                                     _int, _int, _int, _int, _int, _stream]),
     "camli_knn_interp_bwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p,
                                     _int, _int, _int, _int, _int, _stream]),
+    "camli_knn_interp_weights": (_int, [_c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_knn_interp_bwd_sorted": (_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p,
+                                           _int, _int, _int, _int, _stream]),
     "camli_knn_interp_bwd_xyz": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_i64_p, _int, _c_float_p,
                                         _c_float_p, _int, _int, _int, _int, _int, _stream]),
     "camli_corr3d_gather_fwd": (_int, [_c_float_p, _c_float_p, _c_float_p, _c_i64_p, _c_float_p,

@@ -44,6 +44,7 @@ def release_cached_buffers():
     index maps.  Nothing needs them -- the next pass allocates / rebuilds -- call it when a model is done with the device."""
     _clean_grad_pyramids.clear()
     _inverse_maps.clear()
+    _interp_weights.clear()
 
 
 class AllPairsPyramid:
@@ -955,13 +956,44 @@ def gather_rows(data, indices):
     return _GatherCL.apply(rows, flat).view([b] + list(indices.shape[1:]) + [data.shape[2]])
 
 
+_INTERP_SORTED = os.environ.get('CAMLI_INTERP_SORTED', '1') != '0'      # 0: the float-atomic adjoint of the interpolation (A/B)
+_interp_weights = {}        # key -> (tensors kept alive, knn_flat [B, Nq*k] int64, w [B, Nq, k]); small LRU like _inverse_maps
+
+
+def _interp_geometry(in_xyz, q_xyz, knn, k):
+    """(offsets, q_sorted, w_sorted) of an interpolation between two clouds, for the atomic-free adjoint: the CSR bounds of the
+    neighbour table's inverse map and, in segment order, the query and the weight of every (query, slot) pair.  Computed once per
+    (clouds, table) -- the GRU loops interpolate between the same clouds every iteration."""
+    key = (in_xyz.data_ptr(), in_xyz._version, q_xyz.data_ptr(), q_xyz._version, knn.data_ptr(), knn._version,
+           tuple(knn.shape), tuple(knn.stride()), k)
+    hit = _interp_weights.pop(key, None)
+    if hit is None:
+        lib = _lib.load()
+        b, _, m = in_xyz.shape
+        nq = q_xyz.shape[2]
+        w = torch.empty((b, nq, k), dtype=torch.float32, device=in_xyz.device)
+        with _on_device(in_xyz):
+            _lib.launch('camli_knn_interp_weights', lib.camli_knn_interp_weights, in_xyz.data_ptr(), q_xyz.data_ptr(),
+                        knn.data_ptr(), knn.stride(1), w.data_ptr(), b, m, nq, k, _stream_ptr(in_xyz),
+                        work=(8.0 * b * nq * k + 12.0 * b * nq * (1 + k) + 4.0 * b * nq * k, 'B'))
+        order, offsets = inverse_map(knn[:, :, :k].reshape(b, nq * k).contiguous(), m)
+        order = order.long()
+        q_sorted = ((order % (nq * k)) // k).to(torch.int32)
+        hit = ((in_xyz, q_xyz, knn), offsets, q_sorted, w.reshape(-1)[order].contiguous())
+        while len(_interp_weights) >= 8:
+            _interp_weights.pop(next(iter(_interp_weights)))
+    _interp_weights[key] = hit
+    return hit[1], hit[2], hit[3]
+
+
 class _KnnInterp(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, in_xyz, feat, q_xyz, knn, k):
+    def forward(ctx, in_xyz, feat, q_xyz, knn, k, invariant=False):
         lib = _lib.load()
         b, c, m = feat.shape
         nq = q_xyz.shape[2]
+        ctx.invariant = invariant
         out = torch.empty((b, c, nq), dtype=torch.float32, device=feat.device)
         with _on_device(feat):
             _lib.launch('camli_knn_interp_fwd', lib.camli_knn_interp_fwd, in_xyz.data_ptr(), feat.data_ptr(),
@@ -982,7 +1014,19 @@ class _KnnInterp(torch.autograd.Function):
         gout = gout.contiguous().float()
         gfeat = g_in = g_q = None
         with _on_device(gout):
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and _INTERP_SORTED and ctx.invariant and b * nq * k < 2 ** 31 \
+                    and not (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]):
+                # round 5: no atomics -- the weights once per pair of clouds, a segment sum per input point over the inverse map
+                # of the neighbour table (both cached across the iterations of a pass), fixed summation order, no zero-fill.
+                # Only where the caller declares the geometry invariant across calls (the GRU loops' up-sampling of the
+                # 3-D predictions): with clouds that move every call the sort behind the inverse map would cost more than the
+                # atomics do
+                offsets, q_sorted, w_sorted = _interp_geometry(in_xyz, q_xyz, knn, k)
+                gfeat = torch.empty((b, c, m), dtype=torch.float32, device=gout.device)
+                _lib.launch('camli_knn_interp_bwd', lib.camli_knn_interp_bwd_sorted, gout.data_ptr(), w_sorted.data_ptr(),
+                            q_sorted.data_ptr(), offsets.data_ptr(), gfeat.data_ptr(), b, c, m, nq, _stream_ptr(gout),
+                            work=(4.0 * b * c * (nq * k + m) + 8.0 * b * nq * k + 4.0 * b * m, 'B'))
+            elif ctx.needs_input_grad[1]:
                 gfeat = torch.zeros((b, c, m), dtype=torch.float32, device=gout.device)
                 _lib.launch('camli_knn_interp_bwd', lib.camli_knn_interp_bwd, in_xyz.data_ptr(), gout.data_ptr(),
                             q_xyz.data_ptr(), knn.data_ptr(), knn.stride(1), gfeat.data_ptr(), b, c, m, nq, k,
@@ -998,15 +1042,16 @@ class _KnnInterp(torch.autograd.Function):
                             g_in.data_ptr() if g_in is not None else None, g_q.data_ptr() if g_q is not None else None,
                             b, c, m, nq, k, _stream_ptr(gout),
                             work=(4.0 * b * c * nq * (1 + k) + 8.0 * b * nq * k + 12.0 * b * nq * (2 + 2 * k), 'B'))
-        return g_in, gfeat, g_q, None, None
+        return g_in, gfeat, g_q, None, None, None
 
 
-def knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k):
+def knn_interpolate(input_xyz, input_features, query_xyz, knn_indices, k, invariant=False):
     """IDW interpolation given the k nearest inputs per query (utils.py:138-146); differentiable wrt the
-    features and, when they require it, both coordinate sets."""
+    features and, when they require it, both coordinate sets.  ``invariant``: the caller passes the SAME clouds and neighbour
+    table on every call of a pass (the feature adjoint then runs atomic-free on per-pass geometry)."""
     _require_cuda('knn_interpolate', input_xyz, input_features, query_xyz, knn_indices)
     return _KnnInterp.apply(input_xyz.float().contiguous(), input_features.float().contiguous(),
-                            query_xyz.float().contiguous(), knn_indices, k)
+                            query_xyz.float().contiguous(), knn_indices, k, invariant)
 
 
 class _Corr3DGather(torch.autograd.Function):

@@ -221,6 +221,61 @@ __global__ __launch_bounds__(256) void knn_interp_kernel(const float* __restrict
     }
 }
 
+// The interpolation weights alone, w[b][q][j] (the arithmetic of knn_interp_kernel), for the sorted adjoint below: the GRU loops
+// interpolate between the SAME two clouds every iteration, so they are computed once per pass.
+__global__ __launch_bounds__(256) void knn_interp_weights_kernel(const float* __restrict__ in_xyz,
+                                                                  const float* __restrict__ q_xyz,
+                                                                  const int64_t* __restrict__ knn, int knn_stride,
+                                                                  float* __restrict__ wout, int M, int Nq, int k) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    if (q >= Nq) return;
+    const float qx = q_xyz[((size_t)b * 3 + 0) * Nq + q];
+    const float qy = q_xyz[((size_t)b * 3 + 1) * Nq + q];
+    const float qz = q_xyz[((size_t)b * 3 + 2) * Nq + q];
+    float w[KI_MAXK];
+    float wsum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KI_MAXK; ++j) {
+        w[j] = 0.0f;
+        if (j < k) {
+            const int m = (int)knn[((size_t)b * Nq + q) * knn_stride + j];
+            const float dx = in_xyz[((size_t)b * 3 + 0) * M + m] - qx;
+            const float dy = in_xyz[((size_t)b * 3 + 1) * M + m] - qy;
+            const float dz = in_xyz[((size_t)b * 3 + 2) * M + m] - qz;
+            const float dist = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-8f);
+            w[j] = 1.0f / dist;
+            wsum += w[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KI_MAXK; ++j)
+        if (j < k) wout[((size_t)b * Nq + q) * k + j] = w[j] / wsum;
+}
+
+// Adjoint of the interpolation wrt the features WITHOUT atomics (round 5): gfeat[b][c][m] = sum over the (query, slot) pairs
+// that name m of gout[b][c][query] * w[b][query][slot].  The pairs of every m come from the inverse map of the neighbour table
+// (fused.inverse_map), already resolved per pass into q_sorted[e] (the pair's query inside its sample) and w_sorted[e] (its
+// weight), both in ascending (query, slot) order inside a segment: a fixed summation order, every output written once, no
+// zero-fill, and neighbouring threads stream neighbouring segments.  thread = (b, m), blockIdx.y = channel.  The float-atomic
+// form took 26 us for 8 x 8192 queries x 3 channels (12 contributions per target on average, all colliding).
+__global__ __launch_bounds__(256) void knn_interp_bwd_sorted_kernel(const float* __restrict__ gout,
+                                                                     const float* __restrict__ w_sorted,
+                                                                     const int* __restrict__ q_sorted,
+                                                                     const int* __restrict__ offsets,
+                                                                     float* __restrict__ gfeat, int C, int M, int Nq) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    if (m >= M) return;
+    const int beg = offsets[b * M + m], end = offsets[b * M + m + 1];
+    for (int c = blockIdx.y; c < C; c += gridDim.y) {
+        const float* __restrict__ grow = gout + ((size_t)b * C + c) * Nq;
+        float acc = 0.0f;
+        for (int e = beg; e < end; ++e) acc += grow[q_sorted[e]] * w_sorted[e];
+        gfeat[((size_t)b * C + c) * M + m] = acc;
+    }
+}
+
 // Coordinate adjoint of the interpolation (models/utils.py:138-146 differentiated: norm -> clamp(1e-8) ->
 // reciprocal -> normalise -> weighted sum).  With p_j = w_j / W the normalised weights, a_j = sum_c g_c f_cj and
 // S = sum_c g_c out_c:   dL/dw_j = (a_j - S) / W,   dw_j/ddist_j = -w_j^2 (where the clamp is inactive),
@@ -565,6 +620,32 @@ extern "C" int camli_knn_interp_bwd(const float* in_xyz, const float* gout, cons
                        dim3(256), 0, reinterpret_cast<hipStream_t>(stream), in_xyz, q_xyz, knn, knn_stride, gout, gfeat,
                        C, M, Nq, k);
     return camli_check_launch("camli_knn_interp_bwd");
+}
+
+extern "C" int camli_knn_interp_weights(const float* in_xyz, const float* q_xyz, const int64_t* knn, int knn_stride,
+                                        float* w_out, int B, int M, int Nq, int k, void* stream) {
+    if (B == 0 || Nq == 0) return CAMLI_OK;
+    if (!in_xyz || !q_xyz || !knn || !w_out) { camli_set_error("camli_knn_interp_weights: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || M < 1 || Nq < 0 || k < 1 || k > KI_MAXK || knn_stride < k || B > 65535) {
+        camli_set_error("camli_knn_interp_weights: bad shape B=%d M=%d Nq=%d k=%d (k <= %d)", B, M, Nq, k, KI_MAXK);
+        return CAMLI_EINVAL;
+    }
+    hipLaunchKernelGGL(knn_interp_weights_kernel, dim3(camli_divup(Nq, 256), 1, B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), in_xyz, q_xyz, knn, knn_stride, w_out, M, Nq, k);
+    return camli_check_launch("camli_knn_interp_weights");
+}
+
+extern "C" int camli_knn_interp_bwd_sorted(const float* gout, const float* w_sorted, const int* q_sorted, const int* offsets,
+                                           float* gfeat, int B, int C, int M, int Nq, void* stream) {
+    if (B == 0 || M == 0) return CAMLI_OK;
+    if (!gout || !w_sorted || !q_sorted || !offsets || !gfeat) { camli_set_error("camli_knn_interp_bwd_sorted: null pointer"); return CAMLI_EINVAL; }
+    if (B < 0 || C < 1 || M < 1 || Nq < 0 || B > 65535) {
+        camli_set_error("camli_knn_interp_bwd_sorted: bad shape B=%d C=%d M=%d Nq=%d", B, C, M, Nq);
+        return CAMLI_EINVAL;
+    }
+    hipLaunchKernelGGL(knn_interp_bwd_sorted_kernel, dim3(camli_divup(M, 256), grid_y_for(C), B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), gout, w_sorted, q_sorted, offsets, gfeat, C, M, Nq);
+    return camli_check_launch("camli_knn_interp_bwd_sorted");
 }
 
 extern "C" int camli_knn_interp_bwd_xyz(const float* in_xyz, const float* feat, const float* gout, const float* q_xyz,

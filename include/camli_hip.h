@@ -229,6 +229,14 @@ int camli_knn_interp_fwd(const float *in_xyz, const float *feat, const float *q_
                          int knn_stride, float *out, int B, int C, int M, int Nq, int k, void *stream);
 int camli_knn_interp_bwd(const float *in_xyz, const float *gout, const float *q_xyz, const int64_t *knn,
                          int knn_stride, float *gfeat, int B, int C, int M, int Nq, int k, void *stream);
+/* Adjoint of the interpolation wrt the features without atomics: the weights of every (query, slot) pair once
+ * (camli_knn_interp_weights, the arithmetic of camli_knn_interp_fwd: models/utils.py:138-146), then a segment sum per input point:
+ * offsets [B*M+1] = CSR bounds of the (sample, input point) segments of the neighbour table's inverse map, q_sorted / w_sorted = the
+ * query (inside its sample) and the weight of every pair in segment order; fixed summation order, gfeat is written, not added to. */
+int camli_knn_interp_weights(const float *in_xyz, const float *q_xyz, const int64_t *knn, int knn_stride, float *w_out,
+                             int B, int M, int Nq, int k, void *stream);
+int camli_knn_interp_bwd_sorted(const float *gout, const float *w_sorted, const int *q_sorted, const int *offsets, float *gfeat,
+                                int B, int C, int M, int Nq, void *stream);
 int camli_knn_interp_bwd_xyz(const float *in_xyz, const float *feat, const float *gout, const float *q_xyz,
                              const int64_t *knn, int knn_stride, float *g_in_xyz, float *g_q_xyz,
                              int B, int C, int M, int Nq, int k, void *stream);

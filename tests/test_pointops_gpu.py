@@ -41,8 +41,12 @@ def test_gather_golden(golden):
     assert np.array_equal(out.cpu().numpy(), g['out_cf'])
 
 
+@pytest.mark.parametrize('invariant', [False, True], ids=['atomic_adjoint', 'sorted_adjoint'])
 @pytest.mark.parametrize('case', [(2, 3, 2048, 8192, 3), (8, 3, 2048, 256, 3), (1, 67, 512, 1024, 3), (2, 7, 200, 90, 5)], ids=str)
-def test_knn_interpolate(case, oracle_lib):
+def test_knn_interpolate(case, invariant, oracle_lib):
+    """forward and feature adjoint vs the oracle; ``invariant`` (the GRU loops' declaration: same clouds every call) selects the
+    atomic-free adjoint on per-pass geometry (camli_knn_interp_weights + camli_knn_interp_bwd_sorted), which must also give the
+    same bits on a second backward pass through the cached geometry"""
     from camliflow_amd.csrc import fused, k_nearest_neighbor
     b, c, m, nq, k = case
     rng = np.random.default_rng(nq)
@@ -52,13 +56,19 @@ def test_knn_interpolate(case, oracle_lib):
     feat = rng.standard_normal((b, c, m)).astype(np.float32)
     knn = k_nearest_neighbor(dev(in_xyz), dev(q_xyz), k)
     tf = dev(feat).requires_grad_(True)
-    out = fused.knn_interpolate(dev(in_xyz), tf, dev(q_xyz), knn, k)
+    d_in, d_q = dev(in_xyz), dev(q_xyz)
+    out = fused.knn_interpolate(d_in, tf, d_q, knn, k, invariant=invariant)
     want = oracle_lib.knn_interp_fwd(in_xyz, feat, q_xyz, knn.cpu().numpy())
     assert np.allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-6)
     g = rng.standard_normal(out.shape).astype(np.float32)
     out.backward(dev(g))
     assert np.allclose(tf.grad.cpu().numpy(), oracle_lib.knn_interp_bwd(in_xyz, g, q_xyz, knn.cpu().numpy(), m),
                        rtol=1e-4, atol=1e-5)
+    if invariant:       # a second call on the same clouds (cached geometry): bit-identical gradient, fixed summation order
+        first = tf.grad.clone()
+        tf.grad = None
+        fused.knn_interpolate(d_in, tf, d_q, knn, k, invariant=True).backward(dev(g))
+        assert torch.equal(tf.grad, first)
 
 
 @pytest.mark.parametrize('case', [(2, 3, 2048, 1024, 3), (1, 67, 512, 1024, 3), (2, 7, 200, 90, 5)], ids=str)
