@@ -310,10 +310,13 @@ def _kernel_us(fn, reps):
         from torch.profiler import ProfilerActivity, profile
         _lib.TIMER.reset()
         _lib.TIMER.enabled = True
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')         # "Profiler clears events at the end of each cycle": one cycle is all there is
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
         _lib.TIMER.enabled = False
         order = list(_lib.TIMER.order)
         events = prof.profiler.kineto_results.events()
