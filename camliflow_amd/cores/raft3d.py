@@ -129,7 +129,7 @@ class Correlation3D(nn.Module):
             level0 = xyzs2[0]
             # round 5: the previous iteration's neighbours bound this iteration's k-th distances (the target cloud is the same
             # one back-warped a little further): same indices, the scan queues a fraction of the candidates
-            prior = getattr(self, '_prior_crosses', None)
+            prior = getattr(self, '_prior_crosses', None) if os.environ.get('CAMLI_KNN_PRIOR', '1') != '0' else None
             queries = _channel_last(xyz1, True)
             if prior is not None and (len(prior) != len(pyr.sizes) or prior[0].shape[:2] != queries.shape[:2]):
                 prior = None

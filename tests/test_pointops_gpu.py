@@ -386,6 +386,37 @@ def test_nested_pyramid_paths_match_per_level_paths():
         assert (a - c).norm() <= 1e-5 * c.norm() + 1e-7
 
 
+def test_gru_loop_lookups_with_the_previous_neighbours_as_prior_are_unchanged(monkeypatch):
+    """Correlation3D over a sequence of back-warped target clouds (what the GRU loop does): from the second lookup on the
+    prefix search is bounded by the previous lookup's neighbours (camli_knn_prefixes_prior).  CAMLI_KNN_PRIOR=0 searches from
+    scratch every time; the lookups must be bit-identical either way, jumpy flows included (a prior from far-away clouds only
+    costs the speed-up)."""
+    from camliflow_amd.cores import geometry, runtime
+    from camliflow_amd.cores.raft3d import Correlation3D
+    from camliflow_amd.cores.setconv import pass_cache
+    from modelutils import hashed_fill_
+    torch.manual_seed(1)
+    mod = hashed_fill_(Correlation3D(out_channels=128, k=16)).cuda()
+    b, n = 2, 2048
+    xyz1 = torch.rand(b, 3, n, device='cuda') * 4
+    base2 = xyz1 + torch.randn(b, 3, n, device='cuda') * 0.2
+    xyzs2 = [base2[:, :, :m].contiguous() for m in (2048, 1024, 512, 256)]
+    f1, f2 = torch.randn(b, 128, n, device='cuda'), torch.randn(b, 128, n, device='cuda')
+    flows = [torch.randn(b, 3, n, device='cuda') * s for s in (0.0, 0.02, 0.05, 1.5, 0.05)]     # small steps and one jump
+    res = {}
+    with runtime.use_backend('hip'), torch.no_grad():
+        for prior in ('1', '0'):
+            monkeypatch.setenv('CAMLI_KNN_PRIOR', prior)
+            with pass_cache():
+                mod.build_cost_volume_pyramid(f1, f2, xyzs2, nested=True)
+                outs = [mod(xyz1, geometry.backwarp_3d_levels(xyz1, xyzs2, fl, nested=True)) for fl in flows]
+                assert (mod._prior_crosses is not None)
+                mod.release()
+            res[prior] = outs
+    for a, c in zip(res['1'], res['0']):
+        assert torch.equal(a, c)
+
+
 def test_input_side_kernels_vs_oracle_golden_and_torch(golden, oracle_lib):
     """camli_pad_normalize / camli_persp2paral: exact against the oracle and the reference golden for
     the padding + normalisation; the IDS transform bit-identical to the torch composition on the same device (FPS
