@@ -651,8 +651,10 @@ def compact_line(full, detail_path=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    # defaults: a 10-step window after 3 warm-up steps (+1.3 s over 5 / 2): the two lanes need a few steps to settle into their
+    # steady alignment, and 5-step windows read 4-6 ms per step high (profiles/README.md, r05h vs r05b)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='camliraft')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (configs[2]: 8; configs[3] would be 4)')
     ap.add_argument('--iters', type=int, default=None)
