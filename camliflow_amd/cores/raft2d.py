@@ -231,11 +231,11 @@ class MotionEncoder2D(nn.Module):
                 and not torch.is_autocast_enabled())
 
     def forward(self, flow, corr, flow_branch=None):
-        if epilogue_ok(corr) and self._cat_free(flow) and (flow_branch is None or flow_branch[2]):
+        if epilogue_ok(corr) and self._cat_free(flow) and (flow_branch is None or (len(flow_branch) > 2 and flow_branch[2])):
             from ..csrc import fused
             c_raw = conv_bias_act(self.conv_c2, conv_bias_act(self.conv_c1, corr, 'relu'), None, leave_bias=True)
             if flow_branch is not None:
-                branch, f_raw, _ = flow_branch
+                branch, f_raw = flow_branch[0], flow_branch[1]
                 branch.join(f_raw)
             else:
                 f_raw = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), None, leave_bias=True)
@@ -248,7 +248,7 @@ class MotionEncoder2D(nn.Module):
             if flow_branch is not None:
                 branch, f = flow_branch[0], flow_branch[1]
                 branch.join(f)
-                if flow_branch[2]:           # a raw handle (bias and ReLU left to the caller) after the state changed in between
+                if len(flow_branch) > 2 and flow_branch[2]:      # a raw handle (bias and ReLU left to the caller), the state changed in between
                     f = self.relu(f + self.conv_f2.bias.view(1, -1, 1, 1))
             else:
                 f = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), 'relu')
@@ -263,7 +263,7 @@ class MotionEncoder2D(nn.Module):
         if flow_branch is not None:          # issued by begin(): same values, join before use
             flow_branch[0].join(flow_branch[1])
             f = flow_branch[1]
-            if flow_branch[2]:               # begin() left conv_f2's bias + ReLU to the epilogue branch above: finish it here
+            if len(flow_branch) > 2 and flow_branch[2]:      # begin() left conv_f2's bias + ReLU to the epilogue branch: finish it here
                 f = self.relu(f + self.conv_f2.bias.view(1, -1, 1, 1))
         else:
             f = self.relu(self.conv_f1(flow))
