@@ -194,6 +194,9 @@ def conv_bias_act(conv, x, act, leave_bias=False):
         return fused.conv3x3_co2(x, conv.weight, conv.bias)
     if _is_pointwise(conv) and x.dtype == torch.float32 and (x.is_contiguous() or _is_nhwc(x)):
         y = _PointwiseConv.apply(x, conv.weight)
+    elif fused.wino_supported(conv, x):
+        # r6: the update block's wide 3x3 convolutions as Winograd F(2x2,3x3) on the fp32 matrix cores (csrc/hip/winograd.hip)
+        y = fused.conv3x3_wino(x, conv.weight)
     else:
         y = conv._conv_forward(x, conv.weight, None)
     if y.dtype != torch.float32:      # autocast: a fresh fp32 copy the epilogue may overwrite in place

@@ -2404,6 +2404,122 @@ def conv3x3_co2(x, weight, bias):
 
 
 # ------------------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) on the fp32 matrix cores (csrc/hip/winograd.hip, round 6): the 3x3 / stride 1 / padding 1 convolutions of
+# the RAFT update block -- MotionEncoder2D.conv_c2 / conv (models/raft_core.py:148,151), FlowHead2D.conv1 (:173), the mask
+# head's first convolution (:188) -- forward, data gradient (the same three launches on the output gradient with the
+# transposed, tap-reversed weights) and weight gradient.  CAMLI_WINO=0 leaves them with the library (A/B).
+# ------------------------------------------------------------------------------------------------
+_WINO = os.environ.get('CAMLI_WINO', '1') != '0'
+_wino_weights = {}          # id(weight) -> [weakref(weight), version, {flip: U}]
+
+
+def wino_supported(conv, x):
+    """A plain 3x3 / stride 1 / padding 1 convolution on an fp32 NCHW map whose channel counts fill the matrix-core tiles."""
+    return (_WINO and isinstance(conv, torch.nn.Conv2d) and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+            and conv.padding == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
+            and wino_shape_supported(conv.in_channels, conv.out_channels) and x.dim() == 4 and x.is_cuda
+            and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and not torch.is_autocast_enabled())
+
+
+def wino_shape_supported(cin, cout):
+    """Both directions run on the plane GEMMs (contraction over Cin forward, over Cout in the data gradient, each padded to
+    a multiple of 16).  Fewer than 96 rows on a GEMM's M side leave its 128-row tile mostly padding (MotionEncoder2D.conv_f2,
+    128 -> 64: measured 123 us against the library's 95): those stay with the library."""
+    return cin >= 96 and cout >= 96
+
+
+def wino_transformed_weights(w, flip):
+    """U [16][K][Mp] of w [Cout][Cin][3][3] (camli_wino_weights), computed once per value of the weight tensor: the 12 GRU
+    iterations of a pass (and its backward) share it; an optimiser step bumps the tensor's version."""
+    key = id(w)
+    entry = _wino_weights.get(key)
+    if entry is None or entry[0]() is not w or entry[1] != w._version:
+        if len(_wino_weights) > 64:
+            for k in [k for k, e in _wino_weights.items() if e[0]() is None]:
+                del _wino_weights[k]
+        entry = _wino_weights[key] = [weakref.ref(w), w._version, {}]
+    u = entry[2].get(flip)
+    if u is None:
+        lib = _lib.load()
+        cout, cin = w.shape[0], w.shape[1]
+        k, m = (cout, cin) if flip else (cin, cout)
+        u = torch.empty(lib.camli_wino_weight_floats(k, m), dtype=torch.float32, device=w.device)
+        wd = w.detach()
+        wd = wd if wd.is_contiguous() else wd.contiguous()
+        with _on_device(w):
+            _lib.launch('camli_wino_weights', lib.camli_wino_weights, wd.data_ptr(), u.data_ptr(), cout, cin, int(flip), _stream_ptr(w),
+                        work=(4.0 * (9 + 16) * cout * cin, 'B'))
+        u._camli_stream = torch.cuda.current_stream(w.device)
+        entry[2][flip] = u
+    else:
+        # produced on another stream of this pass (a Branch / the weight-gradient side stream): order this stream behind it
+        cur = torch.cuda.current_stream(w.device)
+        if u._camli_stream != cur:
+            cur.wait_stream(u._camli_stream)
+    return u
+
+
+def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, mask=None):
+    """act(conv3x3(x) + bias) for pre-transformed weights u (wino_transformed_weights).  x [B,C,H,W] fp32, dense or a channel
+    slice of a dense NCHW tensor; ``mask``: x reads as zero where mask <= 0; ``out``: an existing [B,n_out,H,W] tensor (or
+    channel slice), ``accumulate``: add into it."""
+    _require_cuda('wino_conv3x3', x, u)
+    lib = _lib.load()
+    b, c, hh, ww = x.shape
+    xbs = _batch_strided(x)
+    if xbs is None:
+        x = x.contiguous()
+        xbs = c * hh * ww
+    mbs = 0
+    if mask is not None:
+        assert mask.shape == x.shape
+        mbs = _batch_strided(mask)
+        if mbs is None:
+            mask = mask.contiguous()
+            mbs = c * hh * ww
+    if out is None:
+        assert not accumulate
+        out = torch.empty((b, n_out, hh, ww), dtype=torch.float32, device=x.device)
+    ybs = _batch_strided(out)
+    if ybs is None or out.shape != (b, n_out, hh, ww):
+        raise _lib.CamliHipError('wino_conv3x3: the output must be a dense fp32 [B,%d,H,W] tensor or a channel slice of one' % n_out)
+    need = lib.camli_wino_workspace_bytes(b, c, n_out, hh, ww)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    tiles = need // (64 * ((c + 15) // 16 * 16 + (n_out + 3) // 4 * 4))
+    with _on_device(x):
+        _lib.launch('camli_wino_conv3x3', lib.camli_wino_conv3x3, x.data_ptr(), xbs, mask.data_ptr() if mask is not None else None, mbs,
+                    u.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ybs, ws.data_ptr(), need, b, c,
+                    n_out, hh, ww, 1 if act == 'relu' else 0, int(bool(accumulate)), _stream_ptr(x),
+                    work=(4.0 * b * hh * ww * (c + n_out) + 2 * need, 'B'), flop=2.0 * 16 * tiles * c * n_out)
+    return out
+
+
+class _Conv3x3Wino(torch.autograd.Function):
+    """conv2d(x, w, padding=1) without bias (the epilogue kernels add it)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return wino_conv3x3(x, wino_transformed_weights(w, False), w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.float()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = wino_conv3x3(gy, wino_transformed_weights(w, True), w.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy.contiguous(), x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return gx, gw
+
+
+def conv3x3_wino(x, weight):
+    return _Conv3x3Wino.apply(x, weight)
+
+
+# ------------------------------------------------------------------------------------------------
 # input side (SURVEY 8f rank 3): models/ids.py:4-33, models/camliraft.py:38-46
 # ------------------------------------------------------------------------------------------------
 def persp2paral_pair(pcs, intrinsics, persp, paral):

@@ -23,6 +23,11 @@
 //
 // Numerics: every accumulator is the k-ascending fmaf chain of its products (v_mfma_f32_16x16x4_f32 adds k = 4 s .. 4 s + 3
 // in order), bit-identical to the 32x32x2 kernel and to the oracle's loop.
+//
+// r6: the wave arrangement is a template parameter (GA x GB groups of 64 rows / columns per wave, WM x WN waves): the
+// default <2, 2, 2> is the 256 x 256 tile above, instruction for instruction; <3, 1, 1> is a 192 x 256 tile (each wave all
+// 192 rows x 64 columns, 192 accumulators) and <2, 1, 1> a 128 x 256 tile for the Winograd-domain contractions whose M is
+// a convolution's output-channel count (winograd.hip).  The LDS image keeps its 256-float k rows whatever the tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -94,18 +99,32 @@ __device__ __forceinline__ void decode_tile(const Problem& p, int t, int& b, int
     tm = band * GROUP_M + (within - tn * rows);
 }
 
-// KS: K step per barrier (16 or 32); NBUF: LDS stages.  LDS: NBUF * KS * 512 floats.
+// KS: K step per barrier (8 or 16); NBUF: LDS stages.  LDS: NBUF * KS * 512 floats.
 // ABL (timing-only ablations, results wrong by design): 1 = no epilogue stores, 2 = no operand loads
-template <int KS, int NBUF, int ABL = 0>
+// GA, GB: 64-row / 64-column groups per wave; WM: waves along M (4 / WM along N).  Macro tile 64 GA WM x 64 GB (4 / WM);
+// the host sets Problem::tiles_m / tiles_n for THAT tile (tile_m<GA, WM>() / tile_n<GB, WM>()).
+template <int GA, int WM> constexpr int tile_m() { return 64 * GA * WM; }
+template <int GB, int WM> constexpr int tile_n() { return 64 * GB * (4 / WM); }
+
+template <int KS, int NBUF, int ABL = 0, int GA = 2, int GB = 2, int WM = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w128_kernel(Problem p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert((KS == 8 || KS == 16) && NBUF >= 3, "one barrier per step needs three stages; SUB must be even");
+    constexpr int WN = 4 / WM;
+    constexpr int MTM = 64 * GA * WM, MTN = 64 * GB * WN;
+    static_assert(WM * WN == 4 && MTM <= 256 && MTN <= 256, "four waves; the LDS image holds 256-float k rows");
+    constexpr int NSLOT = 4 * GA * GB;        // slots of 4 MFMAs per sub-step
+    constexpr int NFRAG = GA + GB;            // ds_read_b128 per sub-step
+    constexpr int ESTORES = 16 * GA * GB;     // epilogue stores per wave and tile
     constexpr int SUB = KS / 4;               // sub-steps (one K = 4 MFMA row) per step
     constexpr int IPS = KS / 2;               // DMA instructions per wave and stage
+    constexpr int DPS = (IPS + NSLOT - 3) / (NSLOT - 2);      // DMA instructions per slot of the last sub-step (1 on the 256 x 256 tile)
+    constexpr int DSLOTS = (IPS + DPS - 1) / DPS;
+    static_assert(NSLOT >= 8 && 2 * NFRAG <= NSLOT && DSLOTS + 2 <= NSLOT, "");
     constexpr int STAGE = KS * 512;           // floats: [KS][256] of A, then [KS][256] of B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 15, q = lane >> 4;
     const int steps = p.K / KS;
 
@@ -122,8 +141,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto load_setup = [&]() {
         int b, tm, tn;
         decode_tile(p, tile_of(l_round), b, tm, tn);
-        ga = p.A + (int64_t)b * p.sa + (int64_t)wave * p.lda + min(tm * MT + 4 * lane, p.M - 4);
-        gb = p.B + (int64_t)b * p.sb + (int64_t)wave * p.ldb + min(tn * MT + 4 * lane, p.N - 4);
+        ga = p.A + (int64_t)b * p.sa + (int64_t)wave * p.lda + min(tm * MTM + 4 * lane, p.M - 4);
+        gb = p.B + (int64_t)b * p.sb + (int64_t)wave * p.ldb + min(tn * MTN + 4 * lane, p.N - 4);
         l_step = 0;
     };
     if (l_valid) load_setup();
@@ -158,37 +177,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    const float* fa = lds + q * 256 + 128 * wm + 4 * r;                  // fragment addresses inside a stage
-    const float* fb = lds + KS * 256 + q * 256 + 128 * wn + 4 * r;
-    f32x4 acc[8][8];
-    f32x4 pa[2], pb[2], qa[2], qb[2];
-#define W128_FRAG(X, BUF, S, WHICH)                                                                              \
-    X = *reinterpret_cast<const f32x4*>(((WHICH) < 2 ? fa : fb) + (BUF) * STAGE + (S) * 1024 + ((WHICH) & 1) * 64)
-    // one sub-step = 16 slots of 4 MFMAs (128 matrix-pipe cycles); what `between(slot)` issues runs in the shadow of the
-    // slot's last MFMA (32 cycles), so it should stay within a handful of instructions.  Everything is pinned: the order
-    // written here is the order executed.
-    auto substep = [&](auto zero, const f32x4 (&xa)[2], const f32x4 (&xb)[2], auto&& between) {
+    const float* fa = lds + q * 256 + 64 * GA * wm + 4 * r;              // fragment addresses inside a stage
+    const float* fb = lds + KS * 256 + q * 256 + 64 * GB * wn + 4 * r;
+    f32x4 acc[4 * GA][4 * GB];
+    f32x4 pa[GA], pb[GB], qa[GA], qb[GB];
+    // fragment WHICH of a sub-step: the wave's GA groups of A, then its GB groups of B
+#define W128_FRAG_LOAD(BUF, S, WHICH)                                                                            \
+    *reinterpret_cast<const f32x4*>(((WHICH) < GA ? fa + (WHICH) * 64 : fb + ((WHICH) - GA) * 64) + (BUF) * STAGE + (S) * 1024)
+    auto frag_into = [&](f32x4 (&ya)[GA], f32x4 (&yb)[GB], int fbuf_, int s_, int which) {
+        if (which < GA) ya[which] = W128_FRAG_LOAD(fbuf_, s_, which);
+        else yb[which - GA] = W128_FRAG_LOAD(fbuf_, s_, which);
+    };
+    // one sub-step = NSLOT slots of 4 MFMAs (128 matrix-pipe cycles each); what `between(slot)` issues runs in the shadow
+    // of the slot's last MFMA (32 cycles), so it should stay within a handful of instructions.  Everything is pinned: the
+    // order written here is the order executed.
+    auto substep = [&](auto zero, const f32x4 (&xa)[GA], const f32x4 (&xb)[GB], auto&& between) {
 #pragma unroll
-        for (int sl = 0; sl < 16; ++sl) {
-            const int ta = sl >> 1, hb = sl & 1;
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int ta = sl / GB, hb = sl % GB;
             mfma_x4<decltype(zero)::value>(acc[ta][4 * hb], acc[ta][4 * hb + 1], acc[ta][4 * hb + 2], acc[ta][4 * hb + 3], xa[ta >> 2][ta & 3], xb[hb]);
             __builtin_amdgcn_sched_barrier(0);
             between(sl);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto prefetch_into = [&](f32x4 (&ya)[2], f32x4 (&yb)[2], int fbuf_, int s_, int first_row) {
-        return [&ya, &yb, fbuf_, s_, first_row, fa, fb](int sl) {
-            if (sl == first_row) W128_FRAG(ya[0], fbuf_, s_, 0);
-            if (sl == first_row + 2) W128_FRAG(ya[1], fbuf_, s_, 1);
-            if (sl == first_row + 4) W128_FRAG(yb[0], fbuf_, s_, 2);
-            if (sl == first_row + 6) W128_FRAG(yb[1], fbuf_, s_, 3);
+    // the next sub-step's fragments: one read every second slot from slot 1 on (every slot on the 8-slot tiles)
+    constexpr int FSTRIDE = 1 + 2 * (NFRAG - 1) < NSLOT ? 2 : 1;
+    auto prefetch_into = [&](f32x4 (&ya)[GA], f32x4 (&yb)[GB], int fbuf_, int s_) {
+        return [&ya, &yb, fbuf_, s_, &frag_into](int sl) {
+            if (sl >= 1 && (sl - 1) % FSTRIDE == 0 && (sl - 1) / FSTRIDE < NFRAG) frag_into(ya, yb, fbuf_, s_, (sl - 1) / FSTRIDE);
         };
+    };
+    // slot of the last sub-step in which fragment i of the NEXT stage is read (behind the barrier of slot 0 and the DMAs)
+    auto last_frag_slot = [](int i) constexpr {
+        return NSLOT == 16 && NFRAG == 4 ? (i == 0 ? 9 : i == 1 ? 11 : i == 2 ? 13 : 14) : NSLOT - NFRAG + i;
     };
 
     int c_round = 0, buf = 0;
     bool after_epilogue = false;
-    W128_FRAG(pa[0], 0, 0, 0); W128_FRAG(pa[1], 0, 0, 1); W128_FRAG(pb[0], 0, 0, 2); W128_FRAG(pb[1], 0, 0, 3);
+#pragma unroll
+    for (int i = 0; i < NFRAG; ++i) frag_into(pa, pb, 0, 0, i);
     for (;;) {      // one tile per trip
         int cb, ctm, ctn;
         decode_tile(p, tile_of(c_round), cb, ctm, ctn);
@@ -198,10 +226,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int s = 0; s + 1 < SUB; ++s) {
                 if ((s & 1) == 0) {
-                    if (s == 0) substep(first, pa, pb, prefetch_into(qa, qb, buf, s + 1, 1));
-                    else substep(std::false_type{}, pa, pb, prefetch_into(qa, qb, buf, s + 1, 1));
+                    if (s == 0) substep(first, pa, pb, prefetch_into(qa, qb, buf, s + 1));
+                    else substep(std::false_type{}, pa, pb, prefetch_into(qa, qb, buf, s + 1));
                 } else {
-                    substep(std::false_type{}, qa, qb, prefetch_into(pa, pb, buf, s + 1, 1));
+                    substep(std::false_type{}, qa, qb, prefetch_into(pa, pb, buf, s + 1));
                 }
             }
             // last sub-step: the next stage must have landed for every wave before its first fragments are read, and
@@ -214,27 +242,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             substep(std::false_type{}, qa, qb, [&](int sl) {
                 if (sl == 0) {
                     // allowed in flight: the NBUF - 3 stages issued after the one needed now.  Right after an epilogue
-                    // its 64 stores (returned in issue order with the loads) sit between the needed stage and anything
-                    // younger: >= 72 operations were issued from that stage on, so "at most 62 in flight" retires it.
+                    // its ESTORES stores (returned in issue order with the loads) sit between the needed stage and anything
+                    // younger: IPS + ESTORES (+ younger stages) operations were issued from that stage on, so "at most
+                    // ESTORES (+ younger) in flight" retires it (62 = the counter's range on the 64-store tile).
                     // Once the loader has run dry the younger stages do not exist: wait for everything.
+                    constexpr int AFTER_EPI = IPS * (NBUF - 3) + ESTORES < 62 ? IPS * (NBUF - 3) + ESTORES : 62;
                     if (!l_valid) wait_vm<0>();
-                    else if (after_epilogue && st < NBUF - 2) wait_vm<62>();
+                    else if (after_epilogue && st < NBUF - 2) wait_vm<AFTER_EPI>();
                     else wait_vm<IPS*(NBUF - 3)>();
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
-                // one DMA per slot: wave w brings k rows w, w + 4, ... of both operands
-                if (sl >= 1 && sl <= IPS && issue && ABL != 2) {
-                    const int j = sl - 1;
-                    if (j < IPS / 2) dma16(ga + (int64_t)(4 * j) * p.lda, sa_ + 4 * j * 256);
-                    else dma16(gb + (int64_t)(4 * (j - IPS / 2)) * p.ldb, sa_ + KS * 256 + 4 * (j - IPS / 2) * 256);
+                // DPS DMAs per slot: wave w brings k rows w, w + 4, ... of both operands
+                if (sl >= 1 && sl <= DSLOTS && issue && ABL != 2) {
+#pragma unroll
+                    for (int j = (sl - 1) * DPS; j < sl * DPS && j < IPS; ++j) {
+                        if (j < IPS / 2) dma16(ga + (int64_t)(4 * j) * p.lda, sa_ + 4 * j * 256);
+                        else dma16(gb + (int64_t)(4 * (j - IPS / 2)) * p.ldb, sa_ + KS * 256 + 4 * (j - IPS / 2) * 256);
+                    }
                 }
-                if (sl == IPS + 1 && issue) advance_loader();
+                if (sl == DSLOTS + 1 && issue) advance_loader();
                 if (!last) {
-                    if (sl == 9) W128_FRAG(pa[0], nbuf, 0, 0);
-                    if (sl == 11) W128_FRAG(pa[1], nbuf, 0, 1);
-                    if (sl == 13) W128_FRAG(pb[0], nbuf, 0, 2);
-                    if (sl == 14) W128_FRAG(pb[1], nbuf, 0, 3);
+#pragma unroll
+                    for (int i = 0; i < NFRAG; ++i)
+                        if (sl == last_frag_slot(i)) frag_into(pa, pb, nbuf, 0, i);
                 }
             });
             buf = nbuf;
@@ -245,30 +276,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         {
             asm volatile("s_nop 15");       // last MFMA's result -> first accumulator read (the asm MFMAs are opaque to hipcc)
             __builtin_amdgcn_sched_barrier(0);
-            const int m0 = ctm * MT + 128 * wm, n0 = ctn * MT + 128 * wn;
+            const int m0 = ctm * MTM + 64 * GA * wm, n0 = ctn * MTN + 64 * GB * wn;
             float* Cb = p.C + (int64_t)cb * p.sc;
             const uint32_t bytes = (uint32_t)p.M * (uint32_t)p.ldc * 4u;
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(Cb, 0, bytes, 0x00020000);
             const uint32_t oob = 0x7FFFFFF0u;
             const int col = n0 + 4 * r;
             const uint32_t lane_off = ((uint32_t)(m0 + 16 * q) * (uint32_t)p.ldc + (uint32_t)col) * 4u;
-            const uint32_t off0 = col < p.N ? lane_off : oob;
-            const uint32_t off1 = col + 64 < p.N ? lane_off + 256u : oob;
+            uint32_t off[GB];
 #pragma unroll
-            for (int ta = 0; ta < 8; ++ta) {
+            for (int hb = 0; hb < GB; ++hb) off[hb] = col + 64 * hb < p.N ? lane_off + 256u * hb : oob;
+#pragma unroll
+            for (int ta = 0; ta < 4 * GA; ++ta) {
                 // the accumulators of this row become visible to hipcc only here (left alone it copies all 256 of them
                 // into vector registers ahead of the first store: spills), are stored, and are zeroed for the next tile
-                asm volatile("" : "+a"(acc[ta][0]), "+a"(acc[ta][1]), "+a"(acc[ta][2]), "+a"(acc[ta][3]), "+a"(acc[ta][4]),
-                             "+a"(acc[ta][5]), "+a"(acc[ta][6]), "+a"(acc[ta][7]));
+#pragma unroll
+                for (int hb = 0; hb < GB; ++hb)
+                    asm volatile("" : "+a"(acc[ta][4 * hb]), "+a"(acc[ta][4 * hb + 1]), "+a"(acc[ta][4 * hb + 2]), "+a"(acc[ta][4 * hb + 3]));
                 if (ABL != 1) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const uint32_t row_off = (uint32_t)(64 * (ta >> 2) + 4 * v + (ta & 3)) * (uint32_t)p.ldc * 4u;
 #pragma unroll
-                        for (int hb = 0; hb < 2; ++hb) {
+                        for (int hb = 0; hb < GB; ++hb) {
                             f32x4 o = {acc[ta][4 * hb][v], acc[ta][4 * hb + 1][v], acc[ta][4 * hb + 2][v], acc[ta][4 * hb + 3][v]};
                             o *= p.alpha;
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, (hb ? off1 : off0) + row_off, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, off[hb] + row_off, 0, 0);
                         }
                     }
                 }
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ++c_round;
         if (!more_tiles) break;
     }
-#undef W128_FRAG
+#undef W128_FRAG_LOAD
 }
 
 }  // namespace w128

@@ -1,0 +1,227 @@
+// Winograd F(2x2, 3x3) for the 3x3, stride-1, "same" convolutions of the RAFT update block (models/raft_core.py:148-151
+// MotionEncoder2D.conv_c2 / conv, :173 FlowHead2D.conv1, :188 the mask head's first convolution), fp32, gfx950.
+//
+//     y[b][n][oy][ox] = sum_c sum_{i,j} x[b][c][oy + i - 1][ox + j - 1] * w[n][c][i][j]          zero outside the image
+//
+// as  Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A  per 2 x 2 output tile: 16 multiplications per 4 outputs and channel pair
+// instead of 36.  The sum over c for the 16 positions of the 4 x 4 transform domain is 16 independent GEMMs
+//
+//     Mo[t][n][tile] = sum_c U[t][c][n] * V[t][c][tile]           t = 0 .. 15
+//
+// on the fp32 matrix cores (gemm_w128.h, batch = the 16 planes, M = output channels, N = tiles, K = input channels):
+// 2.25 x fewer MFMAs than the 9-tap implicit GEMM (convcl.h), paid for with HBM traffic -- V is 4 x the input, Mo 4 x the
+// output.  Three launches:
+//
+//   input_transform   x NCHW [B][C][H][W]  ->  V  [16][C][NT]      one thread = one channel x 4 adjacent tiles: reads the
+//                     4 x 10 input patch (two 16-byte loads + two 4-byte loads per row), writes 16 x 16 bytes, lanes along
+//                     the tiles: every store instruction is 1 KB contiguous.  The data gradient's ReLU mask (gy * (y > 0))
+//                     rides on the loads.
+//   gemm_w128         U [16][C][Mp] x V -> Mo [16][Mp][NT]
+//   output_transform  Mo -> y NCHW (+ bias, ReLU, or += for a gradient accumulated in place): one thread = one output
+//                     channel x 4 adjacent tiles: 16 x 16-byte loads, two rows of 8 pixels = 4 x 16-byte stores.
+//
+// Tiles: NT = B * TH * TWp, TH = ceil(H / 2), TWp = ceil(W / 2) rounded up to a multiple of 4 (a thread's 4 tiles share a
+// tile row; the padding tiles compute on zeros and are never written back).  The data gradient is the same three launches
+// on the output gradient with the weights transposed and the taps reversed (weight_transform with `flip`).
+//
+// Numerics: not the direct form's summation order.  For |x|, |w| ~ 1 and C = 256 the difference to the fp64 convolution
+// is of the size of the direct fp32 form's own (tests/test_winograd_gpu.py states the bound); the transforms use only
+// additions, subtractions and a multiplication by 0.5 (exact), the contraction is the k-ascending fmaf chain of gemm_w128.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wino {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Geometry {
+    int B, H, W;             // image
+    int TH, TWp;             // tile rows, padded tile columns (multiple of 4)
+    int NT;                  // B * TH * TWp
+};
+
+__host__ __device__ inline Geometry make_geometry(int B, int H, int W) {
+    Geometry g;
+    g.B = B; g.H = H; g.W = W;
+    g.TH = (H + 1) / 2;
+    g.TWp = ((W + 1) / 2 + 3) & ~3;
+    g.NT = B * g.TH * g.TWp;
+    return g;
+}
+
+// ---- weights: U[t][k][m] = (G g G^T)[t / 4][t % 4],  g = w[m][k] (forward: k = input channel, m = output channel) or
+// g = w[k][m] rotated by 180 degrees (data gradient: k = output channel, m = input channel).  U is [16][Kp][Mp], Kp >= K,
+// Mp >= M: zeros beyond K / M.  w is [Cout][Cin][3][3].
+__global__ void weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Kp, int Mp, int flip) {
+    const int K = flip ? Cout : Cin, M = flip ? Cin : Cout;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Kp * Mp) return;
+    const int k = i / Mp, m = i - k * Mp;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            float v = 0.f;
+            if (m < M && k < K) v = flip ? w[((size_t)k * Cin + m) * 9 + (2 - a) * 3 + (2 - b)] : w[((size_t)m * Cin + k) * 9 + a * 3 + b];
+            g[a][b] = v;
+        }
+    float t[4][3];      // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+        const size_t plane = (size_t)Kp * Mp;
+        U[(size_t)(4 * a + 0) * plane + i] = u0;
+        U[(size_t)(4 * a + 1) * plane + i] = u1;
+        U[(size_t)(4 * a + 2) * plane + i] = u2;
+        U[(size_t)(4 * a + 3) * plane + i] = u3;
+    }
+}
+
+// ---- input: V[t][c][tile] = (B^T d B)[t / 4][t % 4], d = the 4 x 4 patch of x around output tile `tile`
+// x: channel c of image b at x + b * sxb + c * sxc (H x W, contiguous rows).  mask (optional, same addressing with
+// smb / smc): values of x where mask <= 0 read as zero (the ReLU adjoint).  One thread: 4 tiles (b, ty, 4 tq .. 4 tq + 3).
+// VEC: W % 4 == 0 and 16-byte aligned rows -> 16-byte loads.  V is [16][Cp][NT] (gridDim.y = Cp >= C): zeros for c >= C.
+template <bool VEC>
+__global__ __launch_bounds__(256) void input_transform_kernel(const float* __restrict__ x, int64_t sxb, int64_t sxc,
+                                                             const float* __restrict__ mask, int64_t smb, int64_t smc,
+                                                             float* __restrict__ V, int C, Geometry g) {
+    const int quads = g.NT >> 2;                      // threads per channel
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, Cp = gridDim.y;
+    if (i >= quads) return;
+    if (c >= C) {                                     // padding channel of the contraction
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(V + ((size_t)t * Cp + c) * g.NT + 4 * (size_t)i) = z;
+        return;
+    }
+    const int qpr = g.TWp >> 2;                       // quads per tile row
+    const int tq = i % qpr, ty = (i / qpr) % g.TH, b = i / (qpr * g.TH);
+    const float* xc = x + b * sxb + c * sxc;
+    const float* mc = mask ? mask + b * smb + c * smc : nullptr;
+    const int col0 = 8 * tq;                          // first output column of the quad; the patch spans col0 - 1 .. col0 + 8
+    float d[4][10];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = 2 * ty - 1 + rr;
+        const bool rok = (unsigned)row < (unsigned)g.H;
+        const float* xr = xc + (int64_t)row * g.W;
+        const float* mr = mc ? mc + (int64_t)row * g.W : nullptr;
+        if (VEC && rok && col0 + 8 <= g.W) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + col0), bq = *reinterpret_cast<const f32x4*>(xr + col0 + 4);
+            d[rr][0] = col0 > 0 ? xr[col0 - 1] : 0.f;
+            d[rr][9] = col0 + 8 < g.W ? xr[col0 + 8] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d[rr][1 + e] = a[e]; d[rr][5 + e] = bq[e]; }
+            if (mr) {
+                const f32x4 ma = *reinterpret_cast<const f32x4*>(mr + col0), mb = *reinterpret_cast<const f32x4*>(mr + col0 + 4);
+                if (col0 > 0 && !(mr[col0 - 1] > 0.f)) d[rr][0] = 0.f;
+                if (col0 + 8 < g.W && !(mr[col0 + 8] > 0.f)) d[rr][9] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!(ma[e] > 0.f)) d[rr][1 + e] = 0.f;
+                    if (!(mb[e] > 0.f)) d[rr][5 + e] = 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 10; ++e) {
+                const int col = col0 - 1 + e;
+                const bool ok = rok && (unsigned)col < (unsigned)g.W;
+                float v = ok ? xr[col] : 0.f;
+                if (ok && mr && !(mr[col] > 0.f)) v = 0.f;
+                d[rr][e] = v;
+            }
+        }
+    }
+    // rows: B^T d  (t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3), then the same along the columns per tile
+    float rws[4][10];
+#pragma unroll
+    for (int e = 0; e < 10; ++e) {
+        rws[0][e] = d[0][e] - d[2][e];
+        rws[1][e] = d[1][e] + d[2][e];
+        rws[2][e] = d[2][e] - d[1][e];
+        rws[3][e] = d[1][e] - d[3][e];
+    }
+    const size_t plane = (size_t)Cp * g.NT;
+    float* out = V + (size_t)c * g.NT + 4 * (size_t)i;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        f32x4 v0, v1, v2, v3;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const float e0 = rws[a][2 * tl], e1 = rws[a][2 * tl + 1], e2 = rws[a][2 * tl + 2], e3 = rws[a][2 * tl + 3];
+            v0[tl] = e0 - e2; v1[tl] = e1 + e2; v2[tl] = e2 - e1; v3[tl] = e1 - e3;
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)(4 * a + 0) * plane) = v0;
+        *reinterpret_cast<f32x4*>(out + (size_t)(4 * a + 1) * plane) = v1;
+        *reinterpret_cast<f32x4*>(out + (size_t)(4 * a + 2) * plane) = v2;
+        *reinterpret_cast<f32x4*>(out + (size_t)(4 * a + 3) * plane) = v3;
+    }
+}
+
+// ---- output: y[b][n][2 ty + i][2 tx + j] = (A^T m A)[i][j] (+ bias[n]) (ReLU) (+= y), m = Mo[.][n][tile] as 4 x 4
+// Mo [16][Mp][NT]; y: channel n of image b at y + b * syb + n * syc.  ACT: 0 none, 1 ReLU.  One thread: channel n, 4 tiles.
+enum { OUT_PLAIN = 0, OUT_RELU = 1 };
+template <bool VEC>
+__global__ __launch_bounds__(256) void output_transform_kernel(const float* __restrict__ Mo, int Mp, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int64_t syb, int64_t syc, int act,
+                                                              int accumulate, Geometry g) {
+    const int quads = g.NT >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.y;
+    if (i >= quads) return;
+    const int qpr = g.TWp >> 2;
+    const int tq = i % qpr, ty = (i / qpr) % g.TH, b = i / (qpr * g.TH);
+    const size_t plane = (size_t)Mp * g.NT;
+    const float* in = Mo + (size_t)n * g.NT + 4 * (size_t)i;
+    f32x4 m[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) m[t] = *reinterpret_cast<const f32x4*>(in + (size_t)t * plane);
+    const float bv = bias ? bias[n] : 0.f;
+    float* yc = y + b * syb + n * syc;
+    const int col0 = 8 * tq;
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri) {
+        const int row = 2 * ty + ri;
+        // A^T m: row 0 = m0 + m1 + m2, row 1 = m1 - m2 - m3 (along the first index), then the same along the second
+        f32x4 s[4];
+#pragma unroll
+        for (int cidx = 0; cidx < 4; ++cidx)
+            s[cidx] = ri == 0 ? m[cidx] + m[4 + cidx] + m[8 + cidx] : m[4 + cidx] - m[8 + cidx] - m[12 + cidx];
+        const f32x4 o0 = s[0] + s[1] + s[2] + bv, o1 = s[1] - s[2] - s[3] + bv;       // columns 2 tx, 2 tx + 1 of the 4 tiles
+        float px[8] = {o0[0], o1[0], o0[1], o1[1], o0[2], o1[2], o0[3], o1[3]};
+        if (row >= g.H) continue;
+        float* yr = yc + (int64_t)row * g.W + col0;
+        if (VEC && col0 + 8 <= g.W) {
+            f32x4 lo = {px[0], px[1], px[2], px[3]}, hi = {px[4], px[5], px[6], px[7]};
+            if (accumulate) { lo += *reinterpret_cast<const f32x4*>(yr); hi += *reinterpret_cast<const f32x4*>(yr + 4); }
+            if (act == OUT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+            }
+            *reinterpret_cast<f32x4*>(yr) = lo;
+            *reinterpret_cast<f32x4*>(yr + 4) = hi;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (col0 + e < g.W) {
+                    float v = px[e];
+                    if (accumulate) v += yr[e];
+                    if (act == OUT_RELU) v = fmaxf(v, 0.f);
+                    yr[e] = v;
+                }
+        }
+    }
+}
+
+}  // namespace wino

@@ -1,0 +1,134 @@
+"""Winograd F(2x2,3x3) convolution on the fp32 matrix cores (csrc/hip/winograd.hip: camli_wino_weights / camli_wino_conv3x3,
+round 6) -- the update block's 3x3 convolutions (models/raft_core.py:148-151, 173, 188): forward, data gradient and weight
+gradient against oracle/dense.conv_taps_fwd / _bwd (numpy fp64 accumulation, pinned on the reference's convolutions and on
+torch's conv2d: tests/test_dense_oracle.py).
+
+Tolerance.  The Winograd form is not the direct form's summation order, so equality is not on offer.  With unit-variance
+inputs and weights scaled to unit-variance outputs the measured difference to the fp64 convolution is 1.2e-6 (max abs) at
+256 input channels -- BELOW the direct fp32 fmaf chain's own 4.2e-6 (profiles/r06a_winograd_microbench.txt).  The bound
+used here is 2e-5 x max(1, max |want|), the one tests/test_convcl_gpu.py uses for the direct kernels."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _close(got, want, tol=TOL, what=''):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    scale = max(1.0, float(np.abs(want).max()))
+    assert got.shape == want.shape and np.abs(got - want).max() <= tol * scale, (what, float(np.abs(got - want).max()), scale)
+
+
+# (B, Cin, Cout, H, W): odd sizes (partial tiles at the right / bottom border, padded tile columns), a single tile row, Cout
+# on each of the three GEMM tiles (<= 128, <= 192, 256 and beyond), Cout not a multiple of 4 / 16 (126), Cin = 192 (12 K steps),
+# the product's own channel pairs at a small image
+CASES = [
+    (2, 48, 52, 13, 21), (1, 64, 192, 16, 24), (3, 128, 126, 9, 40), (1, 256, 192, 5, 7), (1, 96, 256, 1, 9), (2, 128, 512, 6, 10),
+    (1, 256, 126, 17, 30), (1, 192, 256, 17, 30), (1, 128, 256, 2, 2), (1, 112, 320, 7, 5),
+]
+
+
+def _case_data(case, seed=0):
+    b, cin, cout, h, w = case
+    rng = np.random.default_rng(sum(case) + seed)
+    x = rng.standard_normal((b, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * (9 * cin) ** -0.5).astype(np.float32)
+    return x, wt, rng
+
+
+@pytest.mark.parametrize('case', CASES, ids=str)
+def test_wino_forward_vs_oracle(case, oracle_dense):
+    from camliflow_amd.csrc import fused
+    x, wt, _ = _case_data(case)
+    w_d = dev(wt)
+    got = fused.wino_conv3x3(dev(x), fused.wino_transformed_weights(w_d, False), wt.shape[0])
+    _close(got, oracle_dense.conv_taps_fwd(x, wt, (1, 1)), what='forward')
+
+
+@pytest.mark.parametrize('case', CASES, ids=str)
+def test_wino_data_gradient_vs_oracle(case, oracle_dense):
+    from camliflow_amd.csrc import fused
+    x, wt, rng = _case_data(case, 1)
+    gy = rng.standard_normal((case[0], case[2], case[3], case[4]), dtype=np.float32)
+    w_d = dev(wt)
+    got = fused.wino_conv3x3(dev(gy), fused.wino_transformed_weights(w_d, True), wt.shape[1])
+    want_gx, _ = oracle_dense.conv_taps_bwd(gy, x, wt, (1, 1))
+    _close(got, want_gx, what='data gradient')
+
+
+def test_wino_epilogue_bias_relu_mask_accumulate_and_slices(oracle_dense):
+    """The transforms' fused forms: bias + ReLU on the way out, += into an existing tensor, the ReLU adjoint's mask on the way
+    in, input / output that are channel slices of wider NCHW tensors."""
+    from camliflow_amd.csrc import fused
+    rng = np.random.default_rng(5)
+    b, cin, cout, h, w = 2, 64, 128, 11, 20
+    wide = rng.standard_normal((b, cin + 32, h, w), dtype=np.float32)
+    x = wide[:, 16:16 + cin]
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * (9 * cin) ** -0.5).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    mask = rng.standard_normal((b, cin, h, w)).astype(np.float32)
+    u = fused.wino_transformed_weights(dev(wt), False)
+    wide_d = dev(wide)
+    want = oracle_dense.conv_taps_fwd(x, wt, (1, 1)) + bias[None, :, None, None]
+    got = fused.wino_conv3x3(wide_d[:, 16:16 + cin], u, cout, bias=dev(bias), act='relu')
+    _close(got, np.maximum(want, 0), what='bias + relu, sliced input')
+    out_wide = torch.full((b, cout + 8, h, w), 7.0, device='cuda')
+    fused.wino_conv3x3(wide_d[:, 16:16 + cin], u, cout, bias=dev(bias), out=out_wide[:, 4:4 + cout])
+    _close(out_wide[:, 4:4 + cout], want, what='sliced output')
+    assert float(out_wide[:, :4].min()) == 7.0 and float(out_wide[:, 4 + cout:].max()) == 7.0
+    base = rng.standard_normal((b, cout, h, w)).astype(np.float32)
+    acc = dev(base)
+    fused.wino_conv3x3(dev(np.ascontiguousarray(x)), u, cout, out=acc, accumulate=True)
+    _close(acc, base + oracle_dense.conv_taps_fwd(x, wt, (1, 1)), what='accumulate')
+    got = fused.wino_conv3x3(dev(np.ascontiguousarray(x)), u, cout, mask=dev(mask))
+    _close(got, oracle_dense.conv_taps_fwd(np.where(mask > 0, x, 0).astype(np.float32), wt, (1, 1)), what='masked input')
+
+
+@pytest.mark.parametrize('case', [(2, 128, 192, 13, 21), (1, 256, 126, 17, 30), (2, 128, 256, 8, 12)], ids=str)
+def test_wino_autograd_node_vs_oracle(case, oracle_dense):
+    """fused.conv3x3_wino as the cores call it (cores/blocks.conv_bias_act): output, input gradient, weight gradient."""
+    from camliflow_amd.csrc import fused
+    x, wt, rng = _case_data(case, 2)
+    gy = rng.standard_normal((case[0], case[2], case[3], case[4]), dtype=np.float32)
+    x_d, w_d = dev(x).requires_grad_(True), dev(wt).requires_grad_(True)
+    y = fused.conv3x3_wino(x_d, w_d)
+    y.backward(dev(gy))
+    want_gx, want_gw = oracle_dense.conv_taps_bwd(gy, x, wt, (1, 1))
+    _close(y, oracle_dense.conv_taps_fwd(x, wt, (1, 1)), what='forward')
+    _close(x_d.grad, want_gx, what='input gradient')
+    _close(w_d.grad, want_gw, tol=5e-5, what='weight gradient')
+
+
+def test_wino_weights_follow_the_parameter():
+    """The transformed weights are cached per value of the weight tensor: an in-place update (an optimiser step) must be seen."""
+    from camliflow_amd.csrc import fused
+    torch.manual_seed(0)
+    w = torch.randn(128, 96, 3, 3, device='cuda') * 0.05
+    x = torch.randn(1, 96, 6, 8, device='cuda')
+    y0 = fused.conv3x3_wino(x, w)
+    assert fused.wino_transformed_weights(w, False) is fused.wino_transformed_weights(w, False)
+    w.mul_(2.0)
+    y1 = fused.conv3x3_wino(x, w)
+    torch.testing.assert_close(y1, 2 * y0, rtol=1e-5, atol=1e-5)
+
+
+def test_update_block_convolutions_take_the_winograd_path():
+    """MotionEncoder2D.conv_c2 / conv, FlowHead2D.conv1 and the mask head's 3x3 (models/raft_core.py:148-151,173,188) are
+    eligible; conv_f2 (128 -> 64) and the 7x7 / 1x1 / two-channel convolutions are not."""
+    from camliflow_amd.csrc import fused
+    from camliflow_amd.cores.raft2d import MotionEncoder2D, FlowHead2D, ConvexUpsampler2D
+    enc, head, up = MotionEncoder2D(4, 4).cuda(), FlowHead2D(128).cuda(), ConvexUpsampler2D(128).cuda()
+    x256, x128 = torch.zeros(1, 256, 8, 8, device='cuda'), torch.zeros(1, 128, 8, 8, device='cuda')
+    assert fused.wino_supported(enc.conv_c2, x256) and fused.wino_supported(enc.conv, x256)
+    assert fused.wino_supported(head.conv1, x128) and fused.wino_supported(up.mask[0], x128)
+    assert not fused.wino_supported(enc.conv_f2, x128) and not fused.wino_supported(enc.conv_c1, torch.zeros(1, 324, 8, 8, device='cuda'))
+    assert not fused.wino_supported(head.conv2, x256) and not fused.wino_supported(enc.conv_f1, torch.zeros(1, 2, 8, 8, device='cuda'))
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert not fused.wino_supported(enc.conv_c2, x256)
