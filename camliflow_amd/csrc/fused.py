@@ -2494,6 +2494,42 @@ def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, m
     return out
 
 
+def wino_wrw(x, gy, mask=None, out=None):
+    """Weight gradient [N,C,3,3] of conv3x3(x) for the output gradient gy [B,N,H,W], contracted in the Winograd domain
+    (camli_wino_wrw); ``mask``: gy reads as zero where mask <= 0; ``out``: add into this tensor instead of creating one."""
+    _require_cuda('wino_wrw', x, gy)
+    lib = _lib.load()
+    b, c, hh, ww = x.shape
+    n = gy.shape[1]
+    assert gy.shape == (b, n, hh, ww)
+    xbs, gbs = _batch_strided(x), _batch_strided(gy)
+    if xbs is None:
+        x, xbs = x.contiguous(), c * hh * ww
+    if gbs is None:
+        gy, gbs = gy.contiguous(), n * hh * ww
+    mbs = 0
+    if mask is not None:
+        mbs = _batch_strided(mask)
+        if mbs is None:
+            mask, mbs = mask.contiguous(), n * hh * ww
+    need = lib.camli_wino_wrw_workspace_bytes(b, c, n, hh, ww)
+    if need <= 0:
+        raise _lib.CamliHipError('wino_wrw: unsupported shape B=%d C=%d N=%d %dx%d' % (b, c, n, hh, ww))
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
+    gw = out if out is not None else torch.empty((n, c, 3, 3), dtype=torch.float32, device=x.device)
+    assert gw.shape == (n, c, 3, 3) and gw.is_contiguous() and gw.dtype == torch.float32
+    tiles = b * ((hh + 1) // 2) * (((ww + 1) // 2 + 3) // 4 * 4)
+    with _on_device(x):
+        _lib.launch('camli_wino_wrw', lib.camli_wino_wrw, x.data_ptr(), xbs, gy.data_ptr(), gbs, mask.data_ptr() if mask is not None else None,
+                    mbs, gw.data_ptr(), ws.data_ptr(), need, b, c, n, hh, ww, int(out is not None), _stream_ptr(x),
+                    work=(4.0 * b * hh * ww * (c + n) + 2.0 * 64 * tiles * (c + n), 'B'), flop=2.0 * 16 * tiles * c * n)
+    return gw
+
+
+# CAMLI_WINO_WRW=lib: the weight gradients of the Winograd convolutions on the library (A/B)
+_WINO_WRW = os.environ.get('CAMLI_WINO_WRW', 'hip') != 'lib'
+
+
 class _Conv3x3Wino(torch.autograd.Function):
     """conv2d(x, w, padding=1) without bias (the epilogue kernels add it)."""
 
@@ -2510,8 +2546,11 @@ class _Conv3x3Wino(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = wino_conv3x3(gy, wino_transformed_weights(w, True), w.shape[1])
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy.contiguous(), x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            if _WINO_WRW:
+                gw = wino_wrw(x, gy)
+            else:
+                gw = torch.ops.aten.convolution_backward(gy.contiguous(), x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         return gx, gw
 
 

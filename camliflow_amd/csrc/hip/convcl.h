@@ -51,6 +51,9 @@ struct Problem {
     int B, H, W, Cin, Cout, T;
     int C0, N0;                   // multiples of 16 / of the wave's channel range
     int ldx, ldx1, ldy, ldy1;     // floats per pixel
+    int ldw;                      // floats per weight row (T * Cin for the packed weights)
+    int xk, wk;                   // floats between consecutive 16-channel K chunks of a row (16: rows are contiguous in k)
+    uint32_t xrec, x1rec, wrec;   // bytes the buffer descriptors of x / x1 / w span (P * ldx * 4, ..., Cout * ldw * 4 for dense rows)
     int tiles_p, tiles_n;         // pixel tiles (256) x channel tiles (NT)
     // epilogue operands (see the EPI_* forms below)
     const float* add;             // [P][ld_add]
@@ -112,13 +115,22 @@ __device__ __forceinline__ void mfma_x4(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& 
         : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
 
-// NTW: 16-channel tiles per wave along the output channels (8: 256-channel workgroup tile, 4: 128).  Workgroup tile =
+// NTW: 16-channel tiles per wave along the output channels (8: 256-channel workgroup tile, 6: 192, 4: 128).  Workgroup tile =
 // 256 pixels x 32 NTW channels, waves 2 (pixels) x 2 (channels), 128 pixels x 16 NTW channels each.  NBUF LDS stages of
-// (256 + 32 NTW) rows x 64 bytes.
+// (256 + 32 NTW) rows x 64 bytes.  The body is a device function: convcl_kernel runs it on the problem it is launched with,
+// winograd_wrw.h on one problem per (plane, K split) of a batched, split contraction.
+// What a workgroup contracts: the problem's own operands (convcl_kernel) or a slice of them -- one plane and K range of a
+// batched, split contraction (winograd_wrw.h).  Kept apart from Problem so that the latter stays in the kernel arguments
+// (its tap tables are indexed at run time: a modified private copy would live in scratch memory).
+struct Operands {
+    const float* x; const float* x1; const float* w;
+    float* y; float* y1;
+    int Cin, C0;
+};
+
 template <int NTW, int NBUF, int EPI = EPI_PLAIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convcl_kernel(Problem p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    static_assert(NBUF >= 3 && (NTW == 8 || NTW == 4), "");
+__device__ __forceinline__ void convcl_body(const Problem& p, const Operands& o, float* lds) {
+    static_assert(NBUF >= 3 && (NTW == 8 || NTW == 6 || NTW == 4), "");
     constexpr int NT = 32 * NTW;                  // output channels per workgroup tile
     constexpr int WROWS = 16 * NTW;               // per wave
     constexpr int STAGE = (256 + NT) * 16;        // floats: pixel rows, then weight rows
@@ -129,11 +141,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 15, q = lane >> 4;
     const int P = p.B * p.H * p.W;
-    const int chunks = p.Cin >> 4, steps = chunks * p.T;
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((uint32_t)P * p.ldx * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1), 0, (int)((uint32_t)P * p.ldx1 * 4u), 0x00020000);
-    const int chunks0 = p.C0 >> 4;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)((uint32_t)p.Cout * p.T * p.Cin * 4u), 0x00020000);
+    const int chunks = o.Cin >> 4, steps = chunks * p.T;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.x), 0, (int)p.xrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.x1), 0, (int)p.x1rec, 0x00020000);
+    const int chunks0 = o.C0 >> 4;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(o.w), 0, (int)p.wrec, 0x00020000);
 
     // DMA geometry of this lane: row (lane >> 2) of a 16-row group, physical 16-byte slot lane & 3 holds logical slot
     // (lane & 3) ^ bank_swizzle(row >> 2)
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         uint32_t woff[IPW];
 #pragma unroll
-        for (int j = 0; j < IPW; ++j) woff[j] = ((uint32_t)(n0 + 16 * (wave + 4 * j) + drow) * (p.T * p.Cin) + kq * 4) * 4u;
+        for (int j = 0; j < IPW; ++j) woff[j] = ((uint32_t)(n0 + 16 * (wave + 4 * j) + drow) * p.ldw + kq * 4) * 4u;
 
         int l_chunk = 0, l_tap = 0, l_left = steps;
         // one DMA of the stage being loaded (slot 0 .. IPS - 1); the step's scalars are read when slot 0 is issued
@@ -175,9 +187,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (slot == 0) {
                 s_tap = l_tap;
                 s_second = l_chunk >= chunks0;
-                s_xshift = s_second ? ((p.dy[l_tap] * p.W + p.dx[l_tap]) * p.ldx1 + (l_chunk - chunks0) * 16) * 4
-                                    : ((p.dy[l_tap] * p.W + p.dx[l_tap]) * p.ldx + l_chunk * 16) * 4;
-                s_wshift = (l_tap * p.Cin + l_chunk * 16) * 4;
+                s_xshift = s_second ? ((p.dy[l_tap] * p.W + p.dx[l_tap]) * p.ldx1 + (l_chunk - chunks0) * p.xk) * 4
+                                    : ((p.dy[l_tap] * p.W + p.dx[l_tap]) * p.ldx + l_chunk * p.xk) * 4;
+                s_wshift = (l_tap * o.Cin + l_chunk * p.wk) * 4;
             }
             if (slot < IPX) {
                 const uint32_t v = ((xmask[slot] >> s_tap) & 1u) ? (s_second ? xoff1[slot] : xoff[slot]) + (uint32_t)s_xshift : OOB;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const bool second_out = nw0 >= p.N0;
             const int ldy = second_out ? p.ldy1 : p.ldy;
             const bool accum = second_out ? p.acc1 != 0 : p.acc0 != 0;
-            const __amdgpu_buffer_rsrc_t rs_y = rsrc(second_out ? p.y1 : p.y, ldy);
+            const __amdgpu_buffer_rsrc_t rs_y = rsrc(second_out ? o.y1 : o.y, ldy);
             const uint32_t ybase = (prow * ldy + (second_out ? nw0 - p.N0 : nw0) + 4 * q) * 4u;
             f32x4 old[2][8];
             auto fetch = [&](int tco, f32x4 (&o)[8]) {
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             static_assert(EPI != EPI_GATES || NTW == 8, "z | r = 256 output channels");
             const bool rwave = wn != 0;                       // channels [128, 256) are r
             const __amdgpu_buffer_rsrc_t rs_add = rsrc(p.add, p.ld_add), rs_h = rsrc(p.h, p.ld_h);
-            const __amdgpu_buffer_rsrc_t rs_o = rsrc(rwave ? p.y1 : p.y, rwave ? p.ldy1 : p.ldy), rs_r = rsrc(p.y2, p.ldy2);
+            const __amdgpu_buffer_rsrc_t rs_o = rsrc(rwave ? o.y1 : o.y, rwave ? p.ldy1 : p.ldy), rs_r = rsrc(p.y2, p.ldy2);
             const int ldo = rwave ? p.ldy1 : p.ldy;
             const uint32_t c4 = 4 * q;                        // + 16 tco: channel inside the wave's 128
             f32x4 av[2][8], hv[2][8];
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else {
             static_assert(EPI != EPI_BLEND || NTW == 4, "q = 128 output channels");
             const __amdgpu_buffer_rsrc_t rs_add = rsrc(p.add, p.ld_add), rs_h = rsrc(p.h, p.ld_h), rs_z = rsrc(p.z, p.ld_z);
-            const __amdgpu_buffer_rsrc_t rs_o = rsrc(p.y, p.ldy), rs_q = rsrc(p.y1, p.ldy1);
+            const __amdgpu_buffer_rsrc_t rs_o = rsrc(o.y, p.ldy), rs_q = rsrc(o.y1, p.ldy1);
             const uint32_t c4 = nw0 + 4 * q;                  // + 16 tco
             f32x4 av[2][8], hv[2][8], zv[2][8];
             auto fetch = [&](int tco, f32x4 (&a)[8], f32x4 (&hh)[8], f32x4 (&zz)[8]) {
@@ -375,6 +387,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+}
+
+template <int NTW, int NBUF, int EPI = EPI_PLAIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void convcl_kernel(Problem p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Operands o = {p.x, p.x1, p.w, p.y, p.y1, p.Cin, p.C0};
+    convcl_body<NTW, NBUF, EPI>(p, o, lds);
 }
 
 }  // namespace ccl

@@ -124,7 +124,8 @@ extern "C" int camli_convcl_fwd(const float* x0, int ldx0, int C0, const float* 
     p.x = x0; p.x1 = C1 > 0 ? x1 : x0; p.w = wp; p.y = y0; p.y1 = N0 < Cout ? y1 : y0;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.T = T; p.C0 = C0; p.N0 = N0;
     p.ldx = ldx0; p.ldx1 = C1 > 0 ? ldx1 : ldx0; p.ldy = ldy0; p.ldy1 = N0 < Cout ? ldy1 : ldy0;
-    p.tiles_p = (int)((P + 255) / 256); p.tiles_n = Cout / NT;
+    p.tiles_p = (int)((P + 255) / 256); p.tiles_n = Cout / NT; p.ldw = T * Cin;
+    p.xk = p.wk = 16; p.xrec = (uint32_t)(P * p.ldx * 4); p.x1rec = (uint32_t)(P * p.ldx1 * 4); p.wrec = (uint32_t)((int64_t)Cout * p.ldw * 4);
     p.add = p.h = p.z = x0; p.y2 = y0; p.ld_add = p.ld_h = p.ld_z = p.ldy2 = 4;
     p.acc0 = accumulate0 ? 1 : 0; p.acc1 = accumulate1 ? 1 : 0; p.sanitize = 0;
     set_taps(p, T, dy, dx);
@@ -232,7 +233,8 @@ void gru_problem(ccl::Problem& p, const float* a0, const float* x, int CX, const
     p.x = a0; p.x1 = x; p.w = wp;
     p.B = B; p.H = H; p.W = W; p.Cin = 128 + CX; p.Cout = Cout; p.T = T; p.C0 = 128; p.N0 = Cout;
     p.ldx = 128; p.ldx1 = CX;
-    p.tiles_p = (int)((P + 255) / 256); p.tiles_n = 1;
+    p.tiles_p = (int)((P + 255) / 256); p.tiles_n = 1; p.ldw = T * p.Cin;
+    p.xk = p.wk = 16; p.xrec = (uint32_t)(P * p.ldx * 4); p.x1rec = (uint32_t)(P * p.ldx1 * 4); p.wrec = (uint32_t)((int64_t)Cout * p.ldw * 4);
     p.acc0 = p.acc1 = p.sanitize = 0;
     set_taps(p, T, dy, dx);
 }

@@ -20,9 +20,21 @@
 //   output_transform  Mo -> y NCHW (+ bias, ReLU, or += for a gradient accumulated in place): one thread = one output
 //                     channel x 4 adjacent tiles: 16 x 16-byte loads, two rows of 8 pixels = 4 x 16-byte stores.
 //
-// Tiles: NT = B * TH * TWp, TH = ceil(H / 2), TWp = ceil(W / 2) rounded up to a multiple of 4 (a thread's 4 tiles share a
-// tile row; the padding tiles compute on zeros and are never written back).  The data gradient is the same three launches
-// on the output gradient with the weights transposed and the taps reversed (weight_transform with `flip`).
+// Tiles: B * TH * TWp of them, TH = ceil(H / 2), TWp = ceil(W / 2) rounded up to a multiple of 4 (a thread's 4 tiles share a
+// tile row), NT = that count rounded up to a multiple of 16 (the weight gradient contracts over the tiles in steps of 16);
+// the padding tiles hold zeros and are never written back.  The data gradient is the same three launches on the output
+// gradient with the weights transposed and the taps reversed (weight_transform with `flip`).
+//
+// Weight gradient, also in the transform domain (the adjoint of the above with respect to U):
+//
+//     gU[t][c][n] = sum_tile V[t][c][tile] * gM[t][n][tile],   gM = A gy A^T per tile,      gw[n][c] = G^T gU[.][c][n] G
+//
+//   input_transform   x  -> V   (as in the forward)
+//   grad_transform    gy -> gM  [16][N][NT]   (2 x 2 -> 4 x 4 per tile; the ReLU mask rides on the loads)
+//   wrw_planes        both operands have the contraction index (the tiles) contiguous: the k-contiguous contraction of
+//                     convcl.h (64-byte LDS rows, direct-to-LDS loads), one workgroup per (plane, K split, tile), parts
+//                     [S][16][rows][cols] written, no atomics
+//   wrw_reduce        sum over the K splits in a fixed order, G^T . G, gw (= | +=)
 //
 // Numerics: not the direct form's summation order.  For |x|, |w| ~ 1 and C = 256 the difference to the fp64 convolution
 // is of the size of the direct fp32 form's own (tests/test_winograd_gpu.py states the bound); the transforms use only
@@ -38,7 +50,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct Geometry {
     int B, H, W;             // image
     int TH, TWp;             // tile rows, padded tile columns (multiple of 4)
-    int NT;                  // B * TH * TWp
+    int tiles;               // B * TH * TWp
+    int NT;                  // tiles rounded up to a multiple of 16: the row length of V / Mo / gM
 };
 
 __host__ __device__ inline Geometry make_geometry(int B, int H, int W) {
@@ -46,7 +59,8 @@ __host__ __device__ inline Geometry make_geometry(int B, int H, int W) {
     g.B = B; g.H = H; g.W = W;
     g.TH = (H + 1) / 2;
     g.TWp = ((W + 1) / 2 + 3) & ~3;
-    g.NT = B * g.TH * g.TWp;
+    g.tiles = B * g.TH * g.TWp;
+    g.NT = (g.tiles + 15) & ~15;
     return g;
 }
 
@@ -89,19 +103,36 @@ __global__ void weight_transform_kernel(const float* __restrict__ w, float* __re
 // ---- input: V[t][c][tile] = (B^T d B)[t / 4][t % 4], d = the 4 x 4 patch of x around output tile `tile`
 // x: channel c of image b at x + b * sxb + c * sxc (H x W, contiguous rows).  mask (optional, same addressing with
 // smb / smc): values of x where mask <= 0 read as zero (the ReLU adjoint).  One thread: 4 tiles (b, ty, 4 tq .. 4 tq + 3).
-// VEC: W % 4 == 0 and 16-byte aligned rows -> 16-byte loads.  V is [16][Cp][NT] (gridDim.y = Cp >= C): zeros for c >= C.
-template <bool VEC>
+// VEC: W % 4 == 0 and 16-byte aligned rows -> 16-byte loads.  Output layout, `rows` >= C channel rows (zeros for c >= C):
+//   CHUNKED = false: V [16][rows][NT], thread = (channel blockIdx.y, quad): lanes along the tiles, 1 KB per store instruction;
+//   CHUNKED = true:  V [16][NT / 16][rows][16] -- the 16 tiles of a K chunk of the weight gradient's contraction contiguous per
+//                    row, consecutive rows 64 bytes apart (what its direct-to-LDS loads fetch 1 KB at a time); thread =
+//                    (channel 64 blockIdx.y + tid / 4, quad 4 blockIdx.x + tid % 4): a wave stores 16 rows x 64 bytes = 1 KB.
+template <bool CHUNKED>
+struct Slot {
+    int row, quad;          // channel row, quad of tiles
+    __device__ __forceinline__ Slot() {
+        if (CHUNKED) { row = 64 * blockIdx.y + (threadIdx.x >> 2); quad = 4 * blockIdx.x + (threadIdx.x & 3); }
+        else { row = blockIdx.y; quad = blockIdx.x * blockDim.x + threadIdx.x; }
+    }
+    // first of the thread's 4 floats in plane t
+    __device__ __forceinline__ size_t at(int t, int rows, int NT) const {
+        if (CHUNKED) return (((size_t)t * (NT >> 4) + (quad >> 2)) * rows + row) * 16 + 4 * (quad & 3);
+        return ((size_t)t * rows + row) * NT + 4 * (size_t)quad;
+    }
+};
+
+template <bool VEC, bool CHUNKED = false>
 __global__ __launch_bounds__(256) void input_transform_kernel(const float* __restrict__ x, int64_t sxb, int64_t sxc,
                                                              const float* __restrict__ mask, int64_t smb, int64_t smc,
-                                                             float* __restrict__ V, int C, Geometry g) {
-    const int quads = g.NT >> 2;                      // threads per channel
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y, Cp = gridDim.y;
-    if (i >= quads) return;
-    if (c >= C) {                                     // padding channel of the contraction
+                                                             float* __restrict__ V, int C, int rows, Geometry g) {
+    const Slot<CHUNKED> slot;
+    const int i = slot.quad, c = slot.row;
+    if (i >= (g.NT >> 2) || c >= rows) return;
+    if (c >= C || 4 * i >= g.tiles) {                 // padding channel of the contraction / padding tiles
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(V + ((size_t)t * Cp + c) * g.NT + 4 * (size_t)i) = z;
+        for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(V + slot.at(t, rows, g.NT)) = z;
         return;
     }
     const int qpr = g.TWp >> 2;                       // quads per tile row
@@ -152,8 +183,6 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const float* __res
         rws[2][e] = d[2][e] - d[1][e];
         rws[3][e] = d[1][e] - d[3][e];
     }
-    const size_t plane = (size_t)Cp * g.NT;
-    float* out = V + (size_t)c * g.NT + 4 * (size_t)i;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         f32x4 v0, v1, v2, v3;
@@ -162,10 +191,10 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const float* __res
             const float e0 = rws[a][2 * tl], e1 = rws[a][2 * tl + 1], e2 = rws[a][2 * tl + 2], e3 = rws[a][2 * tl + 3];
             v0[tl] = e0 - e2; v1[tl] = e1 + e2; v2[tl] = e2 - e1; v3[tl] = e1 - e3;
         }
-        *reinterpret_cast<f32x4*>(out + (size_t)(4 * a + 0) * plane) = v0;
-        *reinterpret_cast<f32x4*>(out + (size_t)(4 * a + 1) * plane) = v1;
-        *reinterpret_cast<f32x4*>(out + (size_t)(4 * a + 2) * plane) = v2;
-        *reinterpret_cast<f32x4*>(out + (size_t)(4 * a + 3) * plane) = v3;
+        *reinterpret_cast<f32x4*>(V + slot.at(4 * a + 0, rows, g.NT)) = v0;
+        *reinterpret_cast<f32x4*>(V + slot.at(4 * a + 1, rows, g.NT)) = v1;
+        *reinterpret_cast<f32x4*>(V + slot.at(4 * a + 2, rows, g.NT)) = v2;
+        *reinterpret_cast<f32x4*>(V + slot.at(4 * a + 3, rows, g.NT)) = v3;
     }
 }
 
@@ -176,10 +205,9 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void output_transform_kernel(const float* __restrict__ Mo, int Mp, const float* __restrict__ bias,
                                                               float* __restrict__ y, int64_t syb, int64_t syc, int act,
                                                               int accumulate, Geometry g) {
-    const int quads = g.NT >> 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = blockIdx.y;
-    if (i >= quads) return;
+    if (4 * i >= g.tiles) return;
     const int qpr = g.TWp >> 2;
     const int tq = i % qpr, ty = (i / qpr) % g.TH, b = i / (qpr * g.TH);
     const size_t plane = (size_t)Mp * g.NT;
@@ -221,6 +249,117 @@ __global__ __launch_bounds__(256) void output_transform_kernel(const float* __re
                     yr[e] = v;
                 }
         }
+    }
+}
+
+// ---- output gradient: gM[t][n][tile] = (A gy A^T)[t / 4][t % 4] (A = the 4 x 2 matrix whose transpose finishes the forward)
+// gy: channel n of image b at gy + b * sgb + n * sgc; mask optional (same geometry): gy reads as zero where mask <= 0.
+// gM has `rows` >= N channel rows (zeros for n >= N and for the padding tiles) in either layout of input_transform_kernel.
+template <bool VEC, bool CHUNKED = false>
+__global__ __launch_bounds__(256) void grad_transform_kernel(const float* __restrict__ gy, int64_t sgb, int64_t sgc,
+                                                            const float* __restrict__ mask, int64_t smb, int64_t smc,
+                                                            float* __restrict__ gM, int N, int rows, Geometry g) {
+    const Slot<CHUNKED> slot;
+    const int i = slot.quad, n = slot.row;
+    if (i >= (g.NT >> 2) || n >= rows) return;
+    if (n >= N || 4 * i >= g.tiles) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(gM + slot.at(t, rows, g.NT)) = z;
+        return;
+    }
+    const int qpr = g.TWp >> 2;
+    const int tq = i % qpr, ty = (i / qpr) % g.TH, b = i / (qpr * g.TH);
+    const float* gc = gy + b * sgb + n * sgc;
+    const float* mc = mask ? mask + b * smb + n * smc : nullptr;
+    const int col0 = 8 * tq;
+    float d[2][8];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int row = 2 * ty + rr;
+        const bool rok = row < g.H;
+        const float* gr = gc + (int64_t)row * g.W + col0;
+        const float* mr = mc ? mc + (int64_t)row * g.W + col0 : nullptr;
+        if (VEC && rok && col0 + 8 <= g.W) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(gr), bq = *reinterpret_cast<const f32x4*>(gr + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d[rr][e] = a[e]; d[rr][4 + e] = bq[e]; }
+            if (mr) {
+                const f32x4 ma = *reinterpret_cast<const f32x4*>(mr), mb = *reinterpret_cast<const f32x4*>(mr + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!(ma[e] > 0.f)) d[rr][e] = 0.f;
+                    if (!(mb[e] > 0.f)) d[rr][4 + e] = 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = rok && col0 + e < g.W;
+                float v = ok ? gr[e] : 0.f;
+                if (ok && mr && !(mr[e] > 0.f)) v = 0.f;
+                d[rr][e] = v;
+            }
+        }
+    }
+    // A g: rows g0, g0 + g1, g0 - g1, -g1; then the same along the columns of each tile
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        float rw[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rw[e] = a == 0 ? d[0][e] : a == 1 ? d[0][e] + d[1][e] : a == 2 ? d[0][e] - d[1][e] : -d[1][e];
+        f32x4 v0, v1, v2, v3;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const float e0 = rw[2 * tl], e1 = rw[2 * tl + 1];
+            v0[tl] = e0; v1[tl] = e0 + e1; v2[tl] = e0 - e1; v3[tl] = -e1;
+        }
+        *reinterpret_cast<f32x4*>(gM + slot.at(4 * a + 0, rows, g.NT)) = v0;
+        *reinterpret_cast<f32x4*>(gM + slot.at(4 * a + 1, rows, g.NT)) = v1;
+        *reinterpret_cast<f32x4*>(gM + slot.at(4 * a + 2, rows, g.NT)) = v2;
+        *reinterpret_cast<f32x4*>(gM + slot.at(4 * a + 3, rows, g.NT)) = v3;
+    }
+}
+
+// ---- gw[n][c][i][j] (= | +=) sum_{a,b} G[a][i] G[b][j] * sum_s part[s][4 a + b][.]: element (c, n) of a part at
+// c * sc + n * sn (the contraction ran with either operand on its row side).  Block = 64 n x 4 plane groups: a thread sums
+// the S parts of its 4 planes (independent loads, lanes along n), the 16 plane sums of an n meet in LDS, the first plane
+// group finishes with G^T . G.  (r6, first form: one thread per (c, n) walking all 16 S loads in turn -- 69 us for 47 MB,
+// a latency chain on 768 waves.)
+__global__ __launch_bounds__(256) void wrw_reduce_kernel(const float* __restrict__ parts, int S, int64_t part_floats, int64_t sc, int64_t sn,
+                                                        float* __restrict__ gw, int C, int N, int accumulate) {
+    __shared__ float us[16][64];
+    const int nl = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nl, c = blockIdx.y;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        const float* q = parts + (size_t)(4 * tg) * part_floats + c * sc + n * sn;
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += q[((size_t)s * 16 + k) * part_floats];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) us[4 * tg + k][nl] = acc[k];
+    __syncthreads();
+    if (tg != 0 || n >= N) return;
+    float u[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) u[t] = us[t][nl];
+    // G^T u G, G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]]
+    float r[3][4];      // rows: G^T applied to the first index
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        r[0][b] = u[b] + 0.5f * (u[4 + b] + u[8 + b]);
+        r[1][b] = 0.5f * (u[4 + b] - u[8 + b]);
+        r[2][b] = 0.5f * (u[4 + b] + u[8 + b]) + u[12 + b];
+    }
+    float* o = gw + ((size_t)n * C + c) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float o0 = r[a][0] + 0.5f * (r[a][1] + r[a][2]), o1 = 0.5f * (r[a][1] - r[a][2]), o2 = 0.5f * (r[a][1] + r[a][2]) + r[a][3];
+        if (accumulate) { o[3 * a] += o0; o[3 * a + 1] += o1; o[3 * a + 2] += o2; }
+        else { o[3 * a] = o0; o[3 * a + 1] = o1; o[3 * a + 2] = o2; }
     }
 }
 

@@ -5,6 +5,7 @@
 #include "camli_common.h"
 #include "gemm_w128.h"
 #include "winograd.h"
+#include "winograd_wrw.h"
 
 namespace {
 
@@ -106,8 +107,8 @@ extern "C" int camli_wino_conv3x3(const float* x, int64_t x_bs, const float* mas
     {
         const bool vec = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0 && (!mask || (aligned16(mask) && mask_bs % 4 == 0));
         const dim3 grid(camli_divup(g.NT / 4, 256), Cp);
-        if (vec) hipLaunchKernelGGL(wino::input_transform_kernel<true>, grid, block, 0, s, x, x_bs, plane, mask, mask_bs, plane, V, C, g);
-        else hipLaunchKernelGGL(wino::input_transform_kernel<false>, grid, block, 0, s, x, x_bs, plane, mask, mask_bs, plane, V, C, g);
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, false>), grid, block, 0, s, x, x_bs, plane, mask, mask_bs, plane, V, C, Cp, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<false, false>), grid, block, 0, s, x, x_bs, plane, mask, mask_bs, plane, V, C, Cp, g);
     }
     int rc;
     if (Mp <= 128) rc = launch_planes<2, 1, 1>(U, V, Mo, Mp, g.NT, Cp, s);
@@ -120,5 +121,138 @@ extern "C" int camli_wino_conv3x3(const float* x, int64_t x_bs, const float* mas
         if (vec) hipLaunchKernelGGL(wino::output_transform_kernel<true>, grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, g);
         else hipLaunchKernelGGL(wino::output_transform_kernel<false>, grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, g);
     }
+    return camli_check_launch(what);
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------
+namespace {
+
+// column-side tile of the k-contiguous contraction (32 NTW channels: 128 / 192 / 256) and the padded row count it needs
+void pad_cols(int n, int& ntw, int& padded) {
+    const int p128 = camli_divup(n, 128) * 128, p192 = camli_divup(n, 192) * 192, p256 = camli_divup(n, 256) * 256;
+    ntw = 8; padded = p256;
+    if (p192 < padded) { ntw = 6; padded = p192; }
+    if (p128 < padded) { ntw = 4; padded = p128; }
+}
+
+struct WrwPlan {
+    bool swap;               // false: rows = input channels (V), columns = output channels (gM); true: the other way round
+    int rows, cols, ntw;     // rows of the row-side operand (as allocated), padded columns, column tile
+    int v_rows, g_rows;      // rows V / gM are allocated (and zero-padded) with
+    int S, q;                // K splits, 16-float chunks per split
+    int64_t part_floats;     // rows x cols
+};
+
+WrwPlan wrw_plan(int C, int N, const wino::Geometry& g) {
+    WrwPlan pl;
+    int ntw_a, pad_a, ntw_b, pad_b;
+    pad_cols(N, ntw_a, pad_a);           // A: rows C, columns N
+    pad_cols(C, ntw_b, pad_b);           // B: rows N, columns C
+    const int64_t cost_a = (int64_t)camli_divup(C, 256) * 256 * pad_a, cost_b = (int64_t)camli_divup(N, 256) * 256 * pad_b;
+    pl.swap = cost_b < cost_a;
+    const int Cp = kp_of(C);
+    if (!pl.swap) { pl.rows = Cp; pl.cols = pad_a; pl.ntw = ntw_a; pl.v_rows = Cp; pl.g_rows = pad_a; }
+    else { pl.rows = N; pl.cols = pad_b; pl.ntw = ntw_b; pl.v_rows = pad_b; pl.g_rows = N; }
+    const int tiles = camli_divup(pl.rows, 256) * (pl.cols / (32 * pl.ntw));
+    const int total = g.NT / 16;
+    int S = cu_count() / (16 * tiles);
+    if (S < 1) S = 1;
+    if (S > total / 2) S = total / 2 > 0 ? total / 2 : 1;
+    int q = camli_divup(total, S);
+    S = camli_divup(total, q);
+    while (S > 1 && total - (S - 1) * q < 2) { ++q; S = camli_divup(total, q); }      // every split at least the pipeline's depth
+    pl.S = S; pl.q = q;
+    pl.part_floats = (int64_t)pl.rows * pl.cols;
+    return pl;
+}
+
+template <int NTW>
+int launch_wrw_planes(const wino::WrwBatch& wb, int tiles, int zdim, hipStream_t s) {
+    constexpr size_t lds = (size_t)NBUF * (256 + 32 * NTW) * 16 * sizeof(float);
+    auto kern = &wino::wrw_planes_kernel<NTW, NBUF>;
+    static bool set = false;
+    if (!set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            camli_set_error("camli_wino_wrw: cannot reserve %zu bytes of LDS", lds);
+            return CAMLI_ELAUNCH;
+        }
+        set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles, zdim), dim3(256), lds, s, wb);
+    return CAMLI_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, int W) {
+    if (B < 1 || C < 1 || N < 1 || H < 1 || W < 1) return 0;
+    const wino::Geometry g = wino::make_geometry(B, H, W);
+    const WrwPlan pl = wrw_plan(C, N, g);
+    return ((int64_t)16 * g.NT * ((int64_t)pl.v_rows + pl.g_rows) + (int64_t)pl.S * 16 * pl.part_floats) * (int64_t)sizeof(float);
+}
+
+// gw [N][C][3][3] (= | +=) the weight gradient of y = conv3x3(x) for the output gradient gy (gy_mask optional: gy reads as
+// zero where gy_mask <= 0).  x [B][C][H][W] (image stride x_bs), gy / gy_mask [B][N][H][W] (image strides gy_bs / mask_bs).
+extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, const float* gy_mask, int64_t mask_bs,
+                              float* gw, float* workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int accumulate,
+                              void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_wino_wrw";
+    if (!x || !gy || !gw || !workspace) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    const int64_t need = camli_wino_wrw_workspace_bytes(B, C, N, H, W);
+    if (B < 0 || C < 1 || N < 1 || need == 0) { camli_set_error("%s: unsupported shape B=%d C=%d N=%d %dx%d", what, B, C, N, H, W); return CAMLI_ENOTSUP; }
+    if (workspace_bytes < need) { camli_set_error("%s: workspace of %lld bytes, %lld needed", what, (long long)workspace_bytes, (long long)need); return CAMLI_EINVAL; }
+    const wino::Geometry g = wino::make_geometry(B, H, W);
+    const WrwPlan pl = wrw_plan(C, N, g);
+    if ((int64_t)(pl.v_rows > pl.g_rows ? pl.v_rows : pl.g_rows) * g.NT * 4 >= (int64_t)0x7FF00000 || pl.part_floats * 4 >= (int64_t)0x7FF00000) {
+        camli_set_error("%s: a transform-domain plane beyond 2 GB (B=%d C=%d N=%d %dx%d)", what, B, C, N, H, W);
+        return CAMLI_ENOTSUP;
+    }
+    if (!aligned16(workspace)) { camli_set_error("%s: workspace must be 16-byte aligned", what); return CAMLI_EINVAL; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* V = workspace;
+    float* gM = V + (size_t)16 * pl.v_rows * g.NT;
+    float* parts = gM + (size_t)16 * pl.g_rows * g.NT;
+    const int64_t plane = (int64_t)H * W;
+    const dim3 block(256);
+    // both operands in the chunk-major layout [16][NT / 16][rows][16]: a K chunk of all rows is one contiguous block
+    {
+        const bool vec = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0;
+        const dim3 grid(g.NT / 16, camli_divup(pl.v_rows, 64));
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, true>), grid, block, 0, s, x, x_bs, plane, nullptr, 0, plane, V, C, pl.v_rows, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<false, true>), grid, block, 0, s, x, x_bs, plane, nullptr, 0, plane, V, C, pl.v_rows, g);
+    }
+    {
+        const bool vec = W % 4 == 0 && aligned16(gy) && gy_bs % 4 == 0 && (!gy_mask || (aligned16(gy_mask) && mask_bs % 4 == 0));
+        const dim3 grid(g.NT / 16, camli_divup(pl.g_rows, 64));
+        if (vec) hipLaunchKernelGGL((wino::grad_transform_kernel<true, true>), grid, block, 0, s, gy, gy_bs, plane, gy_mask, mask_bs, plane, gM, N, pl.g_rows, g);
+        else hipLaunchKernelGGL((wino::grad_transform_kernel<false, true>), grid, block, 0, s, gy, gy_bs, plane, gy_mask, mask_bs, plane, gM, N, pl.g_rows, g);
+    }
+    wino::WrwBatch wb;
+    ccl::Problem& p = wb.base;
+    p.x = p.x1 = pl.swap ? gM : V;
+    p.w = pl.swap ? V : gM;
+    p.y = p.y1 = parts;
+    p.B = 1; p.H = 1; p.W = pl.rows; p.Cin = p.C0 = 16; p.Cout = p.N0 = pl.cols; p.T = 1;
+    const int x_rows = pl.swap ? pl.g_rows : pl.v_rows, w_rows = pl.swap ? pl.v_rows : pl.g_rows;
+    p.ldx = p.ldx1 = 16; p.ldw = 16; p.ldy = p.ldy1 = pl.cols;
+    p.xk = x_rows * 16; p.wk = w_rows * 16;
+    p.xrec = p.x1rec = (uint32_t)((int64_t)x_rows * g.NT * 4); p.wrec = (uint32_t)((int64_t)w_rows * g.NT * 4);
+    p.tiles_p = camli_divup(pl.rows, 256); p.tiles_n = pl.cols / (32 * pl.ntw);
+    p.add = p.h = p.z = V; p.y2 = parts; p.ld_add = p.ld_h = p.ld_z = p.ldy2 = 4;
+    p.acc0 = p.acc1 = p.sanitize = 0;
+    for (int t = 0; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+    wb.q_chunks = pl.q; wb.total_chunks = g.NT / 16;
+    wb.x_plane = (int64_t)x_rows * g.NT;
+    wb.w_plane = (int64_t)w_rows * g.NT;
+    wb.y_part = pl.part_floats;
+    const int tiles = p.tiles_p * p.tiles_n;
+    const int rc = pl.ntw == 8 ? launch_wrw_planes<8>(wb, tiles, 16 * pl.S, s) : pl.ntw == 6 ? launch_wrw_planes<6>(wb, tiles, 16 * pl.S, s)
+                                                                                             : launch_wrw_planes<4>(wb, tiles, 16 * pl.S, s);
+    if (rc != CAMLI_OK) return rc;
+    // element (c, n) of a part: rows are c (V on the row side) or n (swapped)
+    const int64_t sc = pl.swap ? 1 : pl.cols, sn = pl.swap ? pl.cols : 1;
+    hipLaunchKernelGGL(wino::wrw_reduce_kernel, dim3(camli_divup(N, 64), C), dim3(256), 0, s, parts, pl.S, pl.part_floats, sc, sn, gw, C, N,
+                       accumulate ? 1 : 0);
     return camli_check_launch(what);
 }

@@ -622,18 +622,19 @@ int camli_convcl_wrw(const float *x0, int ldx0, int C0, const float *x1, int ldx
  * forward and data gradient, replacing the library's fp32 Winograd / implicit-GEMM kernels.  NCHW fp32 tensors:
  *     y[b][n][oy][ox] (= | +=) act( sum_c sum_{i,j} x[b][c][oy+i-1][ox+j-1] * w[n][c][i][j] + bias[n] )      zero outside the image
  * as three launches: input transform (x -> V [16][C][tiles]), 16 plane GEMMs U[t]^T V[t] (one launch), output transform.
- *   camli_wino_weights: U [16][K][Mp] = G g G^T of w [Cout][Cin][3][3]; flip = 0: K = Cin, M = Cout (forward); flip = 1: K = Cout,
+ *   camli_wino_weights: U [16][Kp][Mp] = G g G^T of w [Cout][Cin][3][3]; flip = 0: K = Cin, M = Cout (forward); flip = 1: K = Cout,
  *     M = Cin, taps reversed -- the weights of the DATA GRADIENT, which is the same convolution of the output gradient.
- *     Mp = M rounded up to a multiple of 4; camli_wino_weight_floats(K, M) = 16 * K * Mp.
+ *     Kp = K rounded up to a multiple of 16, Mp = M to a multiple of 4 (zeros beyond); camli_wino_weight_floats(K, M) = 16 Kp Mp.
  *   camli_wino_conv3x3: image b of x at x + b * x_bs (C dense H x W planes: a channel slice of a wider NCHW tensor is fine), of y
  *     at y + b * y_bs (N planes); mask (optional, x's geometry, image stride mask_bs): x reads as zero where mask <= 0 (the ReLU
- *     adjoint on the way in); bias optional; act 0 none | 1 ReLU; accumulate: y += (before act).  C a multiple of 16, >= 48;
- *     N >= 4; workspace = camli_wino_workspace_bytes(B, C, N, H, W) bytes (V and the transform-domain output, 4 x the input + 4 x
- *     the output), 16-byte aligned.  Differs from the direct fp32 form by its rounding only (tests/test_winograd_gpu.py).
+ *     adjoint on the way in); bias optional; act 0 none | 1 ReLU; accumulate: y += (before act).  C > 32, N >= 4; workspace =
+ *     camli_wino_workspace_bytes(B, C, N, H, W) bytes (V and the transform-domain output: 4 x the input + 4 x the output),
+ *     16-byte aligned.  Differs from the direct fp32 form by its rounding only (tests/test_winograd_gpu.py states the bound).
  *   camli_wino_wrw: WEIGHT GRADIENT in the transform domain: gU[t][c][n] = sum_tiles V[t][c][tile] * (A gy A^T)[t][n][tile], then
  *     gw [N][C][3][3] (= | +=) G^T gU G -- the same 2.25 x fewer multiplications as the forward.  x [B][C][H][W] (image stride
- *     x_bs), gy [B][N][H][W] (gy_bs; gy_mask optional: gy reads as zero where gy_mask <= 0).  C, N multiples of 16 with
- *     max(C, N) a multiple of 128 ... see camli_wino_wrw_workspace_bytes (0 = unsupported shape).
+ *     x_bs), gy [B][N][H][W] (image stride gy_bs); gy_mask optional (gy's geometry, image stride mask_bs): gy reads as zero where
+ *     gy_mask <= 0.  workspace = camli_wino_wrw_workspace_bytes(B, C, N, H, W) bytes (0 = unsupported shape).  The contraction
+ *     over the tiles is split over the CUs, the parts are summed in a fixed order: deterministic, no atomics.
  */
 int64_t camli_wino_weight_floats(int K, int M);
 int camli_wino_weights(const float *w, float *U, int Cout, int Cin, int flip, void *stream);
@@ -641,6 +642,9 @@ int64_t camli_wino_workspace_bytes(int B, int C, int N, int H, int W);
 int camli_wino_conv3x3(const float *x, int64_t x_bs, const float *mask, int64_t mask_bs, const float *U, const float *bias, float *y,
                        int64_t y_bs, float *workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int act,
                        int accumulate, void *stream);
+int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, int W);
+int camli_wino_wrw(const float *x, int64_t x_bs, const float *gy, int64_t gy_bs, const float *gy_mask, int64_t mask_bs, float *gw,
+                   float *workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int accumulate, void *stream);
 int camli_conv3x3_co2_bwd_data(const float *gy, const float *w, float *gx, int B, int Cin, int H, int W, void *stream);
 long long camli_conv3x3_co2_bwd_weight_workspace_bytes(int B, int Cin, int W);
 int camli_conv3x3_co2_bwd_weight(const float *gy, const float *x, float *workspace, float *gw, float *gb, int accumulate,

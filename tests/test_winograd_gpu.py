@@ -63,6 +63,39 @@ def test_wino_data_gradient_vs_oracle(case, oracle_dense):
     _close(got, want_gx, what='data gradient')
 
 
+@pytest.mark.parametrize('case', CASES + [(2, 256, 192, 13, 22), (1, 40, 24, 9, 11), (4, 128, 256, 20, 28)], ids=str)
+def test_wino_weight_gradient_vs_oracle(case, oracle_dense):
+    """camli_wino_wrw: the contraction over the tiles in the transform domain, either operand on the row side (256 -> 192 and
+    256 -> 126 keep the input channels there, 128 -> 256 the output channels), odd images, several K splits."""
+    from camliflow_amd.csrc import fused
+    x, wt, rng = _case_data(case, 3)
+    gy = rng.standard_normal((case[0], case[2], case[3], case[4]), dtype=np.float32)
+    got = fused.wino_wrw(dev(x), dev(gy))
+    _, want_gw = oracle_dense.conv_taps_bwd(gy, x, wt, (1, 1))
+    _close(got, want_gw, tol=5e-5, what='weight gradient')
+
+
+def test_wino_weight_gradient_mask_accumulate_slices_and_repeatability(oracle_dense):
+    from camliflow_amd.csrc import fused
+    rng = np.random.default_rng(9)
+    b, cin, cout, h, w = 2, 96, 128, 11, 20
+    wide = rng.standard_normal((b, cin + 32, h, w), dtype=np.float32)
+    x = np.ascontiguousarray(wide[:, 16:16 + cin])
+    gy = rng.standard_normal((b, cout, h, w), dtype=np.float32)
+    mask = rng.standard_normal((b, cout, h, w)).astype(np.float32)
+    wt = np.zeros((cout, cin, 3, 3), np.float32)
+    _, want = oracle_dense.conv_taps_bwd(np.where(mask > 0, gy, 0).astype(np.float32), x, wt, (1, 1))
+    wide_d = dev(wide)
+    got = fused.wino_wrw(wide_d[:, 16:16 + cin], dev(gy), mask=dev(mask))
+    _close(got, want, tol=5e-5, what='masked, sliced input')
+    again = fused.wino_wrw(wide_d[:, 16:16 + cin], dev(gy), mask=dev(mask))
+    assert torch.equal(got, again), 'the split contraction is summed in a fixed order'
+    base = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    acc = dev(base)
+    fused.wino_wrw(dev(x), dev(gy), mask=dev(mask), out=acc)
+    _close(acc, base + want, tol=5e-5, what='accumulate')
+
+
 def test_wino_epilogue_bias_relu_mask_accumulate_and_slices(oracle_dense):
     """The transforms' fused forms: bias + ReLU on the way out, += into an existing tensor, the ReLU adjoint's mask on the way
     in, input / output that are channel slices of wider NCHW tensors."""

@@ -68,7 +68,7 @@ static void run(int B, int H, int W, int Cin, int Cout, bool vertical, bool chec
     p.x = x; p.x1 = x; p.w = w; p.y = y; p.y1 = y; p.C0 = Cin; p.N0 = Cout; p.ldx1 = Cin; p.ldy1 = Cout; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.T = T; p.ldx = Cin; p.ldy = Cout;
     p.add = p.h = p.z = x; p.y2 = y; p.ld_add = p.ld_h = p.ld_z = p.ldy2 = Cout; p.acc0 = p.acc1 = p.sanitize = 0;
     const int NT = Cout % 256 == 0 ? 256 : 128;
-    p.tiles_p = (P + 255) / 256; p.tiles_n = Cout / NT;
+    p.tiles_p = (P + 255) / 256; p.tiles_n = Cout / NT; p.ldw = T * Cin; p.xk = p.wk = 16; p.xrec = p.x1rec = (uint32_t)((size_t)P * Cin * 4); p.wrec = (uint32_t)(nw * 4);
     for (int t = 0; t < T; ++t) { p.dy[t] = vertical ? t - 2 : 0; p.dx[t] = vertical ? 0 : t - 2; }
     auto go = [&]() { if (NT == 256) launch<8>(p, 0); else launch<4>(p, 0); };
     go();

@@ -105,8 +105,8 @@ static void run(int B, int C, int N, int H, int W, bool check, int reps, int rel
     auto wt = [&]() { hipLaunchKernelGGL(wino::weight_transform_kernel, dim3((C * Mp + 255) / 256), dim3(256), 0, 0, w, U, N, C, C, Mp, 0); };
     auto it = [&]() {
         dim3 grid((g.NT / 4 + 255) / 256, C);
-        if (vec) hipLaunchKernelGGL(wino::input_transform_kernel<true>, grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, 0, 0, V, C, g);
-        else hipLaunchKernelGGL(wino::input_transform_kernel<false>, grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, 0, 0, V, C, g);
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, 0, 0, V, C, C, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<false, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, 0, 0, V, C, C, g);
     };
     auto gm = [&]() { gemm(U, V, Mo, Mp, g.NT, C, 0); };
     auto ot = [&]() {
