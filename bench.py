@@ -61,11 +61,15 @@ NORTH_STAR = {
     'camli_weightnet_fwd': 'hbm', 'camli_weightnet_bwd': 'mfma',
     'camli_knn_interp_fwd': 'hbm', 'camli_knn_interp_bwd': 'hbm', 'camli_knn_interp_bwd_xyz': 'hbm',
     'camli_corr3d_gather_fwd': 'hbm', 'camli_corr3d_gather_bwd': 'hbm',
-    'camli_corr3d_cost_levels_fwd': 'fma', 'camli_corr3d_cost_levels_bwd': 'fma',
     'camli_corr3d_mlp_fwd': 'fma', 'camli_corr3d_mlp_bwd': 'fma',      # plain fp32 FMA on the vector ALU (registers only)
     'camli_convcl_gru_gates': 'mfma', 'camli_convcl_gru_blend': 'mfma', 'camli_convcl_fwd': 'mfma', 'camli_convcl_wrw': 'mfma',
+    'camli_wino_conv3x3': 'mfma', 'camli_wino_wrw': 'mfma',       # flop = the transform-domain MFMA work (4/9 of the direct form's)
     'camli_pwc3d_pair_fwd': 'hbm', 'camli_pwc3d_pair_bwd': 'hbm', 'camli_gather_wsum_fwd': 'hbm', 'camli_gather_wsum_bwd': 'hbm',
 }
+# SURVEY 8(f)2 ("the 2-D convolution side"): the update block's convolutions on own matrix-core kernels.  Everything else in
+# NORTH_STAR is a SURVEY 8(a) row (A1-A15), the path BASELINE.json's north_star names.
+CONV_SIDE = {'camli_convcl_gru_gates', 'camli_convcl_gru_blend', 'camli_convcl_fwd', 'camli_convcl_wrw', 'camli_wino_conv3x3',
+             'camli_wino_wrw'}
 MFMA_F32_PEAK_TFLOPS = 157.3
 VALU_PAIR_PEAK_G = 7865.0
 FPS_STEP_IDEAL_US = 0.35      # one dependent selection step with the cloud resident in registers (tools/kernel_bench.py)
@@ -464,7 +468,8 @@ def side_configs(budget):
             rec = json.loads(res.stdout.strip().splitlines()[-1])
             out[name] = {'ms_per_step': rec['ms_per_step'], 'value': rec['value'], 'dtype': rec['dtype'], 'steps': rec['steps']}
             if name == 'ddp4':
-                out[name].update(batch=4, n_iters=12, sync_bn=True, ranks=1, collectives='1-rank RCCL group')
+                out[name].update(batch=4, n_iters=12, sync_bn=True, ranks=1, collectives='1-rank RCCL group',
+                                 host_enqueue_ms=rec.get('config', {}).get('host_enqueue_ms_per_step'))
         except subprocess.TimeoutExpired:
             out[name] = {'skipped': 'did not finish in %.0f s' % (left - 15)}
         except Exception as exc:      # noqa: BLE001 -- an optional leg never costs the line
@@ -544,6 +549,10 @@ def roofline_report(summary, steps, args, step_ms):
         achieved, peak, unit, per_launch = rec['work'] / secs / 1e9, VALU_PAIR_PEAK_G, 'Gpairs/s', rec['work'] / rec['launches']
     else:                    # fps: fraction of the register-resident ideal step time
         achieved, peak, unit, per_launch = table[name]['frac'] * 100.0, 100.0, '% of ideal step rate', rec['work'] / rec['launches']
+    # the dominant entry point of the path north_star names, next to the overall dominant one (which since
+    # round 5 is a convolution-side kernel, 8(f)2)
+    star = [n for n in fracs if n not in CONV_SIDE]
+    star = max(star, key=fracs.get) if star else None
     traffic, traffic_source = pmc_traffic(name, args)
     roofline = {'kernel': name, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(kind, kind), 'achieved': round(achieved, 2), 'peak': peak, 'unit': unit,
                 'frac': round(achieved / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source, 'launches': rec['launches'],
@@ -555,7 +564,30 @@ def roofline_report(summary, steps, args, step_ms):
         worst = min(heavy, key=lambda n: table[n]['frac'])
         roofline['worst'] = {'kernel': worst, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(NORTH_STAR[worst], NORTH_STAR[worst]),
                              'frac': table[worst]['frac'], 'ms_per_step': table[worst]['ms_per_step']}
+    if star is not None:
+        roofline['north_star'] = {'kernel': star, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(NORTH_STAR[star], NORTH_STAR[star]),
+                                  'frac_in_situ': table[star]['frac'], 'avg_launch_us_in_situ': table[star]['avg_launch_us'],
+                                  'ms_per_step': table[star]['ms_per_step']}
     return roofline, table
+
+
+def kernel_frac(name, rec):
+    """roofline fraction of entry point `name` from a TIMER record (the arithmetic of roofline_report's table)"""
+    kind = NORTH_STAR.get(name)
+    secs = rec['total_ms'] * 1e-3
+    if not secs or not rec['launches']:
+        return None
+    if kind == 'hbm':
+        return rec['work'] / secs / 1e9 / HBM_PEAK_GBS
+    if kind == 'mfma':
+        return rec['flop'] / secs / 1e12 / MFMA_F32_PEAK_TFLOPS
+    if kind == 'fma':
+        return rec['flop'] / secs / 1e12 / (MFMA_F32_PEAK_TFLOPS / 2)
+    if kind == 'valu':
+        return rec['work'] / secs / 1e9 / VALU_PAIR_PEAK_G
+    if kind == 'fps' and rec.get('flop'):
+        return min(FPS_STEP_IDEAL_US / (secs * 1e6 / rec['flop']), 1.0)
+    return None
 
 
 def step_floor(step_fn, step_ms):
@@ -617,13 +649,12 @@ def compact_line(full, detail_path=None):
     line = {k: full[k] for k in CONTRACT_KEYS if k in full}
     roof = full.get('roofline')
     if roof is not None:
-        keep = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'frac_single_lane', 'avg_launch_us',
-                'launches', 'algorithmic_work_per_launch', 'measured', 'step')
+        keep = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_in_situ', 'traffic', 'traffic_source', 'frac_single_lane',
+                'avg_launch_us', 'avg_launch_us_in_situ', 'achieved_in_situ', 'launches', 'algorithmic_work_per_launch', 'measured', 'step')
         line['roofline'] = {k: roof[k] for k in keep if k in roof}
-        if 'single_lane' in roof:
-            line['roofline']['single_lane'] = {k: roof['single_lane'][k] for k in ('avg_launch_us', 'achieved', 'frac')}
-        if 'worst' in roof:
-            line['roofline']['worst'] = roof['worst']
+        for sub in ('north_star', 'worst'):
+            if sub in roof:
+                line['roofline'][sub] = roof[sub]
         assert line['roofline']['frac'] <= 1.0, 'a roofline fraction above 1 is a mis-stated work figure'
     base = full.get('cpu_baseline')
     if base is not None:
@@ -837,18 +868,31 @@ def main():
             torch.cuda.synchronize()
             _lib.TIMER.enabled = False
             runtime.set_overlap(True)
-            rec = _lib.TIMER.summary().get(roofline['kernel'])
+            single = _lib.TIMER.summary()
+            rec = single.get(roofline['kernel'])
             if rec and rec['launches']:
                 secs = rec['total_ms'] * 1e-3
                 rate = (rec['flop'] / secs / 1e12) if roofline['unit'] == 'TFLOP/s' else (rec['work'] / secs / 1e9)
                 if roofline['bound'] == 'latency':
                     rate = min(FPS_STEP_IDEAL_US / (secs * 1e6 / rec['flop']), 1.0) * 100.0
-                roofline['single_lane'] = {'avg_launch_us': round(rec['total_ms'] / rec['launches'] * 1e3, 2),
-                                           'achieved': round(rate, 2), 'frac': round(rate / roofline['peak'], 4),
-                                           'launches': rec['launches'],
-                                           'measured': '2 extra steps after the timed region with CAMLI_OVERLAP=0 semantics'}
-                # the same figure as a scalar (a parser that keeps scalars only dropped the object above in round 4)
-                roofline['frac_single_lane'] = roofline['single_lane']['frac']
+                # WHICH FIGURE IS WHICH (round-5 review): `frac` / `achieved` / `avg_launch_us` are the SINGLE-LANE ones -- the
+                # kernel with the chip to itself inside the step, the setting the committed rocprofv3 trace of this command is
+                # taken in, so they are the ones to check against profiles/; `*_in_situ` are the two-lane figures of the timed
+                # region (HIP events while the point lane shares the chip)
+                roofline.update(frac_in_situ=roofline['frac'], achieved_in_situ=roofline['achieved'],
+                                avg_launch_us_in_situ=roofline['avg_launch_us'])
+                roofline.update(frac=round(rate / roofline['peak'], 4), achieved=round(rate, 2),
+                                avg_launch_us=round(rec['total_ms'] / rec['launches'] * 1e3, 2),
+                                measured='frac / achieved / avg_launch_us: 2 extra steps after the timed region, one lane (CAMLI_OVERLAP=0 '
+                                         'semantics, = the rocprofv3 setting); *_in_situ: HIP events in the two-lane timed region')
+                roofline['frac_single_lane'] = roofline['frac']          # (round-4 / round-5 name of the same figure)
+            star = roofline.get('north_star')
+            if star and single.get(star['kernel']) and single[star['kernel']]['launches']:
+                rec = single[star['kernel']]
+                f = kernel_frac(star['kernel'], rec)
+                if f is not None:
+                    star['frac'] = round(f, 4)
+                    star['avg_launch_us'] = round(rec['total_ms'] / rec['launches'] * 1e3, 2)
         if roofline is not None and graphed is None and not dist_on and os.environ.get('CAMLI_NO_STEP_FLOOR') != '1':
             try:
                 roofline['step'] = step_floor(step, step_ms)

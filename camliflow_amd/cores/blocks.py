@@ -236,8 +236,10 @@ class _CatConvCL(torch.autograd.Function):
         ctx.widths, ctx.hip = widths, hip
         # r5: the contraction itself on this repo's channels-last kernels (csrc/hip/convcl.hip: forward 0.76-0.80 of the fp32
         # MFMA peak where the library's NHWC implicit GEMM runs at 0.66-0.70; both adjoints); CAMLI_CONVCL=0 -> the library
+        # (the own kernels write an H x W output with zeros outside the image: "same" padding only -- any other padding
+        # changes the output size, which the library path below handles)
         ctx.own = (hip and _CONVCL and w.dtype == torch.float32 and fused.convcl_supported(w.shape[1], w.shape[0])
-                   and w.shape[2] * w.shape[3] <= 32)
+                   and w.shape[2] * w.shape[3] <= 32 and 2 * padding[0] == w.shape[2] - 1 and 2 * padding[1] == w.shape[3] - 1)
         if ctx.own:
             wp, ctx.wpt = fused.convcl_pack(w)
             ctx.taps = (w.shape[2], w.shape[3], padding[0], padding[1])

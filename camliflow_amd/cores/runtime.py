@@ -480,7 +480,10 @@ class _WgradSide:
 
 
 def wgrad_side(device):
-    """The weight-gradient side stream of the current stream on `device`, or None where it does not apply."""
+    """The weight-gradient side stream of the current stream on `device`, or None where it does not apply.  Callers ask for
+    it only in the backward of a pass whose FORWARD ran two-lane (they record ``lanes_live()`` at forward time -- in the
+    backward the pass's Lanes object is gone): the priming pass and the models that build no Lanes (RAFTCore, CamLiRAFT-L,
+    CamLiPWC) stay on one stream in both directions, as Branch promises."""
     import torch
     if not (_WGRAD_ASIDE and _OVERLAP and _BACKEND == 'hip' and device.type == 'cuda') or torch.cuda.is_current_stream_capturing():
         return None

@@ -1880,6 +1880,8 @@ class GRU2DPass:
         self.gw = [None] * 4
         self.gc = [None] * 4
         self.side = None            # runtime._WgradSide once a weight gradient has been issued beside the main chain
+        self.done = None            # event behind the last update adjoint's accumulations (the hub node waits on it)
+        self.two_lane = _runtime.lanes_live()       # this pass runs two-lane: its backward may use the weight-gradient side stream
         self.token = _GRU2DHub.apply(self, *self.weights, *self.contexts)
 
 
@@ -1894,7 +1896,17 @@ class _GRU2DHub(torch.autograd.Function):
     def backward(ctx, _gtoken):
         hub = ctx.hub()
         totals = [None] * 8
+        if hub is None and any(ctx.needs_input_grad[1:]):
+            # the pass object owns the running totals: without it the gradients of the GRU's weights / context terms would
+            # silently come out as zeros
+            raise RuntimeError('GRU2DPass was released before its backward ran: keep the object returned by GRU2D.prepare '
+                               'alive until the pass has been differentiated')
         if hub is not None:
+            if hub.done is not None:
+                # the update adjoints return no gradient for the token, so the engine does not order this node's stream behind
+                # theirs: wait for the last accumulation explicitly (they may run in a lane / Branch of their own one day)
+                torch.cuda.current_stream(hub.done[1]).wait_event(hub.done[0])
+                hub.done = None
             if hub.side is not None:        # the weight gradients were accumulated on the side stream
                 hub.side.join()
                 for t in hub.gw:
@@ -1964,7 +1976,7 @@ class _GRU2DStepCL(torch.autograd.Function):
                 return 0, None
             return (hub.gc[slot].data_ptr(), None) if hub.gc[slot] is not None else (0, slot)
 
-        side = _runtime.wgrad_side(g.device)
+        side = _runtime.wgrad_side(g.device) if hub.two_lane else None
         if side is not None:
             hub.side = side
 
@@ -2008,6 +2020,10 @@ class _GRU2DStepCL(torch.autograd.Function):
                 if becomes is not None:
                     hub.gc[izr] = gpre_zr.clone()
                 gcur = gh
+        if not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(g.device))
+            hub.done = (ev, g.device)
         need = ctx.needs_input_grad
         return (_to_nchw(gcur) if need[0] else None, _to_nchw(gm) if need[1] else None, None, None)
 
@@ -2459,6 +2475,20 @@ def wino_transformed_weights(w, flip):
     return u
 
 
+def _image_stride(t):
+    """t [B,C,H,W] fp32 whose images are dense [C,H,W] blocks a fixed stride apart (a contiguous tensor or a channel slice of
+    one) -> that stride in floats, else None.  No alignment demanded: the Winograd transforms fall back to 4-byte accesses."""
+    if t.dtype != torch.float32 or t.dim() != 4:
+        return None
+    inner = 1
+    for size, stride in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+        if size != 1 and stride != inner:
+            return None
+        inner *= size
+    bs = t.stride(0) if t.shape[0] > 1 else inner
+    return bs if bs >= inner else None
+
+
 def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, mask=None):
     """act(conv3x3(x) + bias) for pre-transformed weights u (wino_transformed_weights).  x [B,C,H,W] fp32, dense or a channel
     slice of a dense NCHW tensor; ``mask``: x reads as zero where mask <= 0; ``out``: an existing [B,n_out,H,W] tensor (or
@@ -2466,21 +2496,21 @@ def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, m
     _require_cuda('wino_conv3x3', x, u)
     lib = _lib.load()
     b, c, hh, ww = x.shape
-    xbs = _batch_strided(x)
+    xbs = _image_stride(x)
     if xbs is None:
         x = x.contiguous()
         xbs = c * hh * ww
     mbs = 0
     if mask is not None:
         assert mask.shape == x.shape
-        mbs = _batch_strided(mask)
+        mbs = _image_stride(mask)
         if mbs is None:
             mask = mask.contiguous()
             mbs = c * hh * ww
     if out is None:
         assert not accumulate
         out = torch.empty((b, n_out, hh, ww), dtype=torch.float32, device=x.device)
-    ybs = _batch_strided(out)
+    ybs = _image_stride(out)
     if ybs is None or out.shape != (b, n_out, hh, ww):
         raise _lib.CamliHipError('wino_conv3x3: the output must be a dense fp32 [B,%d,H,W] tensor or a channel slice of one' % n_out)
     need = lib.camli_wino_workspace_bytes(b, c, n_out, hh, ww)
@@ -2502,14 +2532,14 @@ def wino_wrw(x, gy, mask=None, out=None):
     b, c, hh, ww = x.shape
     n = gy.shape[1]
     assert gy.shape == (b, n, hh, ww)
-    xbs, gbs = _batch_strided(x), _batch_strided(gy)
+    xbs, gbs = _image_stride(x), _image_stride(gy)
     if xbs is None:
         x, xbs = x.contiguous(), c * hh * ww
     if gbs is None:
         gy, gbs = gy.contiguous(), n * hh * ww
     mbs = 0
     if mask is not None:
-        mbs = _batch_strided(mask)
+        mbs = _image_stride(mask)
         if mbs is None:
             mask, mbs = mask.contiguous(), n * hh * ww
     need = lib.camli_wino_wrw_workspace_bytes(b, c, n, hh, ww)

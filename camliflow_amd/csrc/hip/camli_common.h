@@ -17,6 +17,18 @@ int camli_check_launch(const char* what);
 
 static inline int camli_divup(int a, int b) { return (a + b - 1) / b; }
 
+// Let kernel `fn` use `bytes` of dynamic LDS on the CURRENT device; `done` = the call site's static bit mask of devices
+// already served (one process per GPU is the rule here, but a process that drives several must not skip the others).
+static inline bool camli_reserve_lds(const void* fn, size_t bytes, unsigned long long& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    done |= bit;
+    return true;
+}
+
 // lexicographic arg-max on (value, lowest index) across the 64 lanes of a wave
 __device__ __forceinline__ void wave_argmax_lowidx(float& v, int& i) {
 #pragma unroll

@@ -11,25 +11,31 @@ namespace {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        cus = n > 0 ? n : 256;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        cus[dev] = n > 0 ? n : 256;
     }
-    return cus;
+    return cus[dev];
 }
 
-// 1 KB of zeros per device: the source of padded rows in the weight-gradient kernel
+// 1 KB of zeros per device: the source of padded rows in the weight-gradient kernel.  A zero-initialised __device__ array
+// of the module (every device gets its copy when the code object is loaded there): nothing is allocated or filled at run time,
+// so the first call may as well happen under stream capture, on any stream, from any thread (r5 advice: the lazily hipMalloc'd
+// + hipMemset page touched the legacy stream inside the first launch).
+__device__ __attribute__((aligned(1024))) float camli_zero_page[256];
+
 const float* zero_page() {
-    static float* pages[64] = {nullptr};
+    static const float* pages[64] = {nullptr};       // address per device (a benign race: every thread computes the same value)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (!pages[dev]) {
-        float* q = nullptr;
-        if (hipMalloc(&q, 1024) != hipSuccess) return nullptr;
-        if (hipMemset(q, 0, 1024) != hipSuccess) { (void)hipFree(q); return nullptr; }
-        pages[dev] = q;
+        void* q = nullptr;
+        if (hipGetSymbolAddress(&q, HIP_SYMBOL(camli_zero_page)) != hipSuccess) return nullptr;
+        pages[dev] = static_cast<const float*>(q);
     }
     return pages[dev];
 }
@@ -51,14 +57,10 @@ void set_taps(Problem& p, int T, const signed char* dy, const signed char* dx) {
 template <int NTW, int EPI = ccl::EPI_PLAIN>
 int launch_conv(const ccl::Problem& p, hipStream_t s) {
     constexpr size_t lds = (size_t)NBUF * (256 + 32 * NTW) * 16 * sizeof(float);
-    static bool set = false;
-    if (!set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ccl::convcl_kernel<NTW, NBUF, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            camli_set_error("camli_convcl_fwd: cannot reserve %zu bytes of LDS", lds);
-            return CAMLI_ELAUNCH;
-        }
-        set = true;
+    static unsigned long long reserved = 0;
+    if (!camli_reserve_lds(reinterpret_cast<const void*>(&ccl::convcl_kernel<NTW, NBUF, EPI>), lds, reserved)) {
+        camli_set_error("camli_convcl_fwd: cannot reserve %zu bytes of LDS", lds);
+        return CAMLI_ELAUNCH;
     }
     const int tiles = p.tiles_p * p.tiles_n;
     const int cus = cu_count();
@@ -69,14 +71,10 @@ int launch_conv(const ccl::Problem& p, hipStream_t s) {
 template <int TBN>
 int launch_wrw(const wrw::Problem& p, hipStream_t s) {
     constexpr size_t lds = (size_t)NBUF * 16 * (256 + 32 * TBN) * sizeof(float);
-    static bool set = false;
-    if (!set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw::wrw_kernel<TBN, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            camli_set_error("camli_convcl_wrw: cannot reserve %zu bytes of LDS", lds);
-            return CAMLI_ELAUNCH;
-        }
-        set = true;
+    static unsigned long long reserved = 0;
+    if (!camli_reserve_lds(reinterpret_cast<const void*>(&wrw::wrw_kernel<TBN, NBUF>), lds, reserved)) {
+        camli_set_error("camli_convcl_wrw: cannot reserve %zu bytes of LDS", lds);
+        return CAMLI_ELAUNCH;
     }
     hipLaunchKernelGGL((wrw::wrw_kernel<TBN, NBUF>), dim3(p.S * p.T * p.tiles_m * p.tiles_n), dim3(256), lds, s, p);
     return CAMLI_OK;
@@ -182,7 +180,7 @@ extern "C" int camli_convcl_wrw(const float* x0, int ldx0, int C0, const float* 
     }
     wrw::Problem p;
     p.zero = zero_page();
-    if (!p.zero) { camli_set_error("%s: cannot allocate the zero page", what); return CAMLI_ELAUNCH; }
+    if (!p.zero) { camli_set_error("%s: cannot resolve the zero page", what); return CAMLI_ELAUNCH; }
     p.part = workspace;
     p.B = B; p.H = H; p.W = W; p.T = T;
     if (mode == 1) {

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
     // bound of the level's k-th distance now -- and the largest such bound over the levels this wave's chunk belongs to caps
     // what the wave ever needs to queue.  With it the scan keeps ~K / NW + a few candidates per lane instead of
     // ~K (1 + ln(chunk / K)).  Same arithmetic as the scan (sqdist), so the prior candidates themselves pass the cap; an
-    // index outside the level switches the cap off.  Wave l evaluates level l for the 64 queries (2 K scattered reads per
+    // index outside the level, or one that occurs twice, switches the cap off.  Wave l evaluates level l for the 64 queries (2 K scattered reads per
     // lane: with every wave doing its own levels the CU's address unit took 15 kiloticks over it) and leaves it in LDS.
     float cap = INFINITY;
     float* level_cap = smem + 2 * QBUF * nthreads + KNN_SLOT_ROWS * NW * 64;       // [levels][64], behind the slots
@@ -479,6 +479,12 @@ __global__ __launch_bounds__(K >= 32 ? 256 : 512) void knn_prefix_kernel(const f
             py[j] = pt[1];
             pz[j] = D == 3 ? pt[2] : 0.0f;
         }
+        // K DIFFERENT candidates bound the k-th distance; a prior that repeats an index (a zeros placeholder, say) does not:
+        // such a query searches unbounded (r5 advice: range alone was checked, and the cap came out too small)
+#pragma unroll
+        for (int j = 1; j < K; ++j)
+#pragma unroll
+            for (int i = 0; i < j; ++i) ok = ok && c[i] != c[j];
         float t = 0.0f;
 #pragma unroll
         for (int j = 0; j < K; ++j) {

@@ -11,14 +11,16 @@ namespace {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        cus = n >= 8 ? n / 8 * 8 : 8;
+int cu_count() {       // rounded down to a multiple of 8: the plane GEMM deals its tiles in 8 chunks (one per XCD)
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        cus[dev] = n >= 8 ? n / 8 * 8 : 8;
     }
-    return cus;
+    return cus[dev];
 }
 
 constexpr int KS = 16, NBUF = 3;
@@ -28,13 +30,10 @@ template <int GA, int GB, int WM>
 int launch_planes(const float* U, const float* V, float* Mo, int Mp, int NT, int K, hipStream_t s) {
     constexpr size_t lds = (size_t)NBUF * KS * 512 * sizeof(float);
     auto kern = &w128::gemm_w128_kernel<KS, NBUF, 0, GA, GB, WM>;
-    static bool set = false;
-    if (!set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            camli_set_error("camli_wino_conv3x3: cannot reserve %zu bytes of LDS", lds);
-            return CAMLI_ELAUNCH;
-        }
-        set = true;
+    static unsigned long long reserved = 0;
+    if (!camli_reserve_lds(reinterpret_cast<const void*>(kern), lds, reserved)) {
+        camli_set_error("camli_wino_conv3x3: cannot reserve %zu bytes of LDS", lds);
+        return CAMLI_ELAUNCH;
     }
     w128::Problem p;
     p.A = U; p.B = V; p.C = Mo; p.M = Mp; p.N = NT; p.K = K;
@@ -170,13 +169,10 @@ template <int NTW>
 int launch_wrw_planes(const wino::WrwBatch& wb, int tiles, int zdim, hipStream_t s) {
     constexpr size_t lds = (size_t)NBUF * (256 + 32 * NTW) * 16 * sizeof(float);
     auto kern = &wino::wrw_planes_kernel<NTW, NBUF>;
-    static bool set = false;
-    if (!set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            camli_set_error("camli_wino_wrw: cannot reserve %zu bytes of LDS", lds);
-            return CAMLI_ELAUNCH;
-        }
-        set = true;
+    static unsigned long long reserved = 0;
+    if (!camli_reserve_lds(reinterpret_cast<const void*>(kern), lds, reserved)) {
+        camli_set_error("camli_wino_wrw: cannot reserve %zu bytes of LDS", lds);
+        return CAMLI_ELAUNCH;
     }
     hipLaunchKernelGGL(kern, dim3(tiles, zdim), dim3(256), lds, s, wb);
     return CAMLI_OK;

@@ -61,7 +61,7 @@ int camli_knn_prefixes(const float *input, const float *query, int64_t *const *o
 /* The same search given the out_levels of an EARLIER call (same sizes, same k) on the same clouds, moved since: the GRU loop
  * (camliraft_l_core.py:62-66, raft3d flow loop) repeats it every iteration on the back-warped target cloud.  The K earlier
  * neighbours of a query bound its k-th distance now, and the scan queues nothing beyond that bound.  Results are identical to
- * camli_knn_prefixes whatever the prior holds (indices outside a level switch the bound off); prior_levels == NULL is
+ * camli_knn_prefixes whatever the prior holds (indices outside a level, or a prior row that repeats an index, switch the bound off for that query); prior_levels == NULL is
  * camli_knn_prefixes. */
 int camli_knn_prefixes_prior(const float *input, const float *query, int64_t *const *out_levels,
                              const int64_t *const *prior_levels, const int *sizes, int L, int B, int M, int Nq, int D, int k,

@@ -12,6 +12,10 @@
                         output of each of its six 1x5 / 5x1 convolutions, the new hidden state
   dense_gru2d_wide      the same module at the product's widths (hidden 128, x = 128 context + 128 motion channels), two updates
                         with autograd: inputs, output, input gradients, fingerprints of the weight gradients (name-hashed weights)
+  dense_update_block    models/raft_core.py MotionEncoder2D (:142-166), FlowHead2D (:169-181) and the mask head of ConvexUpsampler2D
+                        (:184-190) at the product's widths with autograd: inputs, outputs, input gradients, fingerprints of every
+                        parameter gradient (name-hashed weights) -- the module-level pin of the 3x3 convolutions the product
+                        runs as Winograd F(2x2,3x3) (csrc/hip/winograd.hip)
   dense_resnet_glue     the stem max pooling and the bottleneck epilogue of the ResNet trunk the reference instantiates
                         through mmdet (README.md:78-79, models/raft_core.py:10-38; mmdet itself is not under
                         /root/reference -- SURVEY 8c): nn.MaxPool2d(3, 2, 1) and relu(bn-bias + conv + identity) from torch
@@ -32,7 +36,7 @@ import refmodels  # noqa: E402
 
 refmodels.install(native_semantics=True)
 from models.camliraft_l_core import Correlation3D  # noqa: E402
-from models.raft_core import GRU2D, Correlation2D, FlowHead2D  # noqa: E402
+from models.raft_core import GRU2D, ConvexUpsampler2D, Correlation2D, FlowHead2D, MotionEncoder2D  # noqa: E402
 
 
 def save(name, **arrays):
@@ -206,6 +210,42 @@ def golden_gru2d_wide():
     save('dense_gru2d_wide', **arrays)
 
 
+def _fingerprints(module, arrays, prefix):
+    import zlib
+    for name, p in module.named_parameters():
+        d = torch.randn(p.shape, generator=torch.Generator().manual_seed(zlib.crc32(('dir.' + prefix + name).encode())))
+        arrays['fp_' + prefix + name] = torch.stack([p.grad.double().norm(), (p.grad.double() * d.double()).sum()])
+
+
+def golden_update_block():
+    """The reference's MotionEncoder2D, FlowHead2D and mask head (raft_core.py:142-190) at the product's widths (4 levels x 81
+    correlation channels, hidden 128) on a small odd-sized map, with autograd.  Weights name-hashed (modelutils.hashed_fill_),
+    parameter gradients as fingerprints (L2 norm, projection on a name-seeded direction)."""
+    from modelutils import hashed_fill_
+    g = torch.Generator().manual_seed(27)
+    enc = hashed_fill_(MotionEncoder2D(4, 4))
+    head = hashed_fill_(FlowHead2D(128, 256))
+    up = hashed_fill_(ConvexUpsampler2D(128))
+    b, hh, ww = 1, 7, 12
+    flow = (torch.randn(b, 2, hh, ww, generator=g) * 2).requires_grad_()
+    corr = torch.randn(b, 324, hh, ww, generator=g).requires_grad_()
+    hidden = torch.tanh(torch.randn(b, 128, hh, ww, generator=g)).requires_grad_()
+    motion = enc(flow, corr)
+    gmotion = torch.randn(motion.shape, generator=g)
+    motion.backward(gmotion)
+    delta = head(hidden)
+    mask = up.mask(hidden)
+    gdelta, gmask = torch.randn(delta.shape, generator=g), torch.randn(mask.shape, generator=g) * 0.1
+    (delta * gdelta).sum().add((mask * gmask).sum()).backward()
+    arrays = {'flow': flow.detach(), 'corr': corr.detach(), 'hidden': hidden.detach(), 'motion': motion.detach(), 'gmotion': gmotion,
+              'gflow': flow.grad, 'gcorr': corr.grad, 'delta': delta.detach(), 'mask': mask.detach(), 'gdelta': gdelta, 'gmask': gmask,
+              'ghidden': hidden.grad}
+    _fingerprints(enc, arrays, 'enc.')
+    _fingerprints(head, arrays, 'head.')
+    _fingerprints(up, arrays, 'up.')
+    save('dense_update_block', **arrays)
+
+
 def golden_resnet_glue():
     g = torch.Generator().manual_seed(24)
     x = torch.relu(torch.randn(2, 5, 13, 18, generator=g)).requires_grad_(True)     # post-ReLU stem output: zeros tie
@@ -232,5 +272,6 @@ if __name__ == '__main__':
     golden_allpairs('odd', 9, 15)
     golden_gru2d()
     golden_gru2d_wide()
+    golden_update_block()
     golden_resnet_glue()
     golden_point_volume()

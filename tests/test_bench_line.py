@@ -30,7 +30,7 @@ def test_compact_line_fits_the_driver_tail():
     assert len(text) < bench.LINE_LIMIT_BYTES
     for key in bench.CONTRACT_KEYS:
         assert key in line, key
-    assert line['roofline']['frac'] <= 1.0 and line['roofline']['single_lane']['frac'] <= 1.0
+    assert line['roofline']['frac'] <= 1.0
     assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(line['roofline'])
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(line['cpu_baseline'])
     assert line['parity']['ok'] is True and line['detail'] == 'gpurun_out/bench_detail.json'
@@ -158,6 +158,35 @@ def test_compact_line_round5_fields():
     assert set(line['side_configs']) == {'camlipwc', 'kitti', 'ddp4'} and line['side_configs']['ddp4']['batch'] == 4
     assert line['cpu_baseline']['all_cores']['cores'] == 64
     assert 'ddp4' in bench.SIDE_CONFIGS
+
+
+def test_roofline_round6_fields():
+    """Round 6 (VERDICT r5 item 3): `frac` is the single-lane (rocprofv3-comparable) figure and `frac_in_situ` the two-lane one;
+    `roofline.north_star` names the dominant SURVEY 8(a) kernel when the overall dominant one is a convolution-side (8(f)2)
+    entry point; the Winograd entry points are priced as matrix-core kernels; ddp4 carries its host enqueue time."""
+    import types
+    import bench
+    summary = {
+        'camli_wino_conv3x3': {'total_ms': 60.0, 'launches': 200, 'work': 200 * 7.0e8, 'unit': 'B', 'flop': 200 * 2.5e10},
+        'camli_convcl_fwd': {'total_ms': 20.0, 'launches': 48, 'work': 48 * 1.5e8, 'unit': 'B', 'flop': 48 * 3.2e10},
+        'camli_pointconv_dw_fwd': {'total_ms': 30.0, 'launches': 540, 'work': 540 * 1.2e8, 'unit': 'B', 'flop': 0.0},
+        'camli_knn': {'total_ms': 10.0, 'launches': 170, 'work': 170 * 5.0e7, 'unit': 'pairs', 'flop': 0.0},
+    }
+    args = types.SimpleNamespace(batch=8, iters=12, height=540, width=960, points=8192)
+    roof, table = bench.roofline_report(summary, 5, args, step_ms=200.0)
+    assert roof['kernel'] == 'camli_wino_conv3x3' and roof['bound'] == 'mfma' and 0 < roof['frac'] <= 1
+    star = roof['north_star']
+    assert star['kernel'] == 'camli_pointconv_dw_fwd' and star['bound'] == 'hbm' and star['frac_in_situ'] == table['camli_pointconv_dw_fwd']['frac']
+    assert bench.CONV_SIDE <= set(bench.NORTH_STAR) and 'camli_knn' not in bench.CONV_SIDE
+    assert abs(bench.kernel_frac('camli_knn', summary['camli_knn']) - table['camli_knn']['frac']) < 1e-3
+    full = _full_line()
+    full['roofline'].update(frac=0.74, frac_in_situ=0.45, avg_launch_us=275.0, avg_launch_us_in_situ=448.0, north_star=dict(star, frac=0.4, avg_launch_us=50.0))
+    full['side_configs'] = {'ddp4': {'ms_per_step': 120.0, 'value': 33.3, 'dtype': 'f32', 'steps': 5, 'batch': 4, 'host_enqueue_ms': 118.0}}
+    line = bench.compact_line(full, None)
+    assert len(json.dumps(line)) < bench.LINE_LIMIT_BYTES
+    assert line['roofline']['frac_in_situ'] == 0.45 and line['roofline']['north_star']['kernel'] == 'camli_pointconv_dw_fwd'
+    assert line['side_configs']['ddp4']['host_enqueue_ms'] == 118.0
+    assert 'camli_corr3d_cost_levels_fwd' not in bench.NORTH_STAR          # entry points removed in round 5
 
 
 def test_pmc_traffic_names_its_source():

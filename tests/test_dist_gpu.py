@@ -77,3 +77,62 @@ def test_forced_dist_step_matches_plain_step():
     num = sum(((g0[n] - g1[n]).double() ** 2).sum().item() for n in g0) ** 0.5
     den = sum((g0[n].double() ** 2).sum().item() for n in g0) ** 0.5
     assert num / den < 1e-3, num / den
+
+
+def _rccl_worker(rank, world, port, out_path):
+    """One rank of a real multi-GPU run: its own device, RCCL over xGMI, SyncBatchNorm, parameter broadcast, the flat
+    gradient all-reduce of bench.py -- each rank steps on its own sample."""
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(rank)
+    import bench
+    from camliflow_amd.cores import CamLiRAFT, runtime
+    dist.init_process_group('nccl', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = hashed_fill_(CamLiRAFT(camliraft_cfg(n_iters=2, freeze_bn=True)), scale=0.5)
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model).cuda().train()
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+        full = synthetic_inputs(world, 128, 160, 4608, seed=3)
+        shard = {k: v[rank:rank + 1].cuda() for k, v in full.items()}
+        runtime.set_deferred_param_grads(True)
+        with runtime.use_backend('hip'):
+            model(shard)
+            model.get_loss().backward()
+            bench.allreduce_gradients(model, world)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_rccl_step_matches_two_sample_batch(tmp_path):
+    """world = min(2, visible GPUs): on a multi-GPU box the data-parallel path runs on REAL RCCL between two devices (one process
+    per GPU, as bench.py launches them) and the averaged gradients must equal one process stepping on the 2-sample batch --
+    the GPU twin of tests/test_ddp_cpu.py (gloo).  BatchNorm statistics are frozen (freeze_bn) so that the two formulations
+    are the same function.  Skipped where only one GPU is visible (the 1-rank test above covers the code path there)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one GPU visible: the two-rank RCCL step needs two')
+    import torch.multiprocessing as mp
+    from camliflow_amd.cores import CamLiRAFT, runtime
+    out_path = str(tmp_path / 'rank0.pt')
+    mp.spawn(_rccl_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    got = torch.load(out_path)
+    torch.manual_seed(0)
+    model = hashed_fill_(CamLiRAFT(camliraft_cfg(n_iters=2, freeze_bn=True)), scale=0.5).cuda().train()
+    full = {k: v.cuda() for k, v in synthetic_inputs(2, 128, 160, 4608, seed=3).items()}
+    with runtime.use_backend('hip'):
+        model(full)
+        model.get_loss().backward()
+    want = {n: p.grad.cpu() for n, p in model.named_parameters() if p.grad is not None}
+    assert want.keys() == got.keys() and len(want) > 400
+    num = sum(((got[n] - want[n]).double() ** 2).sum().item() for n in want) ** 0.5
+    den = sum((want[n].double() ** 2).sum().item() for n in want) ** 0.5
+    assert num / den < 1e-3, num / den

@@ -321,12 +321,14 @@ def test_knn_prefixes_equal_separate_searches(case, mode, oracle_lib, monkeypatc
 
 @pytest.mark.parametrize('case', [(8, 2048, 2048, 16, (2048, 1024, 512, 256)), (2, 1024, 300, 32, (1024, 512, 256)),
                                   (2, 2048, 500, 16, (2048, 1536, 512)), (1, 2048, 64, 16, (2048, 1024, 512))], ids=str)
-@pytest.mark.parametrize('prior_kind', ['same', 'moved', 'permuted', 'out_of_range'])
+@pytest.mark.parametrize('prior_kind', ['same', 'moved', 'permuted', 'out_of_range', 'zeros', 'repeated'])
 def test_knn_prefixes_with_prior_are_unchanged(case, prior_kind, oracle_lib):
     """camli_knn_prefixes_prior: an earlier result bounds every level's k-th distance and the scan queues nothing beyond the
     bound -- the indices must be those of the plain search (oracle) whatever the prior holds: the result of the same search,
-    of the search on clouds moved since (the GRU loop's case), arbitrary different in-range candidates, or indices outside the
-    level (bound switched off).  25 % exact duplicates in the cloud, so ties at the k-th distance meet the bound."""
+    of the search on clouds moved since (the GRU loop's case), arbitrary different in-range candidates, indices outside the
+    level, or in-range indices that REPEAT (a zeros placeholder; the nearest neighbour k times over) -- K equal candidates
+    bound nothing, the kernel must notice and search unbounded.  25 % exact duplicates in the cloud, so ties at the k-th
+    distance meet the bound."""
     from camliflow_amd.csrc import wrapper
     b, m, nq, k, sizes = case
     rng = np.random.default_rng(m + k + len(prior_kind))
@@ -342,6 +344,12 @@ def test_knn_prefixes_with_prior_are_unchanged(case, prior_kind, oracle_lib):
     elif prior_kind == 'permuted':
         prior = [dev(np.stack([np.stack([rng.permutation(size)[:k] for _ in range(nq)]) for _ in range(b)]).astype(np.int64))
                  for size in sizes]
+    elif prior_kind == 'zeros':
+        prior = [dev(np.zeros((b, nq, k), dtype=np.int64)) for size in sizes]
+    elif prior_kind == 'repeated':
+        # the true nearest neighbour in every slot but one: the largest "bound" is then far below the k-th distance
+        near = [oracle_lib.knn(np.ascontiguousarray(inp[:, :size]), qry, 2) for size in sizes]
+        prior = [dev(np.concatenate([np.repeat(n2[:, :, :1], k - 1, axis=2), n2[:, :, 1:2]], axis=2).astype(np.int64)) for n2 in near]
     else:
         prior = [dev(np.full((b, nq, k), size + 5, dtype=np.int64)) for size in sizes]
     prior = [p.contiguous() for p in prior]

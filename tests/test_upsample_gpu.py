@@ -157,6 +157,41 @@ def test_resnet_trunk_folded_batchnorm_vs_unfolded():
     assert num / den < 5e-3, num / den
 
 
+def test_trunk_identity_block_fork_on_and_off_give_the_same_gradients(monkeypatch):
+    """cores/resnet._PointwiseFork (CAMLI_TRUNK_FORK, default on): conv1 of an identity bottleneck and the shortcut leave
+    through one node whose adjoint ADDS conv1's data gradient into the shortcut's gradient in place (``addmm_`` on the
+    incoming tensor).  Against the plain formulation (autograd adds two tensors): features equal, every parameter
+    gradient and the input gradient equal to fp32 summation order -- an in-place update of a gradient somebody else still
+    reads would show here."""
+    from camliflow_amd.cores import resnet, runtime
+    from camliflow_amd.cores.raft2d import Encoder2D
+    from modelutils import hashed_fill_
+    torch.manual_seed(0)
+    enc = hashed_fill_(Encoder2D()).cuda().train()
+    x = torch.randn(2, 3, 96, 128, device='cuda', requires_grad=True)
+    gout = torch.randn(2, 128, 12, 16, device='cuda')
+    res = {}
+    forks = []
+    real = resnet._PointwiseFork.apply
+    for fork in (True, False):
+        monkeypatch.setattr(resnet, '_FORK', fork)
+        monkeypatch.setattr(resnet._PointwiseFork, 'apply', staticmethod(lambda *a, _r=real: (forks.append(1), _r(*a))[1]))
+        enc.zero_grad()
+        x.grad = None
+        n0 = len(forks)
+        with runtime.use_backend('hip'):
+            y = enc(x)
+        y.backward(gout)
+        res[fork] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in enc.named_parameters()}, len(forks) - n0)
+    (y1, gx1, g1, used1), (y0, gx0, g0, used0) = res[True], res[False]
+    assert used1 > 0 and used0 == 0, (used1, used0)          # the identity blocks did take the fork node, and only when asked to
+    assert (y1 - y0).abs().max() <= 1e-6 * max(1.0, float(y0.abs().max()))     # the forward is the same arithmetic either way
+    assert (gx1 - gx0).abs().max() <= 1e-5 * max(1.0, float(gx0.abs().max()))
+    num = sum(((g1[n] - g0[n]).double() ** 2).sum().item() for n in g1) ** 0.5
+    den = sum((g0[n].double() ** 2).sum().item() for n in g1) ** 0.5
+    assert g1.keys() == g0.keys() and num / den < 1e-5, num / den
+
+
 @pytest.mark.parametrize('case', [(2, 68, 120, 8, 540), (1, 17, 30, 8, 131), (2, 36, 60, 4, 141), (1, 5, 70, 8, 33), (1, 3, 193, 4, 12)], ids=str)
 def test_convex_upsample_keeping_the_first_rows_only(case, oracle_lib):
     """camli_convex_upsample_rows_fwd/bwd: the un-padding of a bottom-padded image (utils.py:7-20) done by the kernel -- the

@@ -28,10 +28,11 @@ def _close(got, want, tol=TOL, what=''):
 
 # (B, Cin, Cout, H, W): odd sizes (partial tiles at the right / bottom border, padded tile columns), a single tile row, Cout
 # on each of the three GEMM tiles (<= 128, <= 192, 256 and beyond), Cout not a multiple of 4 / 16 (126), Cin = 192 (12 K steps),
-# the product's own channel pairs at a small image
+# the product's own channel pairs at a small image, odd channel counts on odd planes (CamLiPWC's 629-channel estimator input:
+# image stride not a multiple of 4 floats -> the 4-byte paths of the transforms)
 CASES = [
     (2, 48, 52, 13, 21), (1, 64, 192, 16, 24), (3, 128, 126, 9, 40), (1, 256, 192, 5, 7), (1, 96, 256, 1, 9), (2, 128, 512, 6, 10),
-    (1, 256, 126, 17, 30), (1, 192, 256, 17, 30), (1, 128, 256, 2, 2), (1, 112, 320, 7, 5),
+    (1, 256, 126, 17, 30), (1, 192, 256, 17, 30), (1, 128, 256, 2, 2), (1, 112, 320, 7, 5), (1, 629, 128, 9, 15), (2, 101, 99, 3, 5),
 ]
 
 
@@ -165,3 +166,45 @@ def test_update_block_convolutions_take_the_winograd_path():
     assert not fused.wino_supported(head.conv2, x256) and not fused.wino_supported(enc.conv_f1, torch.zeros(1, 2, 8, 8, device='cuda'))
     with torch.autocast('cuda', dtype=torch.bfloat16):
         assert not fused.wino_supported(enc.conv_c2, x256)
+
+
+def test_update_block_modules_vs_reference_golden(golden):
+    """cores/raft2d.MotionEncoder2D, FlowHead2D and the mask head on the product path (Winograd 3x3 convolutions, fused
+    epilogues, cat-free concatenations) against what the REFERENCE's modules recorded with autograd
+    (tests/golden/dense_update_block.npz from tests/golden/make_dense_golden.py, models/raft_core.py:142-190; weights
+    name-hashed on both sides): outputs, input gradients, fingerprints of every parameter gradient."""
+    import zlib
+    from modelutils import hashed_fill_
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.blocks import conv_bias_act
+    from camliflow_amd.cores.raft2d import ConvexUpsampler2D, FlowHead2D, MotionEncoder2D
+    from camliflow_amd.csrc import _lib
+    runtime.set_backend('hip')
+    g = golden('dense_update_block')
+    enc = hashed_fill_(MotionEncoder2D(4, 4)).cuda()
+    head = hashed_fill_(FlowHead2D(128, 256)).cuda()
+    up = hashed_fill_(ConvexUpsampler2D(128)).cuda()
+    flow, corr, hidden = (dev(g[k]).requires_grad_() for k in ('flow', 'corr', 'hidden'))
+    runtime.set_census(True)
+    runtime.reset_census()
+    motion = enc(flow, corr)
+    motion.backward(dev(g['gmotion']))
+    delta = head(hidden)
+    mask = conv_bias_act(up.mask[2], conv_bias_act(up.mask[0], hidden, 'relu'), None)
+    (delta * dev(g['gdelta'])).sum().add((mask * dev(g['gmask'])).sum()).backward()
+    census = runtime.census()['fused']
+    runtime.set_census(False)
+    # conv_c2, conv, FlowHead2D.conv1, mask[0]: forward + data gradient (hidden's two are both needed) and weight gradient each
+    assert census.get('camli_wino_conv3x3', 0) == 8 and census.get('camli_wino_wrw', 0) == 4, census
+    _close(motion, g['motion'], tol=2e-5, what='motion features')
+    _close(flow.grad, g['gflow'], tol=5e-5, what='gradient of the flow')
+    _close(corr.grad, g['gcorr'], tol=5e-5, what='gradient of the correlation window')
+    _close(delta, g['delta'], tol=2e-5, what='flow update')
+    _close(mask, g['mask'], tol=2e-5, what='up-sampling mask')
+    _close(hidden.grad, g['ghidden'], tol=5e-5, what='gradient of the hidden state')
+    for prefix, module in (('enc.', enc), ('head.', head), ('up.', up)):
+        for name, p_ in module.named_parameters():
+            d = torch.randn(p_.shape, generator=torch.Generator().manual_seed(zlib.crc32(('dir.' + prefix + name).encode())))
+            fp = np.array([float(p_.grad.double().norm()), float((p_.grad.double().cpu() * d.double()).sum())])
+            want = g['fp_' + prefix + name]
+            assert abs(fp[0] - want[0]) <= 1e-4 * want[0] and abs(fp[1] - want[1]) <= 2e-4 * want[0], (prefix + name, fp, want)

@@ -109,6 +109,18 @@ def cases(batch):
     yield 'gru2d B%d 68x120' % b, gru2d, {'camli_convcl_gru_gates': 'mfma', 'camli_convcl_gru_blend': 'mfma', 'camli_convcl_fwd': 'mfma',
                                          'camli_convcl_wrw': 'mfma'}
 
+    # ---- (f)2 the update block's 3x3 convolutions as Winograd F(2x2,3x3) (csrc/hip/winograd.hip): forward, data gradient,
+    # weight gradient per launch of the entry point (three / four kernels each; flop = the transform-domain MFMA work)
+    for (cin, cout) in [(256, 192), (256, 126), (128, 256)]:
+        wx = _randn(g, b, cin, h, w).requires_grad_(True)
+        ww_ = (_randn(g, cout, cin, 3, 3) * (9 * cin) ** -0.5).requires_grad_(True)
+        wgo = _randn(g, b, cout, h, w)
+
+        def wino(wx=wx, ww_=ww_, wgo=wgo):
+            out = fused.conv3x3_wino(wx, ww_)
+            torch.autograd.grad(out, [wx, ww_], wgo)
+        yield 'wino3x3 B%d %d->%d 68x120' % (b, cin, cout), wino, {'camli_wino_conv3x3': 'mfma', 'camli_wino_wrw': 'mfma'}
+
     # ---- A4 furthest point sampling ---------------------------------------------------------------------------
     xyz = _rand(g, 2 * b, 8192, 3, scale=10.0)
     yield 'fps B%d 8192->4096' % (2 * b), (lambda: csrc.furthest_point_sampling(xyz, 4096)), {'camli_fps': 'fps'}
