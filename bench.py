@@ -469,6 +469,7 @@ def side_configs(budget):
             out[name] = {'ms_per_step': rec['ms_per_step'], 'value': rec['value'], 'dtype': rec['dtype'], 'steps': rec['steps']}
             if name == 'ddp4':
                 out[name].update(batch=4, n_iters=12, sync_bn=True, ranks=1, collectives='1-rank RCCL group',
+                                 hip_graph=rec.get('config', {}).get('hip_graph'),
                                  host_enqueue_ms=rec.get('config', {}).get('host_enqueue_ms_per_step'))
         except subprocess.TimeoutExpired:
             out[name] = {'skipped': 'did not finish in %.0f s' % (left - 15)}
@@ -775,8 +776,11 @@ def main():
     if dist_on:   # identical replicas: broadcast rank 0's parameters and buffers once
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
-    if args.graph is None:      # host-bound batch-1 steps replay 1.6x (camlipwc) / 2.9x (kitti) faster than they enqueue
-        args.graph = args.config in ('camlipwc', 'kitti') and args.mode == 'train'
+    if args.graph is None:
+        # host-bound steps replay faster than they enqueue: the batch-1 configurations 1.6x (camlipwc) / 2.9x (kitti), the
+        # batch-4 CamLiRAFT step (configs[3]'s per-rank batch) 175 -> 128 ms (r6, profiles/r06_experiments.txt); the batch-8
+        # headline step is device-bound and eager there keeps the auxiliary streams (213.7 replayed vs 199.7 eager)
+        args.graph = (args.config in ('camlipwc', 'kitti') or args.batch <= 4) and args.mode == 'train'
     use_graph = args.graph and world == 1
     optimizer = make_optimizer(model, capturable=use_graph) if args.mode == 'train' else None
     batch = {k: v.to(device) for k, v in synthetic_batch(args.batch, args.height, args.width, args.points,

@@ -115,7 +115,9 @@ __device__ __forceinline__ void mfma_x4(f32x4& c0, f32x4& c1, f32x4& c2, f32x4& 
         : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
 
-// NTW: 16-channel tiles per wave along the output channels (8: 256-channel workgroup tile, 6: 192, 4: 128).  Workgroup tile =
+// NTW: 16-channel tiles per wave along the output channels (8: 256-channel workgroup tile, 6: 192, 4: 128, 2: 64 -- the small
+// tiles are for problems whose pixel tiles alone do not fill the chip: batch 4 at 68 x 120 is 128 pixel tiles on 256 CUs).
+// Workgroup tile =
 // 256 pixels x 32 NTW channels, waves 2 (pixels) x 2 (channels), 128 pixels x 16 NTW channels each.  NBUF LDS stages of
 // (256 + 32 NTW) rows x 64 bytes.  The body is a device function: convcl_kernel runs it on the problem it is launched with,
 // winograd_wrw.h on one problem per (plane, K split) of a batched, split contraction.
@@ -130,7 +132,7 @@ struct Operands {
 
 template <int NTW, int NBUF, int EPI = EPI_PLAIN>
 __device__ __forceinline__ void convcl_body(const Problem& p, const Operands& o, float* lds) {
-    static_assert(NBUF >= 3 && (NTW == 8 || NTW == 6 || NTW == 4), "");
+    static_assert(NBUF >= 3 && (NTW == 8 || NTW == 6 || NTW == 4 || NTW == 2), "");
     constexpr int NT = 32 * NTW;                  // output channels per workgroup tile
     constexpr int WROWS = 16 * NTW;               // per wave
     constexpr int STAGE = (256 + NT) * 16;        // floats: pixel rows, then weight rows
@@ -254,10 +256,15 @@ __device__ __forceinline__ void convcl_body(const Problem& p, const Operands& o,
                     asm volatile("" ::: "memory");
                 }
                 if (sl >= 2 && sl < 2 + IPS && issue) dma_slot(fbuf, sl - 2);
-                // fragments of the next step: one read per slot behind the DMA slots
-                if (more && sl >= 2 + IPS && sl < 2 + IPS + NTW + 8) {
-                    if (decltype(parity)::value) read_frag(nbuf, sl - 2 - IPS, pw, px);
-                    else read_frag(nbuf, sl - 2 - IPS, qw, qx);
+                // fragments of the next step: RPS reads per slot behind the DMA slots (one on the wide tiles; the 64-channel
+                // tile has 16 slots for 1 barrier + 5 DMAs + 10 reads)
+                constexpr int RPS = (NTW + 8 + (8 * NTW - 2 - IPS) - 1) / (8 * NTW - 2 - IPS);
+                if (more && sl >= 2 + IPS) {
+#pragma unroll
+                    for (int i = (sl - 2 - IPS) * RPS; i < (sl - 1 - IPS) * RPS && i < NTW + 8; ++i) {
+                        if (decltype(parity)::value) read_frag(nbuf, i, pw, px);
+                        else read_frag(nbuf, i, qw, qx);
+                    }
                 }
             };
             if (decltype(parity)::value) step(zero, qw, qx, between);
@@ -307,18 +314,18 @@ __device__ __forceinline__ void convcl_body(const Problem& p, const Operands& o,
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if constexpr (EPI == EPI_GATES) {
-            static_assert(EPI != EPI_GATES || NTW == 8, "z | r = 256 output channels");
-            const bool rwave = wn != 0;                       // channels [128, 256) are r
+            static_assert(EPI != EPI_GATES || NTW == 8 || NTW == 4, "z | r = 256 output channels: one tile, or a z tile and an r tile");
+            const bool rwave = nw0 >= 128;                    // channels [128, 256) are r
             const __amdgpu_buffer_rsrc_t rs_add = rsrc(p.add, p.ld_add), rs_h = rsrc(p.h, p.ld_h);
             const __amdgpu_buffer_rsrc_t rs_o = rsrc(rwave ? o.y1 : o.y, rwave ? p.ldy1 : p.ldy), rs_r = rsrc(p.y2, p.ldy2);
             const int ldo = rwave ? p.ldy1 : p.ldy;
-            const uint32_t c4 = 4 * q;                        // + 16 tco: channel inside the wave's 128
+            const uint32_t c4 = (nw0 & 127) + 4 * q;          // + 16 tco: channel inside its half (z or r)
             f32x4 av[2][8], hv[2][8];
             auto fetch = [&](int tco, f32x4 (&a)[8], f32x4 (&hh)[8]) {
 #pragma unroll
                 for (int tpx = 0; tpx < 8; ++tpx) {
                     const uint32_t row = prow + 16 * tpx;
-                    a[tpx] = load4(rs_add, (row * p.ld_add + nw0 + 16 * tco + c4) * 4u);
+                    a[tpx] = load4(rs_add, (row * p.ld_add + nw0 + 16 * tco + 4 * q) * 4u);
                     if (rwave) hh[tpx] = load4(rs_h, (row * p.ld_h + 16 * tco + c4) * 4u);
                 }
             };
@@ -344,7 +351,7 @@ __device__ __forceinline__ void convcl_body(const Problem& p, const Operands& o,
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            static_assert(EPI != EPI_BLEND || NTW == 4, "q = 128 output channels");
+            static_assert(EPI != EPI_BLEND || NTW == 4 || NTW == 2, "q = 128 output channels: one tile or two");
             const __amdgpu_buffer_rsrc_t rs_add = rsrc(p.add, p.ld_add), rs_h = rsrc(p.h, p.ld_h), rs_z = rsrc(p.z, p.ld_z);
             const __amdgpu_buffer_rsrc_t rs_o = rsrc(o.y, p.ldy), rs_q = rsrc(o.y1, p.ldy1);
             const uint32_t c4 = nw0 + 4 * q;                  // + 16 tco

@@ -68,6 +68,17 @@ int launch_conv(const ccl::Problem& p, hipStream_t s) {
     return CAMLI_OK;
 }
 
+// r6: tile selection by problem size.  The wide channel tile (256 / 128 channels) is the efficient one when the pixel tiles
+// fill the chip; when they do not -- batch 4 at 68 x 120 (configs[3]'s per-rank batch) is 128 pixel tiles on 256 CUs, KITTI
+// batch 1 is 29 -- halving the channel tile doubles the workgroups, and a half-empty chip gains more from that than the
+// narrower tile loses (DMA issues per MFMA x 1.5).  CAMLI_CONVCL_TILES=wide | narrow forces a choice (A/B, tests).
+bool narrow_tiles(int64_t P, int wide_tiles_n) {
+    const char* e = getenv("CAMLI_CONVCL_TILES");       // read per call: the tests force either choice on one shape
+    if (e && e[0] == 'w') return false;
+    if (e && e[0] == 'n') return true;
+    return ((P + 255) / 256) * wide_tiles_n * 4 < (int64_t)cu_count() * 3;
+}
+
 template <int TBN>
 int launch_wrw(const wrw::Problem& p, hipStream_t s) {
     constexpr size_t lds = (size_t)NBUF * 16 * (256 + 32 * TBN) * sizeof(float);
@@ -100,7 +111,7 @@ extern "C" int camli_convcl_fwd(const float* x0, int ldx0, int C0, const float* 
     if (!taps_ok(what, T, dy, dx)) return CAMLI_EINVAL;
     const int Cin = C0 + C1;
     const int64_t P = (int64_t)B * H * W;
-    const int NT = Cout % 256 == 0 ? 256 : 128;
+    const int NT = Cout % 256 == 0 && !narrow_tiles((int64_t)B * H * W, Cout / 256) ? 256 : 128;
     if (B < 0 || H < 1 || W < 1 || C0 < 16 || C0 % 16 || C1 < 0 || C1 % 16 || Cout < 128 || Cout % 128 || N0 < 1 || N0 > Cout ||
         N0 % (NT / 2) || ldx0 < C0 || ldx0 % 4 || (C1 > 0 && (ldx1 < C1 || ldx1 % 4)) || ldy0 < N0 || ldy0 % 4 ||
         (N0 < Cout && (ldy1 < Cout - N0 || ldy1 % 4))) {
@@ -254,7 +265,9 @@ extern "C" int camli_convcl_gru_gates(const float* h, const float* x, int CX, co
     gru_problem(p, h, x, CX, wp_zr, 256, B, H, W, T, dy, dx);
     p.y = z; p.ldy = 128; p.y1 = rh; p.ldy1 = 128; p.y2 = r; p.ldy2 = 128;
     p.add = ctx_zr; p.ld_add = 256; p.h = h; p.ld_h = 128; p.z = h; p.ld_z = 128;
-    const int rc = launch_conv<8, ccl::EPI_GATES>(p, reinterpret_cast<hipStream_t>(stream));
+    int rc;
+    if (narrow_tiles((int64_t)B * H * W, 1)) { p.tiles_n = 2; rc = launch_conv<4, ccl::EPI_GATES>(p, reinterpret_cast<hipStream_t>(stream)); }
+    else rc = launch_conv<8, ccl::EPI_GATES>(p, reinterpret_cast<hipStream_t>(stream));
     if (rc != CAMLI_OK) return rc;
     return camli_check_launch(what);
 }
@@ -277,7 +290,9 @@ extern "C" int camli_convcl_gru_blend(const float* rh, const float* x, int CX, c
     p.y = h_new; p.ldy = 128; p.y1 = q; p.ldy1 = 128; p.y2 = q; p.ldy2 = 128;
     p.add = ctx_q; p.ld_add = 128; p.h = h; p.ld_h = 128; p.z = z; p.ld_z = 128;
     p.sanitize = nan_to_num ? 1 : 0;
-    const int rc = launch_conv<4, ccl::EPI_BLEND>(p, reinterpret_cast<hipStream_t>(stream));
+    int rc;
+    if (narrow_tiles((int64_t)B * H * W, 1)) { p.tiles_n = 2; rc = launch_conv<2, ccl::EPI_BLEND>(p, reinterpret_cast<hipStream_t>(stream)); }
+    else rc = launch_conv<4, ccl::EPI_BLEND>(p, reinterpret_cast<hipStream_t>(stream));
     if (rc != CAMLI_OK) return rc;
     return camli_check_launch(what);
 }

@@ -30,12 +30,19 @@ FWD_CASES = [
     (1, 32, 0, 256, 7, 9, 1, 5), (2, 64, 0, 128, 20, 30, 5, 1), (3, 16, 32, 256, 17, 33, 5, 1), (2, 16, 16, 128, 16, 40, 1, 5),
     (1, 128, 128, 256, 17, 30, 1, 5), (1, 128, 128, 128, 17, 30, 5, 1), (2, 48, 0, 384, 5, 140, 3, 3), (1, 16, 0, 128, 9, 9, 5, 5),
     (1, 16, 0, 128, 1, 1, 1, 5),
+    # the product's maps at the per-rank batch of configs[3] (4), KITTI's (1, 47 x 156) and batch 2: half-empty chips -> narrow tiles
+    (4, 16, 16, 256, 68, 120, 1, 5), (1, 32, 0, 256, 47, 156, 5, 1), (2, 16, 0, 128, 68, 120, 1, 5),
 ]
 
 
+@pytest.mark.parametrize('tiles', ['auto', 'wide', 'narrow'])
 @pytest.mark.parametrize('case', FWD_CASES, ids=str)
-def test_convcl_forward_vs_oracle(case, oracle_dense):
+def test_convcl_forward_vs_oracle(case, tiles, oracle_dense, monkeypatch):
+    """``tiles``: the channel tile is chosen by problem size (r6: the narrow one where the pixel tiles alone leave CUs idle --
+    every small case here); CAMLI_CONVCL_TILES forces the wide / narrow kernels onto the same shapes."""
     from camliflow_amd.csrc import fused
+    if tiles != 'auto':
+        monkeypatch.setenv('CAMLI_CONVCL_TILES', tiles)
     b, c0, c1, cout, h, w, kh, kw = case
     rng = np.random.default_rng(sum(case))
     x = rng.standard_normal((b, c0 + c1, h, w), dtype=np.float32)
@@ -121,7 +128,8 @@ def test_gru_half_step_convolution_own_kernels_vs_library(vertical, monkeypatch)
         assert float((a - bb).abs().max()) <= 3e-5 * scale, name
 
 
-def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden):
+@pytest.mark.parametrize('tiles', ['narrow', 'wide'])
+def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden, tiles, monkeypatch):
     """cores/raft2d.GRU2D on the product path (fused._GRU2DStepCL: convolutions with the gate arithmetic in their epilogues, both
     adjoints) against what the REFERENCE's GRU2D recorded at the product's widths -- two updates, the new hidden state, both
     input gradients, fingerprints of all twelve parameter gradients (tests/golden/dense_gru2d_wide.npz from
@@ -131,6 +139,7 @@ def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden):
     from camliflow_amd.cores import runtime
     from camliflow_amd.cores.raft2d import GRU2D
     runtime.set_backend('hip')
+    monkeypatch.setenv('CAMLI_CONVCL_TILES', tiles)      # the gates / blend epilogues on the 256 | 128-channel tiles and on their halves
     g = golden('dense_gru2d_wide')
     gru = hashed_fill_(GRU2D(hidden_dim=128, input_dim=256)).cuda()
     h0 = dev(g['h0']).requires_grad_()

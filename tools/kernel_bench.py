@@ -93,21 +93,23 @@ def cases(batch):
                                                 'camli_allpairs_lookup_fwd': 'hbm', 'camli_allpairs_lookup_bwd': 'hbm'}
 
     # ---- (f)2 GRU2D: one update (both half-steps) on the channels-last matrix-core kernels, forward + backward (r5) ----
+    # (batch 8 = the headline step; batch 4 = configs[3]'s per-rank batch, 47 x 156 = KITTI's batch-1 map: there the pixel tiles
+    # alone leave the chip half empty -- the shapes the r6 tile selection is about)
     from camliflow_amd.cores.raft2d import GRU2D
     gru = GRU2D(hidden_dim=128, input_dim=256).cuda()
-    gh0 = torch.tanh(_randn(g, b, 128, h, w)).requires_grad_(True)
-    gctx = _randn(g, b, 128, h, w)
-    gmot = _randn(g, b, 128, h, w).requires_grad_(True)
-    ggo = _randn(g, b, 128, h, w)
-    gstate = {}
+    for (gb, gh_, gw_) in ([(b, h, w), (4, 68, 120), (1, 47, 156)] if b == 8 else [(b, h, w)]):
+        gh0 = torch.tanh(_randn(g, gb, 128, gh_, gw_)).requires_grad_(True)
+        gctx = _randn(g, gb, 128, gh_, gw_)
+        gmot = _randn(g, gb, 128, gh_, gw_).requires_grad_(True)
+        ggo = _randn(g, gb, 128, gh_, gw_)
 
-    def gru2d():
-        if not gstate:
-            gstate['s'] = gru.prepare(gctx)
-        out = gru.step(gh0, gmot, gstate['s'])
-        torch.autograd.grad(out, [gh0, gmot] + [p_ for p_ in gru.parameters() if p_.dim() == 4], ggo, retain_graph=True, allow_unused=True)
-    yield 'gru2d B%d 68x120' % b, gru2d, {'camli_convcl_gru_gates': 'mfma', 'camli_convcl_gru_blend': 'mfma', 'camli_convcl_fwd': 'mfma',
-                                         'camli_convcl_wrw': 'mfma'}
+        def gru2d(gh0=gh0, gctx=gctx, gmot=gmot, ggo=ggo, gstate={}):
+            if not gstate:
+                gstate['s'] = gru.prepare(gctx)
+            out = gru.step(gh0, gmot, gstate['s'])
+            torch.autograd.grad(out, [gh0, gmot] + [p_ for p_ in gru.parameters() if p_.dim() == 4], ggo, retain_graph=True, allow_unused=True)
+        yield 'gru2d B%d %dx%d' % (gb, gh_, gw_), gru2d, {'camli_convcl_gru_gates': 'mfma', 'camli_convcl_gru_blend': 'mfma',
+                                                        'camli_convcl_fwd': 'mfma', 'camli_convcl_wrw': 'mfma'}
 
     # ---- (f)2 the update block's 3x3 convolutions as Winograd F(2x2,3x3) (csrc/hip/winograd.hip): forward, data gradient,
     # weight gradient per launch of the entry point (three / four kernels each; flop = the transform-domain MFMA work)
