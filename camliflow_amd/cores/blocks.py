@@ -192,6 +192,9 @@ def conv_bias_act(conv, x, act, leave_bias=False):
     if act is None and not leave_bias and fused.conv3x3_co2_supported(conv, x):
         # a flow head's last convolution (wide map -> 2 channels): own HBM-bound kernels, bias included
         return fused.conv3x3_co2(x, conv.weight, conv.bias)
+    if not leave_bias and fused.wino_epilogue_ok(conv, x, act):
+        # r6: bias + activation on the Winograd output transform, the ReLU adjoint on the backward's input transforms
+        return fused.wino_conv_cat(x, conv, act)
     if _is_pointwise(conv) and x.dtype == torch.float32 and (x.is_contiguous() or _is_nhwc(x)):
         y = _PointwiseConv.apply(x, conv.weight)
     elif fused.wino_supported(conv, x):

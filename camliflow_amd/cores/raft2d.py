@@ -233,12 +233,19 @@ class MotionEncoder2D(nn.Module):
     def forward(self, flow, corr, flow_branch=None):
         if epilogue_ok(corr) and self._cat_free(flow) and (flow_branch is None or (len(flow_branch) > 2 and flow_branch[2])):
             from ..csrc import fused
-            c_raw = conv_bias_act(self.conv_c2, conv_bias_act(self.conv_c1, corr, 'relu'), None, leave_bias=True)
+            c1 = conv_bias_act(self.conv_c1, corr, 'relu')
+            wino = fused.wino_epilogue_ok(self.conv_c2, c1, 'relu')
+            c_raw = None if wino else conv_bias_act(self.conv_c2, c1, None, leave_bias=True)
             if flow_branch is not None:
                 branch, f_raw = flow_branch[0], flow_branch[1]
                 branch.join(f_raw)
             else:
                 f_raw = conv_bias_act(self.conv_f2, conv_bias_act(self.conv_f1, flow, 'relu'), None, leave_bias=True)
+            if wino:
+                # r6: conv_c2 / conv as Winograd convolutions whose output transform writes bias + ReLU (+ nan_to_num) straight
+                # into the concatenations (fused.wino_conv_cat): no pass over their outputs, forward or backward
+                x = fused.wino_conv_cat(c1, self.conv_c2, 'relu', others=[(f_raw, self.conv_f2.bias, 'relu')])
+                return fused.wino_conv_cat(x, self.conv, 'relu_nan_to_num', tail=flow)
             x = fused.bias_act_cat([(c_raw, self.conv_c2.bias, 'relu'), (f_raw, self.conv_f2.bias, 'relu')])
             joint_raw = conv_bias_act(self.conv, x, None, leave_bias=True)
             # relu + nan_to_num (bias_act code 5) and the flow channels appended, in the pass that writes the motion features

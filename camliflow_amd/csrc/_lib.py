@@ -144,7 +144,7 @@ PROTOTYPES = {
                                   ctypes.c_int64, _c_float_p, ctypes.c_int64] + [_int] * 7 + [_stream]),
     "camli_wino_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 5),
     "camli_wino_wrw": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int64, _c_float_p, _c_float_p,
-                              ctypes.c_int64] + [_int] * 6 + [_stream]),
+                              _c_float_p, ctypes.c_int64] + [_int] * 7 + [_stream]),
     "camli_conv3x3_co2_fwd": (_int, [_c_float_p] * 4 + [_int] * 4 + [_stream]),
     "camli_conv3x3_co2_bwd_data": (_int, [_c_float_p] * 3 + [_int] * 4 + [_stream]),
     "camli_conv3x3_co2_bwd_weight_workspace_bytes": (ctypes.c_longlong, [_int, _int, _int]),

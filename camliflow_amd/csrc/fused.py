@@ -2519,14 +2519,15 @@ def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, m
     with _on_device(x):
         _lib.launch('camli_wino_conv3x3', lib.camli_wino_conv3x3, x.data_ptr(), xbs, mask.data_ptr() if mask is not None else None, mbs,
                     u.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ybs, ws.data_ptr(), need, b, c,
-                    n_out, hh, ww, 1 if act == 'relu' else 0, int(bool(accumulate)), _stream_ptr(x),
+                    n_out, hh, ww, {None: 0, 'relu': 1, 'relu_nan_to_num': 2}[act], int(bool(accumulate)), _stream_ptr(x),
                     work=(4.0 * b * hh * ww * (c + n_out) + 2 * need, 'B'), flop=2.0 * 16 * tiles * c * n_out)
     return out
 
 
-def wino_wrw(x, gy, mask=None, out=None):
+def wino_wrw(x, gy, mask=None, out=None, gbias=None, gbias_accumulate=False):
     """Weight gradient [N,C,3,3] of conv3x3(x) for the output gradient gy [B,N,H,W], contracted in the Winograd domain
-    (camli_wino_wrw); ``mask``: gy reads as zero where mask <= 0; ``out``: add into this tensor instead of creating one."""
+    (camli_wino_wrw); ``mask``: gy reads as zero where mask <= 0; ``out``: add into this tensor instead of creating one;
+    ``gbias`` [N]: also write (or, ``gbias_accumulate``, add) the bias gradient = the per-channel sum of the masked gy."""
     _require_cuda('wino_wrw', x, gy)
     lib = _lib.load()
     b, c, hh, ww = x.shape
@@ -2551,7 +2552,8 @@ def wino_wrw(x, gy, mask=None, out=None):
     tiles = b * ((hh + 1) // 2) * (((ww + 1) // 2 + 3) // 4 * 4)
     with _on_device(x):
         _lib.launch('camli_wino_wrw', lib.camli_wino_wrw, x.data_ptr(), xbs, gy.data_ptr(), gbs, mask.data_ptr() if mask is not None else None,
-                    mbs, gw.data_ptr(), ws.data_ptr(), need, b, c, n, hh, ww, int(out is not None), _stream_ptr(x),
+                    mbs, gw.data_ptr(), gbias.data_ptr() if gbias is not None else None, ws.data_ptr(), need, b, c, n, hh, ww,
+                    int(out is not None), int(bool(gbias_accumulate)), _stream_ptr(x),
                     work=(4.0 * b * hh * ww * (c + n) + 2.0 * 64 * tiles * (c + n), 'B'), flop=2.0 * 16 * tiles * c * n)
     return gw
 
@@ -2586,6 +2588,136 @@ class _Conv3x3Wino(torch.autograd.Function):
 
 def conv3x3_wino(x, weight):
     return _Conv3x3Wino.apply(x, weight)
+
+
+class _WinoConvCat(torch.autograd.Function):
+    """cat([act(conv3x3(x, w) + bias), act_i(raw_i + bias_i) ..., (tail)], dim=1) as ONE node: the Winograd output transform
+    adds the bias, applies the activation and writes its channels straight into the concatenation; the other parts (fresh
+    convolution outputs of other kernels) are written by their epilogue kernel as in _BiasActCat.  In the adjoint the ReLU mask
+    (the saved output > 0) rides on the loads of the two transforms of the output gradient -- no masked copy of it exists --
+    and the bias gradient comes out of the transform-domain plane that holds the tile sums.  act: None | 'relu' |
+    'relu_nan_to_num'.  args = (x, w, bias, raw_0, bias_0, ..., [tail])."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, act, other_acts, has_tail, x, w, bias, *rest):
+        lib = _lib.load()
+        k = len(other_acts)
+        raws = [rest[2 * i].contiguous() for i in range(k)]
+        biases = [rest[2 * i + 1] for i in range(k)]
+        tail = rest[2 * k] if has_tail else None
+        b, _, hh, ww = x.shape
+        p = hh * ww
+        n = w.shape[0]
+        chans = [r.shape[1] for r in raws]
+        total = n + sum(chans) + (tail.shape[1] if has_tail else 0)
+        out = torch.empty((b, total, hh, ww), dtype=torch.float32, device=x.device)
+        wino_conv3x3(x, wino_transformed_weights(w, False), n, bias=bias, act=act, out=out[:, :n])
+        masks, c0 = [], n
+        with _on_device(out):
+            for raw, ob, oact, c in zip(raws, biases, other_acts, chans):
+                mask = None
+                if oact != 0:
+                    assert oact in (1, 2, 5) and p % 4 == 0, 'wino_conv_cat: relu-type parts on planes of 4k elements'
+                    mask = torch.empty(lib.camli_bias_act_mask_bytes(b, c, p) // 8, dtype=torch.int64, device=x.device)
+                _lib.launch('camli_bias_act_fwd', lib.camli_bias_act_into_fwd, raw.data_ptr(), ob.data_ptr(),
+                            mask.data_ptr() if mask is not None else None, out.data_ptr() + 4 * c0 * p, total * p, b, c, p, oact,
+                            _stream_ptr(x), work=(8.0 * b * c * p + (b * c * p / 8.0 if mask is not None else 0.0), 'B'))
+                masks.append(mask)
+                c0 += c
+            if tail is not None:
+                out[:, c0:].copy_(tail)
+        ctx.save_for_backward(x, w, out, *[m for m in masks if m is not None])
+        ctx.has_mask = [m is not None for m in masks]
+        ctx.act, ctx.other_acts, ctx.chans, ctx.has_tail = act, list(other_acts), chans, has_tail
+        ctx.w_param, ctx.b_param = _runtime.deferral_target(w), _runtime.deferral_target(bias)
+        ctx.bias_params = [_runtime.deferral_target(ob) for ob in biases]
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, gout):
+        lib = _lib.load()
+        x, w, out = ctx.saved_tensors[:3]
+        saved = list(ctx.saved_tensors[3:])
+        b, total, hh, ww = out.shape
+        p = hh * ww
+        n, cin = w.shape[0], w.shape[1]
+        gout = gout.float()
+        if _batch_strided(gout) != total * p:
+            gout = gout.contiguous()
+        gs = gout[:, :n]
+        ymask = out[:, :n] if ctx.act is not None else None
+        gx = gw = gb = None
+        if ctx.needs_input_grad[3]:
+            gx = wino_conv3x3(gs, wino_transformed_weights(w, True), cin, mask=ymask)
+        # iteration-shared parameters accumulate in their per-pass buffers (runtime.PARAM_GRADS) and reach .grad once
+        acc_w = _runtime.PARAM_GRADS.slot(ctx.w_param, lambda: torch.zeros_like(w), False) if ctx.w_param is not None else None
+        acc_b = _runtime.PARAM_GRADS.slot(ctx.b_param, lambda: _zero_slice(n, gout), False) if ctx.b_param is not None else None
+        need_w = ctx.needs_input_grad[4] or acc_w is not None
+        need_b = ctx.needs_input_grad[5] or acc_b is not None
+        if need_w or need_b:
+            if need_b and acc_b is None:
+                gb = torch.empty(n, dtype=torch.float32, device=gout.device)
+            if _WINO_WRW:
+                gw = wino_wrw(x, gs, mask=ymask, out=acc_w, gbias=(acc_b if acc_b is not None else gb) if need_b else None,
+                              gbias_accumulate=acc_b is not None)
+                if acc_w is not None:
+                    gw = None
+            else:
+                gm = (gs if ymask is None else gs * (ymask > 0)).contiguous()
+                gw = torch.ops.aten.convolution_backward(gm, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+                if acc_w is not None:
+                    acc_w.add_(gw)
+                    gw = None
+                if need_b:
+                    if acc_b is not None:
+                        acc_b.add_(gm.sum((0, 2, 3)))
+                    else:
+                        gb = gm.sum((0, 2, 3))
+        grads, c0 = [], n
+        with _on_device(gout):
+            for i, (oact, c) in enumerate(zip(ctx.other_acts, ctx.chans)):
+                mask = saved.pop(0) if ctx.has_mask[i] else None
+                identity = oact == 0
+                deferred = ctx.bias_params[i] is not None
+                need_bias = deferred or ctx.needs_input_grad[6 + 2 * i + 1]
+                g_raw = gout[:, c0:c0 + c] if identity else torch.empty((b, c, hh, ww), dtype=torch.float32, device=gout.device)
+                gbias = None
+                if not identity or need_bias:
+                    gbias = (_runtime.PARAM_GRADS.slot(ctx.bias_params[i], lambda c=c: _zero_slice(c, gout), False) if deferred
+                             else _zero_slice(c, gout))
+                    _lib.launch('camli_bias_act_bwd', lib.camli_bias_act_bwd_strided, gout.data_ptr() + 4 * c0 * p, total * p, None,
+                                mask.data_ptr() if mask is not None else None, None if identity else g_raw.data_ptr(), gbias.data_ptr(),
+                                b, c, p, oact, _stream_ptr(gout), work=((4.0 if identity else 8.125) * b * c * p, 'B'))
+                grads += [g_raw, None if (deferred or not need_bias) else gbias]
+                c0 += c
+        if ctx.has_tail:
+            grads.append(gout[:, c0:])
+        return (None, None, None, gx, gw, gb, *grads)
+
+
+def wino_conv_cat(x, conv, act, others=(), tail=None):
+    """cat([act(conv(x)), act_i(raw_i + bias_i) for (raw_i, bias_i, act_i) in others, tail], dim=1) for a convolution that
+    ``wino_supported`` accepts: bias, activation and the concatenation ride on the Winograd output transform (no pass over the
+    convolution output), the ReLU adjoint on the input transforms of the backward."""
+    _require_cuda('wino_conv_cat', x)
+    assert act in (None, 'relu', 'relu_nan_to_num')
+    flat = []
+    for raw, ob, _ in others:
+        flat += [raw.float(), ob.float()]
+    if tail is not None:
+        flat.append(tail.float())
+    bias = conv.bias if conv.bias is not None else torch.zeros(conv.out_channels, dtype=torch.float32, device=x.device)
+    return _WinoConvCat.apply(act, tuple(ACT_CODES[a] for _, _, a in others), tail is not None, x, conv.weight, bias, *flat)
+
+
+# CAMLI_WINO_EPILOGUE=0: bias / activation / concatenation of the Winograd convolutions as separate epilogue passes (A/B)
+_WINO_EPILOGUE = os.environ.get('CAMLI_WINO_EPILOGUE', '1') != '0'
+
+
+def wino_epilogue_ok(conv, x, act):
+    return _WINO_EPILOGUE and act in (None, 'relu', 'relu_nan_to_num') and wino_supported(conv, x)
 
 
 # ------------------------------------------------------------------------------------------------

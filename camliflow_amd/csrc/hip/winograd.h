@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const float* __res
 
 // ---- output: y[b][n][2 ty + i][2 tx + j] = (A^T m A)[i][j] (+ bias[n]) (ReLU) (+= y), m = Mo[.][n][tile] as 4 x 4
 // Mo [16][Mp][NT]; y: channel n of image b at y + b * syb + n * syc.  ACT: 0 none, 1 ReLU.  One thread: channel n, 4 tiles.
-enum { OUT_PLAIN = 0, OUT_RELU = 1 };
+// OUT_RELU_FINITE: ReLU, then torch.nan_to_num (models/raft_core.py:163-164): NaN -> 0 (fmaxf drops it), +inf -> FLT_MAX
+enum { OUT_PLAIN = 0, OUT_RELU = 1, OUT_RELU_FINITE = 2 };
 template <bool VEC>
 __global__ __launch_bounds__(256) void output_transform_kernel(const float* __restrict__ Mo, int Mp, const float* __restrict__ bias,
                                                               float* __restrict__ y, int64_t syb, int64_t syc, int act,
@@ -233,9 +234,13 @@ __global__ __launch_bounds__(256) void output_transform_kernel(const float* __re
         if (VEC && col0 + 8 <= g.W) {
             f32x4 lo = {px[0], px[1], px[2], px[3]}, hi = {px[4], px[5], px[6], px[7]};
             if (accumulate) { lo += *reinterpret_cast<const f32x4*>(yr); hi += *reinterpret_cast<const f32x4*>(yr + 4); }
-            if (act == OUT_RELU) {
+            if (act != OUT_PLAIN) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
+            }
+            if (act == OUT_RELU_FINITE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { lo[e] = fminf(lo[e], 3.402823466e+38f); hi[e] = fminf(hi[e], 3.402823466e+38f); }
             }
             *reinterpret_cast<f32x4*>(yr) = lo;
             *reinterpret_cast<f32x4*>(yr + 4) = hi;
@@ -245,7 +250,8 @@ __global__ __launch_bounds__(256) void output_transform_kernel(const float* __re
                 if (col0 + e < g.W) {
                     float v = px[e];
                     if (accumulate) v += yr[e];
-                    if (act == OUT_RELU) v = fmaxf(v, 0.f);
+                    if (act != OUT_PLAIN) v = fmaxf(v, 0.f);
+                    if (act == OUT_RELU_FINITE) v = fminf(v, 3.402823466e+38f);
                     yr[e] = v;
                 }
         }
@@ -319,6 +325,23 @@ __global__ __launch_bounds__(256) void grad_transform_kernel(const float* __rest
         *reinterpret_cast<f32x4*>(gM + slot.at(4 * a + 2, rows, g.NT)) = v2;
         *reinterpret_cast<f32x4*>(gM + slot.at(4 * a + 3, rows, g.NT)) = v3;
     }
+}
+
+// ---- gbias[n] (= | +=) sum over every pixel of the (masked) output gradient = the row sum of plane 5 of gM: (A g A^T)[1][1]
+// is g00 + g01 + g10 + g11 of the tile.  gM chunk-major [16][NT / 16][rows][16].  One block per channel, fixed summation tree.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ gM, int rows, int NT, float* __restrict__ gbias, int accumulate) {
+    __shared__ float part[256];
+    const int n = blockIdx.x;
+    const float* q = gM + (size_t)5 * rows * NT + (size_t)n * 16;
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < NT; k += 256) acc += q[(size_t)(k >> 4) * rows * 16 + (k & 15)];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gbias[n] = accumulate ? gbias[n] + part[0] : part[0];
 }
 
 // ---- gw[n][c][i][j] (= | +=) sum_{a,b} G[a][i] G[b][j] * sum_s part[s][4 a + b][.]: element (c, n) of a part at

@@ -84,8 +84,8 @@ extern "C" int camli_wino_conv3x3(const float* x, int64_t x_bs, const float* mas
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_wino_conv3x3";
     if (!x || !U || !y || !workspace) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
-    if (B < 0 || H < 1 || W < 1 || C <= (NBUF - 1) * KS || N < 4 || (act != wino::OUT_PLAIN && act != wino::OUT_RELU)) {
-        camli_set_error("%s: unsupported shape B=%d C=%d N=%d %dx%d act=%d (more than %d input channels; act 0 | 1)", what, B, C, N, H, W, act,
+    if (B < 0 || H < 1 || W < 1 || C <= (NBUF - 1) * KS || N < 4 || act < wino::OUT_PLAIN || act > wino::OUT_RELU_FINITE) {
+        camli_set_error("%s: unsupported shape B=%d C=%d N=%d %dx%d act=%d (more than %d input channels; act 0 | 1 | 2)", what, B, C, N, H, W, act,
                         (NBUF - 1) * KS);
         return CAMLI_ENOTSUP;
     }
@@ -189,9 +189,10 @@ extern "C" int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, in
 
 // gw [N][C][3][3] (= | +=) the weight gradient of y = conv3x3(x) for the output gradient gy (gy_mask optional: gy reads as
 // zero where gy_mask <= 0).  x [B][C][H][W] (image stride x_bs), gy / gy_mask [B][N][H][W] (image strides gy_bs / mask_bs).
+// gbias [N] (optional) (= | +=, gbias_accumulate) the bias gradient = the sum of the (masked) output gradient per channel.
 extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, const float* gy_mask, int64_t mask_bs,
-                              float* gw, float* workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int accumulate,
-                              void* stream) {
+                              float* gw, float* gbias, float* workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W,
+                              int accumulate, int gbias_accumulate, void* stream) {
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_wino_wrw";
     if (!x || !gy || !gw || !workspace) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
@@ -224,6 +225,7 @@ extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int
         if (vec) hipLaunchKernelGGL((wino::grad_transform_kernel<true, true>), grid, block, 0, s, gy, gy_bs, plane, gy_mask, mask_bs, plane, gM, N, pl.g_rows, g);
         else hipLaunchKernelGGL((wino::grad_transform_kernel<false, true>), grid, block, 0, s, gy, gy_bs, plane, gy_mask, mask_bs, plane, gM, N, pl.g_rows, g);
     }
+    if (gbias) hipLaunchKernelGGL(wino::bias_grad_kernel, dim3(N), block, 0, s, gM, pl.g_rows, g.NT, gbias, gbias_accumulate ? 1 : 0);
     wino::WrwBatch wb;
     ccl::Problem& p = wb.base;
     p.x = p.x1 = pl.swap ? gM : V;

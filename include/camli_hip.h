@@ -627,13 +627,16 @@ int camli_convcl_wrw(const float *x0, int ldx0, int C0, const float *x1, int ldx
  *     Kp = K rounded up to a multiple of 16, Mp = M to a multiple of 4 (zeros beyond); camli_wino_weight_floats(K, M) = 16 Kp Mp.
  *   camli_wino_conv3x3: image b of x at x + b * x_bs (C dense H x W planes: a channel slice of a wider NCHW tensor is fine), of y
  *     at y + b * y_bs (N planes); mask (optional, x's geometry, image stride mask_bs): x reads as zero where mask <= 0 (the ReLU
- *     adjoint on the way in); bias optional; act 0 none | 1 ReLU; accumulate: y += (before act).  C > 32, N >= 4; workspace =
+ *     adjoint on the way in); bias optional; act 0 none | 1 ReLU | 2 ReLU then nan_to_num (raft_core.py:163-164); accumulate:
+ *     y += (before act).  C > 32, N >= 4; workspace =
  *     camli_wino_workspace_bytes(B, C, N, H, W) bytes (V and the transform-domain output: 4 x the input + 4 x the output),
  *     16-byte aligned.  Differs from the direct fp32 form by its rounding only (tests/test_winograd_gpu.py states the bound).
  *   camli_wino_wrw: WEIGHT GRADIENT in the transform domain: gU[t][c][n] = sum_tiles V[t][c][tile] * (A gy A^T)[t][n][tile], then
  *     gw [N][C][3][3] (= | +=) G^T gU G -- the same 2.25 x fewer multiplications as the forward.  x [B][C][H][W] (image stride
  *     x_bs), gy [B][N][H][W] (image stride gy_bs); gy_mask optional (gy's geometry, image stride mask_bs): gy reads as zero where
- *     gy_mask <= 0.  workspace = camli_wino_wrw_workspace_bytes(B, C, N, H, W) bytes (0 = unsupported shape).  The contraction
+ *     gy_mask <= 0.  gbias [N] (optional) (= | +=, gbias_accumulate) the bias gradient: the per-channel sum of the masked
+ *     gy, taken from the transform-domain plane that holds the tile sums.  workspace = camli_wino_wrw_workspace_bytes(B, C, N,
+ *     H, W) bytes (0 = unsupported shape).  The contraction
  *     over the tiles is split over the CUs, the parts are summed in a fixed order: deterministic, no atomics.
  */
 int64_t camli_wino_weight_floats(int K, int M);
@@ -644,7 +647,8 @@ int camli_wino_conv3x3(const float *x, int64_t x_bs, const float *mask, int64_t 
                        int accumulate, void *stream);
 int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, int W);
 int camli_wino_wrw(const float *x, int64_t x_bs, const float *gy, int64_t gy_bs, const float *gy_mask, int64_t mask_bs, float *gw,
-                   float *workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int accumulate, void *stream);
+                   float *gbias, float *workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int accumulate,
+                   int gbias_accumulate, void *stream);
 int camli_conv3x3_co2_bwd_data(const float *gy, const float *w, float *gx, int B, int Cin, int H, int W, void *stream);
 long long camli_conv3x3_co2_bwd_weight_workspace_bytes(int B, int Cin, int W);
 int camli_conv3x3_co2_bwd_weight(const float *gy, const float *x, float *workspace, float *gw, float *gb, int accumulate,

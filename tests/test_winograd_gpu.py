@@ -208,3 +208,48 @@ def test_update_block_modules_vs_reference_golden(golden):
             fp = np.array([float(p_.grad.double().norm()), float((p_.grad.double().cpu() * d.double()).sum())])
             want = g['fp_' + prefix + name]
             assert abs(fp[0] - want[0]) <= 1e-4 * want[0] and abs(fp[1] - want[1]) <= 2e-4 * want[0], (prefix + name, fp, want)
+
+
+@pytest.mark.parametrize('act', [None, 'relu', 'relu_nan_to_num'])
+@pytest.mark.parametrize('deferred', [False, True])
+def test_wino_conv_cat_node_vs_oracle(act, deferred, oracle_dense):
+    """fused.wino_conv_cat: act(conv3x3(x) + bias) | act(raw + bias2) | tail as one node -- output, every gradient (input,
+    weight, both biases, the raw part, the tail) against the numpy oracle composed with the activation's adjoint; with and
+    without the per-pass parameter accumulators (runtime.PARAM_GRADS)."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.csrc import fused
+    rng = np.random.default_rng(17)
+    b, cin, cout, c2, h, w = 2, 96, 128, 24, 6, 10
+    x = rng.standard_normal((b, cin, h, w), dtype=np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * (9 * cin) ** -0.5).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32) * 0.3
+    raw = rng.standard_normal((b, c2, h, w), dtype=np.float32)
+    bias2 = rng.standard_normal(c2).astype(np.float32) * 0.3
+    tail = rng.standard_normal((b, 2, h, w), dtype=np.float32)
+    gout = rng.standard_normal((b, cout + c2 + 2, h, w), dtype=np.float32)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(dev(wt))
+        conv.bias.copy_(dev(bias))
+    bias2_p = torch.nn.Parameter(dev(bias2))
+    x_d, raw_d, tail_d = dev(x).requires_grad_(), dev(raw).requires_grad_(), dev(tail).requires_grad_()
+    runtime.set_deferred_param_grads(deferred)
+    try:
+        out = fused.wino_conv_cat(x_d, conv, act, others=[(raw_d, bias2_p, 'relu')], tail=tail_d)
+        out.backward(dev(gout))
+    finally:
+        runtime.set_deferred_param_grads(False)
+    pre = oracle_dense.conv_taps_fwd(x, wt, (1, 1)) + bias[None, :, None, None]
+    want_a = pre if act is None else np.maximum(pre, 0)
+    want_b = np.maximum(raw + bias2[None, :, None, None], 0)
+    _close(out, np.concatenate([want_a, want_b, tail], axis=1), what='output')
+    g_a = gout[:, :cout] * (1.0 if act is None else (pre > 0))
+    g_a = g_a.astype(np.float32)
+    want_gx, want_gw = oracle_dense.conv_taps_bwd(g_a, x, wt, (1, 1))
+    _close(x_d.grad, want_gx, what='input gradient')
+    _close(conv.weight.grad, want_gw, tol=5e-5, what='weight gradient')
+    _close(conv.bias.grad, g_a.sum((0, 2, 3)), tol=5e-5, what='bias gradient')
+    g_b = gout[:, cout:cout + c2] * (raw + bias2[None, :, None, None] > 0)
+    _close(raw_d.grad, g_b.astype(np.float32), what='gradient of the raw part')
+    _close(bias2_p.grad, g_b.sum((0, 2, 3)).astype(np.float32), tol=5e-5, what='bias gradient of the raw part')
+    _close(tail_d.grad, gout[:, cout + c2:], what='gradient of the tail')

@@ -86,6 +86,27 @@ pmcv)
   python $ROOT/tools/pmc_summary.py $OUT/pmc_valu/p_counter_collection.csv > $OUT/pmc_kernel_bench_valu.txt 2>&1
   rm -rf $OUT/pmc_valu
   ;;
+pmcw)
+  canary || continue
+  # r6: the Winograd convolution family over tools/kernel_bench.py --only wino (three shapes, forward + both adjoints): HBM
+  # traffic (separate FETCH / WRITE passes), matrix-pipe busy, and the traffic per launch of the two entry points
+  RXW='wino::|gemm_w128_kernel|wrw_planes'
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "$RXW" --output-format csv -d $OUT/pmcw_$c -o p -- \
+        python $ROOT/tools/kernel_bench.py --reps 2 --only wino > /dev/null 2>&1
+    python $ROOT/tools/pmc_summary.py $OUT/pmcw_$c/p_counter_collection.csv > $OUT/pmc_wino_$c.txt 2>&1
+  done
+  python $ROOT/tools/pmc_traffic.py $OUT/pmcw_FETCH_SIZE/p_counter_collection.csv $OUT/pmcw_WRITE_SIZE/p_counter_collection.csv \
+      'input_transform_kernel<true, false>+gemm_w128_kernel+output_transform_kernel' camli_wino_conv3x3 > $OUT/traffic_wino_conv3x3.json 2>&1
+  python $ROOT/tools/pmc_traffic.py $OUT/pmcw_FETCH_SIZE/p_counter_collection.csv $OUT/pmcw_WRITE_SIZE/p_counter_collection.csv \
+      'wrw_planes_kernel+input_transform_kernel<true, true>+grad_transform_kernel+wrw_reduce_kernel' camli_wino_wrw > $OUT/traffic_wino_wrw.json 2>&1
+  rm -rf $OUT/pmcw_FETCH_SIZE $OUT/pmcw_WRITE_SIZE
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace \
+      --kernel-include-regex 'gemm_w128_kernel|wrw_planes' --output-format csv -d $OUT/pmcw_mfma -o p -- \
+      python $ROOT/tools/kernel_bench.py --reps 2 --only wino > /dev/null 2>&1
+  python $ROOT/tools/pmc_summary.py $OUT/pmcw_mfma/p_counter_collection.csv > $OUT/pmc_wino_mfma.txt 2>&1
+  rm -rf $OUT/pmcw_mfma
+  ;;
 pmcb)
   canary || continue
   for c in FETCH_SIZE WRITE_SIZE; do
