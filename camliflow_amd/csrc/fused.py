@@ -2489,10 +2489,27 @@ def _image_stride(t):
     return bs if bs >= inner else None
 
 
-def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, mask=None):
+def wino_mask_bits(b, c, hh, ww, device):
+    """An (uninitialised) activation-bit tensor for a [b,c,hh,ww] map: [b, c, hh, ceil(ww / 8)] bytes, bit j of byte s = pixel
+    8 s + j (camli_wino_mask_bytes)."""
+    return torch.empty((b, c, hh, (ww + 7) // 8), dtype=torch.uint8, device=device)
+
+
+def wino_pack_bits(mask):
+    """bool / 0-1 tensor [B,C,H,W] -> activation bits in the kernels' format (tests; the product's bits come from the output
+    transform)."""
+    b, c, hh, ww = mask.shape
+    pad = (-ww) % 8
+    m = torch.nn.functional.pad(mask.to(torch.uint8), (0, pad)).view(b, c, hh, -1, 8)
+    weights = (2 ** torch.arange(8, device=mask.device)).to(torch.uint8)
+    return (m * weights).sum(-1).to(torch.uint8).contiguous()
+
+
+def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, bits=None, bits_out=None):
     """act(conv3x3(x) + bias) for pre-transformed weights u (wino_transformed_weights).  x [B,C,H,W] fp32, dense or a channel
-    slice of a dense NCHW tensor; ``mask``: x reads as zero where mask <= 0; ``out``: an existing [B,n_out,H,W] tensor (or
-    channel slice), ``accumulate``: add into it."""
+    slice of a dense NCHW tensor; ``bits``: activation bits of x (wino_mask_bits geometry), x reads as zero where its bit is
+    clear; ``out``: an existing [B,n_out,H,W] tensor (or channel slice), ``accumulate``: add into it; ``bits_out``: receives the
+    activation bits of the output (act 'relu' / 'relu_nan_to_num')."""
     _require_cuda('wino_conv3x3', x, u)
     lib = _lib.load()
     b, c, hh, ww = x.shape
@@ -2500,13 +2517,10 @@ def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, m
     if xbs is None:
         x = x.contiguous()
         xbs = c * hh * ww
-    mbs = 0
-    if mask is not None:
-        assert mask.shape == x.shape
-        mbs = _image_stride(mask)
-        if mbs is None:
-            mask = mask.contiguous()
-            mbs = c * hh * ww
+    w8 = (ww + 7) // 8
+    assert bits is None or (bits.dtype == torch.uint8 and bits.shape == (b, c, hh, w8) and bits.is_contiguous())
+    assert bits_out is None or (act is not None and bits_out.dtype == torch.uint8 and bits_out.shape == (b, n_out, hh, w8)
+                                and bits_out.is_contiguous())
     if out is None:
         assert not accumulate
         out = torch.empty((b, n_out, hh, ww), dtype=torch.float32, device=x.device)
@@ -2517,17 +2531,19 @@ def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, m
     ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
     tiles = need // (64 * ((c + 15) // 16 * 16 + (n_out + 3) // 4 * 4))
     with _on_device(x):
-        _lib.launch('camli_wino_conv3x3', lib.camli_wino_conv3x3, x.data_ptr(), xbs, mask.data_ptr() if mask is not None else None, mbs,
-                    u.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ybs, ws.data_ptr(), need, b, c,
+        _lib.launch('camli_wino_conv3x3', lib.camli_wino_conv3x3, x.data_ptr(), xbs, bits.data_ptr() if bits is not None else None,
+                    u.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ybs,
+                    bits_out.data_ptr() if bits_out is not None else None, ws.data_ptr(), need, b, c,
                     n_out, hh, ww, {None: 0, 'relu': 1, 'relu_nan_to_num': 2}[act], int(bool(accumulate)), _stream_ptr(x),
                     work=(4.0 * b * hh * ww * (c + n_out) + 2 * need, 'B'), flop=2.0 * 16 * tiles * c * n_out)
     return out
 
 
-def wino_wrw(x, gy, mask=None, out=None, gbias=None, gbias_accumulate=False):
+def wino_wrw(x, gy, bits=None, out=None, gbias=None, gbias_accumulate=False):
     """Weight gradient [N,C,3,3] of conv3x3(x) for the output gradient gy [B,N,H,W], contracted in the Winograd domain
-    (camli_wino_wrw); ``mask``: gy reads as zero where mask <= 0; ``out``: add into this tensor instead of creating one;
-    ``gbias`` [N]: also write (or, ``gbias_accumulate``, add) the bias gradient = the per-channel sum of the masked gy."""
+    (camli_wino_wrw); ``bits``: the forward's activation bits, gy reads as zero where its bit is clear; ``out``: add into this
+    tensor instead of creating one; ``gbias`` [N]: also write (or, ``gbias_accumulate``, add) the bias gradient = the
+    per-channel sum of the masked gy."""
     _require_cuda('wino_wrw', x, gy)
     lib = _lib.load()
     b, c, hh, ww = x.shape
@@ -2538,11 +2554,7 @@ def wino_wrw(x, gy, mask=None, out=None, gbias=None, gbias_accumulate=False):
         x, xbs = x.contiguous(), c * hh * ww
     if gbs is None:
         gy, gbs = gy.contiguous(), n * hh * ww
-    mbs = 0
-    if mask is not None:
-        mbs = _image_stride(mask)
-        if mbs is None:
-            mask, mbs = mask.contiguous(), n * hh * ww
+    assert bits is None or (bits.dtype == torch.uint8 and bits.shape == (b, n, hh, (ww + 7) // 8) and bits.is_contiguous())
     need = lib.camli_wino_wrw_workspace_bytes(b, c, n, hh, ww)
     if need <= 0:
         raise _lib.CamliHipError('wino_wrw: unsupported shape B=%d C=%d N=%d %dx%d' % (b, c, n, hh, ww))
@@ -2551,8 +2563,8 @@ def wino_wrw(x, gy, mask=None, out=None, gbias=None, gbias_accumulate=False):
     assert gw.shape == (n, c, 3, 3) and gw.is_contiguous() and gw.dtype == torch.float32
     tiles = b * ((hh + 1) // 2) * (((ww + 1) // 2 + 3) // 4 * 4)
     with _on_device(x):
-        _lib.launch('camli_wino_wrw', lib.camli_wino_wrw, x.data_ptr(), xbs, gy.data_ptr(), gbs, mask.data_ptr() if mask is not None else None,
-                    mbs, gw.data_ptr(), gbias.data_ptr() if gbias is not None else None, ws.data_ptr(), need, b, c, n, hh, ww,
+        _lib.launch('camli_wino_wrw', lib.camli_wino_wrw, x.data_ptr(), xbs, gy.data_ptr(), gbs, bits.data_ptr() if bits is not None else None,
+                    gw.data_ptr(), gbias.data_ptr() if gbias is not None else None, ws.data_ptr(), need, b, c, n, hh, ww,
                     int(out is not None), int(bool(gbias_accumulate)), _stream_ptr(x),
                     work=(4.0 * b * hh * ww * (c + n) + 2.0 * 64 * tiles * (c + n), 'B'), flop=2.0 * 16 * tiles * c * n)
     return gw
@@ -2612,7 +2624,9 @@ class _WinoConvCat(torch.autograd.Function):
         chans = [r.shape[1] for r in raws]
         total = n + sum(chans) + (tail.shape[1] if has_tail else 0)
         out = torch.empty((b, total, hh, ww), dtype=torch.float32, device=x.device)
-        wino_conv3x3(x, wino_transformed_weights(w, False), n, bias=bias, act=act, out=out[:, :n])
+        need_bits = act is not None and any(ctx.needs_input_grad[3:6])
+        bits = wino_mask_bits(b, n, hh, ww, x.device) if need_bits else None
+        wino_conv3x3(x, wino_transformed_weights(w, False), n, bias=bias, act=act, out=out[:, :n], bits_out=bits)
         masks, c0 = [], n
         with _on_device(out):
             for raw, ob, oact, c in zip(raws, biases, other_acts, chans):
@@ -2627,7 +2641,8 @@ class _WinoConvCat(torch.autograd.Function):
                 c0 += c
             if tail is not None:
                 out[:, c0:].copy_(tail)
-        ctx.save_for_backward(x, w, out, *[m for m in masks if m is not None])
+        ctx.save_for_backward(x, w, bits, *[m for m in masks if m is not None])
+        ctx.dims = (b, total, hh, ww)
         ctx.has_mask = [m is not None for m in masks]
         ctx.act, ctx.other_acts, ctx.chans, ctx.has_tail = act, list(other_acts), chans, has_tail
         ctx.w_param, ctx.b_param = _runtime.deferral_target(w), _runtime.deferral_target(bias)
@@ -2638,19 +2653,18 @@ class _WinoConvCat(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, gout):
         lib = _lib.load()
-        x, w, out = ctx.saved_tensors[:3]
+        x, w, bits = ctx.saved_tensors[:3]
         saved = list(ctx.saved_tensors[3:])
-        b, total, hh, ww = out.shape
+        b, total, hh, ww = ctx.dims
         p = hh * ww
         n, cin = w.shape[0], w.shape[1]
         gout = gout.float()
         if _batch_strided(gout) != total * p:
             gout = gout.contiguous()
         gs = gout[:, :n]
-        ymask = out[:, :n] if ctx.act is not None else None
         gx = gw = gb = None
         if ctx.needs_input_grad[3]:
-            gx = wino_conv3x3(gs, wino_transformed_weights(w, True), cin, mask=ymask)
+            gx = wino_conv3x3(gs, wino_transformed_weights(w, True), cin, bits=bits)
         # iteration-shared parameters accumulate in their per-pass buffers (runtime.PARAM_GRADS) and reach .grad once
         acc_w = _runtime.PARAM_GRADS.slot(ctx.w_param, lambda: torch.zeros_like(w), False) if ctx.w_param is not None else None
         acc_b = _runtime.PARAM_GRADS.slot(ctx.b_param, lambda: _zero_slice(n, gout), False) if ctx.b_param is not None else None
@@ -2660,12 +2674,12 @@ class _WinoConvCat(torch.autograd.Function):
             if need_b and acc_b is None:
                 gb = torch.empty(n, dtype=torch.float32, device=gout.device)
             if _WINO_WRW:
-                gw = wino_wrw(x, gs, mask=ymask, out=acc_w, gbias=(acc_b if acc_b is not None else gb) if need_b else None,
+                gw = wino_wrw(x, gs, bits=bits, out=acc_w, gbias=(acc_b if acc_b is not None else gb) if need_b else None,
                               gbias_accumulate=acc_b is not None)
                 if acc_w is not None:
                     gw = None
             else:
-                gm = (gs if ymask is None else gs * (ymask > 0)).contiguous()
+                gm = (gs if bits is None else gs * _wino_unpack_bits(bits, ww)).contiguous()
                 gw = torch.ops.aten.convolution_backward(gm, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
                 if acc_w is not None:
                     acc_w.add_(gw)
@@ -2695,6 +2709,13 @@ class _WinoConvCat(torch.autograd.Function):
         if ctx.has_tail:
             grads.append(gout[:, c0:])
         return (None, None, None, gx, gw, gb, *grads)
+
+
+def _wino_unpack_bits(bits, ww):
+    """activation bits -> a 0 / 1 float tensor [B,C,H,W] (the library fall-back of the adjoint, CAMLI_WINO_WRW=lib)"""
+    shifts = torch.arange(8, device=bits.device, dtype=torch.uint8)
+    m = ((bits.unsqueeze(-1) >> shifts) & 1).flatten(3)[..., :ww]
+    return m.to(torch.float32)
 
 
 def wino_conv_cat(x, conv, act, others=(), tail=None):

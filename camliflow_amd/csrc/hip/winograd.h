@@ -101,8 +101,10 @@ __global__ void weight_transform_kernel(const float* __restrict__ w, float* __re
 }
 
 // ---- input: V[t][c][tile] = (B^T d B)[t / 4][t % 4], d = the 4 x 4 patch of x around output tile `tile`
-// x: channel c of image b at x + b * sxb + c * sxc (H x W, contiguous rows).  mask (optional, same addressing with
-// smb / smc): values of x where mask <= 0 read as zero (the ReLU adjoint).  One thread: 4 tiles (b, ty, 4 tq .. 4 tq + 3).
+// x: channel c of image b at x + b * sxb + c * sxc (H x W, contiguous rows).  mask (optional): the activation bits an
+// output transform left behind -- [B][C][H][W8] bytes, W8 = ceil(W / 8), bit j of byte s = pixel 8 s + j "passes the
+// gradient" -- x reads as zero where its bit is clear (the ReLU adjoint at 1/32 of the bytes of re-reading the output).
+// One thread: 4 tiles (b, ty, 4 tq .. 4 tq + 3).
 // VEC: W % 4 == 0 and 16-byte aligned rows -> 16-byte loads.  Output layout, `rows` >= C channel rows (zeros for c >= C):
 //   CHUNKED = false: V [16][rows][NT], thread = (channel blockIdx.y, quad): lanes along the tiles, 1 KB per store instruction;
 //   CHUNKED = true:  V [16][NT / 16][rows][16] -- the 16 tiles of a K chunk of the weight gradient's contraction contiguous per
@@ -124,7 +126,7 @@ struct Slot {
 
 template <bool VEC, bool CHUNKED = false>
 __global__ __launch_bounds__(256) void input_transform_kernel(const float* __restrict__ x, int64_t sxb, int64_t sxc,
-                                                             const float* __restrict__ mask, int64_t smb, int64_t smc,
+                                                             const unsigned char* __restrict__ mask,
                                                              float* __restrict__ V, int C, int rows, Geometry g) {
     const Slot<CHUNKED> slot;
     const int i = slot.quad, c = slot.row;
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const float* __res
     const int qpr = g.TWp >> 2;                       // quads per tile row
     const int tq = i % qpr, ty = (i / qpr) % g.TH, b = i / (qpr * g.TH);
     const float* xc = x + b * sxb + c * sxc;
-    const float* mc = mask ? mask + b * smb + c * smc : nullptr;
+    const int W8 = (g.W + 7) >> 3;
+    const unsigned char* mc = mask ? mask + ((size_t)b * C + c) * g.H * W8 : nullptr;
     const int col0 = 8 * tq;                          // first output column of the quad; the patch spans col0 - 1 .. col0 + 8
     float d[4][10];
 #pragma unroll
@@ -146,32 +149,27 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const float* __res
         const int row = 2 * ty - 1 + rr;
         const bool rok = (unsigned)row < (unsigned)g.H;
         const float* xr = xc + (int64_t)row * g.W;
-        const float* mr = mc ? mc + (int64_t)row * g.W : nullptr;
         if (VEC && rok && col0 + 8 <= g.W) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(xr + col0), bq = *reinterpret_cast<const f32x4*>(xr + col0 + 4);
             d[rr][0] = col0 > 0 ? xr[col0 - 1] : 0.f;
             d[rr][9] = col0 + 8 < g.W ? xr[col0 + 8] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { d[rr][1 + e] = a[e]; d[rr][5 + e] = bq[e]; }
-            if (mr) {
-                const f32x4 ma = *reinterpret_cast<const f32x4*>(mr + col0), mb = *reinterpret_cast<const f32x4*>(mr + col0 + 4);
-                if (col0 > 0 && !(mr[col0 - 1] > 0.f)) d[rr][0] = 0.f;
-                if (col0 + 8 < g.W && !(mr[col0 + 8] > 0.f)) d[rr][9] = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (!(ma[e] > 0.f)) d[rr][1 + e] = 0.f;
-                    if (!(mb[e] > 0.f)) d[rr][5 + e] = 0.f;
-                }
-            }
         } else {
 #pragma unroll
             for (int e = 0; e < 10; ++e) {
                 const int col = col0 - 1 + e;
-                const bool ok = rok && (unsigned)col < (unsigned)g.W;
-                float v = ok ? xr[col] : 0.f;
-                if (ok && mr && !(mr[col] > 0.f)) v = 0.f;
-                d[rr][e] = v;
+                d[rr][e] = rok && (unsigned)col < (unsigned)g.W ? xr[col] : 0.f;
             }
+        }
+        if (mc && rok) {
+            // bits of columns col0 - 1 .. col0 + 8: the top bit of the byte to the left, this quad's byte, bit 0 of the next
+            const unsigned char* mrow = mc + (size_t)row * W8;
+            const unsigned left = tq > 0 ? mrow[tq - 1] : 0u, mid = tq < W8 ? mrow[tq] : 0u, right = tq + 1 < W8 ? mrow[tq + 1] : 0u;
+            const unsigned bits = (left >> 7) | (mid << 1) | ((right & 1u) << 9);
+#pragma unroll
+            for (int e = 0; e < 10; ++e)
+                if (!((bits >> e) & 1u)) d[rr][e] = 0.f;
         }
     }
     // rows: B^T d  (t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3), then the same along the columns per tile
@@ -199,13 +197,15 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const float* __res
 }
 
 // ---- output: y[b][n][2 ty + i][2 tx + j] = (A^T m A)[i][j] (+ bias[n]) (ReLU) (+= y), m = Mo[.][n][tile] as 4 x 4
-// Mo [16][Mp][NT]; y: channel n of image b at y + b * syb + n * syc.  ACT: 0 none, 1 ReLU.  One thread: channel n, 4 tiles.
+// Mo [16][Mp][NT]; y: channel n of image b at y + b * syb + n * syc.  One thread: channel n, 4 tiles.
+// bits (optional, with an activation): [B][N][H][W8] bytes, bit j of byte s = output pixel 8 s + j passes the gradient
+// (pre-activation > 0; OUT_RELU_FINITE: and finite) -- the mask the adjoint's transforms read.
 // OUT_RELU_FINITE: ReLU, then torch.nan_to_num (models/raft_core.py:163-164): NaN -> 0 (fmaxf drops it), +inf -> FLT_MAX
 enum { OUT_PLAIN = 0, OUT_RELU = 1, OUT_RELU_FINITE = 2 };
 template <bool VEC>
 __global__ __launch_bounds__(256) void output_transform_kernel(const float* __restrict__ Mo, int Mp, const float* __restrict__ bias,
                                                               float* __restrict__ y, int64_t syb, int64_t syc, int act,
-                                                              int accumulate, Geometry g) {
+                                                              int accumulate, unsigned char* __restrict__ bits, int N, Geometry g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = blockIdx.y;
     if (4 * i >= g.tiles) return;
@@ -231,39 +231,45 @@ __global__ __launch_bounds__(256) void output_transform_kernel(const float* __re
         float px[8] = {o0[0], o1[0], o0[1], o1[1], o0[2], o1[2], o0[3], o1[3]};
         if (row >= g.H) continue;
         float* yr = yc + (int64_t)row * g.W + col0;
+        if (accumulate) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (col0 + e < g.W) px[e] += yr[e];
+        }
+        if (act != OUT_PLAIN) {
+            unsigned mbits = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mbits |= (px[e] > 0.f && (act != OUT_RELU_FINITE || px[e] <= 3.402823466e+38f) ? 1u : 0u) << e;
+                px[e] = fmaxf(px[e], 0.f);
+                if (act == OUT_RELU_FINITE) px[e] = fminf(px[e], 3.402823466e+38f);
+            }
+            if (bits) {
+                const int W8 = (g.W + 7) >> 3;
+                const int live = g.W - col0;            // pixels of this byte inside the image: the bits beyond stay clear
+                if (live < 8) mbits &= (1u << (live > 0 ? live : 0)) - 1u;
+                if (tq < W8) bits[(((size_t)b * N + n) * g.H + row) * W8 + tq] = (unsigned char)mbits;
+            }
+        }
         if (VEC && col0 + 8 <= g.W) {
-            f32x4 lo = {px[0], px[1], px[2], px[3]}, hi = {px[4], px[5], px[6], px[7]};
-            if (accumulate) { lo += *reinterpret_cast<const f32x4*>(yr); hi += *reinterpret_cast<const f32x4*>(yr + 4); }
-            if (act != OUT_PLAIN) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], 0.f); hi[e] = fmaxf(hi[e], 0.f); }
-            }
-            if (act == OUT_RELU_FINITE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { lo[e] = fminf(lo[e], 3.402823466e+38f); hi[e] = fminf(hi[e], 3.402823466e+38f); }
-            }
+            const f32x4 lo = {px[0], px[1], px[2], px[3]}, hi = {px[4], px[5], px[6], px[7]};
             *reinterpret_cast<f32x4*>(yr) = lo;
             *reinterpret_cast<f32x4*>(yr + 4) = hi;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (col0 + e < g.W) {
-                    float v = px[e];
-                    if (accumulate) v += yr[e];
-                    if (act != OUT_PLAIN) v = fmaxf(v, 0.f);
-                    if (act == OUT_RELU_FINITE) v = fminf(v, 3.402823466e+38f);
-                    yr[e] = v;
-                }
+                if (col0 + e < g.W) yr[e] = px[e];
         }
     }
 }
 
 // ---- output gradient: gM[t][n][tile] = (A gy A^T)[t / 4][t % 4] (A = the 4 x 2 matrix whose transpose finishes the forward)
-// gy: channel n of image b at gy + b * sgb + n * sgc; mask optional (same geometry): gy reads as zero where mask <= 0.
+// gy: channel n of image b at gy + b * sgb + n * sgc; mask optional: the activation bits [B][N][H][W8] of the forward's
+// output transform, gy reads as zero where its bit is clear.
 // gM has `rows` >= N channel rows (zeros for n >= N and for the padding tiles) in either layout of input_transform_kernel.
 template <bool VEC, bool CHUNKED = false>
 __global__ __launch_bounds__(256) void grad_transform_kernel(const float* __restrict__ gy, int64_t sgb, int64_t sgc,
-                                                            const float* __restrict__ mask, int64_t smb, int64_t smc,
+                                                            const unsigned char* __restrict__ mask,
                                                             float* __restrict__ gM, int N, int rows, Geometry g) {
     const Slot<CHUNKED> slot;
     const int i = slot.quad, n = slot.row;
@@ -277,7 +283,8 @@ __global__ __launch_bounds__(256) void grad_transform_kernel(const float* __rest
     const int qpr = g.TWp >> 2;
     const int tq = i % qpr, ty = (i / qpr) % g.TH, b = i / (qpr * g.TH);
     const float* gc = gy + b * sgb + n * sgc;
-    const float* mc = mask ? mask + b * smb + n * smc : nullptr;
+    const int W8 = (g.W + 7) >> 3;
+    const unsigned char* mc = mask ? mask + ((size_t)b * N + n) * g.H * W8 : nullptr;
     const int col0 = 8 * tq;
     float d[2][8];
 #pragma unroll
@@ -285,27 +292,19 @@ __global__ __launch_bounds__(256) void grad_transform_kernel(const float* __rest
         const int row = 2 * ty + rr;
         const bool rok = row < g.H;
         const float* gr = gc + (int64_t)row * g.W + col0;
-        const float* mr = mc ? mc + (int64_t)row * g.W + col0 : nullptr;
         if (VEC && rok && col0 + 8 <= g.W) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(gr), bq = *reinterpret_cast<const f32x4*>(gr + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { d[rr][e] = a[e]; d[rr][4 + e] = bq[e]; }
-            if (mr) {
-                const f32x4 ma = *reinterpret_cast<const f32x4*>(mr), mb = *reinterpret_cast<const f32x4*>(mr + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (!(ma[e] > 0.f)) d[rr][e] = 0.f;
-                    if (!(mb[e] > 0.f)) d[rr][4 + e] = 0.f;
-                }
-            }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool ok = rok && col0 + e < g.W;
-                float v = ok ? gr[e] : 0.f;
-                if (ok && mr && !(mr[e] > 0.f)) v = 0.f;
-                d[rr][e] = v;
-            }
+            for (int e = 0; e < 8; ++e) d[rr][e] = rok && col0 + e < g.W ? gr[e] : 0.f;
+        }
+        if (mc && rok && tq < W8) {
+            const unsigned m = mc[(size_t)row * W8 + tq];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (!((m >> e) & 1u)) d[rr][e] = 0.f;
         }
     }
     // A g: rows g0, g0 + g1, g0 - g1, -g1; then the same along the columns of each tile
@@ -331,11 +330,17 @@ __global__ __launch_bounds__(256) void grad_transform_kernel(const float* __rest
 // is g00 + g01 + g10 + g11 of the tile.  gM chunk-major [16][NT / 16][rows][16].  One block per channel, fixed summation tree.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ gM, int rows, int NT, float* __restrict__ gbias, int accumulate) {
     __shared__ float part[256];
-    const int n = blockIdx.x;
+    const int n = blockIdx.x, chunks = NT >> 4;
     const float* q = gM + (size_t)5 * rows * NT + (size_t)n * 16;
-    float acc = 0.f;
-    for (int k = threadIdx.x; k < NT; k += 256) acc += q[(size_t)(k >> 4) * rows * 16 + (k & 15)];
-    part[threadIdx.x] = acc;
+    // a thread takes whole K chunks (the channel's 16 tiles of a chunk are 64 contiguous bytes): four independent 16-byte loads
+    // per trip (first form: one float per thread and trip, 64 dependent trips on 192 blocks: the launch took longer than the
+    // masked transforms it rides behind)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = threadIdx.x; k < chunks; k += 256) {
+        const f32x4* c4 = reinterpret_cast<const f32x4*>(q + (size_t)k * rows * 16);
+        acc += (c4[0] + c4[1]) + (c4[2] + c4[3]);
+    }
+    part[threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
         if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];

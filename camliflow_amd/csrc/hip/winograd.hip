@@ -75,12 +75,17 @@ extern "C" int64_t camli_wino_workspace_bytes(int B, int C, int N, int H, int W)
     return (int64_t)16 * g.NT * ((int64_t)kp_of(C) + mp_of(N)) * (int64_t)sizeof(float);
 }
 
+extern "C" int64_t camli_wino_mask_bytes(int B, int C, int H, int W) {
+    return B < 1 || C < 1 || H < 1 || W < 1 ? 0 : (int64_t)B * C * H * ((W + 7) / 8);
+}
+
 // y (= or +=) act(conv3x3(x) + bias).  x: B images of C planes H x W, image b at x + b * x_bs (planes dense: a channel slice
-// of a wider NCHW tensor is fine); mask (optional, same geometry, image stride mask_bs): x reads as zero where mask <= 0;
-// U = camli_wino_weights(...) [16][C][Mp]; y: N planes per image, image stride y_bs.
-extern "C" int camli_wino_conv3x3(const float* x, int64_t x_bs, const float* mask, int64_t mask_bs, const float* U, const float* bias,
-                                  float* y, int64_t y_bs, float* workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W,
-                                  int act, int accumulate, void* stream) {
+// of a wider NCHW tensor is fine); x_bits (optional): activation bits [B][C][H][ceil(W / 8)] bytes, x reads as zero where its
+// bit is clear; U = camli_wino_weights(...) [16][C][Mp]; y: N planes per image, image stride y_bs; y_bits (optional, act != 0):
+// the activation bits of y [B][N][H][ceil(W / 8)], written.
+extern "C" int camli_wino_conv3x3(const float* x, int64_t x_bs, const unsigned char* x_bits, const float* U, const float* bias,
+                                  float* y, int64_t y_bs, unsigned char* y_bits, float* workspace, int64_t workspace_bytes, int B,
+                                  int C, int N, int H, int W, int act, int accumulate, void* stream) {
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_wino_conv3x3";
     if (!x || !U || !y || !workspace) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
@@ -104,10 +109,10 @@ extern "C" int camli_wino_conv3x3(const float* x, int64_t x_bs, const float* mas
     const int64_t plane = (int64_t)H * W;
     const dim3 block(256);
     {
-        const bool vec = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0 && (!mask || (aligned16(mask) && mask_bs % 4 == 0));
+        const bool vec = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0;
         const dim3 grid(camli_divup(g.NT / 4, 256), Cp);
-        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, false>), grid, block, 0, s, x, x_bs, plane, mask, mask_bs, plane, V, C, Cp, g);
-        else hipLaunchKernelGGL((wino::input_transform_kernel<false, false>), grid, block, 0, s, x, x_bs, plane, mask, mask_bs, plane, V, C, Cp, g);
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, false>), grid, block, 0, s, x, x_bs, plane, x_bits, V, C, Cp, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<false, false>), grid, block, 0, s, x, x_bs, plane, x_bits, V, C, Cp, g);
     }
     int rc;
     if (Mp <= 128) rc = launch_planes<2, 1, 1>(U, V, Mo, Mp, g.NT, Cp, s);
@@ -117,8 +122,8 @@ extern "C" int camli_wino_conv3x3(const float* x, int64_t x_bs, const float* mas
     {
         const bool vec = W % 4 == 0 && aligned16(y) && y_bs % 4 == 0;
         const dim3 grid(camli_divup(g.NT / 4, 256), N);
-        if (vec) hipLaunchKernelGGL(wino::output_transform_kernel<true>, grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, g);
-        else hipLaunchKernelGGL(wino::output_transform_kernel<false>, grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, g);
+        if (vec) hipLaunchKernelGGL(wino::output_transform_kernel<true>, grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, y_bits, N, g);
+        else hipLaunchKernelGGL(wino::output_transform_kernel<false>, grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, y_bits, N, g);
     }
     return camli_check_launch(what);
 }
@@ -187,10 +192,11 @@ extern "C" int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, in
     return ((int64_t)16 * g.NT * ((int64_t)pl.v_rows + pl.g_rows) + (int64_t)pl.S * 16 * pl.part_floats) * (int64_t)sizeof(float);
 }
 
-// gw [N][C][3][3] (= | +=) the weight gradient of y = conv3x3(x) for the output gradient gy (gy_mask optional: gy reads as
-// zero where gy_mask <= 0).  x [B][C][H][W] (image stride x_bs), gy / gy_mask [B][N][H][W] (image strides gy_bs / mask_bs).
+// gw [N][C][3][3] (= | +=) the weight gradient of y = conv3x3(x) for the output gradient gy (gy_bits optional: the
+// activation bits [B][N][H][ceil(W / 8)] of the forward, gy reads as zero where its bit is clear).  x [B][C][H][W] (image
+// stride x_bs), gy [B][N][H][W] (image stride gy_bs).
 // gbias [N] (optional) (= | +=, gbias_accumulate) the bias gradient = the sum of the (masked) output gradient per channel.
-extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, const float* gy_mask, int64_t mask_bs,
+extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, const unsigned char* gy_bits,
                               float* gw, float* gbias, float* workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W,
                               int accumulate, int gbias_accumulate, void* stream) {
     if (B == 0) return CAMLI_OK;
@@ -216,14 +222,14 @@ extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int
     {
         const bool vec = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0;
         const dim3 grid(g.NT / 16, camli_divup(pl.v_rows, 64));
-        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, true>), grid, block, 0, s, x, x_bs, plane, nullptr, 0, plane, V, C, pl.v_rows, g);
-        else hipLaunchKernelGGL((wino::input_transform_kernel<false, true>), grid, block, 0, s, x, x_bs, plane, nullptr, 0, plane, V, C, pl.v_rows, g);
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, true>), grid, block, 0, s, x, x_bs, plane, nullptr, V, C, pl.v_rows, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<false, true>), grid, block, 0, s, x, x_bs, plane, nullptr, V, C, pl.v_rows, g);
     }
     {
-        const bool vec = W % 4 == 0 && aligned16(gy) && gy_bs % 4 == 0 && (!gy_mask || (aligned16(gy_mask) && mask_bs % 4 == 0));
+        const bool vec = W % 4 == 0 && aligned16(gy) && gy_bs % 4 == 0;
         const dim3 grid(g.NT / 16, camli_divup(pl.g_rows, 64));
-        if (vec) hipLaunchKernelGGL((wino::grad_transform_kernel<true, true>), grid, block, 0, s, gy, gy_bs, plane, gy_mask, mask_bs, plane, gM, N, pl.g_rows, g);
-        else hipLaunchKernelGGL((wino::grad_transform_kernel<false, true>), grid, block, 0, s, gy, gy_bs, plane, gy_mask, mask_bs, plane, gM, N, pl.g_rows, g);
+        if (vec) hipLaunchKernelGGL((wino::grad_transform_kernel<true, true>), grid, block, 0, s, gy, gy_bs, plane, gy_bits, gM, N, pl.g_rows, g);
+        else hipLaunchKernelGGL((wino::grad_transform_kernel<false, true>), grid, block, 0, s, gy, gy_bs, plane, gy_bits, gM, N, pl.g_rows, g);
     }
     if (gbias) hipLaunchKernelGGL(wino::bias_grad_kernel, dim3(N), block, 0, s, gM, pl.g_rows, g.NT, gbias, gbias_accumulate ? 1 : 0);
     wino::WrwBatch wb;

@@ -626,27 +626,30 @@ int camli_convcl_wrw(const float *x0, int ldx0, int C0, const float *x1, int ldx
  *     M = Cin, taps reversed -- the weights of the DATA GRADIENT, which is the same convolution of the output gradient.
  *     Kp = K rounded up to a multiple of 16, Mp = M to a multiple of 4 (zeros beyond); camli_wino_weight_floats(K, M) = 16 Kp Mp.
  *   camli_wino_conv3x3: image b of x at x + b * x_bs (C dense H x W planes: a channel slice of a wider NCHW tensor is fine), of y
- *     at y + b * y_bs (N planes); mask (optional, x's geometry, image stride mask_bs): x reads as zero where mask <= 0 (the ReLU
- *     adjoint on the way in); bias optional; act 0 none | 1 ReLU | 2 ReLU then nan_to_num (raft_core.py:163-164); accumulate:
- *     y += (before act).  C > 32, N >= 4; workspace =
- *     camli_wino_workspace_bytes(B, C, N, H, W) bytes (V and the transform-domain output: 4 x the input + 4 x the output),
- *     16-byte aligned.  Differs from the direct fp32 form by its rounding only (tests/test_winograd_gpu.py states the bound).
+ *     at y + b * y_bs (N planes); bias optional; act 0 none | 1 ReLU | 2 ReLU then nan_to_num (raft_core.py:163-164);
+ *     accumulate: y += (before act).  y_bits (optional, act != 0): the ACTIVATION BITS of y are written -- [B][N][H][ceil(W / 8)]
+ *     bytes (camli_wino_mask_bytes), bit j of byte s = output pixel 8 s + j passes the gradient (pre-activation > 0; act 2: and
+ *     finite); x_bits (optional): such bits for the INPUT, x reads as zero where its bit is clear -- the ReLU adjoint of the
+ *     data gradient rides on the input transform at 1/32 of the bytes of re-reading the forward's output.  C > 32, N >= 4;
+ *     workspace = camli_wino_workspace_bytes(B, C, N, H, W) bytes (V and the transform-domain output: 4 x the input + 4 x the
+ *     output), 16-byte aligned.  Differs from the direct fp32 form by its rounding only (tests/test_winograd_gpu.py).
  *   camli_wino_wrw: WEIGHT GRADIENT in the transform domain: gU[t][c][n] = sum_tiles V[t][c][tile] * (A gy A^T)[t][n][tile], then
  *     gw [N][C][3][3] (= | +=) G^T gU G -- the same 2.25 x fewer multiplications as the forward.  x [B][C][H][W] (image stride
- *     x_bs), gy [B][N][H][W] (image stride gy_bs); gy_mask optional (gy's geometry, image stride mask_bs): gy reads as zero where
- *     gy_mask <= 0.  gbias [N] (optional) (= | +=, gbias_accumulate) the bias gradient: the per-channel sum of the masked
- *     gy, taken from the transform-domain plane that holds the tile sums.  workspace = camli_wino_wrw_workspace_bytes(B, C, N,
- *     H, W) bytes (0 = unsupported shape).  The contraction
- *     over the tiles is split over the CUs, the parts are summed in a fixed order: deterministic, no atomics.
+ *     x_bs), gy [B][N][H][W] (image stride gy_bs); gy_bits optional: the forward's activation bits, gy reads as zero where its
+ *     bit is clear.  gbias [N] (optional) (= | +=, gbias_accumulate) the bias gradient: the per-channel sum of the masked gy,
+ *     taken from the transform-domain plane that holds the tile sums.  workspace = camli_wino_wrw_workspace_bytes(B, C, N, H, W)
+ *     bytes (0 = unsupported shape).  The contraction over the tiles is split over the CUs, the parts are summed in a fixed
+ *     order: deterministic, no atomics.
  */
 int64_t camli_wino_weight_floats(int K, int M);
 int camli_wino_weights(const float *w, float *U, int Cout, int Cin, int flip, void *stream);
 int64_t camli_wino_workspace_bytes(int B, int C, int N, int H, int W);
-int camli_wino_conv3x3(const float *x, int64_t x_bs, const float *mask, int64_t mask_bs, const float *U, const float *bias, float *y,
-                       int64_t y_bs, float *workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int act,
-                       int accumulate, void *stream);
+int64_t camli_wino_mask_bytes(int B, int C, int H, int W);
+int camli_wino_conv3x3(const float *x, int64_t x_bs, const unsigned char *x_bits, const float *U, const float *bias, float *y,
+                       int64_t y_bs, unsigned char *y_bits, float *workspace, int64_t workspace_bytes, int B, int C, int N, int H,
+                       int W, int act, int accumulate, void *stream);
 int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, int W);
-int camli_wino_wrw(const float *x, int64_t x_bs, const float *gy, int64_t gy_bs, const float *gy_mask, int64_t mask_bs, float *gw,
+int camli_wino_wrw(const float *x, int64_t x_bs, const float *gy, int64_t gy_bs, const unsigned char *gy_bits, float *gw,
                    float *gbias, float *workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int accumulate,
                    int gbias_accumulate, void *stream);
 int camli_conv3x3_co2_bwd_data(const float *gy, const float *w, float *gx, int B, int Cin, int H, int W, void *stream);

@@ -87,19 +87,23 @@ def test_wino_weight_gradient_mask_accumulate_slices_and_repeatability(oracle_de
     wt = np.zeros((cout, cin, 3, 3), np.float32)
     _, want = oracle_dense.conv_taps_bwd(np.where(mask > 0, gy, 0).astype(np.float32), x, wt, (1, 1))
     wide_d = dev(wide)
-    got = fused.wino_wrw(wide_d[:, 16:16 + cin], dev(gy), mask=dev(mask))
+    bits = fused.wino_pack_bits(dev(mask) > 0)
+    got = fused.wino_wrw(wide_d[:, 16:16 + cin], dev(gy), bits=bits)
     _close(got, want, tol=5e-5, what='masked, sliced input')
-    again = fused.wino_wrw(wide_d[:, 16:16 + cin], dev(gy), mask=dev(mask))
+    again = fused.wino_wrw(wide_d[:, 16:16 + cin], dev(gy), bits=bits)
     assert torch.equal(got, again), 'the split contraction is summed in a fixed order'
     base = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
     acc = dev(base)
-    fused.wino_wrw(dev(x), dev(gy), mask=dev(mask), out=acc)
+    gb = torch.zeros(cout, device='cuda')
+    fused.wino_wrw(dev(x), dev(gy), bits=bits, out=acc, gbias=gb)
     _close(acc, base + want, tol=5e-5, what='accumulate')
+    _close(gb, np.where(mask > 0, gy, 0).sum((0, 2, 3)).astype(np.float32), tol=5e-5, what='bias gradient from the tile sums')
 
 
 def test_wino_epilogue_bias_relu_mask_accumulate_and_slices(oracle_dense):
-    """The transforms' fused forms: bias + ReLU on the way out, += into an existing tensor, the ReLU adjoint's mask on the way
-    in, input / output that are channel slices of wider NCHW tensors."""
+    """The transforms' fused forms: bias + ReLU on the way out (and the activation bits), += into an existing tensor, the ReLU
+    adjoint's bits on the way in, input / output that are channel slices of wider NCHW tensors.  W = 20: 2.5 mask bytes per
+    row (a partial last byte)."""
     from camliflow_amd.csrc import fused
     rng = np.random.default_rng(5)
     b, cin, cout, h, w = 2, 64, 128, 11, 20
@@ -121,8 +125,12 @@ def test_wino_epilogue_bias_relu_mask_accumulate_and_slices(oracle_dense):
     acc = dev(base)
     fused.wino_conv3x3(dev(np.ascontiguousarray(x)), u, cout, out=acc, accumulate=True)
     _close(acc, base + oracle_dense.conv_taps_fwd(x, wt, (1, 1)), what='accumulate')
-    got = fused.wino_conv3x3(dev(np.ascontiguousarray(x)), u, cout, mask=dev(mask))
+    got = fused.wino_conv3x3(dev(np.ascontiguousarray(x)), u, cout, bits=fused.wino_pack_bits(dev(mask) > 0))
     _close(got, oracle_dense.conv_taps_fwd(np.where(mask > 0, x, 0).astype(np.float32), wt, (1, 1)), what='masked input')
+    # the activation bits the output transform leaves behind = (pre-activation > 0), in the format the adjoint's transforms read
+    bits = fused.wino_mask_bits(b, cout, h, w, 'cuda')
+    fused.wino_conv3x3(wide_d[:, 16:16 + cin], u, cout, bias=dev(bias), act='relu', bits_out=bits)
+    assert torch.equal(bits, fused.wino_pack_bits(dev(want) > 0))
 
 
 @pytest.mark.parametrize('case', [(2, 128, 192, 13, 21), (1, 256, 126, 17, 30), (2, 128, 256, 8, 12)], ids=str)

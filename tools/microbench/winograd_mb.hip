@@ -105,14 +105,14 @@ static void run(int B, int C, int N, int H, int W, bool check, int reps, int rel
     auto wt = [&]() { hipLaunchKernelGGL(wino::weight_transform_kernel, dim3((C * Mp + 255) / 256), dim3(256), 0, 0, w, U, N, C, C, Mp, 0); };
     auto it = [&]() {
         dim3 grid((g.NT / 4 + 255) / 256, C);
-        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, 0, 0, V, C, C, g);
-        else hipLaunchKernelGGL((wino::input_transform_kernel<false, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, 0, 0, V, C, C, g);
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, V, C, C, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<false, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, V, C, C, g);
     };
     auto gm = [&]() { gemm(U, V, Mo, Mp, g.NT, C, 0); };
     auto ot = [&]() {
         dim3 grid((g.NT / 4 + 255) / 256, N);
-        if (vec) hipLaunchKernelGGL(wino::output_transform_kernel<true>, grid, dim3(256), 0, 0, Mo, Mp, bias, y, (int64_t)N * H * W, (int64_t)H * W, relu, 0, g);
-        else hipLaunchKernelGGL(wino::output_transform_kernel<false>, grid, dim3(256), 0, 0, Mo, Mp, bias, y, (int64_t)N * H * W, (int64_t)H * W, relu, 0, g);
+        if (vec) hipLaunchKernelGGL(wino::output_transform_kernel<true>, grid, dim3(256), 0, 0, Mo, Mp, bias, y, (int64_t)N * H * W, (int64_t)H * W, relu, 0, nullptr, N, g);
+        else hipLaunchKernelGGL(wino::output_transform_kernel<false>, grid, dim3(256), 0, 0, Mo, Mp, bias, y, (int64_t)N * H * W, (int64_t)H * W, relu, 0, nullptr, N, g);
     };
     wt(); it(); gm(); ot();
     CK(hipDeviceSynchronize());
