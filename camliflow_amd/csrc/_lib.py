@@ -137,15 +137,15 @@ PROTOTYPES = {
     "camli_convcl_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 6),
     "camli_convcl_wrw": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _int, _c_float_p, ctypes.c_int64,
                                 _c_float_p, _int, _int, _int, _int, _int, _int, ctypes.c_char_p, ctypes.c_char_p, _stream]),
-    "camli_wino_weight_floats": (ctypes.c_int64, [_int, _int]),
-    "camli_wino_weights": (_int, [_c_float_p, _c_float_p, _int, _int, _int, _stream]),
-    "camli_wino_workspace_bytes": (ctypes.c_int64, [_int] * 5),
+    "camli_wino_weight_floats": (ctypes.c_int64, [_int, _int, _int]),
+    "camli_wino_weights": (_int, [_c_float_p, _c_float_p, _int, _int, _int, _int, _stream]),
+    "camli_wino_workspace_bytes": (ctypes.c_int64, [_int] * 6),
     "camli_wino_mask_bytes": (ctypes.c_int64, [_int] * 4),
     "camli_wino_conv3x3": (_int, [_c_float_p, ctypes.c_int64, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p,
-                                  ctypes.c_int64, ctypes.c_void_p, _c_float_p, ctypes.c_int64] + [_int] * 7 + [_stream]),
-    "camli_wino_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 5),
+                                  ctypes.c_int64, ctypes.c_void_p, _c_float_p, ctypes.c_int64] + [_int] * 8 + [_stream]),
+    "camli_wino_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 6),
     "camli_wino_wrw": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int64, ctypes.c_void_p, _c_float_p, _c_float_p,
-                              _c_float_p, ctypes.c_int64] + [_int] * 7 + [_stream]),
+                              _c_float_p, ctypes.c_int64] + [_int] * 8 + [_stream]),
     "camli_conv3x3_co2_fwd": (_int, [_c_float_p] * 4 + [_int] * 4 + [_stream]),
     "camli_conv3x3_co2_bwd_data": (_int, [_c_float_p] * 3 + [_int] * 4 + [_stream]),
     "camli_conv3x3_co2_bwd_weight_workspace_bytes": (ctypes.c_longlong, [_int, _int, _int]),

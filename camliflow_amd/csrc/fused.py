@@ -2426,7 +2426,12 @@ def conv3x3_co2(x, weight, bias):
 # transposed, tap-reversed weights) and weight gradient.  CAMLI_WINO=0 leaves them with the library (A/B).
 # ------------------------------------------------------------------------------------------------
 _WINO = os.environ.get('CAMLI_WINO', '1') != '0'
-_wino_weights = {}          # id(weight) -> [weakref(weight), version, {flip: U}]
+# output tile of the product's Winograd convolutions: F(4x4,3x3) (36 multiplications per 16 outputs: 4 x fewer than the direct
+# form, transform-domain tensors 2.25 x the image-domain ones) or F(2x2,3x3) (16 per 4: 2.25 x fewer, 4 x the bytes, a tenth
+# of the rounding error).  CAMLI_WINO_TILE=2 | 4.
+_WINO_TILE = int(os.environ.get('CAMLI_WINO_TILE', '4'))
+assert _WINO_TILE in (2, 4), 'CAMLI_WINO_TILE must be 2 or 4'
+_wino_weights = {}          # id(weight) -> [weakref(weight), version, {(flip, tile): U}]
 
 
 def wino_supported(conv, x):
@@ -2444,9 +2449,10 @@ def wino_shape_supported(cin, cout):
     return cin >= 96 and cout >= 96
 
 
-def wino_transformed_weights(w, flip):
-    """U [16][K][Mp] of w [Cout][Cin][3][3] (camli_wino_weights), computed once per value of the weight tensor: the 12 GRU
+def wino_transformed_weights(w, flip, tile=None):
+    """U [P][Kp][Mp] of w [Cout][Cin][3][3] (camli_wino_weights), computed once per value of the weight tensor: the 12 GRU
     iterations of a pass (and its backward) share it; an optimiser step bumps the tensor's version."""
+    tile = tile or _WINO_TILE
     key = id(w)
     entry = _wino_weights.get(key)
     if entry is None or entry[0]() is not w or entry[1] != w._version:
@@ -2454,19 +2460,20 @@ def wino_transformed_weights(w, flip):
             for k in [k for k, e in _wino_weights.items() if e[0]() is None]:
                 del _wino_weights[k]
         entry = _wino_weights[key] = [weakref.ref(w), w._version, {}]
-    u = entry[2].get(flip)
+    u = entry[2].get((flip, tile))
     if u is None:
         lib = _lib.load()
         cout, cin = w.shape[0], w.shape[1]
         k, m = (cout, cin) if flip else (cin, cout)
-        u = torch.empty(lib.camli_wino_weight_floats(k, m), dtype=torch.float32, device=w.device)
+        u = torch.empty(lib.camli_wino_weight_floats(k, m, tile), dtype=torch.float32, device=w.device)
         wd = w.detach()
         wd = wd if wd.is_contiguous() else wd.contiguous()
         with _on_device(w):
-            _lib.launch('camli_wino_weights', lib.camli_wino_weights, wd.data_ptr(), u.data_ptr(), cout, cin, int(flip), _stream_ptr(w),
-                        work=(4.0 * (9 + 16) * cout * cin, 'B'))
+            _lib.launch('camli_wino_weights', lib.camli_wino_weights, wd.data_ptr(), u.data_ptr(), cout, cin, int(flip), tile, _stream_ptr(w),
+                        work=(4.0 * (9 + (tile + 2) ** 2) * cout * cin, 'B'))
         u._camli_stream = torch.cuda.current_stream(w.device)
-        entry[2][flip] = u
+        u._camli_tile = tile
+        entry[2][(flip, tile)] = u
     else:
         # produced on another stream of this pass (a Branch / the weight-gradient side stream): order this stream behind it
         cur = torch.cuda.current_stream(w.device)
@@ -2505,6 +2512,12 @@ def wino_pack_bits(mask):
     return (m * weights).sum(-1).to(torch.uint8).contiguous()
 
 
+def _wino_tiles(b, hh, ww, tile):
+    """transform-domain row length NT of a [b, ., hh, ww] map (winograd.h make_geometry)"""
+    tiles = b * ((hh + tile - 1) // tile) * (((ww + 7) // 8) * (8 // tile))
+    return (tiles + 15) // 16 * 16
+
+
 def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, bits=None, bits_out=None):
     """act(conv3x3(x) + bias) for pre-transformed weights u (wino_transformed_weights).  x [B,C,H,W] fp32, dense or a channel
     slice of a dense NCHW tensor; ``bits``: activation bits of x (wino_mask_bits geometry), x reads as zero where its bit is
@@ -2527,19 +2540,20 @@ def wino_conv3x3(x, u, n_out, bias=None, act=None, out=None, accumulate=False, b
     ybs = _image_stride(out)
     if ybs is None or out.shape != (b, n_out, hh, ww):
         raise _lib.CamliHipError('wino_conv3x3: the output must be a dense fp32 [B,%d,H,W] tensor or a channel slice of one' % n_out)
-    need = lib.camli_wino_workspace_bytes(b, c, n_out, hh, ww)
+    tile = getattr(u, '_camli_tile', _WINO_TILE)           # the tile the weights were transformed for
+    need = lib.camli_wino_workspace_bytes(b, c, n_out, hh, ww, tile)
     ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
-    tiles = need // (64 * ((c + 15) // 16 * 16 + (n_out + 3) // 4 * 4))
+    planes, tiles = (tile + 2) ** 2, _wino_tiles(b, hh, ww, tile)
     with _on_device(x):
         _lib.launch('camli_wino_conv3x3', lib.camli_wino_conv3x3, x.data_ptr(), xbs, bits.data_ptr() if bits is not None else None,
                     u.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), ybs,
                     bits_out.data_ptr() if bits_out is not None else None, ws.data_ptr(), need, b, c,
-                    n_out, hh, ww, {None: 0, 'relu': 1, 'relu_nan_to_num': 2}[act], int(bool(accumulate)), _stream_ptr(x),
-                    work=(4.0 * b * hh * ww * (c + n_out) + 2 * need, 'B'), flop=2.0 * 16 * tiles * c * n_out)
+                    n_out, hh, ww, {None: 0, 'relu': 1, 'relu_nan_to_num': 2}[act], int(bool(accumulate)), tile, _stream_ptr(x),
+                    work=(4.0 * b * hh * ww * (c + n_out) + 2 * need, 'B'), flop=2.0 * planes * tiles * c * n_out)
     return out
 
 
-def wino_wrw(x, gy, bits=None, out=None, gbias=None, gbias_accumulate=False):
+def wino_wrw(x, gy, bits=None, out=None, gbias=None, gbias_accumulate=False, tile=None):
     """Weight gradient [N,C,3,3] of conv3x3(x) for the output gradient gy [B,N,H,W], contracted in the Winograd domain
     (camli_wino_wrw); ``bits``: the forward's activation bits, gy reads as zero where its bit is clear; ``out``: add into this
     tensor instead of creating one; ``gbias`` [N]: also write (or, ``gbias_accumulate``, add) the bias gradient = the
@@ -2555,18 +2569,19 @@ def wino_wrw(x, gy, bits=None, out=None, gbias=None, gbias_accumulate=False):
     if gbs is None:
         gy, gbs = gy.contiguous(), n * hh * ww
     assert bits is None or (bits.dtype == torch.uint8 and bits.shape == (b, n, hh, (ww + 7) // 8) and bits.is_contiguous())
-    need = lib.camli_wino_wrw_workspace_bytes(b, c, n, hh, ww)
+    tile = tile or _WINO_TILE
+    need = lib.camli_wino_wrw_workspace_bytes(b, c, n, hh, ww, tile)
     if need <= 0:
         raise _lib.CamliHipError('wino_wrw: unsupported shape B=%d C=%d N=%d %dx%d' % (b, c, n, hh, ww))
     ws = torch.empty(need // 4, dtype=torch.float32, device=x.device)
     gw = out if out is not None else torch.empty((n, c, 3, 3), dtype=torch.float32, device=x.device)
     assert gw.shape == (n, c, 3, 3) and gw.is_contiguous() and gw.dtype == torch.float32
-    tiles = b * ((hh + 1) // 2) * (((ww + 1) // 2 + 3) // 4 * 4)
+    planes, tiles = (tile + 2) ** 2, _wino_tiles(b, hh, ww, tile)
     with _on_device(x):
         _lib.launch('camli_wino_wrw', lib.camli_wino_wrw, x.data_ptr(), xbs, gy.data_ptr(), gbs, bits.data_ptr() if bits is not None else None,
                     gw.data_ptr(), gbias.data_ptr() if gbias is not None else None, ws.data_ptr(), need, b, c, n, hh, ww,
-                    int(out is not None), int(bool(gbias_accumulate)), _stream_ptr(x),
-                    work=(4.0 * b * hh * ww * (c + n) + 2.0 * 64 * tiles * (c + n), 'B'), flop=2.0 * 16 * tiles * c * n)
+                    int(out is not None), int(bool(gbias_accumulate)), tile, _stream_ptr(x),
+                    work=(4.0 * b * hh * ww * (c + n) + 2.0 * 4 * planes * tiles * (c + n), 'B'), flop=2.0 * planes * tiles * c * n)
     return gw
 
 

@@ -1,7 +1,7 @@
-// C-ABI of the Winograd F(2x2,3x3) convolution (winograd.h + gemm_w128.h): the 3x3 convolutions of the RAFT update block
-// (models/raft_core.py:148-151 MotionEncoder2D.conv_c2 / conv, :173 FlowHead2D.conv1, :188 the mask head) forward and data
-// gradient, replacing the library's fp32 Winograd / implicit-GEMM kernels (0.70-0.75 of the fp32 matrix rate counted as a
-// direct convolution; this path: 1.05-1.10, profiles/r06a_winograd_microbench.txt).
+// C-ABI of the Winograd F(M x M, 3 x 3) convolution, M = 2 | 4 (winograd.h + gemm_w128.h + winograd_wrw.h): the 3x3
+// convolutions of the RAFT update block (models/raft_core.py:148-151 MotionEncoder2D.conv_c2 / conv, :173 FlowHead2D.conv1,
+// :188 the mask head) forward, data gradient and weight gradient, replacing the library's fp32 Winograd / implicit-GEMM
+// kernels (0.70-0.75 of the fp32 matrix rate counted as a direct convolution; F(2x2): 1.05-1.10, profiles/r06a_winograd_microbench.txt).
 #include "camli_common.h"
 #include "gemm_w128.h"
 #include "winograd.h"
@@ -25,9 +25,12 @@ int cu_count() {       // rounded down to a multiple of 8: the plane GEMM deals 
 
 constexpr int KS = 16, NBUF = 3;
 
-// the 16 plane GEMMs Mo[t] = U[t]^T V[t]: one launch, batch = 16
+bool tile_ok(int m) { return m == 2 || m == 4; }
+int planes_of(int m) { return (m + 2) * (m + 2); }
+
+// the P plane GEMMs Mo[t] = U[t]^T V[t]: one launch, batch = P
 template <int GA, int GB, int WM>
-int launch_planes(const float* U, const float* V, float* Mo, int Mp, int NT, int K, hipStream_t s) {
+int launch_planes(const float* U, const float* V, float* Mo, int Mp, int NT, int K, int P, hipStream_t s) {
     constexpr size_t lds = (size_t)NBUF * KS * 512 * sizeof(float);
     auto kern = &w128::gemm_w128_kernel<KS, NBUF, 0, GA, GB, WM>;
     static unsigned long long reserved = 0;
@@ -42,7 +45,7 @@ int launch_planes(const float* U, const float* V, float* Mo, int Mp, int NT, int
     p.alpha = 1.0f;
     p.tiles_m = camli_divup(Mp, w128::tile_m<GA, WM>());
     p.tiles_n = camli_divup(NT, w128::tile_n<GB, WM>());
-    p.tiles = 16 * p.tiles_m * p.tiles_n;
+    p.tiles = P * p.tiles_m * p.tiles_n;
     const int cus = cu_count();
     // the kernel's tile order deals 8 chunks (one per XCD) of gridDim.x / 8 consecutive tiles per round
     int nwg = p.tiles < cus ? (p.tiles + 7) / 8 * 8 : cus;
@@ -53,26 +56,64 @@ int launch_planes(const float* U, const float* V, float* Mo, int Mp, int NT, int
 int mp_of(int M) { return (M + 3) & ~3; }
 int kp_of(int K) { return (K + KS - 1) / KS * KS; }
 
+template <int M>
+void launch_input(bool vec, bool chunked, const float* x, int64_t x_bs, int64_t plane, const unsigned char* bits, float* V, int C, int rows,
+                  const wino::Geometry& g, hipStream_t s) {
+    constexpr int TPT = 8 / M, GPC = 16 / TPT;
+    const dim3 block(256);
+    if (chunked) {
+        const dim3 grid(g.NT / 16, camli_divup(rows, 256 / GPC));
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<M, true, true>), grid, block, 0, s, x, x_bs, plane, bits, V, C, rows, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<M, false, true>), grid, block, 0, s, x, x_bs, plane, bits, V, C, rows, g);
+    } else {
+        const dim3 grid(camli_divup(g.NT / TPT, 256), rows);
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<M, true, false>), grid, block, 0, s, x, x_bs, plane, bits, V, C, rows, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<M, false, false>), grid, block, 0, s, x, x_bs, plane, bits, V, C, rows, g);
+    }
+}
+
+template <int M>
+void launch_output(bool vec, const float* Mo, int Mp, const float* bias, float* y, int64_t y_bs, int64_t plane, int act, int accumulate,
+                   unsigned char* y_bits, int N, const wino::Geometry& g, hipStream_t s) {
+    constexpr int TPT = 8 / M;
+    const dim3 grid(camli_divup(g.NT / TPT, 256), N), block(256);
+    if (vec) hipLaunchKernelGGL((wino::output_transform_kernel<M, true>), grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate, y_bits, N, g);
+    else hipLaunchKernelGGL((wino::output_transform_kernel<M, false>), grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate, y_bits, N, g);
+}
+
+template <int M>
+void launch_grad(bool vec, const float* gy, int64_t gy_bs, int64_t plane, const unsigned char* bits, float* gM, int N, int rows,
+                 const wino::Geometry& g, hipStream_t s) {
+    constexpr int TPT = 8 / M, GPC = 16 / TPT;
+    const dim3 grid(g.NT / 16, camli_divup(rows, 256 / GPC)), block(256);
+    if (vec) hipLaunchKernelGGL((wino::grad_transform_kernel<M, true, true>), grid, block, 0, s, gy, gy_bs, plane, bits, gM, N, rows, g);
+    else hipLaunchKernelGGL((wino::grad_transform_kernel<M, false, true>), grid, block, 0, s, gy, gy_bs, plane, bits, gM, N, rows, g);
+}
+
 }  // namespace
 
-extern "C" int64_t camli_wino_weight_floats(int K, int M) { return K < 1 || M < 1 ? 0 : (int64_t)16 * kp_of(K) * mp_of(M); }
+extern "C" int64_t camli_wino_weight_floats(int K, int M, int tile) {
+    return K < 1 || M < 1 || !tile_ok(tile) ? 0 : (int64_t)planes_of(tile) * kp_of(K) * mp_of(M);
+}
 
-// U [16][Kp][Mp] from w [Cout][Cin][3][3]: flip = 0: K = Cin, M = Cout (forward); flip = 1: K = Cout, M = Cin, taps reversed
+// U [P][Kp][Mp] from w [Cout][Cin][3][3]: flip = 0: K = Cin, M = Cout (forward); flip = 1: K = Cout, M = Cin, taps reversed
 // (the data gradient's weights).  Kp = K rounded up to a multiple of 16, Mp = M to a multiple of 4, zeros beyond K / M.
-extern "C" int camli_wino_weights(const float* w, float* U, int Cout, int Cin, int flip, void* stream) {
+extern "C" int camli_wino_weights(const float* w, float* U, int Cout, int Cin, int flip, int tile, void* stream) {
     const char* what = "camli_wino_weights";
     if (!w || !U) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
-    if (Cout < 1 || Cin < 1) { camli_set_error("%s: bad shape %d x %d", what, Cout, Cin); return CAMLI_EINVAL; }
+    if (Cout < 1 || Cin < 1 || !tile_ok(tile)) { camli_set_error("%s: bad shape %d x %d, tile %d (2 | 4)", what, Cout, Cin, tile); return CAMLI_EINVAL; }
     const int Kp = kp_of(flip ? Cout : Cin), Mp = mp_of(flip ? Cin : Cout);
-    hipLaunchKernelGGL(wino::weight_transform_kernel, dim3(camli_divup(Kp * Mp, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, U,
-                       Cout, Cin, Kp, Mp, flip ? 1 : 0);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(camli_divup(Kp * Mp, 256)), block(256);
+    if (tile == 2) hipLaunchKernelGGL(wino::weight_transform_kernel<2>, grid, block, 0, s, w, U, Cout, Cin, Kp, Mp, flip ? 1 : 0);
+    else hipLaunchKernelGGL(wino::weight_transform_kernel<4>, grid, block, 0, s, w, U, Cout, Cin, Kp, Mp, flip ? 1 : 0);
     return camli_check_launch(what);
 }
 
-extern "C" int64_t camli_wino_workspace_bytes(int B, int C, int N, int H, int W) {
-    if (B < 1 || C < 1 || N < 1 || H < 1 || W < 1) return 0;
-    const wino::Geometry g = wino::make_geometry(B, H, W);
-    return (int64_t)16 * g.NT * ((int64_t)kp_of(C) + mp_of(N)) * (int64_t)sizeof(float);
+extern "C" int64_t camli_wino_workspace_bytes(int B, int C, int N, int H, int W, int tile) {
+    if (B < 1 || C < 1 || N < 1 || H < 1 || W < 1 || !tile_ok(tile)) return 0;
+    const wino::Geometry g = wino::make_geometry(B, H, W, tile);
+    return (int64_t)planes_of(tile) * g.NT * ((int64_t)kp_of(C) + mp_of(N)) * (int64_t)sizeof(float);
 }
 
 extern "C" int64_t camli_wino_mask_bytes(int B, int C, int H, int W) {
@@ -81,50 +122,43 @@ extern "C" int64_t camli_wino_mask_bytes(int B, int C, int H, int W) {
 
 // y (= or +=) act(conv3x3(x) + bias).  x: B images of C planes H x W, image b at x + b * x_bs (planes dense: a channel slice
 // of a wider NCHW tensor is fine); x_bits (optional): activation bits [B][C][H][ceil(W / 8)] bytes, x reads as zero where its
-// bit is clear; U = camli_wino_weights(...) [16][C][Mp]; y: N planes per image, image stride y_bs; y_bits (optional, act != 0):
-// the activation bits of y [B][N][H][ceil(W / 8)], written.
+// bit is clear; U = camli_wino_weights(..., tile) [P][Cp][Mp]; y: N planes per image, image stride y_bs; y_bits (optional,
+// act != 0): the activation bits of y [B][N][H][ceil(W / 8)], written.
 extern "C" int camli_wino_conv3x3(const float* x, int64_t x_bs, const unsigned char* x_bits, const float* U, const float* bias,
                                   float* y, int64_t y_bs, unsigned char* y_bits, float* workspace, int64_t workspace_bytes, int B,
-                                  int C, int N, int H, int W, int act, int accumulate, void* stream) {
+                                  int C, int N, int H, int W, int act, int accumulate, int tile, void* stream) {
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_wino_conv3x3";
     if (!x || !U || !y || !workspace) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
-    if (B < 0 || H < 1 || W < 1 || C <= (NBUF - 1) * KS || N < 4 || act < wino::OUT_PLAIN || act > wino::OUT_RELU_FINITE) {
-        camli_set_error("%s: unsupported shape B=%d C=%d N=%d %dx%d act=%d (more than %d input channels; act 0 | 1 | 2)", what, B, C, N, H, W, act,
-                        (NBUF - 1) * KS);
+    if (B < 0 || H < 1 || W < 1 || C <= (NBUF - 1) * KS || N < 4 || act < wino::OUT_PLAIN || act > wino::OUT_RELU_FINITE || !tile_ok(tile)) {
+        camli_set_error("%s: unsupported shape B=%d C=%d N=%d %dx%d act=%d tile=%d (more than %d input channels; act 0 | 1 | 2; tile 2 | 4)", what,
+                        B, C, N, H, W, act, tile, (NBUF - 1) * KS);
         return CAMLI_ENOTSUP;
     }
-    const wino::Geometry g = wino::make_geometry(B, H, W);
-    const int Mp = mp_of(N), Cp = kp_of(C);
-    const int64_t need = camli_wino_workspace_bytes(B, C, N, H, W);
+    const wino::Geometry g = wino::make_geometry(B, H, W, tile);
+    const int Mp = mp_of(N), Cp = kp_of(C), P = planes_of(tile);
+    const int64_t need = camli_wino_workspace_bytes(B, C, N, H, W, tile);
     if (workspace_bytes < need) { camli_set_error("%s: workspace of %lld bytes, %lld needed", what, (long long)workspace_bytes, (long long)need); return CAMLI_EINVAL; }
-    if ((int64_t)(Mp + 256) * g.NT * 4 >= (int64_t)0x7FF00000 || (int64_t)g.NT * 16 >= ((int64_t)1 << 30)) {
+    if ((int64_t)(Mp + 256) * g.NT * 4 >= (int64_t)0x7FF00000 || (int64_t)g.NT * P >= ((int64_t)1 << 30)) {
         camli_set_error("%s: a transform-domain plane beyond 2 GB (B=%d N=%d %dx%d)", what, B, N, H, W);
         return CAMLI_ENOTSUP;
     }
     if (!aligned16(U) || !aligned16(workspace)) { camli_set_error("%s: U / workspace must be 16-byte aligned", what); return CAMLI_EINVAL; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* V = workspace;
-    float* Mo = workspace + (size_t)16 * Cp * g.NT;
+    float* Mo = workspace + (size_t)P * Cp * g.NT;
     const int64_t plane = (int64_t)H * W;
-    const dim3 block(256);
-    {
-        const bool vec = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0;
-        const dim3 grid(camli_divup(g.NT / 4, 256), Cp);
-        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, false>), grid, block, 0, s, x, x_bs, plane, x_bits, V, C, Cp, g);
-        else hipLaunchKernelGGL((wino::input_transform_kernel<false, false>), grid, block, 0, s, x, x_bs, plane, x_bits, V, C, Cp, g);
-    }
+    const bool vec_in = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0;
+    if (tile == 2) launch_input<2>(vec_in, false, x, x_bs, plane, x_bits, V, C, Cp, g, s);
+    else launch_input<4>(vec_in, false, x, x_bs, plane, x_bits, V, C, Cp, g, s);
     int rc;
-    if (Mp <= 128) rc = launch_planes<2, 1, 1>(U, V, Mo, Mp, g.NT, Cp, s);
-    else if (Mp <= 192) rc = launch_planes<3, 1, 1>(U, V, Mo, Mp, g.NT, Cp, s);
-    else rc = launch_planes<2, 2, 2>(U, V, Mo, Mp, g.NT, Cp, s);
+    if (Mp <= 128) rc = launch_planes<2, 1, 1>(U, V, Mo, Mp, g.NT, Cp, P, s);
+    else if (Mp <= 192) rc = launch_planes<3, 1, 1>(U, V, Mo, Mp, g.NT, Cp, P, s);
+    else rc = launch_planes<2, 2, 2>(U, V, Mo, Mp, g.NT, Cp, P, s);
     if (rc != CAMLI_OK) return rc;
-    {
-        const bool vec = W % 4 == 0 && aligned16(y) && y_bs % 4 == 0;
-        const dim3 grid(camli_divup(g.NT / 4, 256), N);
-        if (vec) hipLaunchKernelGGL(wino::output_transform_kernel<true>, grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, y_bits, N, g);
-        else hipLaunchKernelGGL(wino::output_transform_kernel<false>, grid, block, 0, s, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, y_bits, N, g);
-    }
+    const bool vec_out = W % 4 == 0 && aligned16(y) && y_bs % 4 == 0;
+    if (tile == 2) launch_output<2>(vec_out, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, y_bits, N, g, s);
+    else launch_output<4>(vec_out, Mo, Mp, bias, y, y_bs, plane, act, accumulate ? 1 : 0, y_bits, N, g, s);
     return camli_check_launch(what);
 }
 
@@ -159,7 +193,7 @@ WrwPlan wrw_plan(int C, int N, const wino::Geometry& g) {
     else { pl.rows = N; pl.cols = pad_b; pl.ntw = ntw_b; pl.v_rows = pad_b; pl.g_rows = N; }
     const int tiles = camli_divup(pl.rows, 256) * (pl.cols / (32 * pl.ntw));
     const int total = g.NT / 16;
-    int S = cu_count() / (16 * tiles);
+    int S = cu_count() / (planes_of(g.M) * tiles);
     if (S < 1) S = 1;
     if (S > total / 2) S = total / 2 > 0 ? total / 2 : 1;
     int q = camli_divup(total, S);
@@ -185,11 +219,12 @@ int launch_wrw_planes(const wino::WrwBatch& wb, int tiles, int zdim, hipStream_t
 
 }  // namespace
 
-extern "C" int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, int W) {
-    if (B < 1 || C < 1 || N < 1 || H < 1 || W < 1) return 0;
-    const wino::Geometry g = wino::make_geometry(B, H, W);
+extern "C" int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, int W, int tile) {
+    if (B < 1 || C < 1 || N < 1 || H < 1 || W < 1 || !tile_ok(tile)) return 0;
+    const wino::Geometry g = wino::make_geometry(B, H, W, tile);
     const WrwPlan pl = wrw_plan(C, N, g);
-    return ((int64_t)16 * g.NT * ((int64_t)pl.v_rows + pl.g_rows) + (int64_t)pl.S * 16 * pl.part_floats) * (int64_t)sizeof(float);
+    const int P = planes_of(tile);
+    return ((int64_t)P * g.NT * ((int64_t)pl.v_rows + pl.g_rows) + (int64_t)pl.S * P * pl.part_floats) * (int64_t)sizeof(float);
 }
 
 // gw [N][C][3][3] (= | +=) the weight gradient of y = conv3x3(x) for the output gradient gy (gy_bits optional: the
@@ -198,15 +233,16 @@ extern "C" int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, in
 // gbias [N] (optional) (= | +=, gbias_accumulate) the bias gradient = the sum of the (masked) output gradient per channel.
 extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int64_t gy_bs, const unsigned char* gy_bits,
                               float* gw, float* gbias, float* workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W,
-                              int accumulate, int gbias_accumulate, void* stream) {
+                              int accumulate, int gbias_accumulate, int tile, void* stream) {
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_wino_wrw";
     if (!x || !gy || !gw || !workspace) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
-    const int64_t need = camli_wino_wrw_workspace_bytes(B, C, N, H, W);
-    if (B < 0 || C < 1 || N < 1 || need == 0) { camli_set_error("%s: unsupported shape B=%d C=%d N=%d %dx%d", what, B, C, N, H, W); return CAMLI_ENOTSUP; }
+    const int64_t need = camli_wino_wrw_workspace_bytes(B, C, N, H, W, tile);
+    if (B < 0 || C < 1 || N < 1 || need == 0) { camli_set_error("%s: unsupported shape B=%d C=%d N=%d %dx%d tile=%d", what, B, C, N, H, W, tile); return CAMLI_ENOTSUP; }
     if (workspace_bytes < need) { camli_set_error("%s: workspace of %lld bytes, %lld needed", what, (long long)workspace_bytes, (long long)need); return CAMLI_EINVAL; }
-    const wino::Geometry g = wino::make_geometry(B, H, W);
+    const wino::Geometry g = wino::make_geometry(B, H, W, tile);
     const WrwPlan pl = wrw_plan(C, N, g);
+    const int P = planes_of(tile), A = tile + 2;
     if ((int64_t)(pl.v_rows > pl.g_rows ? pl.v_rows : pl.g_rows) * g.NT * 4 >= (int64_t)0x7FF00000 || pl.part_floats * 4 >= (int64_t)0x7FF00000) {
         camli_set_error("%s: a transform-domain plane beyond 2 GB (B=%d C=%d N=%d %dx%d)", what, B, C, N, H, W);
         return CAMLI_ENOTSUP;
@@ -214,24 +250,19 @@ extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int
     if (!aligned16(workspace)) { camli_set_error("%s: workspace must be 16-byte aligned", what); return CAMLI_EINVAL; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* V = workspace;
-    float* gM = V + (size_t)16 * pl.v_rows * g.NT;
-    float* parts = gM + (size_t)16 * pl.g_rows * g.NT;
+    float* gM = V + (size_t)P * pl.v_rows * g.NT;
+    float* parts = gM + (size_t)P * pl.g_rows * g.NT;
     const int64_t plane = (int64_t)H * W;
-    const dim3 block(256);
-    // both operands in the chunk-major layout [16][NT / 16][rows][16]: a K chunk of all rows is one contiguous block
-    {
-        const bool vec = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0;
-        const dim3 grid(g.NT / 16, camli_divup(pl.v_rows, 64));
-        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, true>), grid, block, 0, s, x, x_bs, plane, nullptr, V, C, pl.v_rows, g);
-        else hipLaunchKernelGGL((wino::input_transform_kernel<false, true>), grid, block, 0, s, x, x_bs, plane, nullptr, V, C, pl.v_rows, g);
+    // both operands in the chunk-major layout [P][NT / 16][rows][16]: a K chunk of all rows is one contiguous block
+    const bool vec_x = W % 4 == 0 && aligned16(x) && x_bs % 4 == 0, vec_g = W % 4 == 0 && aligned16(gy) && gy_bs % 4 == 0;
+    if (tile == 2) {
+        launch_input<2>(vec_x, true, x, x_bs, plane, nullptr, V, C, pl.v_rows, g, s);
+        launch_grad<2>(vec_g, gy, gy_bs, plane, gy_bits, gM, N, pl.g_rows, g, s);
+    } else {
+        launch_input<4>(vec_x, true, x, x_bs, plane, nullptr, V, C, pl.v_rows, g, s);
+        launch_grad<4>(vec_g, gy, gy_bs, plane, gy_bits, gM, N, pl.g_rows, g, s);
     }
-    {
-        const bool vec = W % 4 == 0 && aligned16(gy) && gy_bs % 4 == 0;
-        const dim3 grid(g.NT / 16, camli_divup(pl.g_rows, 64));
-        if (vec) hipLaunchKernelGGL((wino::grad_transform_kernel<true, true>), grid, block, 0, s, gy, gy_bs, plane, gy_bits, gM, N, pl.g_rows, g);
-        else hipLaunchKernelGGL((wino::grad_transform_kernel<false, true>), grid, block, 0, s, gy, gy_bs, plane, gy_bits, gM, N, pl.g_rows, g);
-    }
-    if (gbias) hipLaunchKernelGGL(wino::bias_grad_kernel, dim3(N), block, 0, s, gM, pl.g_rows, g.NT, gbias, gbias_accumulate ? 1 : 0);
+    if (gbias) hipLaunchKernelGGL(wino::bias_grad_kernel, dim3(N), dim3(256), 0, s, gM, A + 1, pl.g_rows, g.NT, gbias, gbias_accumulate ? 1 : 0);
     wino::WrwBatch wb;
     ccl::Problem& p = wb.base;
     p.x = p.x1 = pl.swap ? gM : V;
@@ -246,17 +277,19 @@ extern "C" int camli_wino_wrw(const float* x, int64_t x_bs, const float* gy, int
     p.add = p.h = p.z = V; p.y2 = parts; p.ld_add = p.ld_h = p.ld_z = p.ldy2 = 4;
     p.acc0 = p.acc1 = p.sanitize = 0;
     for (int t = 0; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+    wb.planes = P;
     wb.q_chunks = pl.q; wb.total_chunks = g.NT / 16;
     wb.x_plane = (int64_t)x_rows * g.NT;
     wb.w_plane = (int64_t)w_rows * g.NT;
     wb.y_part = pl.part_floats;
     const int tiles = p.tiles_p * p.tiles_n;
-    const int rc = pl.ntw == 8 ? launch_wrw_planes<8>(wb, tiles, 16 * pl.S, s) : pl.ntw == 6 ? launch_wrw_planes<6>(wb, tiles, 16 * pl.S, s)
-                                                                                             : launch_wrw_planes<4>(wb, tiles, 16 * pl.S, s);
+    const int rc = pl.ntw == 8 ? launch_wrw_planes<8>(wb, tiles, P * pl.S, s) : pl.ntw == 6 ? launch_wrw_planes<6>(wb, tiles, P * pl.S, s)
+                                                                                          : launch_wrw_planes<4>(wb, tiles, P * pl.S, s);
     if (rc != CAMLI_OK) return rc;
     // element (c, n) of a part: rows are c (V on the row side) or n (swapped)
     const int64_t sc = pl.swap ? 1 : pl.cols, sn = pl.swap ? pl.cols : 1;
-    hipLaunchKernelGGL(wino::wrw_reduce_kernel, dim3(camli_divup(N, 64), C), dim3(256), 0, s, parts, pl.S, pl.part_floats, sc, sn, gw, C, N,
-                       accumulate ? 1 : 0);
+    const dim3 rgrid(camli_divup(N, 64), C);
+    if (tile == 2) hipLaunchKernelGGL(wino::wrw_reduce_kernel<2>, rgrid, dim3(256), 0, s, parts, pl.S, pl.part_floats, sc, sn, gw, C, N, accumulate ? 1 : 0);
+    else hipLaunchKernelGGL(wino::wrw_reduce_kernel<4>, rgrid, dim3(256), 0, s, parts, pl.S, pl.part_floats, sc, sn, gw, C, N, accumulate ? 1 : 0);
     return camli_check_launch(what);
 }

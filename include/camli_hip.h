@@ -616,42 +616,45 @@ int camli_convcl_wrw(const float *x0, int ldx0, int C0, const float *x1, int ldx
                      int64_t workspace_bytes, float *gw, int accumulate, int B, int H, int W, int Cout, int T, const signed char *dy,
                      const signed char *dx, void *stream);
 /*
- * Winograd F(2x2, 3x3) convolution on the fp32 matrix cores (round 6, csrc/hip/winograd.h + gemm_w128.h): the 3x3 / stride 1 /
+ * Winograd F(M x M, 3x3) convolution, M = `tile` = 2 | 4, on the fp32 matrix cores (round 6, csrc/hip/winograd.h + gemm_w128.h):
+ * (M + 2)^2 multiplications per M^2 outputs and channel pair instead of 9 M^2 (2.25 x | 4 x fewer); tile 4 pays ~10 x the
+ * rounding error of tile 2 (factors up to 8 and 1 / 24 in the transforms; ~3e-6 relative L2 at 256 channels).  The 3x3 / stride 1 /
  * padding 1 convolutions of the RAFT update block -- MotionEncoder2D.conv_c2 (256 -> 192) and .conv (256 -> 126),
  * models/raft_core.py:148,151; FlowHead2D.conv1 (128 -> 256), :173; the mask head's first convolution (128 -> 256), :188 --
  * forward and data gradient, replacing the library's fp32 Winograd / implicit-GEMM kernels.  NCHW fp32 tensors:
  *     y[b][n][oy][ox] (= | +=) act( sum_c sum_{i,j} x[b][c][oy+i-1][ox+j-1] * w[n][c][i][j] + bias[n] )      zero outside the image
- * as three launches: input transform (x -> V [16][C][tiles]), 16 plane GEMMs U[t]^T V[t] (one launch), output transform.
- *   camli_wino_weights: U [16][Kp][Mp] = G g G^T of w [Cout][Cin][3][3]; flip = 0: K = Cin, M = Cout (forward); flip = 1: K = Cout,
+ * as three launches: input transform (x -> V [P][C][tiles], P = (tile + 2)^2), P plane GEMMs U[t]^T V[t] (one launch), output
+ * transform.  Every call of one convolution takes the same `tile`.
+ *   camli_wino_weights: U [P][Kp][Mp] = G g G^T of w [Cout][Cin][3][3]; flip = 0: K = Cin, M = Cout (forward); flip = 1: K = Cout,
  *     M = Cin, taps reversed -- the weights of the DATA GRADIENT, which is the same convolution of the output gradient.
- *     Kp = K rounded up to a multiple of 16, Mp = M to a multiple of 4 (zeros beyond); camli_wino_weight_floats(K, M) = 16 Kp Mp.
+ *     Kp = K rounded up to a multiple of 16, Mp = M to a multiple of 4 (zeros beyond); camli_wino_weight_floats(K, M, tile) = P Kp Mp.
  *   camli_wino_conv3x3: image b of x at x + b * x_bs (C dense H x W planes: a channel slice of a wider NCHW tensor is fine), of y
  *     at y + b * y_bs (N planes); bias optional; act 0 none | 1 ReLU | 2 ReLU then nan_to_num (raft_core.py:163-164);
  *     accumulate: y += (before act).  y_bits (optional, act != 0): the ACTIVATION BITS of y are written -- [B][N][H][ceil(W / 8)]
  *     bytes (camli_wino_mask_bytes), bit j of byte s = output pixel 8 s + j passes the gradient (pre-activation > 0; act 2: and
  *     finite); x_bits (optional): such bits for the INPUT, x reads as zero where its bit is clear -- the ReLU adjoint of the
  *     data gradient rides on the input transform at 1/32 of the bytes of re-reading the forward's output.  C > 32, N >= 4;
- *     workspace = camli_wino_workspace_bytes(B, C, N, H, W) bytes (V and the transform-domain output: 4 x the input + 4 x the
- *     output), 16-byte aligned.  Differs from the direct fp32 form by its rounding only (tests/test_winograd_gpu.py).
+ *     workspace = camli_wino_workspace_bytes(B, C, N, H, W, tile) bytes (V and the transform-domain output: P / tile^2 x the
+ *     input + the output), 16-byte aligned.  Differs from the direct fp32 form by its rounding only (tests/test_winograd_gpu.py).
  *   camli_wino_wrw: WEIGHT GRADIENT in the transform domain: gU[t][c][n] = sum_tiles V[t][c][tile] * (A gy A^T)[t][n][tile], then
  *     gw [N][C][3][3] (= | +=) G^T gU G -- the same 2.25 x fewer multiplications as the forward.  x [B][C][H][W] (image stride
  *     x_bs), gy [B][N][H][W] (image stride gy_bs); gy_bits optional: the forward's activation bits, gy reads as zero where its
  *     bit is clear.  gbias [N] (optional) (= | +=, gbias_accumulate) the bias gradient: the per-channel sum of the masked gy,
- *     taken from the transform-domain plane that holds the tile sums.  workspace = camli_wino_wrw_workspace_bytes(B, C, N, H, W)
- *     bytes (0 = unsupported shape).  The contraction over the tiles is split over the CUs, the parts are summed in a fixed
+ *     taken from the transform-domain plane that holds the tile sums.  workspace = camli_wino_wrw_workspace_bytes(B, C, N, H, W,
+ *     tile) bytes (0 = unsupported shape).  The contraction over the tiles is split over the CUs, the parts are summed in a fixed
  *     order: deterministic, no atomics.
  */
-int64_t camli_wino_weight_floats(int K, int M);
-int camli_wino_weights(const float *w, float *U, int Cout, int Cin, int flip, void *stream);
-int64_t camli_wino_workspace_bytes(int B, int C, int N, int H, int W);
+int64_t camli_wino_weight_floats(int K, int M, int tile);
+int camli_wino_weights(const float *w, float *U, int Cout, int Cin, int flip, int tile, void *stream);
+int64_t camli_wino_workspace_bytes(int B, int C, int N, int H, int W, int tile);
 int64_t camli_wino_mask_bytes(int B, int C, int H, int W);
 int camli_wino_conv3x3(const float *x, int64_t x_bs, const unsigned char *x_bits, const float *U, const float *bias, float *y,
                        int64_t y_bs, unsigned char *y_bits, float *workspace, int64_t workspace_bytes, int B, int C, int N, int H,
-                       int W, int act, int accumulate, void *stream);
-int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, int W);
+                       int W, int act, int accumulate, int tile, void *stream);
+int64_t camli_wino_wrw_workspace_bytes(int B, int C, int N, int H, int W, int tile);
 int camli_wino_wrw(const float *x, int64_t x_bs, const float *gy, int64_t gy_bs, const unsigned char *gy_bits, float *gw,
                    float *gbias, float *workspace, int64_t workspace_bytes, int B, int C, int N, int H, int W, int accumulate,
-                   int gbias_accumulate, void *stream);
+                   int gbias_accumulate, int tile, void *stream);
 int camli_conv3x3_co2_bwd_data(const float *gy, const float *w, float *gx, int B, int Cin, int H, int W, void *stream);
 long long camli_conv3x3_co2_bwd_weight_workspace_bytes(int B, int Cin, int W);
 int camli_conv3x3_co2_bwd_weight(const float *gy, const float *x, float *workspace, float *gw, float *gb, int accumulate,

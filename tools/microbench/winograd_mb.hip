@@ -51,8 +51,14 @@ __global__ void err_kernel(const float* y, const double* r, size_t n, double* ou
 }
 
 template <int GA, int GB, int WM>
+#ifndef MB_TILE
+#define MB_TILE 2
+#endif
+#ifndef MB_NBUF
+#define MB_NBUF 3
+#endif
 static void launch_gemm(const float* U, const float* V, float* Mo, int Mp, int NT, int K, hipStream_t s) {
-    constexpr int KS = 16, NBUF = 3;
+    constexpr int KS = 16, NBUF = MB_NBUF;
     constexpr size_t lds = (size_t)NBUF * KS * 512 * sizeof(float);
     auto kern = &w128::gemm_w128_kernel<KS, NBUF, 0, GA, GB, WM>;
     static bool set = false;
@@ -64,7 +70,7 @@ static void launch_gemm(const float* U, const float* V, float* Mo, int Mp, int N
     p.alpha = 1.0f;
     p.tiles_m = (Mp + w128::tile_m<GA, WM>() - 1) / w128::tile_m<GA, WM>();
     p.tiles_n = (NT + w128::tile_n<GB, WM>() - 1) / w128::tile_n<GB, WM>();
-    p.tiles = 16 * p.tiles_m * p.tiles_n;
+    p.tiles = (MB_TILE + 2) * (MB_TILE + 2) * p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL(kern, dim3(256), dim3(256), lds, s, p);
 }
 
@@ -91,28 +97,29 @@ struct Timer {
 };
 
 static void run(int B, int C, int N, int H, int W, bool check, int reps, int relu) {
-    const wino::Geometry g = wino::make_geometry(B, H, W);
+    const wino::Geometry g = wino::make_geometry(B, H, W, MB_TILE);
+    constexpr int PL = (MB_TILE + 2) * (MB_TILE + 2), TPT = 8 / MB_TILE;
     const int Mp = (N + 3) & ~3;
     const size_t nx = (size_t)B * C * H * W, ny = (size_t)B * N * H * W, nw = (size_t)N * C * 9;
     float *x, *w, *bias, *y, *U, *V, *Mo;
     CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&y, ny * 4));
-    CK(hipMalloc(&U, (size_t)16 * C * Mp * 4)); CK(hipMalloc(&V, (size_t)16 * C * g.NT * 4)); CK(hipMalloc(&Mo, (size_t)16 * Mp * g.NT * 4));
+    CK(hipMalloc(&U, (size_t)PL * C * Mp * 4)); CK(hipMalloc(&V, (size_t)PL * C * g.NT * 4)); CK(hipMalloc(&Mo, (size_t)PL * Mp * g.NT * 4));
     hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, x, nx, 12345u, 1.0f);
     hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, w, nw, 777u, 1.0f / sqrtf(9.0f * C));
     hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, 0, bias, (size_t)N, 99u, 0.1f);
     CK(hipMemset(y, 0xFF, ny * 4));
     const bool vec = W % 4 == 0;
-    auto wt = [&]() { hipLaunchKernelGGL(wino::weight_transform_kernel, dim3((C * Mp + 255) / 256), dim3(256), 0, 0, w, U, N, C, C, Mp, 0); };
+    auto wt = [&]() { hipLaunchKernelGGL(wino::weight_transform_kernel<MB_TILE>, dim3((C * Mp + 255) / 256), dim3(256), 0, 0, w, U, N, C, C, Mp, 0); };
     auto it = [&]() {
-        dim3 grid((g.NT / 4 + 255) / 256, C);
-        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<true, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, V, C, C, g);
-        else hipLaunchKernelGGL((wino::input_transform_kernel<false, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, V, C, C, g);
+        dim3 grid((g.NT / TPT + 255) / 256, C);
+        if (vec) hipLaunchKernelGGL((wino::input_transform_kernel<MB_TILE, true, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, V, C, C, g);
+        else hipLaunchKernelGGL((wino::input_transform_kernel<MB_TILE, false, false>), grid, dim3(256), 0, 0, x, (int64_t)C * H * W, (int64_t)H * W, nullptr, V, C, C, g);
     };
     auto gm = [&]() { gemm(U, V, Mo, Mp, g.NT, C, 0); };
     auto ot = [&]() {
-        dim3 grid((g.NT / 4 + 255) / 256, N);
-        if (vec) hipLaunchKernelGGL(wino::output_transform_kernel<true>, grid, dim3(256), 0, 0, Mo, Mp, bias, y, (int64_t)N * H * W, (int64_t)H * W, relu, 0, nullptr, N, g);
-        else hipLaunchKernelGGL(wino::output_transform_kernel<false>, grid, dim3(256), 0, 0, Mo, Mp, bias, y, (int64_t)N * H * W, (int64_t)H * W, relu, 0, nullptr, N, g);
+        dim3 grid((g.NT / TPT + 255) / 256, N);
+        if (vec) hipLaunchKernelGGL((wino::output_transform_kernel<MB_TILE, true>), grid, dim3(256), 0, 0, Mo, Mp, bias, y, (int64_t)N * H * W, (int64_t)H * W, relu, 0, nullptr, N, g);
+        else hipLaunchKernelGGL((wino::output_transform_kernel<MB_TILE, false>), grid, dim3(256), 0, 0, Mo, Mp, bias, y, (int64_t)N * H * W, (int64_t)H * W, relu, 0, nullptr, N, g);
     };
     wt(); it(); gm(); ot();
     CK(hipDeviceSynchronize());
@@ -127,7 +134,7 @@ static void run(int B, int C, int N, int H, int W, bool check, int reps, int rel
             CK(hipMemset(stats, 0, 64));
             hipLaunchKernelGGL(err_kernel, dim3(1024), dim3(256), 0, 0, which ? r32 : y, r64, ny, stats);
             CK(hipMemcpy(h, stats, 32, hipMemcpyDeviceToHost));
-            printf("  %-22s vs fp64 direct: max abs err %.3e (max |ref| %.3f), relative L2 %.3e\n", which ? "fp32 direct (fmaf chain)" : "winograd F(2x2,3x3)",
+            printf("  %-22s vs fp64 direct: max abs err %.3e (max |ref| %.3f), relative L2 %.3e\n", which ? "fp32 direct (fmaf chain)" : (MB_TILE == 2 ? "winograd F(2x2,3x3)" : "winograd F(4x4,3x3)"),
                    h[0], h[1], sqrt(h[2] / h[3]));
         }
         CK(hipFree(r64)); CK(hipFree(r32)); CK(hipFree(stats));
@@ -136,11 +143,11 @@ static void run(int B, int C, int N, int H, int W, bool check, int reps, int rel
         Timer t;
         const float t_in = t.us(it, reps), t_g = t.us(gm, reps), t_out = t.us(ot, reps), t_w = t.us(wt, reps);
         const float t_all = t.us([&]() { it(); gm(); ot(); }, reps);
-        const double direct = 2.0 * B * H * W * (double)C * N * 9, wflop = 2.0 * 16 * (double)Mp * g.NT * C;
+        const double direct = 2.0 * B * H * W * (double)C * N * 9, wflop = 2.0 * PL * (double)Mp * g.NT * C;
         printf("B=%d %d->%d %dx%d (tiles %d, Mp %d): weights %.1f us | input %.1f us (%.2f TB/s) | gemm %.1f us (%.3f of 157.3 TF) | output %.1f us (%.2f TB/s) | "
                "all three %.1f us = %.1f TF/s direct-equivalent (%.3f of the fp32 matrix peak)\n",
-               B, C, N, H, W, g.NT, Mp, t_w, t_in, (nx * 4.0 + 16.0 * C * g.NT * 4) / t_in / 1e6, t_g, wflop / t_g / 1e6 / 157.3, t_out,
-               (16.0 * Mp * g.NT * 4 + ny * 4.0) / t_out / 1e6, t_all, direct / t_all / 1e6, direct / t_all / 1e6 / 157.3);
+               B, C, N, H, W, g.NT, Mp, t_w, t_in, (nx * 4.0 + (double)PL * C * g.NT * 4) / t_in / 1e6, t_g, wflop / t_g / 1e6 / 157.3, t_out,
+               ((double)PL * Mp * g.NT * 4 + ny * 4.0) / t_out / 1e6, t_all, direct / t_all / 1e6, direct / t_all / 1e6 / 157.3);
     }
     CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(bias)); CK(hipFree(y)); CK(hipFree(U)); CK(hipFree(V)); CK(hipFree(Mo));
 }
