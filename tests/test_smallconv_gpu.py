@@ -64,4 +64,9 @@ def test_flow_head_module_uses_the_kernels_and_defers_parameter_gradients():
         got, census = run('hip', deferred)
         assert census['fused'].get('camli_conv3x3_co2_fwd', 0) == 3 and census['fused'].get('camli_conv3x3_co2_bwd_weight', 0) == 3
         for n in want:
-            assert (got[n] - want[n]).norm() <= 2e-4 * want[n].norm() + 1e-6, (deferred, n)
+            # conv1 runs as a Winograd F(4x4,3x3) convolution (r6) whose rounding differs from the library's by ~3e-6 relative:
+            # of the 286,720 ReLU decisions behind it one falls on the other side in this seed, and on random data a single
+            # term is 1 / sqrt(active elements) = 2.6e-3 of a gradient's norm -- the bound for everything upstream of that ReLU
+            # (tools/wino_flip_probe.py shows the same on the reference golden; tests/test_winograd_gpu.py has the kernel's bounds)
+            bound = 5e-3 if n.startswith('conv1') else 2e-4
+            assert (got[n] - want[n]).norm() <= bound * want[n].norm() + 1e-6, (deferred, n)

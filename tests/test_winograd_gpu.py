@@ -199,13 +199,14 @@ def _close_through_relus(got, want, tol, what):
     reference's did, and each such flip moves the gradients around it by one discrete term (tests/test_upsample_gpu.py has the
     same remark for the folded trunk).  Tile 2 reproduces every decision of the recorded maps; tile 4 (ten times the rounding
     error) flips ONE of the 16,128 activations of conv_c2 here -- the one whose fp64 pre-activation is 3.9e-7
-    (tools/wino_flip_probe.py) -- and on this 7 x 12 map that single term is 1 % of the correlation gradient's norm.  So:
-    relative L2 within 2e-2, and all but 2 % of the elements within `tol`."""
+    (tools/wino_flip_probe.py) -- and on this 7 x 12 map that single term is 1 % of the correlation gradient's norm and reaches
+    the 3 x 3 neighbourhood of its pixel (9 of 84 pixels, every channel).  So: relative L2 within 2e-2, and all but 15 % of the
+    elements within `tol`."""
     got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
     scale = max(1.0, float(np.abs(want).max()))
     err = np.abs(got - want)
     rel = float(np.sqrt((err ** 2).sum() / (want.astype(np.float64) ** 2).sum()))
-    assert got.shape == want.shape and rel <= 2e-2 and float((err > tol * scale).mean()) <= 0.02, (what, rel, float((err > tol * scale).mean()))
+    assert got.shape == want.shape and rel <= 2e-2 and float((err > tol * scale).mean()) <= 0.15, (what, rel, float((err > tol * scale).mean()))
 
 
 @pytest.mark.parametrize('tile', TILES)
