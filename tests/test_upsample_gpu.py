@@ -186,10 +186,13 @@ def test_trunk_identity_block_fork_on_and_off_give_the_same_gradients(monkeypatc
     (y1, gx1, g1, used1), (y0, gx0, g0, used0) = res[True], res[False]
     assert used1 > 0 and used0 == 0, (used1, used0)          # the identity blocks did take the fork node, and only when asked to
     assert (y1 - y0).abs().max() <= 1e-6 * max(1.0, float(y0.abs().max()))     # the forward is the same arithmetic either way
-    assert (gx1 - gx0).abs().max() <= 1e-5 * max(1.0, float(gx0.abs().max()))
+    # the two passes call the library's convolution adjoints separately, and which algorithm it picks depends on the workspace
+    # it is offered (see the remark in test_resnet_trunk_folded_batchnorm_vs_unfolded): seen 0 ... 1e-4 between the passes
+    # with the caching allocator off.  An in-place update of a gradient somebody else still reads would be an O(1) error.
+    assert (gx1 - gx0).abs().max() <= 2e-3 * max(1.0, float(gx0.abs().max()))
     num = sum(((g1[n] - g0[n]).double() ** 2).sum().item() for n in g1) ** 0.5
     den = sum((g0[n].double() ** 2).sum().item() for n in g1) ** 0.5
-    assert g1.keys() == g0.keys() and num / den < 1e-5, num / den
+    assert g1.keys() == g0.keys() and num / den < 2e-3, num / den
 
 
 @pytest.mark.parametrize('case', [(2, 68, 120, 8, 540), (1, 17, 30, 8, 131), (2, 36, 60, 4, 141), (1, 5, 70, 8, 33), (1, 3, 193, 4, 12)], ids=str)
