@@ -139,12 +139,16 @@ class GRU2D(nn.Module):
             gates = [getattr(self, 'conv%s%s' % (g, suffix)) for g in 'zrq']
             w_ctx = torch.cat([g.weight[:, hd:hd + cd] for g in gates], dim=0)
             bias = torch.cat([g.bias for g in gates], dim=0)
-            ctx = torch.nn.functional.conv2d(context, w_ctx, bias, padding=padding)
+            if torch.is_autocast_enabled() and runtime.own_kernels_allowed():
+                with torch.autocast('cuda', enabled=False):        # the hoisted context terms feed the fp32 own kernels
+                    ctx = torch.nn.functional.conv2d(context.float(), w_ctx.float(), bias.float(), padding=padding)
+            else:
+                ctx = torch.nn.functional.conv2d(context, w_ctx, bias, padding=padding)
             keep = [torch.cat([g.weight[:, :hd], g.weight[:, hd + cd:]], dim=1) for g in gates]
             # contiguous once per pass: the gate kernels would otherwise copy these channel slices every iteration
             state[suffix] = (torch.cat(keep[:2], dim=0), keep[2], ctx[:, :2 * hd].contiguous(),
                              ctx[:, 2 * hd:].contiguous(), padding)
-            if (runtime.fused() and context.is_cuda and ctx.dtype == torch.float32 and not torch.is_autocast_enabled()
+            if (runtime.fused() and context.is_cuda and ctx.dtype == torch.float32 and runtime.own_kernels_allowed()
                     and os.environ.get('CAMLI_GRU_CL', '1') != '0'):
                 # r5 (default): the whole update as ONE node on channels-last tensors, convolutions + gate arithmetic on this
                 # repo's matrix-core kernels (csrc/hip/convcl.hip, fused._GRU2DStepCL); the hoisted context terms are laid out
@@ -163,7 +167,7 @@ class GRU2D(nn.Module):
         from ..csrc import fused
         conv2d = torch.nn.functional.conv2d
         hd = h.shape[1]
-        if 'hub' in state and not torch.is_autocast_enabled() and fused.gru2d_step_supported(h, motion, state['1'][0]):
+        if 'hub' in state and runtime.own_kernels_allowed() and fused.gru2d_step_supported(h, motion, state['1'][0]):
             return fused.gru2d_step_cl(h, motion, state['hub'])
         fusable = h.is_cuda and (hd * h.shape[2] * h.shape[3]) % 4 == 0
         for suffix in ('1', '2'):
@@ -228,7 +232,7 @@ class MotionEncoder2D(nn.Module):
         """bias + activation epilogues write straight into the concatenated tensors (fused.bias_act_cat): planes of 4k
         elements, fp32 outside autocast; CAMLI_BIAS_CAT=0 restores epilogue + torch.cat."""
         return (os.environ.get('CAMLI_BIAS_CAT', '1') == '1' and (t.shape[2] * t.shape[3]) % 4 == 0
-                and not torch.is_autocast_enabled())
+                and runtime.own_kernels_allowed())
 
     def forward(self, flow, corr, flow_branch=None):
         if epilogue_ok(corr) and self._cat_free(flow) and (flow_branch is None or (len(flow_branch) > 2 and flow_branch[2])):

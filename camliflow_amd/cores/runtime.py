@@ -164,6 +164,19 @@ def use_tuned_gemms(path=None):
         return False
 
 
+# Under torch.autocast the reference's update block runs its convolutions in the reduced precision (train.py:113,147-152).
+# CAMLI_AUTOCAST_OWN=1: the update block's own fp32 kernels (GRU2D's tap convolutions, the Winograd 3x3s, their fused
+# epilogues) also run inside an autocast region -- in fp32, i.e. at least the precision asked for -- instead of handing those
+# layers to the library's reduced-precision kernels.
+_AUTOCAST_OWN = os.environ.get('CAMLI_AUTOCAST_OWN', '0') == '1'
+
+
+def own_kernels_allowed():
+    """The fp32 own-kernel routes of the update block may be taken here: always outside autocast, inside it only when asked."""
+    import torch
+    return _AUTOCAST_OWN or not torch.is_autocast_enabled()
+
+
 def set_deferred_param_grads(enabled):
     global _DEFER_PARAM_GRADS
     _DEFER_PARAM_GRADS = bool(enabled)

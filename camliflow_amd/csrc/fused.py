@@ -2439,7 +2439,7 @@ def wino_supported(conv, x):
     return (_WINO and isinstance(conv, torch.nn.Conv2d) and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
             and conv.padding == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.padding_mode == 'zeros'
             and wino_shape_supported(conv.in_channels, conv.out_channels) and x.dim() == 4 and x.is_cuda
-            and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and not torch.is_autocast_enabled())
+            and x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and _runtime.own_kernels_allowed())
 
 
 def wino_shape_supported(cin, cout):
