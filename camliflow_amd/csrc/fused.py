@@ -2472,13 +2472,17 @@ def wino_transformed_weights(w, flip, tile=None):
             _lib.launch('camli_wino_weights', lib.camli_wino_weights, wd.data_ptr(), u.data_ptr(), cout, cin, int(flip), tile, _stream_ptr(w),
                         work=(4.0 * (9 + (tile + 2) ** 2) * cout * cin, 'B'))
         u._camli_stream = torch.cuda.current_stream(w.device)
+        u._camli_seen = {u._camli_stream.cuda_stream}
         u._camli_tile = tile
         entry[2][(flip, tile)] = u
     else:
-        # produced on another stream of this pass (a Branch / the weight-gradient side stream): order this stream behind it
+        # produced on another stream (a Branch, the priming pass's single lane): order this stream behind the producer ONCE --
+        # the tensor never changes afterwards, and waiting on every use would serialise an auxiliary stream behind the main
+        # one for good where the weights stay put (inference)
         cur = torch.cuda.current_stream(w.device)
-        if u._camli_stream != cur:
+        if cur.cuda_stream not in u._camli_seen:
             cur.wait_stream(u._camli_stream)
+            u._camli_seen.add(cur.cuda_stream)
     return u
 
 
