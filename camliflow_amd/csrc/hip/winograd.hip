@@ -6,6 +6,7 @@
 #include "gemm_w128.h"
 #include "winograd.h"
 #include "winograd_wrw.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -47,8 +48,14 @@ int launch_planes(const float* U, const float* V, float* Mo, int Mp, int NT, int
     p.tiles_n = camli_divup(NT, w128::tile_n<GB, WM>());
     p.tiles = P * p.tiles_m * p.tiles_n;
     const int cus = cu_count();
-    // the kernel's tile order deals 8 chunks (one per XCD) of gridDim.x / 8 consecutive tiles per round
-    int nwg = p.tiles < cus ? (p.tiles + 7) / 8 * 8 : cus;
+    // the kernel's tile order deals 8 chunks (one per XCD) of gridDim.x / 8 consecutive tiles per round.  Every workgroup
+    // walks ceil(tiles / workgroups) tiles whatever the count, so the launch takes the FEWEST workgroups that still finish in
+    // that many rounds: 576 tiles (256 -> 192 at tile 4) are three rounds on 256 CUs and on 192 alike -- the other 64 CUs
+    // stay free for the point lane's kernels (CAMLI_WINO_GRID=full: one workgroup per CU, A/B)
+    static const bool full = []() { const char* e = getenv("CAMLI_WINO_GRID"); return e && e[0] == 'f'; }();
+    const int rounds = camli_divup(p.tiles, cus);
+    int nwg = p.tiles < cus ? (p.tiles + 7) / 8 * 8 : (full ? cus : (camli_divup(p.tiles, rounds) + 7) / 8 * 8);
+    if (nwg > cus) nwg = cus;
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, s, p);
     return CAMLI_OK;
 }

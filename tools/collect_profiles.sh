@@ -97,9 +97,9 @@ pmcw)
     python $ROOT/tools/pmc_summary.py $OUT/pmcw_$c/p_counter_collection.csv > $OUT/pmc_wino_$c.txt 2>&1
   done
   python $ROOT/tools/pmc_traffic.py $OUT/pmcw_FETCH_SIZE/p_counter_collection.csv $OUT/pmcw_WRITE_SIZE/p_counter_collection.csv \
-      'input_transform_kernel<true, false>+gemm_w128_kernel+output_transform_kernel' camli_wino_conv3x3 > $OUT/traffic_wino_conv3x3.json 2>&1
+      "input_transform_kernel<${CAMLI_WINO_TILE:-4}, true, false>+gemm_w128_kernel+output_transform_kernel" camli_wino_conv3x3 > $OUT/traffic_wino_conv3x3.json 2>&1
   python $ROOT/tools/pmc_traffic.py $OUT/pmcw_FETCH_SIZE/p_counter_collection.csv $OUT/pmcw_WRITE_SIZE/p_counter_collection.csv \
-      'wrw_planes_kernel+input_transform_kernel<true, true>+grad_transform_kernel+wrw_reduce_kernel' camli_wino_wrw > $OUT/traffic_wino_wrw.json 2>&1
+      "wrw_planes_kernel+input_transform_kernel<${CAMLI_WINO_TILE:-4}, true, true>+grad_transform_kernel+wrw_reduce_kernel+bias_grad_kernel" camli_wino_wrw > $OUT/traffic_wino_wrw.json 2>&1
   rm -rf $OUT/pmcw_FETCH_SIZE $OUT/pmcw_WRITE_SIZE
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace \
       --kernel-include-regex 'gemm_w128_kernel|wrw_planes' --output-format csv -d $OUT/pmcw_mfma -o p -- \
