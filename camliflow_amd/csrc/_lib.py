@@ -134,6 +134,14 @@ PROTOTYPES = {
     "camli_gru_gates_bwd_into": (_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int64, _c_float_p, _c_float_p, _c_float_p,
                                         _c_float_p, _c_float_p, _c_float_p, _int, _int, _int, _stream]),
     "camli_gru_blend_bwd_acc": (_int, [_c_float_p] * 8 + [_int, _int, _int, _int, _stream]),
+    "camli_wino1d_workspace_bytes": (ctypes.c_int64, [_int] * 6),
+    "camli_wino1d_weights": (_int, [_c_float_p, _c_float_p, _int, _int, _int, _stream]),
+    "camli_wino1d_conv": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _c_float_p, _int, _int, _c_float_p, _int,
+                                 _c_float_p, ctypes.c_int64] + [_int] * 7 + [_stream]),
+    "camli_wino1d_gru_gates": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                      _c_float_p, ctypes.c_int64] + [_int] * 4 + [_stream]),
+    "camli_wino1d_gru_blend": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                      _c_float_p, _int, _c_float_p, ctypes.c_int64] + [_int] * 4 + [_stream]),
     "camli_convcl_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 6),
     "camli_convcl_wrw": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _int, _c_float_p, ctypes.c_int64,
                                 _c_float_p, _int, _int, _int, _int, _int, _int, ctypes.c_char_p, ctypes.c_char_p, _stream]),

@@ -1866,6 +1866,60 @@ def _to_nchw(x_n):
     return channels_last_to_nchw(x_n.permute(0, 3, 1, 2), 0, x_n.shape[3])
 
 
+# CAMLI_GRU_WINO=1: GRU2D's half-step convolutions and their data gradients as 1-D Winograd F(4,5) (csrc/hip/wino1d.hip:
+# 8 multiplications per 4 outputs where the 5-tap form spends 20); 0: the tap convolutions of convcl.hip
+_GRU_WINO = os.environ.get('CAMLI_GRU_WINO', '1') != '0'
+
+
+def wino1d_weights(wp, flip):
+    """U [8][N][C] of packed weights wp [N][5][C] (convcl_pack), for the forward (flip False) or -- from the transposed packing
+    -- the data gradient (flip True)."""
+    lib = _lib.load()
+    n, t, c = wp.shape
+    assert t == 5 and wp.is_contiguous() and wp.dtype == torch.float32
+    u = torch.empty((8, n, c), dtype=torch.float32, device=wp.device)
+    with _on_device(wp):
+        _lib.launch('camli_wino1d_weights', lib.camli_wino1d_weights, wp.data_ptr(), u.data_ptr(), n, c, int(flip), _stream_ptr(wp),
+                    work=(4.0 * 13 * n * c, 'B'))
+    return u
+
+
+def _wino1d_workspace(b, hh, ww, cin, cout, axis, device):
+    need = _lib.load().camli_wino1d_workspace_bytes(b, hh, ww, cin, cout, axis)
+    return torch.empty(need // 4, dtype=torch.float32, device=device), need
+
+
+def wino1d_conv(xs, u, axis, split=None, out=None, accumulate=(False, False)):
+    """convcl(xs, wp, taps of a 1x5 (axis 0) / 5x1 (axis 1) kernel) on the Winograd form; u = wino1d_weights(wp, ...)."""
+    _require_cuda('wino1d_conv', u, *xs)
+    lib = _lib.load()
+    x0 = xs[0]
+    x1 = xs[1] if len(xs) > 1 else None
+    b, hh, ww, c0 = x0.shape
+    c1 = x1.shape[3] if x1 is not None else 0
+    cout = u.shape[1]
+    assert u.shape == (8, cout, c0 + c1)
+    ld0, ld1 = _nhwc_ld(x0), (_nhwc_ld(x1) if x1 is not None else 0)
+    n0 = cout if split is None else int(split)
+    if out is None:
+        y0 = torch.empty((b, hh, ww, n0), dtype=torch.float32, device=x0.device)
+        y1 = torch.empty((b, hh, ww, cout - n0), dtype=torch.float32, device=x0.device) if n0 < cout else None
+        assert not any(accumulate)
+    else:
+        y0, y1 = (out, None) if torch.is_tensor(out) else out
+    ldy0, ldy1 = _nhwc_ld(y0), (_nhwc_ld(y1) if y1 is not None else 0)
+    if None in (ld0, ld1, ldy0, ldy1):
+        raise _lib.CamliHipError('wino1d_conv: operands must be dense fp32 NHWC tensors (16-byte aligned, pixel stride a multiple of 4)')
+    ws, need = _wino1d_workspace(b, hh, ww, c0 + c1, cout, axis, x0.device)
+    tiles = need // (32 * (c0 + c1 + cout))
+    with _on_device(x0):
+        _lib.launch('camli_wino1d_conv', lib.camli_wino1d_conv, x0.data_ptr(), ld0, c0, x1.data_ptr() if x1 is not None else 0, ld1, c1,
+                    u.data_ptr(), y0.data_ptr(), ldy0, n0, y1.data_ptr() if y1 is not None else 0, ldy1, ws.data_ptr(), need, b, hh, ww,
+                    cout, axis, int(bool(accumulate[0])), int(bool(accumulate[1])), _stream_ptr(x0),
+                    work=(4.0 * b * hh * ww * (c0 + c1 + cout) + 2.0 * need, 'B'), flop=2.0 * 8 * tiles * cout * (c0 + c1))
+    return y0 if y1 is None else (y0, y1)
+
+
 class GRU2DPass:
     """What the GRU2D updates of one pass share: the four weight blocks and the four hoisted context terms (NHWC), and the
     running totals of their gradients.  Every update's adjoint ADDS into the totals (the weight gradients through
@@ -1882,7 +1936,14 @@ class GRU2DPass:
         self.side = None            # runtime._WgradSide once a weight gradient has been issued beside the main chain
         self.done = None            # event behind the last update adjoint's accumulations (the hub node waits on it)
         self.two_lane = _runtime.lanes_live()       # this pass runs two-lane: its backward may use the weight-gradient side stream
+        self.wino = {}              # (id of a packed weight tensor, flip) -> its Winograd transform, once per pass
         self.token = _GRU2DHub.apply(self, *self.weights, *self.contexts)
+
+    def wino_u(self, wp, flip):
+        key = (id(wp), flip)
+        if key not in self.wino:
+            self.wino[key] = (wp, wino1d_weights(wp, flip))         # (the packed tensor is kept: its id stays unique)
+        return self.wino[key][1]
 
 
 class _GRU2DHub(torch.autograd.Function):
@@ -1943,13 +2004,28 @@ class _GRU2DStepCL(torch.autograd.Function):
                 wp_q, wpt_q = convcl_pack(w_q)
                 z, rh, r, q, hn = (torch.empty_like(h0) for _ in range(5))
                 flop = 2.0 * b * hh * ww * (hd + cx) * t
-                _lib.launch('camli_convcl_gru_gates', lib.camli_convcl_gru_gates, hcur.data_ptr(), mn.data_ptr(), cx, wp_zr.data_ptr(),
-                            c_zr.data_ptr(), z.data_ptr(), rh.data_ptr(), r.data_ptr(), b, hh, ww, t, dy, dx, _stream_ptr(h),
-                            work=(4.0 * b * hh * ww * (6 * hd + cx), 'B'), flop=flop * 2 * hd)
-                _lib.launch('camli_convcl_gru_blend', lib.camli_convcl_gru_blend, rh.data_ptr(), mn.data_ptr(), cx, wp_q.data_ptr(),
-                            c_q.data_ptr(), z.data_ptr(), hcur.data_ptr(), hn.data_ptr(), q.data_ptr(), int(half == 1), b, hh, ww, t,
-                            dy, dx, _stream_ptr(h), work=(4.0 * b * hh * ww * (6 * hd + cx), 'B'), flop=flop * hd)
-                ctx.geom.append((geom, wpt_zr, wpt_q))
+                wino = _GRU_WINO and t == 5 and (kh, kw) in ((1, 5), (5, 1)) and hd == 128
+                if wino:
+                    # r6: the two convolutions as 1-D Winograd F(4,5) with the same epilogues (csrc/hip/wino1d.hip)
+                    axis = 0 if kh == 1 else 1
+                    ws, need = _wino1d_workspace(b, hh, ww, hd + cx, 2 * hd, axis, h.device)
+                    tiles = need // (32 * (3 * hd + cx))
+                    _lib.launch('camli_wino1d_gru_gates', lib.camli_wino1d_gru_gates, hcur.data_ptr(), mn.data_ptr(), cx,
+                                hub.wino_u(wp_zr, False).data_ptr(), c_zr.data_ptr(), z.data_ptr(), rh.data_ptr(), r.data_ptr(), ws.data_ptr(),
+                                need, b, hh, ww, axis, _stream_ptr(h), work=(4.0 * b * hh * ww * (6 * hd + cx) + 2.0 * need, 'B'),
+                                flop=2.0 * 8 * tiles * (hd + cx) * 2 * hd)
+                    _lib.launch('camli_wino1d_gru_blend', lib.camli_wino1d_gru_blend, rh.data_ptr(), mn.data_ptr(), cx,
+                                hub.wino_u(wp_q, False).data_ptr(), c_q.data_ptr(), z.data_ptr(), hcur.data_ptr(), hn.data_ptr(), q.data_ptr(),
+                                int(half == 1), ws.data_ptr(), need, b, hh, ww, axis, _stream_ptr(h),
+                                work=(4.0 * b * hh * ww * (6 * hd + cx) + 1.5 * need, 'B'), flop=2.0 * 8 * tiles * (hd + cx) * hd)
+                else:
+                    _lib.launch('camli_convcl_gru_gates', lib.camli_convcl_gru_gates, hcur.data_ptr(), mn.data_ptr(), cx, wp_zr.data_ptr(),
+                                c_zr.data_ptr(), z.data_ptr(), rh.data_ptr(), r.data_ptr(), b, hh, ww, t, dy, dx, _stream_ptr(h),
+                                work=(4.0 * b * hh * ww * (6 * hd + cx), 'B'), flop=flop * 2 * hd)
+                    _lib.launch('camli_convcl_gru_blend', lib.camli_convcl_gru_blend, rh.data_ptr(), mn.data_ptr(), cx, wp_q.data_ptr(),
+                                c_q.data_ptr(), z.data_ptr(), hcur.data_ptr(), hn.data_ptr(), q.data_ptr(), int(half == 1), b, hh, ww, t,
+                                dy, dx, _stream_ptr(h), work=(4.0 * b * hh * ww * (6 * hd + cx), 'B'), flop=flop * hd)
+                ctx.geom.append((geom, wpt_zr, wpt_q, wino))
                 saved += [z, r, rh, q]
                 if half == 0:
                     saved.append(hn)
@@ -1992,8 +2068,17 @@ class _GRU2DStepCL(torch.autograd.Function):
 
         with _on_device(g):
             for half, (hin, z, r, rh, q) in ((1, (h1, z2, r2, rh2, q2)), (0, (h0, z1, r1, rh1, q1))):
-                geom, wpt_zr, wpt_q = ctx.geom[half]
+                geom, wpt_zr, wpt_q, wino = ctx.geom[half]
                 taps, ntaps = convcl_taps(*geom), convcl_taps(*geom, negate=True)
+                axis = 0 if geom[0] == 1 else 1
+
+                def data_gradient(gpre, wpt, out, accumulate):
+                    """the convolution of the pre-activation gradient with the transposed, tap-reversed weights, split into
+                    (hidden-side | motion) gradients"""
+                    if wino:
+                        wino1d_conv([gpre], hub.wino_u(wpt, True), axis, split=hd, out=out, accumulate=accumulate)
+                    else:
+                        convcl([gpre], wpt, ntaps, split=hd, out=out, accumulate=accumulate)
                 izr, iq = 2 * half, 2 * half + 1
                 gpre_q, gz, gh = torch.empty_like(h0), torch.empty_like(h0), torch.empty_like(h0)
                 acc_ptr, becomes = total(iq, None, need_c[iq])
@@ -2002,7 +2087,7 @@ class _GRU2DStepCL(torch.autograd.Function):
                             work=(28.0 * npix * hd, 'B'))
                 # q convolution: input gradient = (gradient of r h | + gradient of m), weight gradient
                 grh = torch.empty_like(h0)
-                convcl([gpre_q], wpt_q, ntaps, split=hd, out=(grh, gm), accumulate=(False, not first_m))
+                data_gradient(gpre_q, wpt_q, (grh, gm), (False, not first_m))
                 first_m = False
                 if need_w[iq]:
                     wgrad(iq, [rh, mn], gpre_q, taps, geom[:2])
@@ -2014,7 +2099,7 @@ class _GRU2DStepCL(torch.autograd.Function):
                             r.data_ptr(), hin.data_ptr(), gpre_zr.data_ptr(), gh.data_ptr(), acc_ptr, npix, hd, 1, _stream_ptr(g),
                             work=(36.0 * npix * hd, 'B'))
                 # z | r convolution: its input gradient completes the gradient of this half-step's hidden input and of m
-                convcl([gpre_zr], wpt_zr, ntaps, split=hd, out=(gh, gm), accumulate=(True, True))
+                data_gradient(gpre_zr, wpt_zr, (gh, gm), (True, True))
                 if need_w[izr]:
                     wgrad(izr, [hin, mn], gpre_zr, taps, geom[:2])
                 if becomes is not None:

@@ -1,0 +1,152 @@
+// C-ABI of the 1-D Winograd F(4, 5) form of GRU2D's 1x5 / 5x1 convolutions (wino1d.h; models/raft_core.py:110-140): the
+// half-step convolutions with their gate / blend arithmetic and the data gradient, on NHWC tensors, as three launches each
+// (input transform, 8 plane contractions on the k-contiguous core of convcl.h, output transform + epilogue): 8
+// multiplications per 4 outputs and channel pair where the tap convolution of convcl.hip spends 20.
+#include "camli_common.h"
+#include "wino1d.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int NBUF = 3;
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int NTW>
+int launch_planes(const w1d::PlanesBatch& pb, hipStream_t s) {
+    constexpr size_t lds = (size_t)NBUF * (256 + 32 * NTW) * 16 * sizeof(float);
+    auto kern = &w1d::planes_cl_kernel<NTW, NBUF>;
+    static unsigned long long reserved = 0;
+    if (!camli_reserve_lds(reinterpret_cast<const void*>(kern), lds, reserved)) {
+        camli_set_error("camli_wino1d: cannot reserve %zu bytes of LDS", lds);
+        return CAMLI_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(pb.base.tiles_p * pb.base.tiles_n, 8), dim3(256), lds, s, pb);
+    return CAMLI_OK;
+}
+
+// x -> V -> Mo for one convolution; the caller finishes with its output transform
+int transform_and_contract(const char* what, const float* x0, int ldx0, int C0, const float* x1, int ldx1, int C1, const float* U,
+                           int Cout, float* workspace, int64_t workspace_bytes, int B, int H, int W, int axis, w1d::Lines& l, float*& Mo,
+                           hipStream_t s) {
+    const int C = C0 + C1;
+    if (!x0 || !U || !workspace || (C1 > 0 && !x1)) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    if (B < 1 || H < 1 || W < 1 || (axis != 0 && axis != 1) || C0 < 16 || C0 % 16 || C1 < 0 || C1 % 16 || C / 16 < NBUF - 1 || Cout < 128 ||
+        Cout % 128 || ldx0 < C0 || ldx0 % 4 || (C1 > 0 && (ldx1 < C1 || ldx1 % 4))) {
+        camli_set_error("%s: unsupported shape B=%d %dx%d C0=%d C1=%d Cout=%d axis=%d (input channels in multiples of 16, output of 128)", what, B,
+                        H, W, C0, C1, Cout, axis);
+        return CAMLI_ENOTSUP;
+    }
+    l = w1d::make_lines(B, H, W, axis);
+    const int64_t need = (int64_t)8 * l.tiles * ((int64_t)C + Cout) * 4;
+    if (workspace_bytes < need) { camli_set_error("%s: workspace of %lld bytes, %lld needed", what, (long long)workspace_bytes, (long long)need); return CAMLI_EINVAL; }
+    if ((int64_t)l.tiles * (C > Cout ? C : Cout) * 4 >= (int64_t)0x7FF00000 || (int64_t)B * H * W >= ((int64_t)1 << 29)) {
+        camli_set_error("%s: a transform-domain plane beyond 2 GB", what);
+        return CAMLI_ENOTSUP;
+    }
+    if (!aligned16(x0) || !aligned16(x1) || !aligned16(U) || !aligned16(workspace)) { camli_set_error("%s: pointers must be 16-byte aligned", what); return CAMLI_EINVAL; }
+    float* V = workspace;
+    Mo = workspace + (size_t)8 * l.tiles * C;
+    hipLaunchKernelGGL(w1d::input_transform_1d_kernel, dim3(camli_divup(l.tiles, 4)), dim3(256), 0, s, x0, ldx0, C0, C1 > 0 ? x1 : x0, C1 > 0 ? ldx1 : ldx0,
+                       C1, V, l);
+    w1d::PlanesBatch pb;
+    ccl::Problem& p = pb.base;
+    p.x = p.x1 = V; p.w = U; p.y = p.y1 = Mo;
+    p.B = 1; p.H = 1; p.W = l.tiles; p.Cin = p.C0 = C; p.Cout = p.N0 = Cout; p.T = 1;
+    p.ldx = p.ldx1 = C; p.ldw = C; p.ldy = p.ldy1 = Cout;
+    p.xk = p.wk = 16;
+    p.xrec = p.x1rec = (uint32_t)((int64_t)l.tiles * C * 4); p.wrec = (uint32_t)((int64_t)Cout * C * 4);
+    const int NT = Cout % 256 == 0 ? 256 : 128;
+    p.tiles_p = camli_divup(l.tiles, 256); p.tiles_n = Cout / NT;
+    p.add = p.h = p.z = V; p.y2 = Mo; p.ld_add = p.ld_h = p.ld_z = p.ldy2 = 4;
+    p.acc0 = p.acc1 = p.sanitize = 0;
+    for (int t = 0; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+    pb.x_plane = (int64_t)l.tiles * C; pb.w_plane = (int64_t)Cout * C; pb.y_plane = (int64_t)l.tiles * Cout;
+    return NT == 256 ? launch_planes<8>(pb, s) : launch_planes<4>(pb, s);
+}
+
+template <int EPI>
+void launch_output(const float* Mo, const w1d::Epilogue& e, const w1d::Lines& l, hipStream_t s) {
+    hipLaunchKernelGGL(w1d::output_transform_1d_kernel<EPI>, dim3(camli_divup(l.tiles, 4)), dim3(256), 0, s, Mo, e, l);
+}
+
+}  // namespace
+
+extern "C" int64_t camli_wino1d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int axis) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1 || (axis != 0 && axis != 1)) return 0;
+    const w1d::Lines l = w1d::make_lines(B, H, W, axis);
+    return (int64_t)8 * l.tiles * ((int64_t)Cin + Cout) * 4;
+}
+
+// U [8][N][C] from the packed weights wp [N][5][C] of camli_convcl_* (flip: taps reversed -- with the transposed packing
+// [Cin][5][Cout] that is the data gradient's weights)
+extern "C" int camli_wino1d_weights(const float* wp, float* U, int N, int C, int flip, void* stream) {
+    const char* what = "camli_wino1d_weights";
+    if (!wp || !U || N < 1 || C < 1) { camli_set_error("%s: bad arguments", what); return CAMLI_EINVAL; }
+    hipLaunchKernelGGL(w1d::weight_transform_1d_kernel, dim3(camli_divup(N * C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), wp, U, N, C,
+                       flip ? 1 : 0);
+    return camli_check_launch(what);
+}
+
+// y0 | y1 (= | +=) the 5-tap convolution of cat[x0, x1] along `axis` (camli_convcl_fwd's PLAIN form with dy / dx = the taps of
+// a 1 x 5 (axis 0) or 5 x 1 (axis 1) kernel)
+extern "C" int camli_wino1d_conv(const float* x0, int ldx0, int C0, const float* x1, int ldx1, int C1, const float* U, float* y0, int ldy0,
+                                 int N0, float* y1, int ldy1, float* workspace, int64_t workspace_bytes, int B, int H, int W, int Cout,
+                                 int axis, int accumulate0, int accumulate1, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_wino1d_conv";
+    if (!y0 || (N0 < Cout && !y1) || N0 < 4 || N0 > Cout || N0 % 4 || ldy0 < N0 || ldy0 % 4 || (N0 < Cout && (ldy1 < Cout - N0 || ldy1 % 4)) ||
+        !aligned16(y0) || !aligned16(y1)) {
+        camli_set_error("%s: bad outputs (N0=%d Cout=%d ld %d %d)", what, N0, Cout, ldy0, ldy1);
+        return CAMLI_EINVAL;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    w1d::Lines l;
+    float* Mo = nullptr;
+    const int rc = transform_and_contract(what, x0, ldx0, C0, x1, ldx1, C1, U, Cout, workspace, workspace_bytes, B, H, W, axis, l, Mo, s);
+    if (rc != CAMLI_OK) return rc;
+    w1d::Epilogue e = {};
+    e.N = Cout; e.N0 = N0; e.y = y0; e.ldy = ldy0; e.y1 = N0 < Cout ? y1 : y0; e.ldy1 = N0 < Cout ? ldy1 : ldy0;
+    e.acc0 = accumulate0 ? 1 : 0; e.acc1 = accumulate1 ? 1 : 0;
+    launch_output<ccl::EPI_PLAIN>(Mo, e, l, s);
+    return camli_check_launch(what);
+}
+
+// camli_convcl_gru_gates / _gru_blend on the Winograd form: same tensors, same arithmetic in the epilogue
+extern "C" int camli_wino1d_gru_gates(const float* h, const float* x, int CX, const float* U_zr, const float* ctx_zr, float* z, float* rh,
+                                      float* r, float* workspace, int64_t workspace_bytes, int B, int H, int W, int axis, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_wino1d_gru_gates";
+    if (!ctx_zr || !z || !rh || !r || !aligned16(ctx_zr) || !aligned16(z) || !aligned16(rh) || !aligned16(r)) { camli_set_error("%s: bad pointers", what); return CAMLI_EINVAL; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    w1d::Lines l;
+    float* Mo = nullptr;
+    const int rc = transform_and_contract(what, h, 128, 128, x, CX, CX, U_zr, 256, workspace, workspace_bytes, B, H, W, axis, l, Mo, s);
+    if (rc != CAMLI_OK) return rc;
+    w1d::Epilogue e = {};
+    e.N = 256; e.N0 = 256; e.y = z; e.ldy = 128; e.y1 = rh; e.ldy1 = 128; e.y2 = r; e.ldy2 = 128;
+    e.add = ctx_zr; e.ld_add = 256; e.h = h; e.ld_h = 128;
+    launch_output<ccl::EPI_GATES>(Mo, e, l, s);
+    return camli_check_launch(what);
+}
+
+extern "C" int camli_wino1d_gru_blend(const float* rh, const float* x, int CX, const float* U_q, const float* ctx_q, const float* z,
+                                      const float* h, float* h_new, float* q, int nan_to_num, float* workspace, int64_t workspace_bytes,
+                                      int B, int H, int W, int axis, void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_wino1d_gru_blend";
+    if (!ctx_q || !z || !h || !h_new || !q || !aligned16(ctx_q) || !aligned16(z) || !aligned16(h) || !aligned16(h_new) || !aligned16(q)) {
+        camli_set_error("%s: bad pointers", what);
+        return CAMLI_EINVAL;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    w1d::Lines l;
+    float* Mo = nullptr;
+    const int rc = transform_and_contract(what, rh, 128, 128, x, CX, CX, U_q, 128, workspace, workspace_bytes, B, H, W, axis, l, Mo, s);
+    if (rc != CAMLI_OK) return rc;
+    w1d::Epilogue e = {};
+    e.N = 128; e.N0 = 128; e.y = h_new; e.ldy = 128; e.y1 = q; e.ldy1 = 128;
+    e.add = ctx_q; e.ld_add = 128; e.h = h; e.ld_h = 128; e.z = z; e.ld_z = 128; e.sanitize = nan_to_num ? 1 : 0;
+    launch_output<ccl::EPI_BLEND>(Mo, e, l, s);
+    return camli_check_launch(what);
+}

@@ -604,6 +604,27 @@ int camli_convcl_gru_blend(const float *rh, const float *x, int CX, const float 
                            const float *h, float *h_new, float *q, int nan_to_num, int B, int H, int W, int T, const signed char *dy,
                            const signed char *dx, void *stream);
 /*
+ * The same half-step convolutions and their data gradient as 1-D Winograd F(4, 5) (round 6, csrc/hip/wino1d.h): 8 multiplications
+ * per 4 outputs and channel pair where the 5-tap form spends 20; three launches each -- input transform (cat[x0, x1] -> V
+ * [8][tiles][C], tile = 4 consecutive pixels along the kernel's axis), 8 plane contractions on the k-contiguous core of the tap
+ * convolution (one launch), output transform with the SAME epilogue arithmetic.  axis 0: a 1 x 5 kernel with padding (0, 2),
+ * axis 1: 5 x 1 with (2, 0).  U = camli_wino1d_weights(wp, ...): [8][N][C] from the packed weights wp [N][5][C] of the entry
+ * points above (flip = 1 on the transposed packing [Cin][5][Cout]: the data gradient's weights).  workspace =
+ * camli_wino1d_workspace_bytes(B, H, W, Cin, Cout, axis) bytes.  Rounding differs from the tap form's (factors up to 21/4 and 8
+ * in the transforms): 1.3e-6 relative L2 at 256 channels.  camli_wino1d_conv = camli_convcl_fwd's plain form (two inputs, output
+ * split at N0, = or +=); _gru_gates / _gru_blend = camli_convcl_gru_gates / _gru_blend.
+ */
+int64_t camli_wino1d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int axis);
+int camli_wino1d_weights(const float *wp, float *U, int N, int C, int flip, void *stream);
+int camli_wino1d_conv(const float *x0, int ldx0, int C0, const float *x1, int ldx1, int C1, const float *U, float *y0, int ldy0, int N0,
+                      float *y1, int ldy1, float *workspace, int64_t workspace_bytes, int B, int H, int W, int Cout, int axis,
+                      int accumulate0, int accumulate1, void *stream);
+int camli_wino1d_gru_gates(const float *h, const float *x, int CX, const float *U_zr, const float *ctx_zr, float *z, float *rh, float *r,
+                           float *workspace, int64_t workspace_bytes, int B, int H, int W, int axis, void *stream);
+int camli_wino1d_gru_blend(const float *rh, const float *x, int CX, const float *U_q, const float *ctx_q, const float *z, const float *h,
+                           float *h_new, float *q, int nan_to_num, float *workspace, int64_t workspace_bytes, int B, int H, int W,
+                           int axis, void *stream);
+/*
  * Weight gradient of the same convolution: gw [Cout][C0 + C1][T] (= the [Cout, Cin, kh, kw] weight tensor) = or += (accumulate)
  *     sum_p gy[p][n] * x[p + (dy[t], dx[t])][c]
  * gy NHWC [P][ldg].  Split over the pixels into about one workgroup per CU, parts in `workspace`

@@ -128,8 +128,43 @@ def test_gru_half_step_convolution_own_kernels_vs_library(vertical, monkeypatch)
         assert float((a - bb).abs().max()) <= 3e-5 * scale, name
 
 
+WINO1D_CASES = [  # (B, C0, C1, Cout, H, W, axis): lines that are not multiples of 4, a single tile per line, two inputs, both axes
+    (1, 32, 0, 128, 7, 9, 0), (2, 64, 0, 256, 20, 30, 1), (3, 16, 32, 256, 17, 33, 1), (2, 128, 128, 256, 6, 13, 0),
+    (1, 128, 128, 128, 17, 30, 1), (1, 48, 0, 128, 1, 3, 0), (1, 48, 0, 128, 3, 1, 1), (2, 128, 128, 256, 68, 120, 0),
+]
+
+
+@pytest.mark.parametrize('case', WINO1D_CASES, ids=str)
+def test_wino1d_conv_vs_oracle(case, oracle_dense):
+    """camli_wino1d_conv (1-D Winograd F(4,5) of a 1x5 / 5x1 convolution, csrc/hip/wino1d.hip) against the numpy oracle, forward
+    weights and -- through the transposed packing with reversed taps -- the data gradient.  Bound 5e-5 x max(1, max |want|): the
+    transforms carry factors up to 21/4 and 8 (measured 8e-6 max abs at 256 channels on unit-variance data)."""
+    from camliflow_amd.csrc import fused
+    b, c0, c1, cout, h, w, axis = case
+    kh, kw = (1, 5) if axis == 0 else (5, 1)
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((b, c0 + c1, h, w), dtype=np.float32)
+    wt = (rng.standard_normal((cout, c0 + c1, kh, kw)) * (5 * (c0 + c1)) ** -0.5).astype(np.float32)
+    pad = (kh // 2, kw // 2)
+    wp, wpt = fused.convcl_pack(dev(wt))
+    xs = [nhwc(x[:, :c0])] + ([nhwc(x[:, c0:])] if c1 else [])
+    got = fused.wino1d_conv(xs, fused.wino1d_weights(wp, False), axis)
+    _close(got.permute(0, 3, 1, 2), oracle_dense.conv_taps_fwd(x, wt, pad), tol=5e-5, what='forward')
+    if (c0 + c1) % 128 == 0:          # the data gradient's output width = the forward's input width
+        gy = rng.standard_normal((b, cout, h, w), dtype=np.float32)
+        base = rng.standard_normal((b, h, w, c0 + c1), dtype=np.float32)
+        half = (c0 + c1) // 2
+        g0, g1 = dev(base[..., :half]), dev(base[..., half:])
+        fused.wino1d_conv([nhwc(gy)], fused.wino1d_weights(wpt, True), axis, split=half, out=(g0, g1), accumulate=(False, True))
+        want_gx, _ = oracle_dense.conv_taps_bwd(gy, x, wt, pad)
+        want = np.transpose(want_gx, (0, 2, 3, 1))
+        _close(g0, want[..., :half], tol=5e-5, what='data gradient, first output (written)')
+        _close(g1, want[..., half:] + base[..., half:], tol=5e-5, what='data gradient, second output (accumulated)')
+
+
+@pytest.mark.parametrize('wino', [True, False], ids=['winograd', 'taps'])
 @pytest.mark.parametrize('tiles', ['narrow', 'wide'])
-def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden, tiles, monkeypatch):
+def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden, tiles, wino, monkeypatch):
     """cores/raft2d.GRU2D on the product path (fused._GRU2DStepCL: convolutions with the gate arithmetic in their epilogues, both
     adjoints) against what the REFERENCE's GRU2D recorded at the product's widths -- two updates, the new hidden state, both
     input gradients, fingerprints of all twelve parameter gradients (tests/golden/dense_gru2d_wide.npz from
@@ -140,6 +175,8 @@ def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden, tile
     from camliflow_amd.cores.raft2d import GRU2D
     runtime.set_backend('hip')
     monkeypatch.setenv('CAMLI_CONVCL_TILES', tiles)      # the gates / blend epilogues on the 256 | 128-channel tiles and on their halves
+    from camliflow_amd.csrc import fused
+    monkeypatch.setattr(fused, '_GRU_WINO', wino)        # r6: the half-step convolutions as 1-D Winograd F(4,5), or as tap convolutions
     g = golden('dense_gru2d_wide')
     gru = hashed_fill_(GRU2D(hidden_dim=128, input_dim=256)).cuda()
     h0 = dev(g['h0']).requires_grad_()
@@ -147,9 +184,16 @@ def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden, tile
     context, motion = x[:, :128], x[:, 128:]       # GRU2D.prepare: the first channels of x are the per-pass context
     state = gru.prepare(context)
     assert 'cl1' in state and 'cl2' in state
+    from camliflow_amd.cores import runtime as rt
+    rt.set_census(True)
+    rt.reset_census()
     out = gru.step(gru.step(h0, motion, state), motion, state)
     _close(out, g['out'], tol=2e-5, what='new hidden state')
     out.backward(dev(g['gout']))
+    census = rt.census()['fused']
+    rt.set_census(False)
+    assert (census.get('camli_wino1d_gru_gates', 0), census.get('camli_convcl_gru_gates', 0)) == ((4, 0) if wino else (0, 4)), census
+    assert census.get('camli_wino1d_conv', 0) == (8 if wino else 0)
     _close(h0.grad, g['gh0'], tol=5e-5, what='gradient of h')
     _close(x.grad, g['gx'], tol=5e-5, what='gradient of x')
     for name, p_ in gru.named_parameters():
