@@ -64,13 +64,13 @@ NORTH_STAR = {
     'camli_corr3d_mlp_fwd': 'fma', 'camli_corr3d_mlp_bwd': 'fma',      # plain fp32 FMA on the vector ALU (registers only)
     'camli_convcl_gru_gates': 'mfma', 'camli_convcl_gru_blend': 'mfma', 'camli_convcl_fwd': 'mfma', 'camli_convcl_wrw': 'mfma',
     'camli_wino_conv3x3': 'mfma', 'camli_wino_wrw': 'mfma',       # flop = the transform-domain MFMA work (4/9 | 1/4 of the direct form's)
-    'camli_wino1d_gru_gates': 'mfma', 'camli_wino1d_gru_blend': 'mfma', 'camli_wino1d_conv': 'mfma',       # 1-D F(4,5): 2/5 of the 5-tap form's
+    'camli_wino1d_gru_gates': 'mfma', 'camli_wino1d_gru_blend': 'mfma', 'camli_wino1d_conv': 'mfma', 'camli_wino1d_wrw': 'mfma',       # 1-D F(4,5): 2/5 of the 5-tap form's
     'camli_pwc3d_pair_fwd': 'hbm', 'camli_pwc3d_pair_bwd': 'hbm', 'camli_gather_wsum_fwd': 'hbm', 'camli_gather_wsum_bwd': 'hbm',
 }
 # SURVEY 8(f)2 ("the 2-D convolution side"): the update block's convolutions on own matrix-core kernels.  Everything else in
 # NORTH_STAR is a SURVEY 8(a) row (A1-A15), the path BASELINE.json's north_star names.
 CONV_SIDE = {'camli_convcl_gru_gates', 'camli_convcl_gru_blend', 'camli_convcl_fwd', 'camli_convcl_wrw', 'camli_wino_conv3x3',
-             'camli_wino_wrw', 'camli_wino1d_gru_gates', 'camli_wino1d_gru_blend', 'camli_wino1d_conv'}
+             'camli_wino_wrw', 'camli_wino1d_gru_gates', 'camli_wino1d_gru_blend', 'camli_wino1d_conv', 'camli_wino1d_wrw'}
 MFMA_F32_PEAK_TFLOPS = 157.3
 VALU_PAIR_PEAK_G = 7865.0
 FPS_STEP_IDEAL_US = 0.35      # one dependent selection step with the cloud resident in registers (tools/kernel_bench.py)

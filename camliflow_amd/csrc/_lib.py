@@ -142,6 +142,9 @@ PROTOTYPES = {
                                       _c_float_p, ctypes.c_int64] + [_int] * 4 + [_stream]),
     "camli_wino1d_gru_blend": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                       _c_float_p, _int, _c_float_p, ctypes.c_int64] + [_int] * 4 + [_stream]),
+    "camli_wino1d_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 6),
+    "camli_wino1d_wrw": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _int, _c_float_p, _c_float_p, ctypes.c_int64]
+                         + [_int] * 6 + [_stream]),
     "camli_convcl_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 6),
     "camli_convcl_wrw": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _int, _c_float_p, ctypes.c_int64,
                                 _c_float_p, _int, _int, _int, _int, _int, _int, ctypes.c_char_p, ctypes.c_char_p, _stream]),

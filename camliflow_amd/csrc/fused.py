@@ -1869,6 +1869,8 @@ def _to_nchw(x_n):
 # CAMLI_GRU_WINO=1: GRU2D's half-step convolutions and their data gradients as 1-D Winograd F(4,5) (csrc/hip/wino1d.hip:
 # 8 multiplications per 4 outputs where the 5-tap form spends 20); 0: the tap convolutions of convcl.hip
 _GRU_WINO = os.environ.get('CAMLI_GRU_WINO', '1') != '0'
+# CAMLI_GRU_WINO_WRW=0: their weight gradients stay on the tap form (camli_convcl_wrw) while the rest runs the Winograd form
+_GRU_WINO_WRW = os.environ.get('CAMLI_GRU_WINO_WRW', '1') != '0'
 
 
 def wino1d_weights(wp, flip):
@@ -1918,6 +1920,32 @@ def wino1d_conv(xs, u, axis, split=None, out=None, accumulate=(False, False)):
                     cout, axis, int(bool(accumulate[0])), int(bool(accumulate[1])), _stream_ptr(x0),
                     work=(4.0 * b * hh * ww * (c0 + c1 + cout) + 2.0 * need, 'B'), flop=2.0 * 8 * tiles * cout * (c0 + c1))
     return y0 if y1 is None else (y0, y1)
+
+
+def wino1d_wrw(xs, gy, axis, out=None):
+    """convcl_wrw(xs, gy, taps of a 1x5 (axis 0) / 5x1 (axis 1) kernel) contracted in the Winograd domain: the weight gradient
+    [Cout, Cin, 1, 5] | [Cout, Cin, 5, 1]; ``out``: add into this tensor."""
+    _require_cuda('wino1d_wrw', gy, *xs)
+    lib = _lib.load()
+    x0 = xs[0]
+    x1 = xs[1] if len(xs) > 1 else None
+    b, hh, ww, c0 = x0.shape
+    c1 = x1.shape[3] if x1 is not None else 0
+    cout = gy.shape[3]
+    ld0, ld1, ldg = _nhwc_ld(x0), (_nhwc_ld(x1) if x1 is not None else 0), _nhwc_ld(gy)
+    need = lib.camli_wino1d_wrw_workspace_bytes(b, hh, ww, c0 + c1, cout, axis)
+    if None in (ld0, ld1, ldg) or need <= 0:
+        raise _lib.CamliHipError('wino1d_wrw: unsupported operands (dense fp32 NHWC, Cin a multiple of 256, Cout of 128)')
+    ws = torch.empty(need // 4, dtype=torch.float32, device=gy.device)
+    shape = (cout, c0 + c1, 1, 5) if axis == 0 else (cout, c0 + c1, 5, 1)
+    gw = out if out is not None else torch.empty(shape, dtype=torch.float32, device=gy.device)
+    assert gw.shape == shape and gw.is_contiguous()
+    tiles = b * (hh * ((ww + 3) // 4) if axis == 0 else ww * ((hh + 3) // 4))
+    with _on_device(gy):
+        _lib.launch('camli_wino1d_wrw', lib.camli_wino1d_wrw, x0.data_ptr(), ld0, c0, x1.data_ptr() if x1 is not None else 0, ld1, c1,
+                    gy.data_ptr(), ldg, gw.data_ptr(), ws.data_ptr(), need, b, hh, ww, cout, axis, int(out is not None), _stream_ptr(gy),
+                    work=(4.0 * b * hh * ww * (c0 + c1 + cout) * 3.0, 'B'), flop=2.0 * 8 * tiles * cout * (c0 + c1))
+    return gw
 
 
 class GRU2DPass:
@@ -2056,15 +2084,19 @@ class _GRU2DStepCL(torch.autograd.Function):
         if side is not None:
             hub.side = side
 
-        def wgrad(slot, xs, gpre, taps, khw):
+        def wgrad(slot, xs, gpre, taps, khw, wino=False):
             """the weight gradient of one convolution, added into the pass total -- beside the data-gradient chain when a side
             stream is available (runtime.wgrad_side): nothing downstream needs it before the hub hands the totals over"""
+            def run():
+                if wino and _GRU_WINO_WRW:
+                    return wino1d_wrw(xs, gpre, 0 if khw[0] == 1 else 1, out=hub.gw[slot])
+                return convcl_wrw(xs, gpre, taps, khw, out=hub.gw[slot])
             if side is None:
-                hub.gw[slot] = convcl_wrw(xs, gpre, taps, khw, out=hub.gw[slot])
+                hub.gw[slot] = run()
                 return
             side.fork(gpre, *xs)
             with side.stream():
-                hub.gw[slot] = convcl_wrw(xs, gpre, taps, khw, out=hub.gw[slot])
+                hub.gw[slot] = run()
 
         with _on_device(g):
             for half, (hin, z, r, rh, q) in ((1, (h1, z2, r2, rh2, q2)), (0, (h0, z1, r1, rh1, q1))):
@@ -2090,7 +2122,7 @@ class _GRU2DStepCL(torch.autograd.Function):
                 data_gradient(gpre_q, wpt_q, (grh, gm), (False, not first_m))
                 first_m = False
                 if need_w[iq]:
-                    wgrad(iq, [rh, mn], gpre_q, taps, geom[:2])
+                    wgrad(iq, [rh, mn], gpre_q, taps, geom[:2], wino)
                 if becomes is not None:      # the first contribution starts the total (a copy: gpre_q itself may still be read
                     hub.gc[iq] = gpre_q.clone()      # by the weight gradient on the side stream when later updates add into it)
                 gpre_zr = torch.empty((b, hh, ww, 2 * hd), dtype=torch.float32, device=g.device)
@@ -2101,7 +2133,7 @@ class _GRU2DStepCL(torch.autograd.Function):
                 # z | r convolution: its input gradient completes the gradient of this half-step's hidden input and of m
                 data_gradient(gpre_zr, wpt_zr, (gh, gm), (True, True))
                 if need_w[izr]:
-                    wgrad(izr, [hin, mn], gpre_zr, taps, geom[:2])
+                    wgrad(izr, [hin, mn], gpre_zr, taps, geom[:2], wino)
                 if becomes is not None:
                     hub.gc[izr] = gpre_zr.clone()
                 gcur = gh

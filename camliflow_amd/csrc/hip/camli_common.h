@@ -16,6 +16,8 @@ void camli_set_error(const char* fmt, ...);
 int camli_check_launch(const char* what);
 
 static inline int camli_divup(int a, int b) { return (a + b - 1) / b; }
+// 1 KB of zeros on the current device (convcl.hip): the source of padded rows of wrw::wrw_kernel
+const float* camli_zero_page();
 
 // Let kernel `fn` use `bytes` of dynamic LDS on the CURRENT device; `done` = the call site's static bit mask of devices
 // already served (one process per GPU is the rule here, but a process that drives several must not skip the others).

@@ -40,6 +40,10 @@ const float* zero_page() {
     return pages[dev];
 }
 
+}  // namespace
+const float* camli_zero_page() { return zero_page(); }
+namespace {
+
 int taps_ok(const char* what, int T, const signed char* dy, const signed char* dx) {
     if (T < 1 || T > ccl::MAX_TAPS || !dy || !dx) { camli_set_error("%s: 1 <= T <= %d taps with offset arrays", what, ccl::MAX_TAPS); return 0; }
     return 1;

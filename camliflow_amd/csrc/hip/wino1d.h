@@ -22,7 +22,7 @@
 // variance data at 256 channels: 8e-6 max abs / 1.3e-6 relative L2 against an fp64 convolution (the direct fp32 chain:
 // 4e-6 / 9e-7), profiles/r06_experiments.txt item 14.
 #pragma once
-#include "convcl.h"
+#include "wrwcl.h"
 
 namespace w1d {
 
@@ -103,12 +103,21 @@ __global__ void weight_transform_1d_kernel(const float* __restrict__ wp, float* 
 // ---- input: V[t][tile][c] = (B^T d)[t], d[j] = x[pos0 - 2 + j] along the line (zero outside it)
 // x = cat[x0 (C0 channels, ldx0 floats per pixel), x1 (C1 channels)]; block 256 = 4 waves, 64 lanes x 4 channels = 256
 // channels per pass; one tile per wave and pass
+// V has `rows` >= tiles rows per plane (the weight gradient pads the tile count so that its K splits do not straddle planes):
+// rows beyond the tiles are written as zeros.
 __global__ __launch_bounds__(256) void input_transform_1d_kernel(const float* __restrict__ x0, int ldx0, int C0, const float* __restrict__ x1,
-                                                                int ldx1, int C1, float* __restrict__ V, Lines l) {
+                                                                int ldx1, int C1, float* __restrict__ V, int rows, Lines l) {
     const int C = C0 + C1;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= l.tiles) return;
+    if (tile >= rows) return;
+    if (tile >= l.tiles) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 4 * lane; c < C; c += 256)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(V + ((size_t)j * rows + tile) * C + c) = z;
+        return;
+    }
     const int line = tile / l.tpl, pos0 = 4 * (tile - line * l.tpl);
     const int p0 = line_start(l, line);
     for (int c = 4 * lane; c < C; c += 256) {
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void input_transform_1d_kernel(const float* __
         }
         bt8(d, t);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(V + ((size_t)j * l.tiles + tile) * C + c) = t[j];
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(V + ((size_t)j * rows + tile) * C + c) = t[j];
     }
 }
 
@@ -206,6 +215,75 @@ __global__ __launch_bounds__(256) void output_transform_1d_kernel(const float* _
             }
         }
     }
+}
+
+// ---- weight gradient in the transform domain:  gU[t][c][n] = sum_tile V[t][tile][c] * gM[t][tile][n],  gM = A g per tile (A = the
+// transpose of at8's matrix), then gw[n][c][k] (= | +=) sum_t G[t][k] gU[t][c][n].  The contraction runs over the tiles with both
+// operands tile-major and channel-contiguous -- the layout wrwcl.h contracts over pixels -- so it IS wrw::wrw_kernel with one tap
+// on the 8 planes laid end to end as 8 * rows "pixels": `rows` = the tile count padded to a multiple of the K split, so that no
+// split straddles two planes; part s = plane s / Sp, split s % Sp.
+__device__ __forceinline__ void ag8(const f32x4 (&g)[4], f32x4 (&t)[8]) {
+    const f32x4 e = g[0] + g[2], o = g[1] + g[3];
+    t[0] = g[0];
+    t[1] = e + o;
+    t[2] = e - o;
+    const f32x4 e2 = g[0] + 4.f * g[2], o2 = 2.f * g[1] + 8.f * g[3];
+    t[3] = e2 + o2;
+    t[4] = e2 - o2;
+    const f32x4 e3 = g[0] + 0.25f * g[2], o3 = 0.5f * g[1] + 0.125f * g[3];
+    t[5] = e3 + o3;
+    t[6] = e3 - o3;
+    t[7] = g[3];
+}
+
+// gy [P][ldg] (N channels) -> gM [8][rows][N]; one wave per tile, lanes along the channels
+__global__ __launch_bounds__(256) void grad_transform_1d_kernel(const float* __restrict__ gy, int ldg, int N, float* __restrict__ gM, int rows, Lines l) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= rows) return;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (tile >= l.tiles) {
+        for (int n = 4 * lane; n < N; n += 256)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(gM + ((size_t)j * rows + tile) * N + n) = z;
+        return;
+    }
+    const int line = tile / l.tpl, pos0 = 4 * (tile - line * l.tpl);
+    const int p0 = line_start(l, line);
+    for (int n = 4 * lane; n < N; n += 256) {
+        f32x4 g[4], t[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            g[i] = pos0 + i < l.len ? *reinterpret_cast<const f32x4*>(gy + (size_t)(p0 + (pos0 + i) * l.step) * ldg + n) : z;
+        ag8(g, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(gM + ((size_t)j * rows + tile) * N + n) = t[j];
+    }
+}
+
+// gw[(n * C + c) * 5 + k] (= | +=) sum_t G[t][k] * sum_{j < Sp} part[t * Sp + j][c][n]; one thread per (c, n), lanes along n
+__global__ __launch_bounds__(256) void wrw_reduce_1d_kernel(const float* __restrict__ part, int Sp, float* __restrict__ gw, int C, int N, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)C * N) return;
+    const int n = (int)(i % N), c = (int)(i / N);
+    const size_t el = (size_t)C * N;
+    float u[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        float acc = 0.f;
+        for (int j = 0; j < Sp; ++j) acc += part[((size_t)t * Sp + j) * el + i];
+        u[t] = acc;
+    }
+    const float s12 = u[1] + u[2], d12 = u[1] - u[2], s34 = u[3] + u[4], d34 = u[3] - u[4], s56 = u[5] + u[6], d56 = u[5] - u[6];
+    float o[5];
+    o[0] = -u[0] - (2.f / 9.f) * s12 + (1.f / 90.f) * s34 + (32.f / 45.f) * s56;
+    o[1] = -(2.f / 9.f) * d12 + (1.f / 45.f) * d34 + (16.f / 45.f) * d56;
+    o[2] = -(2.f / 9.f) * s12 + (2.f / 45.f) * s34 + (8.f / 45.f) * s56;
+    o[3] = -(2.f / 9.f) * d12 + (4.f / 45.f) * d34 + (4.f / 45.f) * d56;
+    o[4] = -(2.f / 9.f) * s12 + (8.f / 45.f) * s34 + (2.f / 45.f) * s56 + u[7];
+    float* dst = gw + ((size_t)n * C + c) * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) dst[k] = accumulate ? dst[k] + o[k] : o[k];
 }
 
 }  // namespace w1d

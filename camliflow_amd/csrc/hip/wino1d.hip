@@ -48,7 +48,7 @@ int transform_and_contract(const char* what, const float* x0, int ldx0, int C0, 
     float* V = workspace;
     Mo = workspace + (size_t)8 * l.tiles * C;
     hipLaunchKernelGGL(w1d::input_transform_1d_kernel, dim3(camli_divup(l.tiles, 4)), dim3(256), 0, s, x0, ldx0, C0, C1 > 0 ? x1 : x0, C1 > 0 ? ldx1 : ldx0,
-                       C1, V, l);
+                       C1, V, l.tiles, l);
     w1d::PlanesBatch pb;
     ccl::Problem& p = pb.base;
     p.x = p.x1 = V; p.w = U; p.y = p.y1 = Mo;
@@ -148,5 +148,91 @@ extern "C" int camli_wino1d_gru_blend(const float* rh, const float* x, int CX, c
     e.N = 128; e.N0 = 128; e.y = h_new; e.ldy = 128; e.y1 = q; e.ldy1 = 128;
     e.add = ctx_q; e.ld_add = 128; e.h = h; e.ld_h = 128; e.z = z; e.ld_z = 128; e.sanitize = nan_to_num ? 1 : 0;
     launch_output<ccl::EPI_BLEND>(Mo, e, l, s);
+    return camli_check_launch(what);
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------
+namespace {
+
+struct WrwPlan1d {
+    int Sp;          // K splits per plane
+    int rows;        // tiles per plane as allocated: a multiple of 16 Sp (the K split is rows / Sp pixels, a multiple of 16)
+};
+
+WrwPlan1d wrw_plan_1d(int tiles, int out_tiles) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    WrwPlan1d pl;
+    int sp = cus / (8 * out_tiles);
+    if (sp < 1) sp = 1;
+    while (sp > 1 && tiles / sp < 48) --sp;          // at least the pipeline's depth per split
+    pl.Sp = sp;
+    pl.rows = camli_divup(tiles, 16 * sp) * 16 * sp;
+    return pl;
+}
+
+template <int TBN>
+int launch_wrw_1d(const wrw::Problem& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)NBUF * 16 * (256 + 32 * TBN) * sizeof(float);
+    auto kern = &wrw::wrw_kernel<TBN, NBUF>;
+    static unsigned long long reserved = 0;
+    if (!camli_reserve_lds(reinterpret_cast<const void*>(kern), lds, reserved)) {
+        camli_set_error("camli_wino1d_wrw: cannot reserve %zu bytes of LDS", lds);
+        return CAMLI_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.S * p.T * p.tiles_m * p.tiles_n), dim3(256), lds, s, p);
+    return CAMLI_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t camli_wino1d_wrw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int axis) {
+    if (B < 1 || H < 1 || W < 1 || Cin < 256 || Cin % 256 || Cout < 128 || Cout % 128 || (axis != 0 && axis != 1)) return 0;
+    const w1d::Lines l = w1d::make_lines(B, H, W, axis);
+    const WrwPlan1d pl = wrw_plan_1d(l.tiles, (Cin / 256) * (Cout / (Cout % 256 == 0 ? 256 : 128)));
+    return ((int64_t)8 * pl.rows * ((int64_t)Cin + Cout) + (int64_t)8 * pl.Sp * Cin * Cout) * 4;
+}
+
+// gw [Cout][C0 + C1][5] (= the [Cout, Cin, 1, 5] | [Cout, Cin, 5, 1] weight tensor) (= | +=) the weight gradient of the 5-tap
+// convolution of cat[x0, x1] along `axis` for the output gradient gy [P][ldg]: camli_convcl_wrw's result, contracted in the
+// transform domain (8 planes x (tiles x Cin x Cout) instead of 5 taps x (pixels x Cin x Cout): 2.5 x fewer multiplications).
+// C0 + C1 a multiple of 256, Cout of 128.  Deterministic (fixed summation order).
+extern "C" int camli_wino1d_wrw(const float* x0, int ldx0, int C0, const float* x1, int ldx1, int C1, const float* gy, int ldg, float* gw,
+                                float* workspace, int64_t workspace_bytes, int B, int H, int W, int Cout, int axis, int accumulate,
+                                void* stream) {
+    if (B == 0) return CAMLI_OK;
+    const char* what = "camli_wino1d_wrw";
+    const int C = C0 + C1;
+    if (!x0 || !gy || !gw || !workspace || (C1 > 0 && !x1)) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    const int64_t need = camli_wino1d_wrw_workspace_bytes(B, H, W, C, Cout, axis);
+    if (need == 0 || C0 < 16 || C0 % 16 || C1 < 0 || C1 % 16 || ldx0 < C0 || ldx0 % 4 || (C1 > 0 && (ldx1 < C1 || ldx1 % 4)) || ldg < Cout || ldg % 4) {
+        camli_set_error("%s: unsupported shape B=%d %dx%d C0=%d C1=%d Cout=%d (input channels a multiple of 256, output of 128)", what, B, H, W, C0, C1, Cout);
+        return CAMLI_ENOTSUP;
+    }
+    if (workspace_bytes < need) { camli_set_error("%s: workspace of %lld bytes, %lld needed", what, (long long)workspace_bytes, (long long)need); return CAMLI_EINVAL; }
+    if (!aligned16(x0) || !aligned16(x1) || !aligned16(gy) || !aligned16(gw) || !aligned16(workspace)) { camli_set_error("%s: pointers must be 16-byte aligned", what); return CAMLI_EINVAL; }
+    const w1d::Lines l = w1d::make_lines(B, H, W, axis);
+    const int NB = Cout % 256 == 0 ? 256 : 128;
+    const WrwPlan1d pl = wrw_plan_1d(l.tiles, (C / 256) * (Cout / NB));
+    if ((int64_t)8 * pl.rows * (C > Cout ? C : Cout) * 4 >= (int64_t)0x7FF00000) { camli_set_error("%s: transform domain beyond 2 GB", what); return CAMLI_ENOTSUP; }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* V = workspace;
+    float* gM = V + (size_t)8 * pl.rows * C;
+    float* parts = gM + (size_t)8 * pl.rows * Cout;
+    hipLaunchKernelGGL(w1d::input_transform_1d_kernel, dim3(camli_divup(pl.rows, 4)), dim3(256), 0, s, x0, ldx0, C0, C1 > 0 ? x1 : x0, C1 > 0 ? ldx1 : ldx0,
+                       C1, V, pl.rows, l);
+    hipLaunchKernelGGL(w1d::grad_transform_1d_kernel, dim3(camli_divup(pl.rows, 4)), dim3(256), 0, s, gy, ldg, Cout, gM, pl.rows, l);
+    // the 8 planes end to end are 8 * rows "pixels" of an image one pixel high; one tap, no shift; parts = 8 Sp K ranges
+    wrw::Problem p;
+    p.x = p.x1 = V; p.zero = camli_zero_page(); p.gy = gM; p.part = parts;
+    if (!p.zero) { camli_set_error("%s: cannot resolve the zero page", what); return CAMLI_ELAUNCH; }
+    p.B = 1; p.H = 1; p.W = 8 * pl.rows; p.Cin = C; p.Cout = Cout; p.T = 1;
+    p.C0 = C; p.ldx = p.ldx1 = C; p.ldg = Cout;
+    p.S = 8 * pl.Sp; p.ksplit = pl.rows / pl.Sp;
+    p.tiles_m = C / 256; p.tiles_n = Cout / NB;
+    for (int t = 0; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
+    const int rc = NB == 256 ? launch_wrw_1d<8>(p, s) : launch_wrw_1d<4>(p, s);
+    if (rc != CAMLI_OK) return rc;
+    hipLaunchKernelGGL(w1d::wrw_reduce_1d_kernel, dim3(camli_divup(C * Cout, 256)), dim3(256), 0, s, parts, pl.Sp, gw, C, Cout, accumulate ? 1 : 0);
     return camli_check_launch(what);
 }

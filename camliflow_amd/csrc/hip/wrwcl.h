@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // gw[(n * Cin + c) * T + t] (+)= sum_s part[s][t][c][n]   (parts added in order; thread = one (t, c, n)).
 // swapped != 0: the parts were computed with the operands' roles exchanged (camli_convcl_wrw on 128-wide inputs): part[s][t][n][c],
 // i.e. the kernel's M index is the output channel -- `Cin` / `Cout` are still those of the convolution.
-__global__ __launch_bounds__(256) void wrw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int S, int T,
+static __global__ __launch_bounds__(256) void wrw_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int S, int T,
                                                           int Cin, int Cout, int accumulate, int swapped) {
     const size_t n_el = (size_t)T * Cin * Cout;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

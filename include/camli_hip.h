@@ -624,6 +624,13 @@ int camli_wino1d_gru_gates(const float *h, const float *x, int CX, const float *
 int camli_wino1d_gru_blend(const float *rh, const float *x, int CX, const float *U_q, const float *ctx_q, const float *z, const float *h,
                            float *h_new, float *q, int nan_to_num, float *workspace, int64_t workspace_bytes, int B, int H, int W,
                            int axis, void *stream);
+/* camli_convcl_wrw's result for a 1 x 5 / 5 x 1 kernel, contracted in the transform domain (gw [Cout][C0 + C1][5] = | +=): input
+ * transform of cat[x0, x1], A-transform of gy, 8 plane contractions over the tiles on the weight-gradient core of wrwcl.h (the
+ * planes laid end to end, K splits that do not straddle planes), G^T over the planes.  C0 + C1 a multiple of 256, Cout of 128;
+ * workspace = camli_wino1d_wrw_workspace_bytes (0 = unsupported shape).  Deterministic. */
+int64_t camli_wino1d_wrw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int axis);
+int camli_wino1d_wrw(const float *x0, int ldx0, int C0, const float *x1, int ldx1, int C1, const float *gy, int ldg, float *gw,
+                     float *workspace, int64_t workspace_bytes, int B, int H, int W, int Cout, int axis, int accumulate, void *stream);
 /*
  * Weight gradient of the same convolution: gw [Cout][C0 + C1][T] (= the [Cout, Cin, kh, kw] weight tensor) = or += (accumulate)
  *     sum_p gy[p][n] * x[p + (dy[t], dx[t])][c]

@@ -162,6 +162,29 @@ def test_wino1d_conv_vs_oracle(case, oracle_dense):
         _close(g1, want[..., half:] + base[..., half:], tol=5e-5, what='data gradient, second output (accumulated)')
 
 
+@pytest.mark.parametrize('case', [(1, 128, 128, 256, 7, 9, 0), (2, 256, 0, 128, 20, 30, 1), (2, 128, 128, 128, 17, 33, 1), (1, 256, 0, 256, 6, 13, 0),
+                                  (2, 128, 128, 256, 68, 120, 1)], ids=str)
+def test_wino1d_weight_gradient_vs_oracle(case, oracle_dense):
+    """camli_wino1d_wrw: the weight gradient of a 1x5 / 5x1 convolution contracted in the Winograd domain (the 8 planes laid end
+    to end through the weight-gradient core of wrwcl.h, K splits aligned with the planes), written and accumulated, repeatable."""
+    from camliflow_amd.csrc import fused
+    b, c0, c1, cout, h, w, axis = case
+    kh, kw = (1, 5) if axis == 0 else (5, 1)
+    rng = np.random.default_rng(sum(case) + 5)
+    x = rng.standard_normal((b, c0 + c1, h, w), dtype=np.float32)
+    gy = rng.standard_normal((b, cout, h, w), dtype=np.float32)
+    wt = np.zeros((cout, c0 + c1, kh, kw), np.float32)
+    _, want = oracle_dense.conv_taps_bwd(gy, x, wt, (kh // 2, kw // 2))
+    xs = [nhwc(x[:, :c0])] + ([nhwc(x[:, c0:])] if c1 else [])
+    got = fused.wino1d_wrw(xs, nhwc(gy), axis)
+    _close(got, want, tol=5e-5, what='weight gradient')
+    assert torch.equal(got, fused.wino1d_wrw(xs, nhwc(gy), axis)), 'fixed summation order'
+    base = rng.standard_normal(want.shape).astype(np.float32)
+    acc = dev(base)
+    fused.wino1d_wrw(xs, nhwc(gy), axis, out=acc)
+    _close(acc, base + want, tol=5e-5, what='accumulated')
+
+
 @pytest.mark.parametrize('wino', [True, False], ids=['winograd', 'taps'])
 @pytest.mark.parametrize('tiles', ['narrow', 'wide'])
 def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden, tiles, wino, monkeypatch):
@@ -193,7 +216,7 @@ def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden, tile
     census = rt.census()['fused']
     rt.set_census(False)
     assert (census.get('camli_wino1d_gru_gates', 0), census.get('camli_convcl_gru_gates', 0)) == ((4, 0) if wino else (0, 4)), census
-    assert census.get('camli_wino1d_conv', 0) == (8 if wino else 0)
+    assert census.get('camli_wino1d_conv', 0) == (8 if wino else 0) and census.get('camli_wino1d_wrw', 0) == (8 if wino else 0)
     _close(h0.grad, g['gh0'], tol=5e-5, what='gradient of h')
     _close(x.grad, g['gx'], tol=5e-5, what='gradient of x')
     for name, p_ in gru.named_parameters():

@@ -111,7 +111,7 @@ def cases(batch):
         yield 'gru2d B%d %dx%d' % (gb, gh_, gw_), gru2d, {'camli_convcl_gru_gates': 'mfma', 'camli_convcl_gru_blend': 'mfma',
                                                         'camli_convcl_fwd': 'mfma', 'camli_convcl_wrw': 'mfma',
                                                         'camli_wino1d_gru_gates': 'mfma', 'camli_wino1d_gru_blend': 'mfma',
-                                                        'camli_wino1d_conv': 'mfma'}
+                                                        'camli_wino1d_conv': 'mfma', 'camli_wino1d_wrw': 'mfma'}
 
     # ---- (f)2 the update block's 3x3 convolutions as Winograd F(2x2,3x3) (csrc/hip/winograd.hip): forward, data gradient,
     # weight gradient per launch of the entry point (three / four kernels each; flop = the transform-domain MFMA work)
