@@ -566,6 +566,12 @@ def roofline_report(summary, steps, args, step_ms):
         worst = min(heavy, key=lambda n: table[n]['frac'])
         roofline['worst'] = {'kernel': worst, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(NORTH_STAR[worst], NORTH_STAR[worst]),
                              'frac': table[worst]['frac'], 'ms_per_step': table[worst]['ms_per_step']}
+    if kind == 'mfma' and rec.get('flop', 0) > 0 and rec.get('unit') == 'B' and rec.get('work', 0) > 0:
+        # an entry point of several kernels (transforms + contraction: the Winograd families) declares its matrix flop AND the bytes
+        # its transform domain moves; its floor is both, un-overlapped -- `frac` above prices the flop alone
+        floor_s = rec['flop'] / (MFMA_F32_PEAK_TFLOPS * 1e12) + rec['work'] / (HBM_PEAK_GBS * 1e9)
+        roofline['floor'] = {'mfma_us': round(rec['flop'] / rec['launches'] / (MFMA_F32_PEAK_TFLOPS * 1e6), 1),
+                             'hbm_us': round(rec['work'] / rec['launches'] / (HBM_PEAK_GBS * 1e3), 1), 'frac_in_situ': round(floor_s / secs, 4)}
     if star is not None:
         roofline['north_star'] = {'kernel': star, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(NORTH_STAR[star], NORTH_STAR[star]),
                                   'frac_in_situ': table[star]['frac'], 'avg_launch_us_in_situ': table[star]['avg_launch_us'],
@@ -652,7 +658,7 @@ def compact_line(full, detail_path=None):
     roof = full.get('roofline')
     if roof is not None:
         keep = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_in_situ', 'traffic', 'traffic_source', 'frac_single_lane',
-                'avg_launch_us', 'avg_launch_us_in_situ', 'achieved_in_situ', 'launches', 'algorithmic_work_per_launch', 'measured', 'step')
+                'avg_launch_us', 'avg_launch_us_in_situ', 'achieved_in_situ', 'launches', 'algorithmic_work_per_launch', 'measured', 'step', 'floor')
         line['roofline'] = {k: roof[k] for k in keep if k in roof}
         for sub in ('north_star', 'worst'):
             if sub in roof:
@@ -891,6 +897,8 @@ def main():
                                 measured='frac / achieved / avg_launch_us: 2 extra steps after the timed region, one lane (CAMLI_OVERLAP=0 '
                                          'semantics, = the rocprofv3 setting); *_in_situ: HIP events in the two-lane timed region')
                 roofline['frac_single_lane'] = roofline['frac']          # (round-4 / round-5 name of the same figure)
+                if 'floor' in roofline and rec.get('work', 0) > 0:
+                    roofline['floor']['frac'] = round((rec['flop'] / (MFMA_F32_PEAK_TFLOPS * 1e12) + rec['work'] / (HBM_PEAK_GBS * 1e9)) / secs, 4)
             star = roofline.get('north_star')
             if star and single.get(star['kernel']) and single[star['kernel']]['launches']:
                 rec = single[star['kernel']]
