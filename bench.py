@@ -566,7 +566,7 @@ def roofline_report(summary, steps, args, step_ms):
         worst = min(heavy, key=lambda n: table[n]['frac'])
         roofline['worst'] = {'kernel': worst, 'bound': {'fma': 'valu', 'fps': 'latency'}.get(NORTH_STAR[worst], NORTH_STAR[worst]),
                              'frac': table[worst]['frac'], 'ms_per_step': table[worst]['ms_per_step']}
-    if kind == 'mfma' and rec.get('flop', 0) > 0 and rec.get('unit') == 'B' and rec.get('work', 0) > 0:
+    if kind == 'mfma' and 'wino' in name and rec.get('flop', 0) > 0 and rec.get('unit') == 'B' and rec.get('work', 0) > 0:
         # an entry point of several kernels (transforms + contraction: the Winograd families) declares its matrix flop AND the bytes
         # its transform domain moves; its floor is both, un-overlapped -- `frac` above prices the flop alone
         floor_s = rec['flop'] / (MFMA_F32_PEAK_TFLOPS * 1e12) + rec['work'] / (HBM_PEAK_GBS * 1e9)
@@ -897,7 +897,7 @@ def main():
                                 measured='frac / achieved / avg_launch_us: 2 extra steps after the timed region, one lane (CAMLI_OVERLAP=0 '
                                          'semantics, = the rocprofv3 setting); *_in_situ: HIP events in the two-lane timed region')
                 roofline['frac_single_lane'] = roofline['frac']          # (round-4 / round-5 name of the same figure)
-                if 'floor' in roofline and rec.get('work', 0) > 0:
+                if 'floor' in roofline:
                     roofline['floor']['frac'] = round((rec['flop'] / (MFMA_F32_PEAK_TFLOPS * 1e12) + rec['work'] / (HBM_PEAK_GBS * 1e9)) / secs, 4)
             star = roofline.get('north_star')
             if star and single.get(star['kernel']) and single[star['kernel']]['launches']:
