@@ -814,16 +814,40 @@ def main():
         torch.cuda.synchronize()
         _log('first step of the process (one lane, first-use work of the libraries included): %.1f s' % (time.perf_counter() - t_first))
     graphed = GraphedStep(step) if use_graph else None       # primes on its own side stream
-    for _ in range(args.warmup):
+    # The step is close to host-bound (169 ms of enqueue in a 178 ms step, profiles/r06i_ab_timer_graph.txt), and an event pair
+    # around a launch costs ~6 us of host time: bracketing all ~780 north-star launches of a step inside the timed region cost
+    # 5 ms of the step itself.  So the per-entry-point table (`hip_kernels`) is measured in the last warm-up steps (same
+    # two-lane execution, every north-star entry point bracketed), and inside the timed region only the roofline kernel (the
+    # dominant entry point of that table) and the dominant point-lane one (`roofline.north_star`) are bracketed.
+    # CAMLI_TIME_ALL=1: every launch, in the timed region; CAMLI_NO_TIMER=1: none.
+    warm_timed = 0
+    time_all = os.environ.get('CAMLI_TIME_ALL') == '1'
+    timer_on = graphed is None and os.environ.get('CAMLI_NO_TIMER') != '1'      # events cannot be recorded through a graph replay
+    if timer_on and not time_all and rank == 0:
+        warm_timed = min(2, args.warmup)
+    _lib.TIMER.reset()
+    for i in range(args.warmup):
+        if warm_timed and i == args.warmup - warm_timed:
+            _lib.TIMER.only = set(NORTH_STAR)
+            _lib.TIMER.enabled = True
         graphed() if graphed else step()
+    warm_summary = None
+    if warm_timed:
+        torch.cuda.synchronize()
+        _lib.TIMER.enabled = False
+        warm_summary = _lib.TIMER.summary()
     barrier()
     runtime.set_census(True)
     runtime.reset_census()
     _lib.TIMER.reset()
-    # only the north-star entry points are bracketed by events inside the timed region: the step is host-bound, and an
-    # event pair around each of the ~2,000 launches of a step costs ~20 ms of host time (CAMLI_TIME_ALL=1 times them all)
-    _lib.TIMER.only = None if os.environ.get('CAMLI_TIME_ALL') == '1' else set(NORTH_STAR)
-    _lib.TIMER.enabled = graphed is None and os.environ.get('CAMLI_NO_TIMER') != '1'   # events cannot be recorded through a graph replay
+    if time_all:
+        _lib.TIMER.only = None
+    elif warm_summary:
+        picked, _ = roofline_report(warm_summary, warm_timed, args, 0.0)
+        _lib.TIMER.only = {picked['kernel']} | ({picked['north_star']['kernel']} if picked.get('north_star') else set()) if picked else set()
+    else:
+        _lib.TIMER.only = set(NORTH_STAR)
+    _lib.TIMER.enabled = timer_on
     t0 = time.perf_counter()
     host_s = 0.0
     for _ in range(args.steps):
@@ -864,6 +888,19 @@ def main():
         global_batch = args.batch * world
         step_ms = elapsed / args.steps * 1e3
         roofline, kernel_table = roofline_report(_lib.TIMER.summary(), roofline_steps, args, step_ms)
+        if warm_summary:
+            # the whole table from the warm-up steps; the rows bracketed in the timed region replace theirs, and `worst` is
+            # taken over the whole table
+            warm_roofline, warm_table = roofline_report(warm_summary, warm_timed, args, step_ms)
+            warm_table.update(kernel_table)
+            kernel_table = warm_table
+            if roofline is None:
+                roofline = warm_roofline
+            elif warm_roofline is not None:
+                if 'worst' in warm_roofline:
+                    roofline['worst'] = warm_roofline['worst']
+                roofline['table_measured'] = ('hip_kernels: the last %d warm-up steps (two lanes, every north-star entry point bracketed by HIP '
+                                              'events); %s: the timed region' % (warm_timed, ' and '.join(sorted(_lib.TIMER.only))))
         if roofline is not None and roofline_how:
             roofline['measured'] = roofline_how
         if roofline is not None and runtime.overlap() and graphed is None and not dist_on:

@@ -261,17 +261,38 @@ __global__ __launch_bounds__(256) void grad_transform_1d_kernel(const float* __r
     }
 }
 
-// gw[(n * C + c) * 5 + k] (= | +=) sum_t G[t][k] * sum_{j < Sp} part[t * Sp + j][c][n]; one thread per (c, n), lanes along n
+// gw[(n * C + c) * 5 + k] (= | +=) sum_t G[t][k] * sum_{j < Sp} part[t * Sp + j][c][n].  One block per (c, 128 output channels):
+// 32 lanes x float4 along n, 8 groups of threads sharing the Sp partial sums of each plane (group g takes j = g, g + 8, ...: with
+// one thread per element the 8 * Sp dependent loads of a thread were a 66 us latency chain for 67 MB), combined through LDS in a
+// fixed order, then one thread per n applies G.  N a multiple of 128.
 __global__ __launch_bounds__(256) void wrw_reduce_1d_kernel(const float* __restrict__ part, int Sp, float* __restrict__ gw, int C, int N, int accumulate) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)C * N) return;
-    const int n = (int)(i % N), c = (int)(i / N);
+    __shared__ f32x4 sm[8][8][32];
+    const int nb = N / 128;
+    const int c = blockIdx.x / nb, n0 = (blockIdx.x % nb) * 128;
+    const int lane = threadIdx.x & 31, g = threadIdx.x >> 5;
     const size_t el = (size_t)C * N;
+    const float* src = part + (size_t)c * N + n0 + 4 * lane;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        f32x4 a0 = z, a1 = z;
+        int j = g;
+        for (; j + 8 < Sp; j += 16) {
+            a0 += *reinterpret_cast<const f32x4*>(src + ((size_t)t * Sp + j) * el);
+            a1 += *reinterpret_cast<const f32x4*>(src + ((size_t)t * Sp + j + 8) * el);
+        }
+        if (j < Sp) a0 += *reinterpret_cast<const f32x4*>(src + ((size_t)t * Sp + j) * el);
+        sm[g][t][lane] = a0 + a1;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 128) return;
+    const int n = threadIdx.x;
     float u[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         float acc = 0.f;
-        for (int j = 0; j < Sp; ++j) acc += part[((size_t)t * Sp + j) * el + i];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += reinterpret_cast<const float*>(&sm[q][t][0])[n];
         u[t] = acc;
     }
     const float s12 = u[1] + u[2], d12 = u[1] - u[2], s34 = u[3] + u[4], d34 = u[3] - u[4], s56 = u[5] + u[6], d56 = u[5] - u[6];
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(256) void wrw_reduce_1d_kernel(const float* __restr
     o[2] = -(2.f / 9.f) * s12 + (2.f / 45.f) * s34 + (8.f / 45.f) * s56;
     o[3] = -(2.f / 9.f) * d12 + (4.f / 45.f) * d34 + (4.f / 45.f) * d56;
     o[4] = -(2.f / 9.f) * s12 + (8.f / 45.f) * s34 + (2.f / 45.f) * s56 + u[7];
-    float* dst = gw + ((size_t)n * C + c) * 5;
+    float* dst = gw + ((size_t)(n0 + n) * C + c) * 5;
 #pragma unroll
     for (int k = 0; k < 5; ++k) dst[k] = accumulate ? dst[k] + o[k] : o[k];
 }

@@ -233,6 +233,6 @@ extern "C" int camli_wino1d_wrw(const float* x0, int ldx0, int C0, const float* 
     for (int t = 0; t < ccl::MAX_TAPS; ++t) p.dy[t] = p.dx[t] = 0;
     const int rc = NB == 256 ? launch_wrw_1d<8>(p, s) : launch_wrw_1d<4>(p, s);
     if (rc != CAMLI_OK) return rc;
-    hipLaunchKernelGGL(w1d::wrw_reduce_1d_kernel, dim3(camli_divup(C * Cout, 256)), dim3(256), 0, s, parts, pl.Sp, gw, C, Cout, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(w1d::wrw_reduce_1d_kernel, dim3(C * (Cout / 128)), dim3(256), 0, s, parts, pl.Sp, gw, C, Cout, accumulate ? 1 : 0);
     return camli_check_launch(what);
 }
