@@ -808,6 +808,8 @@ def main():
     # hipBLASLt solution look-ups and code-object loads: 20-60 s on most boxes, 231 s measured on a slow one
     # (profiles/r03_first_step_probe.txt).  Round 2 mistook that stall for a two-stream dead-lock and restarted the run
     # from a watchdog; there is no watchdog any more, only this log line.
+    if os.environ.get('CAMLI_PRIO_MAIN') and device.type == 'cuda':       # experiment: the step's own stream at a HIP priority
+        torch.cuda.set_stream(torch.cuda.Stream(device, priority=int(os.environ['CAMLI_PRIO_MAIN'])))
     t_first = time.perf_counter()
     if not use_graph:
         step()
@@ -822,8 +824,9 @@ def main():
     # CAMLI_TIME_ALL=1: every launch, in the timed region; CAMLI_NO_TIMER=1: none.
     warm_timed = 0
     time_all = os.environ.get('CAMLI_TIME_ALL') == '1'
-    timer_on = graphed is None and os.environ.get('CAMLI_NO_TIMER') != '1'      # events cannot be recorded through a graph replay
-    if timer_on and not time_all and rank == 0:
+    # (events cannot be recorded through a graph replay; only rank 0 reports, the other ranks record none)
+    timer_on = graphed is None and rank == 0 and os.environ.get('CAMLI_NO_TIMER') != '1'
+    if timer_on and not time_all:
         warm_timed = min(2, args.warmup)
     _lib.TIMER.reset()
     for i in range(args.warmup):

@@ -24,6 +24,14 @@ import weakref
 _BACKEND = 'hip'
 
 
+
+def _stream_priority(lane):
+    """HIP stream priority of a lane's stream (CAMLI_PRIO_SIDE | _AUX | _WGRAD; 0 = the default stream's, -1 = high: torch
+    clamps to what the device offers and has nothing BELOW the default, so the point lane is put behind the image lane by
+    raising the image lane's streams, see bench.py CAMLI_PRIO_MAIN)."""
+    return int(os.environ.get('CAMLI_PRIO_' + lane, '0'))
+
+
 def backend():
     return _BACKEND
 
@@ -359,7 +367,7 @@ class Lanes:
             self.main = torch.cuda.current_stream(device)
             key = (device.index, self.main.cuda_stream)
             if key not in _side_streams:
-                _side_streams[key] = torch.cuda.Stream(device)
+                _side_streams[key] = torch.cuda.Stream(device, priority=_stream_priority('SIDE'))
             self.side_stream = _side_streams[key]
 
     def side(self):
@@ -431,7 +439,7 @@ class Branch:
             self.main = torch.cuda.current_stream(dev)
             key = (dev.index, self.main.cuda_stream, 0 if _BRANCH_SHARE else slot)
             if key not in _aux_streams:
-                _aux_streams[key] = torch.cuda.Stream(dev)
+                _aux_streams[key] = torch.cuda.Stream(dev, priority=_stream_priority('AUX'))
             self.aux = _aux_streams[key]
             self.aux.wait_stream(self.main)
             for t in _flatten(inputs):
@@ -504,7 +512,7 @@ def wgrad_side(device):
     key = (device.index, main.cuda_stream)
     side = _wgrad_streams.get(key)
     if side is None:
-        side = _wgrad_streams[key] = torch.cuda.Stream(device)
+        side = _wgrad_streams[key] = torch.cuda.Stream(device, priority=_stream_priority('WGRAD'))
     return _WgradSide(main, side)
 
 
