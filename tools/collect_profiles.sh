@@ -50,7 +50,7 @@ trace)
   cp $OUT/trace_bench/b_kernel_stats.csv $OUT/bench_whole_process_kernel_stats.csv 2>/dev/null
   rm -rf $OUT/trace_bench
   # isolated kernels: rocprofv3 --kernel-trace --stats of tools/kernel_bench.py (the roofline_rows command)
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_kb -o kb -- \
+  CAMLI_KB_KINETO=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_kb -o kb -- \
       python $ROOT/tools/kernel_bench.py --reps 5 --json $OUT/kernel_bench_rows.json > $OUT/kernel_bench.log 2>&1
   cp $OUT/trace_kb/kb_kernel_stats.csv $OUT/kernel_bench_kernel_stats.csv 2>/dev/null
   rm -rf $OUT/trace_kb
@@ -101,9 +101,21 @@ pmcw)
   python $ROOT/tools/pmc_traffic.py $OUT/pmcw_FETCH_SIZE/p_counter_collection.csv $OUT/pmcw_WRITE_SIZE/p_counter_collection.csv \
       "wrw_planes_kernel+input_transform_kernel<${CAMLI_WINO_TILE:-4}, true, true>+grad_transform_kernel+wrw_reduce_kernel+bias_grad_kernel" camli_wino_wrw > $OUT/traffic_wino_wrw.json 2>&1
   rm -rf $OUT/pmcw_FETCH_SIZE $OUT/pmcw_WRITE_SIZE
+  # the 1-D family (GRU2D's convolutions) over the batch-8 row of tools/kernel_bench.py: four entry points share the input transform
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex 'w1d::|wrw::wrw_kernel' --output-format csv -d $OUT/pmcg_$c -o p -- \
+        python $ROOT/tools/kernel_bench.py --reps 2 --only 'gru2d B8' > /dev/null 2>&1
+    python $ROOT/tools/pmc_summary.py $OUT/pmcg_$c/p_counter_collection.csv > $OUT/pmc_wino1d_$c.txt 2>&1
+  done
+  for e in "gru_gates:output_transform_1d_kernel<1>~input_transform_1d_kernel~planes_cl_kernel<8" "gru_blend:output_transform_1d_kernel<2>~input_transform_1d_kernel~planes_cl_kernel<4" \
+           "conv:output_transform_1d_kernel<0>~input_transform_1d_kernel~planes_cl_kernel<8" "wrw:grad_transform_1d_kernel~input_transform_1d_kernel~wrw::wrw_kernel~wrw_reduce_1d_kernel"; do
+    python $ROOT/tools/pmc_traffic.py $OUT/pmcg_FETCH_SIZE/p_counter_collection.csv $OUT/pmcg_WRITE_SIZE/p_counter_collection.csv \
+        "${e#*:}" camli_wino1d_${e%%:*} > $OUT/traffic_wino1d_${e%%:*}.json 2>&1
+  done
+  rm -rf $OUT/pmcg_FETCH_SIZE $OUT/pmcg_WRITE_SIZE
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --kernel-trace \
-      --kernel-include-regex 'gemm_w128_kernel|wrw_planes' --output-format csv -d $OUT/pmcw_mfma -o p -- \
-      python $ROOT/tools/kernel_bench.py --reps 2 --only wino > /dev/null 2>&1
+      --kernel-include-regex 'gemm_w128_kernel|wrw_planes|planes_cl_kernel|wrw::wrw_kernel' --output-format csv -d $OUT/pmcw_mfma -o p -- \
+      python $ROOT/tools/kernel_bench.py --reps 2 --only 'wino|gru2d B8' > /dev/null 2>&1
   python $ROOT/tools/pmc_summary.py $OUT/pmcw_mfma/p_counter_collection.csv > $OUT/pmc_wino_mfma.txt 2>&1
   rm -rf $OUT/pmcw_mfma
   ;;

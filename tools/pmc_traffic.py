@@ -7,6 +7,10 @@ An entry point that launches SEVERAL kernels (camli_wino_conv3x3 = input transfo
 kernels as a '+'-separated list, the FIRST of which runs exactly once per launch of the entry point: the traffic per launch is
 the sum of every listed kernel's counter over the pass divided by the number of launches of the first.
 
+Kernels SHARED between entry points (the 1-D Winograd family: one input transform serves four entry points) are given as a
+'~'-separated list: the traffic per launch is the sum of the listed kernels' MEAN counters (each runs once per launch of the
+entry point; the mean of a shared kernel is taken over all its launches in the pass).
+
 Units: the counters are KiB.  gfx950 correction (guide, section HBM): FETCH_SIZE counts a wide
 coalesced 16-B/lane read stream at exactly half its bytes -> doubled; WRITE_SIZE is taken as is.
 tools/pmc_probe.py re-checks both on a 256 MiB copy (131,083 KiB fetched / 262,144 KiB written).
@@ -38,7 +42,12 @@ def per_entry_launch(path, needles):
 
 def main():
     fetch_csv, write_csv, needle, entry = sys.argv[1:5]
-    if '+' in needle:
+    if '~' in needle:
+        parts_f = [mean_counter(fetch_csv, n) for n in needle.split('~')]
+        parts_w = [mean_counter(write_csv, n) for n in needle.split('~')]
+        fetch, n1 = sum(p[0] for p in parts_f), parts_f[0][1]
+        write, n2 = sum(p[0] for p in parts_w), parts_w[0][1]
+    elif '+' in needle:
         fetch, n1 = per_entry_launch(fetch_csv, needle.split('+'))
         write, n2 = per_entry_launch(write_csv, needle.split('+'))
     else:
