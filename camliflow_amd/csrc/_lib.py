@@ -139,11 +139,12 @@ PROTOTYPES = {
     "camli_wino1d_conv": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _c_float_p, _int, _int, _c_float_p, _int,
                                  _c_float_p, ctypes.c_int64] + [_int] * 7 + [_stream]),
     "camli_wino1d_gru_gates": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                                      _c_float_p, ctypes.c_int64] + [_int] * 4 + [_stream]),
+                                      _c_float_p, _c_float_p, ctypes.c_int64] + [_int] * 4 + [_stream]),
     "camli_wino1d_gru_blend": (_int, [_c_float_p, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p,
-                                      _c_float_p, _int, _c_float_p, ctypes.c_int64] + [_int] * 4 + [_stream]),
+                                      _c_float_p, _int, _c_float_p, _c_float_p, ctypes.c_int64] + [_int] * 4 + [_stream]),
     "camli_wino1d_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 6),
-    "camli_wino1d_wrw": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _int, _c_float_p, _c_float_p, ctypes.c_int64]
+    "camli_wino1d_wrw_reuse": (_int, [_int] * 6),
+    "camli_wino1d_wrw": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _int, _c_float_p, _c_float_p, _c_float_p, ctypes.c_int64]
                          + [_int] * 6 + [_stream]),
     "camli_convcl_wrw_workspace_bytes": (ctypes.c_int64, [_int] * 6),
     "camli_convcl_wrw": (_int, [_c_float_p, _int, _int, _c_float_p, _int, _int, _c_float_p, _int, _c_float_p, ctypes.c_int64,

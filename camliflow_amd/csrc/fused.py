@@ -1871,6 +1871,9 @@ def _to_nchw(x_n):
 _GRU_WINO = os.environ.get('CAMLI_GRU_WINO', '1') != '0'
 # CAMLI_GRU_WINO_WRW=0: their weight gradients stay on the tap form (camli_convcl_wrw) while the rest runs the Winograd form
 _GRU_WINO_WRW = os.environ.get('CAMLI_GRU_WINO_WRW', '1') != '0'
+# CAMLI_GRU_KEEP_V=0: the weight gradients transform their inputs again instead of contracting the transformed input [8][tiles][C] the
+# forward kept (134 MB per convolution at batch 8, 6.4 GB over the 12 updates of a pass)
+_GRU_KEEP_V = os.environ.get('CAMLI_GRU_KEEP_V', '1') != '0'
 
 
 def wino1d_weights(wp, flip):
@@ -1922,9 +1925,10 @@ def wino1d_conv(xs, u, axis, split=None, out=None, accumulate=(False, False)):
     return y0 if y1 is None else (y0, y1)
 
 
-def wino1d_wrw(xs, gy, axis, out=None):
+def wino1d_wrw(xs, gy, axis, out=None, v=None):
     """convcl_wrw(xs, gy, taps of a 1x5 (axis 0) / 5x1 (axis 1) kernel) contracted in the Winograd domain: the weight gradient
-    [Cout, Cin, 1, 5] | [Cout, Cin, 5, 1]; ``out``: add into this tensor."""
+    [Cout, Cin, 1, 5] | [Cout, Cin, 5, 1]; ``out``: add into this tensor; ``v``: the transformed input the forward kept
+    (camli_wino1d_gru_gates / _blend's v_keep), contracted as it lies instead of transforming xs again."""
     _require_cuda('wino1d_wrw', gy, *xs)
     lib = _lib.load()
     x0 = xs[0]
@@ -1943,8 +1947,9 @@ def wino1d_wrw(xs, gy, axis, out=None):
     tiles = b * (hh * ((ww + 3) // 4) if axis == 0 else ww * ((hh + 3) // 4))
     with _on_device(gy):
         _lib.launch('camli_wino1d_wrw', lib.camli_wino1d_wrw, x0.data_ptr(), ld0, c0, x1.data_ptr() if x1 is not None else 0, ld1, c1,
-                    gy.data_ptr(), ldg, gw.data_ptr(), ws.data_ptr(), need, b, hh, ww, cout, axis, int(out is not None), _stream_ptr(gy),
-                    work=(4.0 * b * hh * ww * (c0 + c1 + cout) * 3.0, 'B'), flop=2.0 * 8 * tiles * cout * (c0 + c1))
+                    gy.data_ptr(), ldg, gw.data_ptr(), v.data_ptr() if v is not None else None, ws.data_ptr(), need, b, hh, ww, cout, axis,
+                    int(out is not None), _stream_ptr(gy),
+                    work=(4.0 * b * hh * ww * ((c0 + c1) * (2.0 if v is not None else 3.0) + cout * 3.0), 'B'), flop=2.0 * 8 * tiles * cout * (c0 + c1))
     return gw
 
 
@@ -2021,6 +2026,7 @@ class _GRU2DStepCL(torch.autograd.Function):
         h0, mn = _to_nhwc(h.float()), _to_nhwc(m.float())
         ctx.geom = []
         ctx.hub = hub
+        kept = ctx.kept = []        # per half-step: the transformed inputs (z|r convolution, q convolution) or (None, None)
         saved = [h0, mn]
         hcur = h0
         with _on_device(h):
@@ -2038,15 +2044,23 @@ class _GRU2DStepCL(torch.autograd.Function):
                     axis = 0 if kh == 1 else 1
                     ws, need = _wino1d_workspace(b, hh, ww, hd + cx, 2 * hd, axis, h.device)
                     tiles = need // (32 * (3 * hd + cx))
+                    # the transformed inputs stay for the weight gradients when those can contract them as they lie
+                    keep = (_GRU_KEEP_V and _GRU_WINO_WRW and any(ctx.needs_input_grad[:2]) and any(w.requires_grad for w in (w_zr, w_q))
+                            and lib.camli_wino1d_wrw_reuse(b, hh, ww, hd + cx, 2 * hd, axis) and lib.camli_wino1d_wrw_reuse(b, hh, ww, hd + cx, hd, axis))
+                    v_zr, v_q = ((torch.empty(8 * tiles * (hd + cx), dtype=torch.float32, device=h.device) for _ in range(2)) if keep
+                                 else (None, None))
+                    kept.append((v_zr, v_q))
                     _lib.launch('camli_wino1d_gru_gates', lib.camli_wino1d_gru_gates, hcur.data_ptr(), mn.data_ptr(), cx,
-                                hub.wino_u(wp_zr, False).data_ptr(), c_zr.data_ptr(), z.data_ptr(), rh.data_ptr(), r.data_ptr(), ws.data_ptr(),
+                                hub.wino_u(wp_zr, False).data_ptr(), c_zr.data_ptr(), z.data_ptr(), rh.data_ptr(), r.data_ptr(),
+                                v_zr.data_ptr() if keep else None, ws.data_ptr(),
                                 need, b, hh, ww, axis, _stream_ptr(h), work=(4.0 * b * hh * ww * (6 * hd + cx) + 2.0 * need, 'B'),
                                 flop=2.0 * 8 * tiles * (hd + cx) * 2 * hd)
                     _lib.launch('camli_wino1d_gru_blend', lib.camli_wino1d_gru_blend, rh.data_ptr(), mn.data_ptr(), cx,
                                 hub.wino_u(wp_q, False).data_ptr(), c_q.data_ptr(), z.data_ptr(), hcur.data_ptr(), hn.data_ptr(), q.data_ptr(),
-                                int(half == 1), ws.data_ptr(), need, b, hh, ww, axis, _stream_ptr(h),
+                                int(half == 1), v_q.data_ptr() if keep else None, ws.data_ptr(), need, b, hh, ww, axis, _stream_ptr(h),
                                 work=(4.0 * b * hh * ww * (6 * hd + cx) + 1.5 * need, 'B'), flop=2.0 * 8 * tiles * (hd + cx) * hd)
                 else:
+                    kept.append((None, None))
                     _lib.launch('camli_convcl_gru_gates', lib.camli_convcl_gru_gates, hcur.data_ptr(), mn.data_ptr(), cx, wp_zr.data_ptr(),
                                 c_zr.data_ptr(), z.data_ptr(), rh.data_ptr(), r.data_ptr(), b, hh, ww, t, dy, dx, _stream_ptr(h),
                                 work=(4.0 * b * hh * ww * (6 * hd + cx), 'B'), flop=flop * 2 * hd)
@@ -2084,17 +2098,17 @@ class _GRU2DStepCL(torch.autograd.Function):
         if side is not None:
             hub.side = side
 
-        def wgrad(slot, xs, gpre, taps, khw, wino=False):
+        def wgrad(slot, xs, gpre, taps, khw, wino=False, v=None):
             """the weight gradient of one convolution, added into the pass total -- beside the data-gradient chain when a side
             stream is available (runtime.wgrad_side): nothing downstream needs it before the hub hands the totals over"""
             def run():
                 if wino and _GRU_WINO_WRW:
-                    return wino1d_wrw(xs, gpre, 0 if khw[0] == 1 else 1, out=hub.gw[slot])
+                    return wino1d_wrw(xs, gpre, 0 if khw[0] == 1 else 1, out=hub.gw[slot], v=v)
                 return convcl_wrw(xs, gpre, taps, khw, out=hub.gw[slot])
             if side is None:
                 hub.gw[slot] = run()
                 return
-            side.fork(gpre, *xs)
+            side.fork(gpre, *xs, *([v] if v is not None else []))
             with side.stream():
                 hub.gw[slot] = run()
 
@@ -2122,7 +2136,7 @@ class _GRU2DStepCL(torch.autograd.Function):
                 data_gradient(gpre_q, wpt_q, (grh, gm), (False, not first_m))
                 first_m = False
                 if need_w[iq]:
-                    wgrad(iq, [rh, mn], gpre_q, taps, geom[:2], wino)
+                    wgrad(iq, [rh, mn], gpre_q, taps, geom[:2], wino, ctx.kept[half][1])
                 if becomes is not None:      # the first contribution starts the total (a copy: gpre_q itself may still be read
                     hub.gc[iq] = gpre_q.clone()      # by the weight gradient on the side stream when later updates add into it)
                 gpre_zr = torch.empty((b, hh, ww, 2 * hd), dtype=torch.float32, device=g.device)
@@ -2133,7 +2147,7 @@ class _GRU2DStepCL(torch.autograd.Function):
                 # z | r convolution: its input gradient completes the gradient of this half-step's hidden input and of m
                 data_gradient(gpre_zr, wpt_zr, (gh, gm), (True, True))
                 if need_w[izr]:
-                    wgrad(izr, [hin, mn], gpre_zr, taps, geom[:2], wino)
+                    wgrad(izr, [hin, mn], gpre_zr, taps, geom[:2], wino, ctx.kept[half][0])
                 if becomes is not None:
                     hub.gc[izr] = gpre_zr.clone()
                 gcur = gh

@@ -28,7 +28,7 @@ int launch_planes(const w1d::PlanesBatch& pb, hipStream_t s) {
 // x -> V -> Mo for one convolution; the caller finishes with its output transform
 int transform_and_contract(const char* what, const float* x0, int ldx0, int C0, const float* x1, int ldx1, int C1, const float* U,
                            int Cout, float* workspace, int64_t workspace_bytes, int B, int H, int W, int axis, w1d::Lines& l, float*& Mo,
-                           hipStream_t s) {
+                           hipStream_t s, float* V_keep = nullptr) {
     const int C = C0 + C1;
     if (!x0 || !U || !workspace || (C1 > 0 && !x1)) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
     if (B < 1 || H < 1 || W < 1 || (axis != 0 && axis != 1) || C0 < 16 || C0 % 16 || C1 < 0 || C1 % 16 || C / 16 < NBUF - 1 || Cout < 128 ||
@@ -44,9 +44,10 @@ int transform_and_contract(const char* what, const float* x0, int ldx0, int C0, 
         camli_set_error("%s: a transform-domain plane beyond 2 GB", what);
         return CAMLI_ENOTSUP;
     }
-    if (!aligned16(x0) || !aligned16(x1) || !aligned16(U) || !aligned16(workspace)) { camli_set_error("%s: pointers must be 16-byte aligned", what); return CAMLI_EINVAL; }
-    float* V = workspace;
-    Mo = workspace + (size_t)8 * l.tiles * C;
+    if (!aligned16(x0) || !aligned16(x1) || !aligned16(U) || !aligned16(workspace) || !aligned16(V_keep)) { camli_set_error("%s: pointers must be 16-byte aligned", what); return CAMLI_EINVAL; }
+    // V_keep: the caller keeps the transformed input [8][tiles][C] (the weight gradient contracts it again: camli_wino1d_wrw's v_in)
+    float* V = V_keep ? V_keep : workspace;
+    Mo = V_keep ? workspace : workspace + (size_t)8 * l.tiles * C;
     hipLaunchKernelGGL(w1d::input_transform_1d_kernel, dim3(camli_divup(l.tiles, 4)), dim3(256), 0, s, x0, ldx0, C0, C1 > 0 ? x1 : x0, C1 > 0 ? ldx1 : ldx0,
                        C1, V, l.tiles, l);
     w1d::PlanesBatch pb;
@@ -114,14 +115,14 @@ extern "C" int camli_wino1d_conv(const float* x0, int ldx0, int C0, const float*
 
 // camli_convcl_gru_gates / _gru_blend on the Winograd form: same tensors, same arithmetic in the epilogue
 extern "C" int camli_wino1d_gru_gates(const float* h, const float* x, int CX, const float* U_zr, const float* ctx_zr, float* z, float* rh,
-                                      float* r, float* workspace, int64_t workspace_bytes, int B, int H, int W, int axis, void* stream) {
+                                      float* r, float* v_keep, float* workspace, int64_t workspace_bytes, int B, int H, int W, int axis, void* stream) {
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_wino1d_gru_gates";
     if (!ctx_zr || !z || !rh || !r || !aligned16(ctx_zr) || !aligned16(z) || !aligned16(rh) || !aligned16(r)) { camli_set_error("%s: bad pointers", what); return CAMLI_EINVAL; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     w1d::Lines l;
     float* Mo = nullptr;
-    const int rc = transform_and_contract(what, h, 128, 128, x, CX, CX, U_zr, 256, workspace, workspace_bytes, B, H, W, axis, l, Mo, s);
+    const int rc = transform_and_contract(what, h, 128, 128, x, CX, CX, U_zr, 256, workspace, workspace_bytes, B, H, W, axis, l, Mo, s, v_keep);
     if (rc != CAMLI_OK) return rc;
     w1d::Epilogue e = {};
     e.N = 256; e.N0 = 256; e.y = z; e.ldy = 128; e.y1 = rh; e.ldy1 = 128; e.y2 = r; e.ldy2 = 128;
@@ -131,7 +132,7 @@ extern "C" int camli_wino1d_gru_gates(const float* h, const float* x, int CX, co
 }
 
 extern "C" int camli_wino1d_gru_blend(const float* rh, const float* x, int CX, const float* U_q, const float* ctx_q, const float* z,
-                                      const float* h, float* h_new, float* q, int nan_to_num, float* workspace, int64_t workspace_bytes,
+                                      const float* h, float* h_new, float* q, int nan_to_num, float* v_keep, float* workspace, int64_t workspace_bytes,
                                       int B, int H, int W, int axis, void* stream) {
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_wino1d_gru_blend";
@@ -142,7 +143,7 @@ extern "C" int camli_wino1d_gru_blend(const float* rh, const float* x, int CX, c
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     w1d::Lines l;
     float* Mo = nullptr;
-    const int rc = transform_and_contract(what, rh, 128, 128, x, CX, CX, U_q, 128, workspace, workspace_bytes, B, H, W, axis, l, Mo, s);
+    const int rc = transform_and_contract(what, rh, 128, 128, x, CX, CX, U_q, 128, workspace, workspace_bytes, B, H, W, axis, l, Mo, s, v_keep);
     if (rc != CAMLI_OK) return rc;
     w1d::Epilogue e = {};
     e.N = 128; e.N0 = 128; e.y = h_new; e.ldy = 128; e.y1 = q; e.ldy1 = 128;
@@ -159,13 +160,22 @@ struct WrwPlan1d {
     int rows;        // tiles per plane as allocated: a multiple of 16 Sp (the K split is rows / Sp pixels, a multiple of 16)
 };
 
-WrwPlan1d wrw_plan_1d(int tiles, int out_tiles) {
+WrwPlan1d wrw_plan_1d(int tiles, int out_tiles, bool exact = false) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     WrwPlan1d pl;
     int sp = cus / (8 * out_tiles);
     if (sp < 1) sp = 1;
     while (sp > 1 && tiles / sp < 48) --sp;          // at least the pipeline's depth per split
+    if (exact) {
+        // the planes as the forward left them ([8][tiles][C], no padding rows): the K split must divide the plane into whole
+        // 16-row steps; rows = 0 when no split within 3/4 of the wanted one does (the caller transforms again)
+        const int want = sp;
+        while (sp >= 1 && tiles % (16 * sp) != 0) --sp;
+        pl.Sp = sp;
+        pl.rows = (sp >= 1 && 4 * sp >= 3 * want) ? tiles : 0;
+        return pl;
+    }
     pl.Sp = sp;
     pl.rows = camli_divup(tiles, 16 * sp) * 16 * sp;
     return pl;
@@ -193,17 +203,26 @@ extern "C" int64_t camli_wino1d_wrw_workspace_bytes(int B, int H, int W, int Cin
     return ((int64_t)8 * pl.rows * ((int64_t)Cin + Cout) + (int64_t)8 * pl.Sp * Cin * Cout) * 4;
 }
 
+// 1 when camli_wino1d_wrw can contract a transformed input kept by the forward (v_keep of camli_wino1d_gru_gates / _blend) as it
+// lies -- [8][tiles][Cin], no padding rows -- on a K split that fills the device; 0: it transforms the input again
+extern "C" int camli_wino1d_wrw_reuse(int B, int H, int W, int Cin, int Cout, int axis) {
+    if (camli_wino1d_wrw_workspace_bytes(B, H, W, Cin, Cout, axis) == 0) return 0;
+    const w1d::Lines l = w1d::make_lines(B, H, W, axis);
+    return wrw_plan_1d(l.tiles, (Cin / 256) * (Cout / (Cout % 256 == 0 ? 256 : 128)), true).rows > 0 ? 1 : 0;
+}
+
 // gw [Cout][C0 + C1][5] (= the [Cout, Cin, 1, 5] | [Cout, Cin, 5, 1] weight tensor) (= | +=) the weight gradient of the 5-tap
 // convolution of cat[x0, x1] along `axis` for the output gradient gy [P][ldg]: camli_convcl_wrw's result, contracted in the
 // transform domain (8 planes x (tiles x Cin x Cout) instead of 5 taps x (pixels x Cin x Cout): 2.5 x fewer multiplications).
-// C0 + C1 a multiple of 256, Cout of 128.  Deterministic (fixed summation order).
+// C0 + C1 a multiple of 256, Cout of 128.  Deterministic (fixed summation order).  v_in (may be null): the transformed input the
+// forward kept (camli_wino1d_wrw_reuse must say 1); x0 / x1 are then not read.
 extern "C" int camli_wino1d_wrw(const float* x0, int ldx0, int C0, const float* x1, int ldx1, int C1, const float* gy, int ldg, float* gw,
-                                float* workspace, int64_t workspace_bytes, int B, int H, int W, int Cout, int axis, int accumulate,
+                                const float* v_in, float* workspace, int64_t workspace_bytes, int B, int H, int W, int Cout, int axis, int accumulate,
                                 void* stream) {
     if (B == 0) return CAMLI_OK;
     const char* what = "camli_wino1d_wrw";
     const int C = C0 + C1;
-    if (!x0 || !gy || !gw || !workspace || (C1 > 0 && !x1)) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
+    if ((!v_in && (!x0 || (C1 > 0 && !x1))) || !gy || !gw || !workspace) { camli_set_error("%s: null pointer", what); return CAMLI_EINVAL; }
     const int64_t need = camli_wino1d_wrw_workspace_bytes(B, H, W, C, Cout, axis);
     if (need == 0 || C0 < 16 || C0 % 16 || C1 < 0 || C1 % 16 || ldx0 < C0 || ldx0 % 4 || (C1 > 0 && (ldx1 < C1 || ldx1 % 4)) || ldg < Cout || ldg % 4) {
         camli_set_error("%s: unsupported shape B=%d %dx%d C0=%d C1=%d Cout=%d (input channels a multiple of 256, output of 128)", what, B, H, W, C0, C1, Cout);
@@ -213,14 +232,16 @@ extern "C" int camli_wino1d_wrw(const float* x0, int ldx0, int C0, const float* 
     if (!aligned16(x0) || !aligned16(x1) || !aligned16(gy) || !aligned16(gw) || !aligned16(workspace)) { camli_set_error("%s: pointers must be 16-byte aligned", what); return CAMLI_EINVAL; }
     const w1d::Lines l = w1d::make_lines(B, H, W, axis);
     const int NB = Cout % 256 == 0 ? 256 : 128;
-    const WrwPlan1d pl = wrw_plan_1d(l.tiles, (C / 256) * (Cout / NB));
+    const WrwPlan1d pl = wrw_plan_1d(l.tiles, (C / 256) * (Cout / NB), v_in != nullptr);
+    if (v_in && (pl.rows == 0 || !aligned16(v_in))) { camli_set_error("%s: the kept transform cannot be contracted as it lies (camli_wino1d_wrw_reuse)", what); return CAMLI_ENOTSUP; }
     if ((int64_t)8 * pl.rows * (C > Cout ? C : Cout) * 4 >= (int64_t)0x7FF00000) { camli_set_error("%s: transform domain beyond 2 GB", what); return CAMLI_ENOTSUP; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    float* V = workspace;
-    float* gM = V + (size_t)8 * pl.rows * C;
+    float* V = v_in ? const_cast<float*>(v_in) : workspace;
+    float* gM = v_in ? workspace : workspace + (size_t)8 * pl.rows * C;
     float* parts = gM + (size_t)8 * pl.rows * Cout;
-    hipLaunchKernelGGL(w1d::input_transform_1d_kernel, dim3(camli_divup(pl.rows, 4)), dim3(256), 0, s, x0, ldx0, C0, C1 > 0 ? x1 : x0, C1 > 0 ? ldx1 : ldx0,
-                       C1, V, pl.rows, l);
+    if (!v_in)
+        hipLaunchKernelGGL(w1d::input_transform_1d_kernel, dim3(camli_divup(pl.rows, 4)), dim3(256), 0, s, x0, ldx0, C0, C1 > 0 ? x1 : x0, C1 > 0 ? ldx1 : ldx0,
+                           C1, V, pl.rows, l);
     hipLaunchKernelGGL(w1d::grad_transform_1d_kernel, dim3(camli_divup(pl.rows, 4)), dim3(256), 0, s, gy, ldg, Cout, gM, pl.rows, l);
     // the 8 planes end to end are 8 * rows "pixels" of an image one pixel high; one tap, no shift; parts = 8 Sp K ranges
     wrw::Problem p;

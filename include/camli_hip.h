@@ -612,7 +612,9 @@ int camli_convcl_gru_blend(const float *rh, const float *x, int CX, const float 
  * points above (flip = 1 on the transposed packing [Cin][5][Cout]: the data gradient's weights).  workspace =
  * camli_wino1d_workspace_bytes(B, H, W, Cin, Cout, axis) bytes.  Rounding differs from the tap form's (factors up to 21/4 and 8
  * in the transforms): 1.3e-6 relative L2 at 256 channels.  camli_wino1d_conv = camli_convcl_fwd's plain form (two inputs, output
- * split at N0, = or +=); _gru_gates / _gru_blend = camli_convcl_gru_gates / _gru_blend.
+ * split at N0, = or +=); _gru_gates / _gru_blend = camli_convcl_gru_gates / _gru_blend.  v_keep (may be null): [8][tiles][128 + CX]
+ * floats that receive the transformed input V instead of the workspace -- the weight gradient of the same convolution contracts
+ * it again (camli_wino1d_wrw's v_in) instead of transforming the input a second time.
  */
 int64_t camli_wino1d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int axis);
 int camli_wino1d_weights(const float *wp, float *U, int N, int C, int flip, void *stream);
@@ -620,17 +622,20 @@ int camli_wino1d_conv(const float *x0, int ldx0, int C0, const float *x1, int ld
                       float *y1, int ldy1, float *workspace, int64_t workspace_bytes, int B, int H, int W, int Cout, int axis,
                       int accumulate0, int accumulate1, void *stream);
 int camli_wino1d_gru_gates(const float *h, const float *x, int CX, const float *U_zr, const float *ctx_zr, float *z, float *rh, float *r,
-                           float *workspace, int64_t workspace_bytes, int B, int H, int W, int axis, void *stream);
+                           float *v_keep, float *workspace, int64_t workspace_bytes, int B, int H, int W, int axis, void *stream);
 int camli_wino1d_gru_blend(const float *rh, const float *x, int CX, const float *U_q, const float *ctx_q, const float *z, const float *h,
-                           float *h_new, float *q, int nan_to_num, float *workspace, int64_t workspace_bytes, int B, int H, int W,
-                           int axis, void *stream);
+                           float *h_new, float *q, int nan_to_num, float *v_keep, float *workspace, int64_t workspace_bytes, int B, int H,
+                           int W, int axis, void *stream);
 /* camli_convcl_wrw's result for a 1 x 5 / 5 x 1 kernel, contracted in the transform domain (gw [Cout][C0 + C1][5] = | +=): input
  * transform of cat[x0, x1], A-transform of gy, 8 plane contractions over the tiles on the weight-gradient core of wrwcl.h (the
  * planes laid end to end, K splits that do not straddle planes), G^T over the planes.  C0 + C1 a multiple of 256, Cout of 128;
- * workspace = camli_wino1d_wrw_workspace_bytes (0 = unsupported shape).  Deterministic. */
+ * workspace = camli_wino1d_wrw_workspace_bytes (0 = unsupported shape).  Deterministic.  v_in (may be null): the transformed input a
+ * forward launch kept (v_keep above; x0 / x1 are then not read) -- allowed when camli_wino1d_wrw_reuse says 1: the planes are
+ * contracted as they lie, [8][tiles][Cin] without padding rows, so a K split that fills the device must divide them. */
 int64_t camli_wino1d_wrw_workspace_bytes(int B, int H, int W, int Cin, int Cout, int axis);
+int camli_wino1d_wrw_reuse(int B, int H, int W, int Cin, int Cout, int axis);
 int camli_wino1d_wrw(const float *x0, int ldx0, int C0, const float *x1, int ldx1, int C1, const float *gy, int ldg, float *gw,
-                     float *workspace, int64_t workspace_bytes, int B, int H, int W, int Cout, int axis, int accumulate, void *stream);
+                     const float *v_in, float *workspace, int64_t workspace_bytes, int B, int H, int W, int Cout, int axis, int accumulate, void *stream);
 /*
  * Weight gradient of the same convolution: gw [Cout][C0 + C1][T] (= the [Cout, Cin, kh, kw] weight tensor) = or += (accumulate)
  *     sum_p gy[p][n] * x[p + (dy[t], dx[t])][c]

@@ -226,7 +226,7 @@ def test_gru2d_update_as_one_channels_last_node_vs_reference_module(golden, tile
         assert abs(fp[0] - want[0]) <= 1e-4 * want[0] and abs(fp[1] - want[1]) <= 2e-4 * want[0], (name, fp, want)
 
 
-@pytest.mark.parametrize('shape', [(2, 19, 35), (1, 68, 120)], ids=str)
+@pytest.mark.parametrize('shape', [(2, 19, 35), (1, 68, 120), (2, 16, 64)], ids=str)      # (2, 16, 64): the weight gradients contract the forward's kept transforms
 def test_gru2d_update_one_node_vs_per_convolution_nodes(shape, monkeypatch):
     """The one-node channels-last update (CAMLI_GRU_CL, default) against the per-convolution formulation it replaces
     (cat -> library convolution -> gate kernels): new hidden state and every gradient (h, motion, context, the six weights and
@@ -259,3 +259,44 @@ def test_gru2d_update_one_node_vs_per_convolution_nodes(shape, monkeypatch):
     for a, bb, name in zip(res['1'], res['0'], names):
         scale = max(1.0, float(bb.abs().max()))
         assert float((a - bb).abs().max()) <= 1e-4 * scale, (name, float((a - bb).abs().max()), scale)
+
+
+def test_gru2d_weight_gradients_from_the_kept_transforms(monkeypatch):
+    """r6: the forward keeps the transformed inputs V of its four convolutions and camli_wino1d_wrw contracts them as they lie
+    (v_in) instead of transforming [h | m] / [r h | m] again -- same weight gradients as with CAMLI_GRU_KEEP_V=0 up to the
+    summation order of the K splits (the kept planes have no padding rows, so the split differs), and the shape below is one
+    camli_wino1d_wrw_reuse accepts on both axes."""
+    from camliflow_amd.cores import runtime
+    from camliflow_amd.cores.raft2d import GRU2D
+    from camliflow_amd.csrc import _lib, fused
+    runtime.set_backend('hip')
+    b, hh, ww = 2, 16, 64
+    lib = _lib.load()
+    for axis in (0, 1):
+        for cout in (256, 128):
+            assert lib.camli_wino1d_wrw_reuse(b, hh, ww, 256, cout, axis) == 1
+    assert lib.camli_wino1d_wrw_reuse(1, 47, 156, 256, 256, 0) == 0          # 47 x 39 tiles: no 16-row K split divides the plane
+    torch.manual_seed(11)
+    gru = GRU2D(hidden_dim=128, input_dim=256).cuda()
+    h0 = torch.tanh(torch.randn(b, 128, hh, ww, device='cuda'))
+    context, motion, gout = (torch.randn(b, 128, hh, ww, device='cuda') for _ in range(3))
+    res = {}
+    for keep in (True, False):
+        monkeypatch.setattr(fused, '_GRU_KEEP_V', keep)
+        for p_ in gru.parameters():
+            p_.grad = None
+        h, m = h0.clone().requires_grad_(), motion.clone().requires_grad_()
+        runtime.set_census(True)
+        runtime.reset_census()
+        state = gru.prepare(context)
+        out = gru.step(gru.step(h, m, state), m, state)
+        out.backward(gout)
+        census = runtime.census()['fused']
+        runtime.set_census(False)
+        assert census.get('camli_wino1d_wrw', 0) == 8, census
+        res[keep] = [out.detach(), h.grad, m.grad] + [p_.grad.clone() for p_ in gru.parameters()]
+    for a, bb in zip(res[True][:3], res[False][:3]):
+        assert torch.equal(a, bb)                   # the forward and the data gradients do not depend on where V lives
+    for a, bb, (name, _) in zip(res[True][3:], res[False][3:], gru.named_parameters()):
+        scale = max(1.0, float(bb.abs().max()))
+        assert float((a - bb).abs().max()) <= 2e-5 * scale, name
