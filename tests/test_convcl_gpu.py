@@ -296,7 +296,9 @@ def test_gru2d_weight_gradients_from_the_kept_transforms(monkeypatch):
         assert census.get('camli_wino1d_wrw', 0) == 8, census
         res[keep] = [out.detach(), h.grad, m.grad] + [p_.grad.clone() for p_ in gru.parameters()]
     for a, bb in zip(res[True][:3], res[False][:3]):
-        assert torch.equal(a, bb)                   # the forward and the data gradients do not depend on where V lives
+        # the forward and the data gradients do not depend on where V lives (not torch.equal: the context terms come from a
+        # library convolution in each pass, and which algorithm it picks is not fixed from call to call)
+        assert float((a - bb).abs().max()) <= 1e-5 * max(1.0, float(bb.abs().max()))
     for a, bb, (name, _) in zip(res[True][3:], res[False][3:], gru.named_parameters()):
         scale = max(1.0, float(bb.abs().max()))
         assert float((a - bb).abs().max()) <= 2e-5 * scale, name

@@ -185,7 +185,9 @@ def test_trunk_identity_block_fork_on_and_off_give_the_same_gradients(monkeypatc
         res[fork] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in enc.named_parameters()}, len(forks) - n0)
     (y1, gx1, g1, used1), (y0, gx0, g0, used0) = res[True], res[False]
     assert used1 > 0 and used0 == 0, (used1, used0)          # the identity blocks did take the fork node, and only when asked to
-    assert (y1 - y0).abs().max() <= 1e-6 * max(1.0, float(y0.abs().max()))     # the forward is the same arithmetic either way
+    # the forward is the same arithmetic either way -- up to which algorithm the library picks for each of the trunk's
+    # convolutions in each pass (r6: 4.5e-6 of a 4.4 maximum seen once in three full runs; the bound had been 1e-6)
+    assert (y1 - y0).abs().max() <= 1e-4 * max(1.0, float(y0.abs().max()))
     # the two passes call the library's convolution adjoints separately, and which algorithm it picks depends on the workspace
     # it is offered (see the remark in test_resnet_trunk_folded_batchnorm_vs_unfolded): seen 0 ... 1e-4 between the passes
     # with the caching allocator off.  An in-place update of a gradient somebody else still reads would be an O(1) error.
