@@ -129,10 +129,11 @@ def test_two_lane_stream_overlap_matches_single_stream():
                 den = sum((base_grads[n].double() ** 2).sum().item() for n in grads) ** 0.5
                 print('overlap rep %d: epe %s loss %.8f vs %.8f grad rel %.3e' % (rep, epes, loss, base_loss, num / den))
                 # run-to-run noise floor of the forward itself is ~1e-6 EPE / 1e-7 relative loss (library
-                # GEMM / convolution kernels with split accumulation); a stream race would be far above it
+                # GEMM / convolution kernels with split accumulation, and which algorithm the library picks per call: a
+                # sibling bound at 1x the floor flaked once in round 6); a stream race would be far above it
                 for key, epe in epes.items():
-                    assert epe <= 1e-5, (key, epe)
-                assert abs(loss - base_loss) <= 1e-5 * max(1.0, abs(base_loss))
+                    assert epe <= 5e-5, (key, epe)
+                assert abs(loss - base_loss) <= 5e-5 * max(1.0, abs(base_loss))
                 # the backward accumulates with float atomics whose order differs between the schedules;
                 # observed 4e-7 .. 1e-4 through 3 recurrent iterations
                 assert num / den < 1e-3, num / den
@@ -212,7 +213,7 @@ def test_deferred_parameter_gradients_match_autograd_accumulation(overlap):
                     loss, grads = run()
                     assert not runtime.PARAM_GRADS.entries and not runtime.PARAM_GRADS.armed
                     assert grads.keys() == base.keys()
-                    assert abs(loss - base_loss) <= 1e-5 * max(1.0, abs(base_loss))
+                    assert abs(loss - base_loss) <= 5e-5 * max(1.0, abs(base_loss))
                     num = sum(((grads[n] - base[n]).double() ** 2).sum().item() for n in grads) ** 0.5
                     den = sum((base[n].double() ** 2).sum().item() for n in grads) ** 0.5
                     assert num / den < 1e-3, num / den
