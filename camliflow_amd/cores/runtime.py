@@ -24,11 +24,11 @@ import weakref
 _BACKEND = 'hip'
 
 
-
 def _stream_priority(lane):
     """HIP stream priority of a lane's stream (CAMLI_PRIO_SIDE | _AUX | _WGRAD; 0 = the default stream's, -1 = high: torch
     clamps to what the device offers and has nothing BELOW the default, so the point lane is put behind the image lane by
-    raising the image lane's streams, see bench.py CAMLI_PRIO_MAIN)."""
+    raising the image lane's streams, see bench.py CAMLI_PRIO_MAIN).  Measured in round 6 and left at 0: a high-priority stream
+    beside normal ones costs the two-lane step 65 ms on this stack (profiles/r06_experiments.txt 15c)."""
     return int(os.environ.get('CAMLI_PRIO_' + lane, '0'))
 
 
