@@ -54,3 +54,26 @@ def test_eligibility():
     assert fused.wino_shape_supported(128, 256) and fused.wino_shape_supported(629, 128)
     assert not fused.wino_shape_supported(128, 64) and not fused.wino_shape_supported(64, 128)
     assert fused._WINO_TILE in (2, 4)
+
+
+@pytest.mark.parametrize('case', [(8, 68, 120), (4, 68, 120), (1, 47, 156), (2, 16, 64), (2, 19, 35)], ids=str)
+def test_wino1d_workspace_and_kept_transform_arithmetic(case):
+    """Host functions of the 1-D Winograd family (no launch): the forward's workspace is the two transform-domain planes
+    [8][tiles][Cin + Cout], tiles = 4 pixels along the kernel's axis; the weight gradient may contract a transform the forward
+    kept only where a 16-row K split that fills the device divides the unpadded planes (camli_wino1d_wrw_reuse)."""
+    from camliflow_amd.csrc import _lib
+    lib = _lib.load()
+    b, h, w = case
+    for axis in (0, 1):
+        tiles = b * (h * -(-w // 4) if axis == 0 else w * -(-h // 4))
+        for cout in (256, 128):
+            assert lib.camli_wino1d_workspace_bytes(b, h, w, 256, cout, axis) == 8 * tiles * (256 + cout) * 4
+            need = lib.camli_wino1d_wrw_workspace_bytes(b, h, w, 256, cout, axis)
+            assert need >= 8 * tiles * (256 + cout) * 4            # both operands' planes (padded rows) + the K-split partial sums
+            reuse = lib.camli_wino1d_wrw_reuse(b, h, w, 256, cout, axis)
+            assert reuse in (0, 1) and (reuse == 0 or tiles % 16 == 0)
+    assert lib.camli_wino1d_wrw_workspace_bytes(b, h, w, 384, 256, 0) == 0 and lib.camli_wino1d_wrw_reuse(b, h, w, 384, 256, 0) == 0   # Cin % 256
+    if case == (8, 68, 120):          # the bench step's shape: 16,320 tiles = 30 splits of 34 K-steps per plane
+        assert all(lib.camli_wino1d_wrw_reuse(b, h, w, 256, n, a) == 1 for n in (256, 128) for a in (0, 1))
+    if case == (1, 47, 156):          # KITTI: 47 x 39 = 1,833 tiles along x -- no whole 16-row split
+        assert lib.camli_wino1d_wrw_reuse(b, h, w, 256, 256, 0) == 0
