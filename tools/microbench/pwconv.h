@@ -98,8 +98,7 @@ __global__ __launch_bounds__(256, 2) void pwconv128_fwd_kernel(const float* __re
 // ---- pipelined form: persistent workgroups walk sub-tiles of 64 positions, the next sub-tile's loads in flight (registers) while
 // the matrix pipe works on the current one (LDS double buffer, one barrier per sub-tile) ----
 constexpr int SP = 64;             // positions per sub-tile
-constexpr int LDS2 = SP;           // row stride in dwords: unpadded -- a b128 phase mixes lanes of two lane groups (rows 4 apart, or 1 apart
-                                   // in the staging writes) whose 16-byte pieces then tile the 64 banks exactly
+constexpr int LDS2 = SP + 4;       // row stride in dwords (rows 4 apart land 16 banks apart)
 constexpr size_t LDS2_BYTES = (size_t)2 * C * LDS2 * sizeof(float);
 
 // grid <= B * ceil(P / 64) workgroups of 256 threads, dynamic LDS LDS2_BYTES.  P % 4 == 0.
@@ -115,9 +114,11 @@ __global__ __launch_bounds__(256, 2) void pwconv128_pipe_kernel(const float* __r
     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
         for (int j = 0; j < 8; ++j) wa[mf][j] = *reinterpret_cast<const f32x4*>(w + (size_t)(o0 + 16 * mf + l16) * C + 16 * j + 4 * g);
-    float bvo[2];
+    float bv[2][4];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) bvo[mf] = bias ? bias[o0 + 16 * mf + l16] : 0.f;
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[mf][r] = bias ? bias[o0 + 16 * mf + 4 * g + r] : 0.f;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     // thread's share of a sub-tile: 8 float4, element e = tid + 256 u -> row c = e / 16, float4 column q = e % 16
     f32x4 pre[8];
@@ -156,31 +157,31 @@ __global__ __launch_bounds__(256, 2) void pwconv128_pipe_kernel(const float* __r
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                // A = x^T: fragment f's row m is position 4 m + f, so ONE b128 read feeds the four fragments of a K step;
-                // B = w^T from registers.  D_f[row 4 g + r][o = lane % 16] = position 16 g + 4 r + f
-                const f32x4 xa = *reinterpret_cast<const f32x4*>(buf + (16 * j + 4 * g + i) * LDS2 + 4 * l16);
+                const float* row = buf + (16 * j + 4 * g + i) * LDS2 + l16;
+                float bf[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) bf[f] = row[16 * f];
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
-                    acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[f], wa[0][j][i], acc[0][f], 0, 0, 0);
-                    acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[f], wa[1][j][i], acc[1][f], 0, 0, 0);
+                    acc[0][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][j][i], bf[f], acc[0][f], 0, 0, 0);
+                    acc[1][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][j][i], bf[f], acc[1][f], 0, 0, 0);
                 }
             }
         }
+        // (tried: x as the A operand with fragment row m = position 4 m + f -- one ds_read_b128 per K step and float4 stores along
+        // p, unpadded rows: 32.6 us against this form's 29.5)
         const int b = t / tiles, p0 = (t - b * tiles) * SP;
         float* __restrict__ yb = y + (size_t)b * y_bs;
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf) {
-            float* __restrict__ yrow = yb + (size_t)(o0 + 16 * mf + l16) * P + p0 + 16 * g;
+        for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (p0 + 16 * g + 4 * r < P) {          // P % 4 == 0: a float4 is inside or outside as a whole
-                    f32x4 o;
+            for (int f = 0; f < 4; ++f) {
+                const int p = p0 + 16 * f + l16;
+                if (p < P) {
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) o[f] = act<ACT>(acc[mf][f][r] + bvo[mf]);
-                    *reinterpret_cast<f32x4*>(yrow + 4 * r) = o;
+                    for (int r = 0; r < 4; ++r) yb[(size_t)(o0 + 16 * mf + 4 * g + r) * P + p] = act<ACT>(acc[mf][f][r] + bv[mf][r]);
                 }
             }
-        }
         if (nxt < total) stash(xs + (cur ^ 1) * (C * LDS2));
         __syncthreads();
         cur ^= 1;
